@@ -1,0 +1,222 @@
+/*
+ * m3p2i_hip.h -- C-ABI of libm3p2i_hip.so: the MI355X (gfx950) implementation of the
+ * MPPI / M3P2I command() hot path of tud-amr/m3p2i-aip.
+ *
+ * The reference is pure Python; the "FFI" a maintainer binds is ctypes (see
+ * INTEGRATION.md).  Each entry point names the reference interface it replaces
+ * (paths relative to the reference repository root):
+ *
+ *   m3_create / m3_destroy      MPPI.__init__ / M3P2I.__init__
+ *                                 src/m3p2i_aip/planners/motion_planner/mppi.py:82-203,
+ *                                 m3p2i.py:5-8; IsaacGymWrapper.__init__/start_sim
+ *                                 src/m3p2i_aip/utils/isaacgym_utils/isaacgym_wrapper.py:39-90
+ *   m3_set_noise                MPPI.get_samples (cached Halton-spline delta) mppi.py:458-483
+ *   m3_set_objective            Objective.update_objective cost_functions.py:15-17,
+ *                                 M3P2I.update_gripper_command m3p2i.py:10-14
+ *   m3_set_world / m3_bind_sim  run_tamp state upload scripts/reactive_tamp.py:45-48
+ *                                 (set_dof_state_tensor / set_actor_root_state_tensor,
+ *                                 isaacgym_wrapper.py:190-194)
+ *   m3_command                  MPPI.command mppi.py:211-264 (whole call)
+ *   m3_rollout                  _compute_total_cost_batch_halton/_simple + _compute_rollout_costs
+ *                                 mppi.py:275-332, 335-363, 381-428 with dynamics/running_cost
+ *                                 of reactive_tamp.py:63-73 and Objective.compute_cost
+ *                                 cost_functions.py:19-169 fused in
+ *   m3_update                   _exp_util mppi.py:430-456, _multi_modal_exp_util +
+ *                                 update_infinite_beta m3p2i.py:24-64, weighted sums
+ *                                 mppi.py:493-498, m3p2i.py:75-83
+ *   m3_finalize                 mean update mppi.py:502-503 / m3p2i.py:86-87, top-k +
+ *                                 Savitzky-Golay mppi.py:245-264, simple-mode U update :231
+ *   m3_sim_*                    IsaacGymWrapper step-mode surface: set_dof_velocity_target_tensor
+ *                                 :196, step :354-360, apply_rigid_body_force_tensors :202,
+ *                                 refresh of _dof_state/_root_state/_rigid_body_state/
+ *                                 _net_contact_force :98-118
+ *   m3_cost                     Objective.compute_cost (step mode) cost_functions.py:19-36
+ *   m3_get_buffer               attribute access MPPI.states/actions/weights/top_trajs/...
+ *   m3_get_info                 M3P2I.get_pull_preference m3p2i.py:16-22 (+ diagnostics)
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every call returns 0 on success
+ * or a negative m3_status; m3_last_error() gives the message.  All device work is enqueued
+ * on the handle's HIP stream (m3_set_stream); calls are asynchronous unless stated.  A
+ * handle is not thread-safe; different handles are independent.  The library owns all
+ * device buffers; m3_get_buffer hands out non-owning device pointers valid until
+ * m3_destroy.
+ */
+#ifndef M3P2I_HIP_H
+#define M3P2I_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3_MAX_NU 9
+#define M3_TOPK 20
+#define M3_ABI_VERSION 1
+
+typedef enum {
+    M3_OK = 0,
+    M3_ERR_BAD_ARG = -1,
+    M3_ERR_HIP = -2,
+    M3_ERR_SHAPE = -3,
+    M3_ERR_STATE = -4,
+    M3_ERR_UNSUPPORTED = -5
+} m3_status;
+
+typedef enum { M3_ENV_POINT = 0, M3_ENV_PANDA = 1 } m3_env;
+
+/* cost_functions.py:19-36 task strings */
+typedef enum {
+    M3_TASK_NAVIGATION = 0,
+    M3_TASK_PUSH = 1,
+    M3_TASK_PULL = 2,
+    M3_TASK_PUSH_PULL = 3,
+    M3_TASK_REACH = 4,
+    M3_TASK_PICK = 5,
+    M3_TASK_PLACE = 6,
+    M3_TASK_IDLE = 7
+} m3_task;
+
+typedef struct {
+    int abi_version;        /* M3_ABI_VERSION */
+    int device;             /* HIP device ordinal */
+    /* sampling / sharding: rank owns global samples [k_offset, k_offset + K_local) */
+    int K_global;
+    int K_local;
+    int k_offset;
+    int T;                  /* horizon */
+    int nu;                 /* 2 (point_env) or 9 (panda_env) */
+    int env_type;           /* m3_env */
+    int multi_modal;        /* cfg.multi_modal */
+    int mode_simple;        /* mppi_mode == 'simple' */
+    int sampling_random;    /* sampling_method == 'random' (in-kernel xoshiro128++) */
+    int sample_null_action;
+    int filter_u;
+    int u_per_command;
+    float u_min[M3_MAX_NU];
+    float u_max[M3_MAX_NU];
+    float noise_sigma_diag[M3_MAX_NU]; /* diagonal of cfg.mppi.noise_sigma */
+    float u_scale;
+    float gamma;            /* rollout_var_discount */
+    float lambda_;
+    float step_size_mean;   /* 0.98, mppi.py:178 */
+    float kp_suction;       /* config_point.yaml:9 */
+    float pre_height_diff;  /* config_panda.yaml:9 */
+    float dt;               /* isaacgym/{point,panda}.yaml:4 */
+    int substeps;           /* isaacgym_wrapper.py:10 */
+    int solver_iters;       /* isaacgym_wrapper.py:28 */
+    int cube_on_shelf;      /* reactive_tamp.py:29 */
+    unsigned long long seed;
+} m3_config;
+
+/* Planar world state of ONE environment, as the caller sees it through the wrapper's
+ * tensors (dof_state = [x, vx, y, vy]; boxes = x, y, yaw quaternion (z, w), vx, vy, wz). */
+typedef struct {
+    float robot[4];      /* x, y, vx, vy */
+    float box[7];        /* x, y, qz, qw, vx, vy, wz */
+    float dyn_obs[7];
+} m3_point_world;
+
+typedef struct {
+    float eta, eta_1, eta_2;
+    float beta, beta_1, beta_2;  /* beta AFTER the call (panda single-mode persists it) */
+    int iters, iters_1, iters_2; /* beta-search passes */
+    int best_idx, best_idx_1, best_idx_2; /* GLOBAL sample indices */
+    float wsum_push, wsum_pull;  /* sum of weights of the two halves (m3p2i.py:18-19) */
+    int pull_preference;
+    int calls;
+} m3_info;
+
+typedef struct {
+    float rollout_ms, update_ms, finalize_ms, total_ms; /* HIP-event times of the last
+                                                           m3_command with timing enabled */
+} m3_timing;
+
+/* buffers for m3_get_buffer; shapes in comments (Kl = K_local, Kg = K_global).
+ * Layouts are TIME-MAJOR so that consecutive lanes (samples) touch consecutive addresses. */
+typedef enum {
+    M3_BUF_STATES = 0,      /* f32 [T][Kl][4]   (x, vx, y, vy)  mppi.py:318 (transposed) */
+    M3_BUF_ACTIONS = 1,     /* f32 [T][Kl][nu]                 mppi.py:317 (transposed) */
+    M3_BUF_COST_HORIZON = 2,/* f32 [T][Kl]                     mppi.py:310 (transposed) */
+    M3_BUF_TRAJ_COST = 3,   /* f32 [Kl]  discounted J (halton) / S + perturbation (simple) */
+    M3_BUF_TRAJ_COST_ALL = 4,/* f32 [Kg] gathered J used by m3_update */
+    M3_BUF_WEIGHTS = 5,     /* f32 [Kg] */
+    M3_BUF_WEIGHTS_1 = 6,   /* f32 [Kg/2] */
+    M3_BUF_WEIGHTS_2 = 7,   /* f32 [Kg - Kg/2] */
+    M3_BUF_MEAN = 8,        /* f32 [T][nu] mean_action (U in simple mode) */
+    M3_BUF_MEAN_1 = 9,
+    M3_BUF_MEAN_2 = 10,
+    M3_BUF_BEST = 11,       /* f32 [T][nu] best_traj */
+    M3_BUF_BEST_1 = 12,
+    M3_BUF_BEST_2 = 13,
+    M3_BUF_ACTION_OUT = 14, /* f32 [T][nu] returned plan (filtered) */
+    M3_BUF_TOP_IDX = 15,    /* i32 [M3_TOPK] global indices */
+    M3_BUF_TOP_TRAJS = 16,  /* f32 [M3_TOPK][T][2] */
+    M3_BUF_REDUCE = 17,     /* f32 [reduce_len] packed partial sums: all-reduce(sum) this
+                               buffer between m3_update and m3_finalize when sharded */
+    M3_BUF_NOISE = 18,      /* f32 [T][Kl][nu] delta (time-major copy of m3_set_noise) */
+    M3_BUF_PENDING_FORCE = 19, /* f32 [4][Kl] suction force pending for the next step */
+    M3_BUF_INFO = 20,       /* device copy of m3_info */
+    M3_BUF_COUNT = 21
+} m3_buffer_id;
+
+typedef struct m3_handle m3_handle;
+
+int m3_abi_version(void);
+const char* m3_last_error(const m3_handle* h); /* h may be NULL: error of the last failed
+                                                  m3_create on this thread */
+void m3_default_config(m3_config* cfg, int env_type);
+int m3_create(const m3_config* cfg, m3_handle** out);
+void m3_destroy(m3_handle* h);
+int m3_set_stream(m3_handle* h, void* hip_stream);
+int m3_enable_timing(m3_handle* h, int on);
+
+/* delta: [K_local][T][nu] row-major (the reference's layout, rows of THIS shard).
+ * on_device: 0 host pointer, 1 device pointer. */
+int m3_set_noise(m3_handle* h, const float* delta, int on_device);
+int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd);
+/* warm-start state (means, best trajs, U): which = M3_BUF_MEAN.., host pointer [T][nu] */
+int m3_set_plan(m3_handle* h, int which, const float* host_values);
+int m3_reset(m3_handle* h); /* zero means/best/pending forces, beta = 1, call counter = 0 */
+
+/* initial state of every rollout (host values; copied by value into the launch) */
+int m3_set_world_point(m3_handle* h, const m3_point_world* w);
+/* same in the library's internal layout, 18 floats: robot x y vx vy | box x y cos sin vx vy wz
+ * | dyn-obs likewise (no quaternion round trip; used by the bit-parity tests) */
+int m3_set_world_point_raw(m3_handle* h, const float* w18);
+/* ... or read it from env 0 of the wrapper's device tensors at launch time (zero-copy):
+ * dof_state f32 [*,4], root_state f32 [*,n_actors,13] */
+int m3_bind_sim_point(m3_handle* h, const float* dof_state_dev, const float* root_state_dev,
+                      int n_actors, int box_actor, int dyn_obs_actor);
+
+/* one MPPI iteration = rollout + update + finalize.  action_host: optional [T][nu] (or
+ * [u_per_command][nu] in simple mode) host buffer; if non-NULL the call synchronises. */
+int m3_command(m3_handle* h, float* action_host);
+/* the three phases, for sharded use: rollout -> (all-gather TRAJ_COST into TRAJ_COST_ALL)
+ * -> update -> (all-reduce REDUCE) -> finalize.  With K_local == K_global m3_update copies
+ * TRAJ_COST itself. */
+int m3_rollout(m3_handle* h);
+int m3_update(m3_handle* h);
+int m3_finalize(m3_handle* h);
+
+int m3_get_buffer(m3_handle* h, int which, void** dev_ptr, long long* nbytes);
+int m3_reduce_len(const m3_handle* h);
+int m3_get_info(m3_handle* h, m3_info* out);     /* synchronises the stream */
+int m3_get_timing(m3_handle* h, m3_timing* out); /* synchronises the stream */
+
+/* ---- step mode: the K rollout environments as an IsaacGymWrapper-like simulator ---- */
+/* bind the wrapper's torch-owned views (device pointers, may be NULL to skip a view):
+ * dof_state [Kl][2*ndof], root_state [Kl][nA][13], rigid_body_state [Kl][nB][13],
+ * net_contact_force [Kl][nB][3] */
+int m3_sim_bind_views(m3_handle* h, float* dof_state, float* root_state,
+                      float* rigid_body_state, float* net_contact_force, int n_actors,
+                      int n_bodies);
+int m3_sim_pull_state(m3_handle* h); /* views -> internal state (set_*_state_tensor) */
+int m3_sim_push_state(m3_handle* h); /* internal state -> views (refresh_*) */
+int m3_sim_set_velocity_target(m3_handle* h, const float* u_dev /* [Kl][nu] */);
+int m3_sim_apply_body_forces(m3_handle* h, const float* f_dev /* [Kl][nB][3] */);
+int m3_sim_step(m3_handle* h);       /* one step(): dt with substeps, then push views */
+int m3_cost(m3_handle* h, float* cost_dev /* [Kl] */); /* Objective.compute_cost */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,44 @@
+"""Build libm3p2i_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m m3p2i_aip_amd.build [--force]
+
+-ffp-contract=off / no fast-math: the dynamics are specified as a fixed sequence of IEEE
+binary32 operations so that the CPU oracle can check them bit-for-bit.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib", "libm3p2i_hip.so")
+SOURCES = ["rollout_point.hip", "update.hip", "m3_api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "m3p2i_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,520 @@
+// m3_api.hip -- C-ABI of libm3p2i_hip.so (see include/m3p2i_hip.h for what each entry
+// point replaces in the reference).  Host code only: argument checking, buffer ownership,
+// launch sequencing on the handle's HIP stream.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "m3_internal.hpp"
+
+using namespace m3;
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(h, expr)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                \
+            return M3_ERR_HIP;                                                           \
+        }                                                                                \
+    } while (0)
+
+static int fail(m3_handle* h, int code, const char* msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+extern "C" int m3_abi_version(void) { return M3_ABI_VERSION; }
+
+extern "C" const char* m3_last_error(const m3_handle* h) {
+    return h ? h->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" void m3_default_config(m3_config* c, int env_type) {
+    std::memset(c, 0, sizeof(*c));
+    c->abi_version = M3_ABI_VERSION;
+    c->env_type = env_type;
+    c->u_scale = 1.0f;
+    c->gamma = 0.95f;         // MPPIConfig.rollout_var_discount, mppi.py:50
+    c->step_size_mean = 0.98f;  // mppi.py:178
+    c->sample_null_action = 1;
+    c->filter_u = 1;
+    c->substeps = 2;          // isaacgym_wrapper.py:10
+    c->solver_iters = 6;      // isaacgym_wrapper.py:28
+    if (env_type == M3_ENV_POINT) {  // config/mppi/point.yaml, config_point.yaml, isaacgym/point.yaml
+        c->nu = 2; c->K_global = c->K_local = 200; c->T = 15; c->u_per_command = 15;
+        c->lambda_ = 0.5f; c->kp_suction = 400.0f; c->dt = 0.05f;
+        for (int j = 0; j < 2; ++j) { c->u_min[j] = -3.0f; c->u_max[j] = 3.0f; c->noise_sigma_diag[j] = 3.0f; }
+    } else {  // config/mppi/panda.yaml, config_panda.yaml, isaacgym/panda.yaml
+        c->nu = 9; c->K_global = c->K_local = 200; c->T = 12; c->u_per_command = 12;
+        c->lambda_ = 0.05f; c->pre_height_diff = 0.05f; c->dt = 0.01f;
+        for (int j = 0; j < 9; ++j) {
+            c->u_min[j] = j < 7 ? -2.0f : -1.5f; c->u_max[j] = j < 7 ? 2.0f : 1.5f;
+            c->noise_sigma_diag[j] = j < 7 ? 10.0f : 0.8f;
+        }
+    }
+}
+
+// "Planar contact dynamics spec v1" constants (sources: config/point_env/*.yaml,
+// pointRobot.urdf, isaacgym_wrapper.py:18-37,341-344,462-469)
+static void build_point_scene(const m3_config& c, PointScene& s) {
+    const float h = c.dt / (float)c.substeps;
+    s.h = h; s.substeps = c.substeps; s.iters = c.solver_iters;
+    const float g = 9.8f;
+    s.robot_r = 0.2f; s.invm_r = 1.0f / 10.0f;
+    s.gam = 1.0f / (h * 600.0f);
+    s.md = 1.0f / (s.invm_r + s.gam);
+    s.dmax = 1000.0f * h;
+    const float req = 0.3825978f * 0.4f;
+    s.box_hx = 0.2f; s.box_hy = 0.2f; s.box_m = 16.0f;
+    s.box_I = 16.0f * (0.4f * 0.4f + 0.4f * 0.4f) / 12.0f;
+    s.invm_b = 1.0f / s.box_m; s.invI_b = 1.0f / s.box_I;
+    s.LlinB = ((0.75f * s.box_m) * g) * h; s.LangB = s.LlinB * req;
+    s.dyn_hx = 0.2f; s.dyn_hy = 0.2f; s.dyn_m = 16.0f;
+    s.dyn_I = 16.0f * (0.4f * 0.4f + 0.4f * 0.4f) / 12.0f;
+    s.invm_d = 1.0f / s.dyn_m; s.invI_d = 1.0f / s.dyn_I;
+    s.LlinD = ((1.0f * s.dyn_m) * g) * h; s.LangD = s.LlinD * req;
+    s.obs_x = 2.0f; s.obs_y = 2.0f; s.obs_hx = 0.15f; s.obs_hy = 0.2f;
+    s.wall = 3.95f;
+    s.mu_rb = 0.275f; s.mu_rd = 0.525f; s.mu_ro = 0.525f; s.mu_rw = 0.525f;
+    s.mu_bw = 0.75f; s.mu_dw = 1.0f; s.mu_bd = 0.75f; s.mu_bo = 0.75f; s.mu_do = 1.0f;
+    s.contact_offset = 0.01f; s.baumgarte = 0.2f; s.slop = 0.005f; s.max_bias = 2.0f;
+    s.face_tol = 0.0005f;
+    s.rad_b = std::sqrt(s.box_hx * s.box_hx + s.box_hy * s.box_hy);
+    s.rad_d = std::sqrt(s.dyn_hx * s.dyn_hx + s.dyn_hy * s.dyn_hy);
+    s.rad_o = std::sqrt(s.obs_hx * s.obs_hx + s.obs_hy * s.obs_hy);
+}
+
+static void default_world(float* w) {
+    const float init[18] = {0, 0, 0, 0, /*box 7_box.yaml*/ 0, 2, 1, 0, 0, 0, 0,
+                            /*dyn-obs 6_dyn_obs.yaml*/ -2, 2, 1, 0, 0, 0, 0};
+    std::memcpy(w, init, sizeof(init));
+}
+
+static int alloc_buf(m3_handle* h, int id, long long bytes) {
+    if (bytes < 16) bytes = 16;
+    HIPCHK(h, hipMalloc(&h->buf[id], (size_t)bytes));
+    HIPCHK(h, hipMemsetAsync(h->buf[id], 0, (size_t)bytes, h->stream));
+    h->nbytes[id] = bytes;
+    return M3_OK;
+}
+
+extern "C" int m3_create(const m3_config* c, m3_handle** out) {
+    if (!c || !out) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: null argument");
+    if (c->abi_version != M3_ABI_VERSION) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: abi_version mismatch");
+    if (c->K_global < 1 || c->K_local < 1 || c->k_offset < 0 || c->k_offset + c->K_local > c->K_global)
+        return fail(nullptr, M3_ERR_SHAPE, "m3_create: bad K_global/K_local/k_offset");
+    if (c->T < 1 || c->T > 4096) return fail(nullptr, M3_ERR_SHAPE, "m3_create: bad horizon T");
+    if (c->env_type == M3_ENV_POINT && c->nu != 2) return fail(nullptr, M3_ERR_SHAPE, "m3_create: point_env needs nu == 2");
+    if (c->env_type == M3_ENV_PANDA && c->nu != 9) return fail(nullptr, M3_ERR_SHAPE, "m3_create: panda_env needs nu == 9");
+    if (c->env_type != M3_ENV_POINT && c->env_type != M3_ENV_PANDA) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad env_type");
+    if (c->env_type == M3_ENV_PANDA) return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: panda_env kernels are not built yet");
+    if (c->K_global < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: K must be >= 20 (torch.topk(weights, 20), mppi.py:248)");
+    if (c->filter_u && (c->mode_simple ? c->u_per_command : c->T) < 9)
+        return fail(nullptr, M3_ERR_SHAPE, "m3_create: filter_u needs >= 9 rows (savgol window, mppi.py:190)");
+    if (c->mode_simple && (c->u_per_command < 1 || c->u_per_command > c->T))
+        return fail(nullptr, M3_ERR_SHAPE, "m3_create: bad u_per_command");
+    if (c->substeps < 1 || c->solver_iters < 1 || !(c->dt > 0.0f)) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad dt/substeps/solver_iters");
+    for (int j = 0; j < c->nu; ++j)
+        if (!(c->noise_sigma_diag[j] > 0.0f) || !(c->u_max[j] >= c->u_min[j]))
+            return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad noise_sigma / bounds");
+    if (!(c->gamma > 0.0f) || !(c->u_scale != 0.0f) || (c->mode_simple && !(c->lambda_ > 0.0f)))
+        return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad gamma / u_scale / lambda_");
+
+    m3_handle* h = new (std::nothrow) m3_handle();
+    if (!h) return fail(nullptr, M3_ERR_HIP, "m3_create: out of host memory");
+    h->cfg = *c;
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) {
+        g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        delete h;
+        return M3_ERR_HIP;
+    }
+    build_point_scene(*c, h->scene);
+    default_world(h->world0);
+    const long long Kl = c->K_local, Kg = c->K_global, T = c->T, nu = c->nu;
+    const long long f = sizeof(float);
+    int rc = M3_OK;
+    auto A = [&](int id, long long bytes) { if (rc == M3_OK) rc = alloc_buf(h, id, bytes); };
+    A(M3_BUF_STATES, T * Kl * 4 * f);
+    A(M3_BUF_ACTIONS, T * Kl * nu * f);
+    A(M3_BUF_COST_HORIZON, T * Kl * f);
+    A(M3_BUF_TRAJ_COST, Kl * f);
+    A(M3_BUF_TRAJ_COST_ALL, Kg * f);
+    A(M3_BUF_WEIGHTS, Kg * f);
+    A(M3_BUF_WEIGHTS_1, (Kg / 2) * f);
+    A(M3_BUF_WEIGHTS_2, (Kg - Kg / 2) * f);
+    for (int id = M3_BUF_MEAN; id <= M3_BUF_ACTION_OUT; ++id) A(id, T * nu * f);
+    A(M3_BUF_TOP_IDX, M3_TOPK * sizeof(int));
+    A(M3_BUF_TOP_TRAJS, M3_TOPK * T * 2 * f);
+    A(M3_BUF_REDUCE, (long long)reduce_length((int)T, (int)nu) * f);
+    A(M3_BUF_NOISE, T * Kl * nu * f);
+    A(M3_BUF_PENDING_FORCE, 4 * Kl * f);
+    A(M3_BUF_INFO, sizeof(m3_info));
+    if (rc == M3_OK && hipMalloc((void**)&h->world0_dev, 18 * f) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK) {
+        m3_info init;
+        std::memset(&init, 0, sizeof(init));
+        init.beta = init.beta_1 = init.beta_2 = 1.0f;  // mppi.py:184-187
+        if (hipMemcpy(h->buf[M3_BUF_INFO], &init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) rc = M3_ERR_HIP;
+    }
+    if (rc != M3_OK) {
+        g_create_err = h->err.empty() ? "m3_create: device allocation failed" : h->err;
+        m3_destroy(h);
+        return rc;
+    }
+    (void)hipDeviceSynchronize();
+    *out = h;
+    return M3_OK;
+}
+
+extern "C" void m3_destroy(m3_handle* h) {
+    if (!h) return;
+    for (int i = 0; i < M3_BUF_COUNT; ++i)
+        if (h->buf[i]) (void)hipFree(h->buf[i]);
+    if (h->world0_dev) (void)hipFree(h->world0_dev);
+    if (h->sim_world) (void)hipFree(h->sim_world);
+    if (h->sim_u) (void)hipFree(h->sim_u);
+    if (h->noise_stage) (void)hipFree(h->noise_stage);
+    for (auto& ev : h->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete h;
+}
+
+extern "C" int m3_set_stream(m3_handle* h, void* s) {
+    if (!h) return M3_ERR_BAD_ARG;
+    h->stream = (hipStream_t)s;
+    return M3_OK;
+}
+
+extern "C" int m3_enable_timing(m3_handle* h, int on) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (on && !h->ev[0])
+        for (auto& ev : h->ev) HIPCHK(h, hipEventCreate(&ev));
+    h->timing = on != 0;
+    return M3_OK;
+}
+
+extern "C" int m3_set_noise(m3_handle* h, const float* delta, int on_device) {
+    if (!h || !delta) return fail(h, M3_ERR_BAD_ARG, "m3_set_noise: null argument");
+    const m3_config& c = h->cfg;
+    const size_t bytes = (size_t)c.K_local * c.T * c.nu * sizeof(float);
+    const float* src = delta;
+    if (!on_device) {
+        if (!h->noise_stage) HIPCHK(h, hipMalloc((void**)&h->noise_stage, bytes));
+        HIPCHK(h, hipMemcpyAsync(h->noise_stage, delta, bytes, hipMemcpyHostToDevice, h->stream));
+        src = h->noise_stage;
+    }
+    launch_transpose_noise(src, (float*)h->buf[M3_BUF_NOISE], c.K_local, c.T, c.nu, h->stream);
+    HIPCHK(h, hipGetLastError());
+    if (!on_device) HIPCHK(h, hipStreamSynchronize(h->stream));  // host buffer may be released
+    h->have_noise = true;
+    return M3_OK;
+}
+
+extern "C" int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (task < 0 || task > M3_TASK_IDLE) return fail(h, M3_ERR_BAD_ARG, "m3_set_objective: unknown task");
+    if (goal_len < 0 || goal_len > 7 || (goal_len > 0 && !goal)) return fail(h, M3_ERR_SHAPE, "m3_set_objective: bad goal");
+    if (h->cfg.env_type == M3_ENV_POINT && task > M3_TASK_PUSH_PULL)
+        return fail(h, M3_ERR_UNSUPPORTED, "m3_set_objective: task not defined for point_env");
+    if (h->cfg.env_type == M3_ENV_POINT && goal_len < 2) return fail(h, M3_ERR_SHAPE, "m3_set_objective: point_env goal needs 2 values");
+    if (task == M3_TASK_PUSH_PULL && !h->cfg.multi_modal)
+        return fail(h, M3_ERR_STATE, "m3_set_objective: push_pull needs multi_modal (cost_functions.py:27-29)");
+    h->task = task;
+    for (int i = 0; i < goal_len; ++i) h->goal[i] = goal[i];
+    h->gripper_cmd = gripper_cmd;
+    return M3_OK;
+}
+
+extern "C" int m3_set_plan(m3_handle* h, int which, const float* v) {
+    if (!h || !v) return M3_ERR_BAD_ARG;
+    if (which < M3_BUF_MEAN || which > M3_BUF_BEST_2) return fail(h, M3_ERR_BAD_ARG, "m3_set_plan: not a plan buffer");
+    HIPCHK(h, hipMemcpyAsync(h->buf[which], v, (size_t)h->cfg.T * h->cfg.nu * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return M3_OK;
+}
+
+extern "C" int m3_reset(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    for (int id = M3_BUF_MEAN; id <= M3_BUF_ACTION_OUT; ++id)
+        HIPCHK(h, hipMemsetAsync(h->buf[id], 0, (size_t)h->nbytes[id], h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf[M3_BUF_PENDING_FORCE], 0, (size_t)h->nbytes[M3_BUF_PENDING_FORCE], h->stream));
+    m3_info init;
+    std::memset(&init, 0, sizeof(init));
+    init.beta = init.beta_1 = init.beta_2 = 1.0f;
+    HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_INFO], &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->calls = 0;
+    return M3_OK;
+}
+
+extern "C" int m3_set_world_point(m3_handle* h, const m3_point_world* w) {
+    if (!h || !w) return M3_ERR_BAD_ARG;
+    float* o = h->world0;
+    o[0] = w->robot[0]; o[1] = w->robot[1]; o[2] = w->robot[2]; o[3] = w->robot[3];
+    const float* src[2] = {w->box, w->dyn_obs};
+    for (int b = 0; b < 2; ++b) {
+        const float* r = src[b];
+        float* p = o + 4 + b * 7;
+        const float qz = r[2], qw = r[3];
+        p[0] = r[0]; p[1] = r[1];
+        p[2] = 1.0f - 2.0f * (qz * qz);  // yaw from the (0,0,qz,qw) quaternion
+        p[3] = 2.0f * (qz * qw);
+        p[4] = r[4]; p[5] = r[5]; p[6] = r[6];
+    }
+    h->world0_bound = nullptr;
+    h->bind_dof = nullptr;
+    return M3_OK;
+}
+
+// internal-format variant used by the parity tests: 18 floats, boxes as (x, y, cos, sin, ...)
+extern "C" int m3_set_world_point_raw(m3_handle* h, const float* w18) {
+    if (!h || !w18) return M3_ERR_BAD_ARG;
+    std::memcpy(h->world0, w18, 18 * sizeof(float));
+    h->world0_bound = nullptr;
+    h->bind_dof = nullptr;
+    return M3_OK;
+}
+
+extern "C" int m3_bind_sim_point(m3_handle* h, const float* dof, const float* root, int n_actors, int box_actor, int dyn_actor) {
+    if (!h || !dof || !root) return M3_ERR_BAD_ARG;
+    if (n_actors < 1 || box_actor < 0 || box_actor >= n_actors || dyn_actor < 0 || dyn_actor >= n_actors)
+        return fail(h, M3_ERR_SHAPE, "m3_bind_sim_point: actor index out of range");
+    h->bind_dof = dof; h->bind_root = root; h->bind_nact = n_actors; h->bind_box = box_actor; h->bind_dyn = dyn_actor;
+    return M3_OK;
+}
+
+static void fill_cost_params(const m3_handle* h, CostParams& cp) {
+    cp.task = h->task;
+    cp.multi_modal = h->cfg.multi_modal;
+    cp.half_K = h->cfg.K_global / 2;
+    for (int i = 0; i < 7; ++i) cp.goal[i] = h->goal[i];
+    cp.kp_suction = h->cfg.kp_suction;
+    cp.suction_thresh = (h->cfg.K_global == 1) ? 1.5f : 1.8f;  // skill_utils.py:75-82
+}
+
+extern "C" int m3_rollout(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    const m3_config& c = h->cfg;
+    if (!c.sampling_random && !c.mode_simple && !h->have_noise)
+        return fail(h, M3_ERR_STATE, "m3_rollout: no noise set (m3_set_noise) and sampling_random == 0");
+    if (c.mode_simple && !c.sampling_random && !h->have_noise)
+        return fail(h, M3_ERR_STATE, "m3_rollout: simple mode needs m3_set_noise or sampling_random");
+    if (h->task == M3_TASK_PUSH_PULL && !c.multi_modal) return fail(h, M3_ERR_STATE, "m3_rollout: push_pull needs multi_modal");
+    RolloutArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.Kg = c.K_global; a.Kl = c.K_local; a.k0 = c.k_offset; a.T = c.T; a.nu = c.nu;
+    a.multi_modal = c.multi_modal; a.mode_simple = c.mode_simple;
+    a.sampling_random = c.sampling_random; a.sample_null_action = c.sample_null_action;
+    a.gripper_cmd = h->gripper_cmd;
+    for (int j = 0; j < c.nu; ++j) {
+        a.u_min[j] = c.u_min[j]; a.u_max[j] = c.u_max[j];
+        a.scale_tril[j] = std::sqrt(c.noise_sigma_diag[j]);  // mppi.py:175-176
+        a.sigma_inv[j] = 1.0f / c.noise_sigma_diag[j];       // mppi.py:128 (diagonal)
+    }
+    a.u_scale = c.u_scale; a.gamma = c.gamma; a.lambda_ = c.lambda_;
+    a.seed = c.seed; a.call = h->calls;
+    fill_cost_params(h, a.cp);
+    std::memcpy(a.world0, h->world0, sizeof(a.world0));
+    if (h->bind_dof) {
+        launch_world_from_sim(h->bind_dof, h->bind_root, h->bind_nact, h->bind_box, h->bind_dyn, h->world0_dev, h->stream);
+        a.world0_dev = h->world0_dev;
+    }
+    a.delta = (const float*)h->buf[M3_BUF_NOISE];
+    a.mean = (const float*)h->buf[M3_BUF_MEAN];
+    a.mean1 = (const float*)h->buf[M3_BUF_MEAN_1];
+    a.mean2 = (const float*)h->buf[M3_BUF_MEAN_2];
+    a.best1 = (const float*)h->buf[M3_BUF_BEST_1];
+    a.best2 = (const float*)h->buf[M3_BUF_BEST_2];
+    a.pend = (float*)h->buf[M3_BUF_PENDING_FORCE];
+    a.states = (float*)h->buf[M3_BUF_STATES];
+    a.actions = (float*)h->buf[M3_BUF_ACTIONS];
+    a.cost_h = (float*)h->buf[M3_BUF_COST_HORIZON];
+    a.J = (float*)h->buf[M3_BUF_TRAJ_COST];
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    launch_rollout_point(a, h->scene, h->stream);
+    HIPCHK(h, hipGetLastError());
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    return M3_OK;
+}
+
+static void fill_update_args(m3_handle* h, UpdateArgs& a) {
+    const m3_config& c = h->cfg;
+    std::memset(&a, 0, sizeof(a));
+    a.Kg = c.K_global; a.Kl = c.K_local; a.k0 = c.k_offset; a.T = c.T; a.nu = c.nu;
+    a.multi_modal = c.multi_modal; a.mode_simple = c.mode_simple; a.env_type = c.env_type;
+    a.filter_u = c.filter_u; a.u_per_command = c.u_per_command;
+    a.lambda_ = c.lambda_; a.step_size_mean = c.step_size_mean;
+    a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST_ALL];
+    a.w = (float*)h->buf[M3_BUF_WEIGHTS];
+    a.w1 = (float*)h->buf[M3_BUF_WEIGHTS_1];
+    a.w2 = (float*)h->buf[M3_BUF_WEIGHTS_2];
+    a.top_idx = (int*)h->buf[M3_BUF_TOP_IDX];
+    a.info = (m3_info*)h->buf[M3_BUF_INFO];
+    a.actions = (const float*)h->buf[M3_BUF_ACTIONS];
+    a.states = (const float*)h->buf[M3_BUF_STATES];
+    a.reduce = (float*)h->buf[M3_BUF_REDUCE];
+    a.mean = (float*)h->buf[M3_BUF_MEAN];
+    a.mean1 = (float*)h->buf[M3_BUF_MEAN_1];
+    a.mean2 = (float*)h->buf[M3_BUF_MEAN_2];
+    a.best = (float*)h->buf[M3_BUF_BEST];
+    a.best1 = (float*)h->buf[M3_BUF_BEST_1];
+    a.best2 = (float*)h->buf[M3_BUF_BEST_2];
+    a.action_out = (float*)h->buf[M3_BUF_ACTION_OUT];
+    a.top_trajs = (float*)h->buf[M3_BUF_TOP_TRAJS];
+}
+
+extern "C" int m3_update(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    const m3_config& c = h->cfg;
+    if (c.K_local == c.K_global)  // unsharded: the local costs are the global costs
+        HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_TRAJ_COST_ALL], h->buf[M3_BUF_TRAJ_COST], (size_t)c.K_global * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    UpdateArgs a;
+    fill_update_args(h, a);
+    launch_weights(a, h->stream);
+    launch_wsum(a, h->stream);
+    HIPCHK(h, hipGetLastError());
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    return M3_OK;
+}
+
+extern "C" int m3_finalize(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    UpdateArgs a;
+    fill_update_args(h, a);
+    launch_finalize(a, h->stream);
+    HIPCHK(h, hipGetLastError());
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    h->calls += 1;
+    return M3_OK;
+}
+
+extern "C" int m3_command(m3_handle* h, float* action_host) {
+    int rc = m3_rollout(h);
+    if (rc != M3_OK) return rc;
+    rc = m3_update(h);
+    if (rc != M3_OK) return rc;
+    rc = m3_finalize(h);
+    if (rc != M3_OK) return rc;
+    if (action_host) {
+        const m3_config& c = h->cfg;
+        const int rows = c.mode_simple ? c.u_per_command : c.T;
+        HIPCHK(h, hipMemcpyAsync(action_host, h->buf[M3_BUF_ACTION_OUT], (size_t)rows * c.nu * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return M3_OK;
+}
+
+extern "C" int m3_get_buffer(m3_handle* h, int which, void** p, long long* nbytes) {
+    if (!h || !p) return M3_ERR_BAD_ARG;
+    if (which < 0 || which >= M3_BUF_COUNT) return fail(h, M3_ERR_BAD_ARG, "m3_get_buffer: unknown buffer id");
+    *p = h->buf[which];
+    if (nbytes) *nbytes = h->nbytes[which];
+    return M3_OK;
+}
+
+extern "C" int m3_reduce_len(const m3_handle* h) {
+    return h ? reduce_length(h->cfg.T, h->cfg.nu) : M3_ERR_BAD_ARG;
+}
+
+extern "C" int m3_get_info(m3_handle* h, m3_info* out) {
+    if (!h || !out) return M3_ERR_BAD_ARG;
+    HIPCHK(h, hipMemcpyAsync(out, h->buf[M3_BUF_INFO], sizeof(m3_info), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out->calls = (int)h->calls;
+    return M3_OK;
+}
+
+extern "C" int m3_get_timing(m3_handle* h, m3_timing* out) {
+    if (!h || !out) return M3_ERR_BAD_ARG;
+    if (!h->timing) return fail(h, M3_ERR_STATE, "m3_get_timing: timing not enabled");
+    HIPCHK(h, hipEventSynchronize(h->ev[3]));
+    HIPCHK(h, hipEventElapsedTime(&out->rollout_ms, h->ev[0], h->ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&out->update_ms, h->ev[1], h->ev[2]));
+    HIPCHK(h, hipEventElapsedTime(&out->finalize_ms, h->ev[2], h->ev[3]));
+    HIPCHK(h, hipEventElapsedTime(&out->total_ms, h->ev[0], h->ev[3]));
+    return M3_OK;
+}
+
+// ---------------------------------- step mode ------------------------------------------
+static int ensure_sim(m3_handle* h) {
+    const m3_config& c = h->cfg;
+    if (!h->sim_world) {
+        HIPCHK(h, hipMalloc((void**)&h->sim_world, (size_t)NW * c.K_local * sizeof(float)));
+        HIPCHK(h, hipMemsetAsync(h->sim_world, 0, (size_t)NW * c.K_local * sizeof(float), h->stream));
+        HIPCHK(h, hipMalloc((void**)&h->sim_u, (size_t)c.K_local * c.nu * sizeof(float)));
+        HIPCHK(h, hipMemsetAsync(h->sim_u, 0, (size_t)c.K_local * c.nu * sizeof(float), h->stream));
+    }
+    return M3_OK;
+}
+
+extern "C" int m3_sim_bind_views(m3_handle* h, float* dof, float* root, float* rb, float* ncf, int n_actors, int n_bodies) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (h->cfg.env_type != M3_ENV_POINT) return fail(h, M3_ERR_UNSUPPORTED, "m3_sim_bind_views: point_env only");
+    // actor table of this build (DESIGN.md "Scene tables"): walls 0-3, obs 4, dyn-obs 5,
+    // box 6, goal 7, yaxis 8, xaxis 9, robot 10 (robot last: skill_utils.py:89-90)
+    if (n_actors != 11 || n_bodies != 13) return fail(h, M3_ERR_SHAPE, "m3_sim_bind_views: point_env has 11 actors / 13 bodies");
+    int rc = ensure_sim(h);
+    if (rc != M3_OK) return rc;
+    SimViews& v = h->views;
+    v.dof_state = dof; v.root_state = root; v.rigid_body_state = rb; v.net_contact_force = ncf;
+    v.n_actors = n_actors; v.n_bodies = n_bodies;
+    v.box_actor = 6; v.dyn_actor = 5; v.robot_actor = 10;
+    v.box_body = 6; v.dyn_body = 5; v.robot_body = 12;
+    h->views_bound = true;
+    return M3_OK;
+}
+
+extern "C" int m3_sim_pull_state(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->views_bound || !h->views.dof_state || !h->views.root_state) return fail(h, M3_ERR_STATE, "m3_sim_pull_state: views not bound");
+    launch_sim_pull(h->views, h->sim_world, h->cfg.K_local, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
+extern "C" int m3_sim_push_state(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->views_bound) return fail(h, M3_ERR_STATE, "m3_sim_push_state: views not bound");
+    launch_sim_push(h->views, h->sim_world, h->cfg.K_local, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
+extern "C" int m3_sim_set_velocity_target(m3_handle* h, const float* u) {
+    if (!h || !u) return M3_ERR_BAD_ARG;
+    int rc = ensure_sim(h);
+    if (rc != M3_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->sim_u, u, (size_t)h->cfg.K_local * h->cfg.nu * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return M3_OK;
+}
+
+extern "C" int m3_sim_apply_body_forces(m3_handle* h, const float* f) {
+    if (!h || !f) return M3_ERR_BAD_ARG;
+    if (!h->views_bound) return fail(h, M3_ERR_STATE, "m3_sim_apply_body_forces: views not bound");
+    launch_sim_forces(h->views, h->sim_world, f, h->cfg.K_local, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
+extern "C" int m3_sim_step(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->views_bound) return fail(h, M3_ERR_STATE, "m3_sim_step: views not bound");
+    launch_sim_step(h->scene, h->sim_world, h->sim_u, h->cfg.K_local, h->stream);
+    launch_sim_push(h->views, h->sim_world, h->cfg.K_local, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
+extern "C" int m3_cost(m3_handle* h, float* cost) {
+    if (!h || !cost) return M3_ERR_BAD_ARG;
+    if (!h->sim_world) return fail(h, M3_ERR_STATE, "m3_cost: step-mode state not initialised");
+    CostParams cp;
+    fill_cost_params(h, cp);
+    launch_sim_cost(cp, h->sim_world, h->cfg.K_local, h->cfg.k_offset, cost, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}

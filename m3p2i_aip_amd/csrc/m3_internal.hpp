@@ -1,0 +1,130 @@
+// m3_internal.hpp -- structures shared by the kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/m3p2i_hip.h"
+#include "planar_dyn.hpp"
+#include "point_cost.hpp"
+
+namespace m3 {
+
+// ---- kernel argument blocks (passed by value; wave-uniform, live in SGPRs) -------------
+struct RolloutArgs {
+    int Kg, Kl, k0, T, nu;
+    int multi_modal, mode_simple, sampling_random, sample_null_action;
+    int gripper_cmd;
+    float u_min[M3_MAX_NU], u_max[M3_MAX_NU], scale_tril[M3_MAX_NU], sigma_inv[M3_MAX_NU];
+    float u_scale, gamma, lambda_;
+    unsigned long long seed;
+    unsigned call;
+    CostParams cp;
+    float world0[18];         // rx ry rvx rvy | B: x y c s vx vy w | D: x y c s vx vy w
+    const float* world0_dev;  // if non-null, read the 18 floats from device memory instead
+    const float* delta;       // [T][Kl][nu]
+    const float* mean;        // [T][nu] (U in simple mode)
+    const float* mean1;
+    const float* mean2;
+    const float* best1;
+    const float* best2;
+    float* pend;              // [4][Kl]
+    float* states;            // [T][Kl][4]
+    float* actions;           // [T][Kl][nu]
+    float* cost_h;            // [T][Kl]
+    float* J;                 // [Kl]
+};
+
+struct UpdateArgs {
+    int Kg, Kl, k0, T, nu;
+    int multi_modal, mode_simple, env_type, filter_u, u_per_command;
+    float lambda_, step_size_mean;
+    const float* Jall;   // [Kg]
+    float* w;            // [Kg]
+    float* w1;           // [Kg/2]
+    float* w2;           // [Kg - Kg/2]
+    int* top_idx;        // [M3_TOPK]
+    m3_info* info;       // device
+    const float* actions;  // [T][Kl][nu]
+    const float* states;   // [T][Kl][4]
+    float* reduce;         // packed partial sums, see reduce_layout()
+    float* mean;
+    float* mean1;
+    float* mean2;
+    float* best;
+    float* best1;
+    float* best2;
+    float* action_out;   // [T][nu]
+    float* top_trajs;    // [M3_TOPK][T][2]
+};
+
+// REDUCE buffer: [3][T][nu] weighted sums (all, mode 1, mode 2) | [3][T][nu] best rows
+// (best, best_1, best_2; zero unless this rank owns the row) | [TOPK][T][2] top trajectories
+__host__ __device__ inline int reduce_off_psum(int which, int T, int nu) { return which * T * nu; }
+__host__ __device__ inline int reduce_off_best(int which, int T, int nu) { return (3 + which) * T * nu; }
+__host__ __device__ inline int reduce_off_top(int T, int nu) { return 6 * T * nu; }
+__host__ __device__ inline int reduce_length(int T, int nu) { return 6 * T * nu + M3_TOPK * T * 2; }
+
+// ---- launchers (defined in the .hip files) ---------------------------------------------
+void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s);
+void launch_transpose_noise(const float* src_ktn, float* dst_tkn, int K, int T, int nu,
+                            hipStream_t s);
+void launch_weights(const UpdateArgs& a, hipStream_t s);
+void launch_wsum(const UpdateArgs& a, hipStream_t s);
+void launch_finalize(const UpdateArgs& a, hipStream_t s);
+void launch_world_from_sim(const float* dof_state, const float* root_state, int n_actors,
+                           int box_actor, int dyn_actor, float* world0_dev, hipStream_t s);
+
+// step mode
+struct SimViews {
+    float* dof_state;          // [Kl][2*ndof]
+    float* root_state;         // [Kl][nA][13]
+    float* rigid_body_state;   // [Kl][nB][13]
+    float* net_contact_force;  // [Kl][nB][3]
+    int n_actors, n_bodies;
+    int box_actor, dyn_actor, robot_actor;
+    int box_body, dyn_body, robot_body;  // robot_body = link_y (last body)
+};
+void launch_sim_pull(const SimViews& v, float* world /*[NW][Kl]*/, int Kl, hipStream_t s);
+void launch_sim_push(const SimViews& v, const float* world, int Kl, hipStream_t s);
+void launch_sim_step(const PointScene& sc, float* world, const float* u /*[Kl][2]*/, int Kl,
+                     hipStream_t s);
+void launch_sim_forces(const SimViews& v, float* world, const float* f /*[Kl][nB][3]*/, int Kl,
+                       hipStream_t s);
+void launch_sim_cost(const CostParams& cp, float* world, int Kl, int k0, float* cost,
+                     hipStream_t s);
+
+constexpr int NW = 28;  // floats per env in the step-mode SoA world (PointWorld fields)
+
+}  // namespace m3
+
+struct m3_handle {
+    m3_config cfg;
+    m3::PointScene scene;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // objective
+    int task = M3_TASK_PUSH;
+    float goal[7] = {0, 0, 0, 0, 0, 0, 1};
+    int gripper_cmd = 0;
+    // world
+    float world0[18];
+    const float* world0_bound = nullptr;  // device, 18 floats (filled by world_from_sim)
+    const float* bind_dof = nullptr;
+    const float* bind_root = nullptr;
+    int bind_nact = 0, bind_box = 0, bind_dyn = 0;
+    bool have_noise = false;
+    unsigned calls = 0;
+    // device buffers
+    void* buf[M3_BUF_COUNT] = {};
+    long long nbytes[M3_BUF_COUNT] = {};
+    float* world0_dev = nullptr;
+    float* sim_world = nullptr;  // step mode SoA [NW][Kl]
+    float* sim_u = nullptr;      // [Kl][nu]
+    float* noise_stage = nullptr;
+    m3::SimViews views{};
+    bool views_bound = false;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[4] = {};
+};

@@ -1,0 +1,531 @@
+// planar_dyn.hpp -- device-side "Planar contact dynamics spec v1" (DESIGN.md).
+//
+// Replaces, for the point_env scene, what the reference delegates to Isaac Gym / PhysX:
+//   IsaacGymWrapper.step()                    isaacgym_wrapper.py:354-360
+//   set_dof_velocity_target_tensor()          isaacgym_wrapper.py:196
+//   apply_rigid_body_force_tensors()          isaacgym_wrapper.py:202-203
+// Scene constants: config/point_env/*.yaml, assets/urdf/pointRobot.urdf; solver constants
+// isaacgym_wrapper.py:18-37; velocity drive isaacgym_wrapper.py:341-344.
+//
+// Mapping: ONE LANE PER SAMPLE, the whole world (robot disc + 2 boxes, 18 floats) and all 19
+// contact slots live in VGPRs.  Slots are STATIC (slot i always means the same body pair), so
+// no dynamic register indexing and every `if (slot.on)` is a plain exec-mask branch that
+// costs nothing when no lane of the wave is in that contact.  Only + - * / sqrt min max and
+// compares are used, in a fixed expression order (compiled with -ffp-contract=off), so the
+// result is bit-identical to the scalar CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace m3 {
+
+struct PointScene {
+    float h;  // substep = dt / substeps
+    int substeps;
+    int iters;
+    float robot_r, invm_r;
+    float gam, md, dmax;  // velocity drive: 1/(h*D), 1/(invm_r+gam), fmax*h
+    float box_hx, box_hy, box_m, box_I, invm_b, invI_b, LlinB, LangB;
+    float dyn_hx, dyn_hy, dyn_m, dyn_I, invm_d, invI_d, LlinD, LangD;
+    float obs_x, obs_y, obs_hx, obs_hy;
+    float wall;
+    float mu_rb, mu_rd, mu_ro, mu_rw, mu_bw, mu_dw, mu_bd, mu_bo, mu_do;
+    float contact_offset, baumgarte, slop, max_bias, face_tol;
+    float rad_b, rad_d, rad_o;  // bounding radii for the (conservative) broad phase
+};
+
+struct Box {
+    float x, y, c, s, vx, vy, w;
+};
+
+struct PointWorld {
+    float rx, ry, rvx, rvy;  // robot disc (2 prismatic dofs, no rotation)
+    Box B, D;                // pushable box, dynamic obstacle
+    float fRx, fRy, fBx, fBy;  // pending external (suction) force, consumed by next step
+    float fcDx, fcDy;          // net contact force on dyn-obs during the last substep
+    float fcBx, fcBy, fcRx, fcRy;  // (step mode only)
+};
+
+enum BodyId { ROBOT = 0, BOXB = 1, BOXD = 2, STATIC = 3 };
+
+struct Slot {
+    float nx, ny;              // unit normal from body a to body b
+    float rna, rnb, rta, rtb;  // r x n, r x t for both bodies
+    float mn, mt, bias;
+    float ln, lt;
+    bool on;
+};
+
+struct Vel {
+    float rvx, rvy;
+    float bvx, bvy, bw;
+    float dvx, dvy, dw;
+};
+
+template <int ID> __device__ __forceinline__ float gvx(const Vel& v) {
+    if constexpr (ID == ROBOT) return v.rvx;
+    else if constexpr (ID == BOXB) return v.bvx;
+    else if constexpr (ID == BOXD) return v.dvx;
+    else return 0.0f;
+}
+template <int ID> __device__ __forceinline__ float gvy(const Vel& v) {
+    if constexpr (ID == ROBOT) return v.rvy;
+    else if constexpr (ID == BOXB) return v.bvy;
+    else if constexpr (ID == BOXD) return v.dvy;
+    else return 0.0f;
+}
+template <int ID> __device__ __forceinline__ float gw(const Vel& v) {
+    if constexpr (ID == BOXB) return v.bw;
+    else if constexpr (ID == BOXD) return v.dw;
+    else return 0.0f;
+}
+template <int ID> __device__ __forceinline__ float invm(const PointScene& sc) {
+    if constexpr (ID == ROBOT) return sc.invm_r;
+    else if constexpr (ID == BOXB) return sc.invm_b;
+    else if constexpr (ID == BOXD) return sc.invm_d;
+    else return 0.0f;
+}
+template <int ID> __device__ __forceinline__ float invI(const PointScene& sc) {
+    if constexpr (ID == BOXB) return sc.invI_b;
+    else if constexpr (ID == BOXD) return sc.invI_d;
+    else return 0.0f;
+}
+template <int ID> constexpr bool rotates() { return ID == BOXB || ID == BOXD; }
+template <int ID> constexpr bool moves() { return ID != STATIC; }
+
+// apply impulse dl along (dx,dy) with angular arm ra to body ID, sign sg (-1 for a, +1 for b)
+template <int ID, int SG>
+__device__ __forceinline__ void apply(const PointScene& sc, Vel& v, float dl, float dx, float dy,
+                                      float arm) {
+    if constexpr (!moves<ID>()) return;
+    const float im = invm<ID>(sc) * dl;
+    if constexpr (ID == ROBOT) {
+        if (SG < 0) { v.rvx -= im * dx; v.rvy -= im * dy; }
+        else { v.rvx += im * dx; v.rvy += im * dy; }
+    } else if constexpr (ID == BOXB) {
+        const float ia = (invI<ID>(sc) * arm) * dl;
+        if (SG < 0) { v.bvx -= im * dx; v.bvy -= im * dy; v.bw -= ia; }
+        else { v.bvx += im * dx; v.bvy += im * dy; v.bw += ia; }
+    } else if constexpr (ID == BOXD) {
+        const float ia = (invI<ID>(sc) * arm) * dl;
+        if (SG < 0) { v.dvx -= im * dx; v.dvy -= im * dy; v.dw -= ia; }
+        else { v.dvx += im * dx; v.dvy += im * dy; v.dw += ia; }
+    }
+}
+
+// spec: prepare (effective masses, bias) of one contact
+template <int A, int B>
+__device__ __forceinline__ void prepare(const PointScene& sc, Slot& c, float nx, float ny,
+                                        float rax, float ray, float rbx, float rby, float sep) {
+    const float tx = -ny, ty = nx;
+    c.nx = nx; c.ny = ny;
+    c.rna = rotates<A>() ? (rax * ny - ray * nx) : 0.0f;
+    c.rnb = rotates<B>() ? (rbx * ny - rby * nx) : 0.0f;
+    c.rta = rotates<A>() ? (rax * ty - ray * tx) : 0.0f;
+    c.rtb = rotates<B>() ? (rbx * ty - rby * tx) : 0.0f;
+    float kn = invm<A>(sc), kt = invm<A>(sc);
+    if constexpr (moves<B>()) { kn = kn + invm<B>(sc); kt = kt + invm<B>(sc); }
+    if constexpr (rotates<A>()) {
+        kn = kn + invI<A>(sc) * c.rna * c.rna;
+        kt = kt + invI<A>(sc) * c.rta * c.rta;
+    }
+    if constexpr (rotates<B>()) {
+        kn = kn + invI<B>(sc) * c.rnb * c.rnb;
+        kt = kt + invI<B>(sc) * c.rtb * c.rtb;
+    }
+    c.mn = 1.0f / kn;
+    c.mt = 1.0f / kt;
+    if (sep > 0.0f) {
+        c.bias = sep / sc.h;
+    } else {
+        float pen = -sep - sc.slop;
+        if (pen < 0.0f) pen = 0.0f;
+        float push = sc.baumgarte * pen / sc.h;
+        if (push > sc.max_bias) push = sc.max_bias;
+        c.bias = -push;
+    }
+    c.ln = 0.0f; c.lt = 0.0f;
+    c.on = true;
+}
+
+template <int A, int B>
+__device__ __forceinline__ void solve(const PointScene& sc, Vel& v, Slot& c, float mu) {
+    const float tx = -c.ny, ty = c.nx;
+    float dvx = gvx<B>(v) - gvx<A>(v), dvy = gvy<B>(v) - gvy<A>(v);
+    float vn = dvx * c.nx + dvy * c.ny;
+    if constexpr (rotates<B>()) vn = vn + gw<B>(v) * c.rnb;
+    if constexpr (rotates<A>()) vn = vn - gw<A>(v) * c.rna;
+    float dl = -c.mn * (vn + c.bias);
+    float l0 = c.ln;
+    float l1 = l0 + dl;
+    if (l1 < 0.0f) l1 = 0.0f;
+    c.ln = l1;
+    dl = l1 - l0;
+    apply<A, -1>(sc, v, dl, c.nx, c.ny, c.rna);
+    apply<B, +1>(sc, v, dl, c.nx, c.ny, c.rnb);
+    dvx = gvx<B>(v) - gvx<A>(v); dvy = gvy<B>(v) - gvy<A>(v);
+    float vt = dvx * tx + dvy * ty;
+    if constexpr (rotates<B>()) vt = vt + gw<B>(v) * c.rtb;
+    if constexpr (rotates<A>()) vt = vt - gw<A>(v) * c.rta;
+    dl = -c.mt * vt;
+    const float maxf = mu * c.ln;
+    l0 = c.lt;
+    l1 = l0 + dl;
+    if (l1 > maxf) l1 = maxf;
+    if (l1 < -maxf) l1 = -maxf;
+    c.lt = l1;
+    dl = l1 - l0;
+    apply<A, -1>(sc, v, dl, tx, ty, c.rta);
+    apply<B, +1>(sc, v, dl, tx, ty, c.rtb);
+}
+
+// ---- narrow phase ---------------------------------------------------------------------
+// robot disc (A) vs box (B, possibly static)
+template <int B>
+__device__ __forceinline__ void detect_disc_box(const PointScene& sc, Slot& c, float px, float py,
+                                                float qx, float qy, float bc, float bs, float hx,
+                                                float hy, float rad) {
+    c.on = false;
+    const float r = sc.robot_r;
+    const float dx = px - qx, dy = py - qy;
+    {   // conservative broad phase (does not change results)
+        const float lim = r + rad + sc.contact_offset + 1e-3f;
+        if (dx * dx + dy * dy > lim * lim) return;
+    }
+    const float lx = bc * dx + bs * dy;
+    const float ly = bc * dy - bs * dx;
+    float cx = fminf(fmaxf(lx, -hx), hx);
+    float cy = fminf(fmaxf(ly, -hy), hy);
+    const float ex = lx - cx, ey = ly - cy;
+    const float d2 = ex * ex + ey * ey;
+    float nlx, nly, sep;
+    if (d2 > 0.0f) {
+        const float d = sqrtf(d2);
+        nlx = ex / d; nly = ey / d;
+        sep = d - r;
+    } else {
+        const float ppx = hx - fabsf(lx), ppy = hy - fabsf(ly);
+        if (ppx < ppy) {
+            const float sg = (lx >= 0.0f) ? 1.0f : -1.0f;
+            nlx = sg; nly = 0.0f; cx = sg * hx; cy = ly; sep = -ppx - r;
+        } else {
+            const float sg = (ly >= 0.0f) ? 1.0f : -1.0f;
+            nlx = 0.0f; nly = sg; cx = lx; cy = sg * hy; sep = -ppy - r;
+        }
+    }
+    if (!(sep < sc.contact_offset)) return;
+    const float wx = bc * nlx - bs * nly;
+    const float wy = bs * nlx + bc * nly;
+    const float rbx = bc * cx - bs * cy;
+    const float rby = bs * cx + bc * cy;
+    prepare<ROBOT, B>(sc, c, -wx, -wy, 0.0f, 0.0f, rbx, rby, sep);
+}
+
+__device__ __forceinline__ void detect_disc_walls(const PointScene& sc, Slot& cx_, Slot& cy_,
+                                                  float px, float py) {
+    cx_.on = false; cy_.on = false;
+    float sg = (px >= 0.0f) ? 1.0f : -1.0f;
+    float sep = (sc.wall - sg * px) - sc.robot_r;
+    if (sep < sc.contact_offset) prepare<ROBOT, STATIC>(sc, cx_, sg, 0.0f, 0.f, 0.f, 0.f, 0.f, sep);
+    sg = (py >= 0.0f) ? 1.0f : -1.0f;
+    sep = (sc.wall - sg * py) - sc.robot_r;
+    if (sep < sc.contact_offset) prepare<ROBOT, STATIC>(sc, cy_, 0.0f, sg, 0.f, 0.f, 0.f, 0.f, sep);
+}
+
+template <int A>
+__device__ __forceinline__ void detect_box_walls(const PointScene& sc, Slot& x1, Slot& x2,
+                                                 Slot& y1, Slot& y2, const Box& X, float hx,
+                                                 float hy, float rad) {
+    x1.on = x2.on = y1.on = y2.on = false;
+    const float lim = rad + sc.contact_offset + 1e-3f;
+    const bool nearx = (sc.wall - fabsf(X.x)) <= lim;
+    const bool neary = (sc.wall - fabsf(X.y)) <= lim;
+    if (!(nearx || neary)) return;
+    const float r0x = X.c * hx - X.s * hy, r0y = X.s * hx + X.c * hy;
+    const float r1x = -X.c * hx - X.s * hy, r1y = -X.s * hx + X.c * hy;
+    if (nearx) {
+        const float sg = (X.x >= 0.0f) ? 1.0f : -1.0f;
+        const float base = sc.wall - sg * X.x;
+        const float pa = sg * r0x, pb = sg * r1x;
+        const float sep1 = base - fabsf(pa), sep2 = base - fabsf(pb);
+        if (sep1 < sc.contact_offset) {
+            const float f = (pa >= 0.0f) ? 1.0f : -1.0f;
+            prepare<A, STATIC>(sc, x1, sg, 0.0f, f * r0x, f * r0y, 0.f, 0.f, sep1);
+        }
+        if (sep2 < sc.contact_offset) {
+            const float f = (pb >= 0.0f) ? 1.0f : -1.0f;
+            prepare<A, STATIC>(sc, x2, sg, 0.0f, f * r1x, f * r1y, 0.f, 0.f, sep2);
+        }
+    }
+    if (neary) {
+        const float sg = (X.y >= 0.0f) ? 1.0f : -1.0f;
+        const float base = sc.wall - sg * X.y;
+        const float pa = sg * r0y, pb = sg * r1y;
+        const float sep1 = base - fabsf(pa), sep2 = base - fabsf(pb);
+        if (sep1 < sc.contact_offset) {
+            const float f = (pa >= 0.0f) ? 1.0f : -1.0f;
+            prepare<A, STATIC>(sc, y1, 0.0f, sg, f * r0x, f * r0y, 0.f, 0.f, sep1);
+        }
+        if (sep2 < sc.contact_offset) {
+            const float f = (pb >= 0.0f) ? 1.0f : -1.0f;
+            prepare<A, STATIC>(sc, y2, 0.0f, sg, f * r1x, f * r1y, 0.f, 0.f, sep2);
+        }
+    }
+}
+
+// box A vs box B: SAT over the 4 face axes, reference face + clipped incident edge
+template <int A, int B>
+__device__ __forceinline__ void detect_box_box(const PointScene& sc, Slot& c1, Slot& c2, float ax,
+                                               float ay, float ca, float sa, float hax, float hay,
+                                               float rada, float bx, float by, float cb, float sb,
+                                               float hbx, float hby, float radb) {
+    c1.on = false; c2.on = false;
+    const float dxw = bx - ax, dyw = by - ay;
+    {
+        const float lim = rada + radb + sc.contact_offset + 1e-3f;
+        if (dxw * dxw + dyw * dyw > lim * lim) return;
+    }
+    const float dx = ca * dxw + sa * dyw;
+    const float dy = ca * dyw - sa * dxw;
+    const float cr = ca * cb + sa * sb;
+    const float sr = ca * sb - sa * cb;
+    const float acr = fabsf(cr), asr = fabsf(sr);
+    const float sAx = fabsf(dx) - (hax + (acr * hbx + asr * hby));
+    const float sAy = fabsf(dy) - (hay + (asr * hbx + acr * hby));
+    const float ex = -(cr * dx + sr * dy);
+    const float ey = -(cr * dy - sr * dx);
+    const float sBx = fabsf(ex) - (hbx + (acr * hax + asr * hay));
+    const float sBy = fabsf(ey) - (hby + (asr * hax + acr * hay));
+    float best = sAx;
+    int axis = 0;
+    if (sAy > best + sc.face_tol) { best = sAy; axis = 1; }
+    if (sBx > best + sc.face_tol) { best = sBx; axis = 2; }
+    if (sBy > best + sc.face_tol) { best = sBy; axis = 3; }
+    if (!(best < sc.contact_offset)) return;
+
+    const bool refA = axis < 2;
+    const float drx = refA ? dx : ex, dry = refA ? dy : ey;
+    const float crr = cr, srr = refA ? sr : -sr;
+    const float hrx = refA ? hax : hbx, hry = refA ? hay : hby;
+    const float hix = refA ? hbx : hax, hiy = refA ? hby : hay;
+    const bool xface = (axis & 1) == 0;
+    const float dn = xface ? drx : dry;
+    const float sg = (dn >= 0.0f) ? 1.0f : -1.0f;
+    const float hn = xface ? hrx : hry;
+    const float ht = xface ? hry : hrx;
+    const float r0x = crr * hix - srr * hiy, r0y = srr * hix + crr * hiy;
+    const float r1x = -crr * hix - srr * hiy, r1y = -srr * hix + crr * hiy;
+    const float pa = sg * (xface ? r0x : r0y);
+    const float pb = sg * (xface ? r1x : r1y);
+    const float f0 = (pa <= 0.0f) ? 1.0f : -1.0f;
+    const float f1 = (pb <= 0.0f) ? 1.0f : -1.0f;
+    const float p1x = drx + f0 * r0x, p1y = dry + f0 * r0y;
+    const float p2x = drx + f1 * r1x, p2y = dry + f1 * r1y;
+    const float s1 = sg * (xface ? p1x : p1y) - hn;
+    const float s2 = sg * (xface ? p2x : p2y) - hn;
+    const float t1 = xface ? p1y : p1x;
+    const float t2 = xface ? p2y : p2x;
+    float cs1 = s1, ct1 = t1, cs2 = s2, ct2 = t2;
+    bool ok = true;
+    if (t1 > ht) {
+        if (t2 > ht) ok = false;
+        else { const float lam = (ht - t2) / (t1 - t2); cs1 = s2 + lam * (s1 - s2); ct1 = ht; }
+    } else if (t1 < -ht) {
+        if (t2 < -ht) ok = false;
+        else { const float lam = (-ht - t2) / (t1 - t2); cs1 = s2 + lam * (s1 - s2); ct1 = -ht; }
+    }
+    if (t2 > ht) {
+        if (!(t1 > ht)) { const float lam = (ht - t1) / (t2 - t1); cs2 = s1 + lam * (s2 - s1); ct2 = ht; }
+    } else if (t2 < -ht) {
+        if (!(t1 < -ht)) { const float lam = (-ht - t1) / (t2 - t1); cs2 = s1 + lam * (s2 - s1); ct2 = -ht; }
+    }
+    if (!ok) return;
+    const float qrx = refA ? ax : bx, qry = refA ? ay : by;
+    const float rc = refA ? ca : cb, rs = refA ? sa : sb;
+    const float nrx = xface ? sg : 0.0f, nry = xface ? 0.0f : sg;
+    float nwx = rc * nrx - rs * nry, nwy = rs * nrx + rc * nry;
+    if (!refA) { nwx = -nwx; nwy = -nwy; }
+    if (cs1 < sc.contact_offset) {
+        const float pn = sg * (hn + cs1);
+        const float plx = xface ? pn : ct1, ply = xface ? ct1 : pn;
+        const float pwx = qrx + (rc * plx - rs * ply);
+        const float pwy = qry + (rs * plx + rc * ply);
+        prepare<A, B>(sc, c1, nwx, nwy, pwx - ax, pwy - ay, pwx - bx, pwy - by, cs1);
+    }
+    if (cs2 < sc.contact_offset) {
+        const float pn = sg * (hn + cs2);
+        const float plx = xface ? pn : ct2, ply = xface ? ct2 : pn;
+        const float pwx = qrx + (rc * plx - rs * ply);
+        const float pwy = qry + (rs * plx + rc * ply);
+        prepare<A, B>(sc, c2, nwx, nwy, pwx - ax, pwy - ay, pwx - bx, pwy - by, cs2);
+    }
+}
+
+struct Fric {
+    float lx, ly, la;
+};
+
+template <int ID>
+__device__ __forceinline__ void solve_ground_friction(const PointScene& sc, Vel& v, Fric& f,
+                                                      float m, float I, float Llin, float Lang) {
+    float nlx = f.lx + (-m * gvx<ID>(v));
+    float nly = f.ly + (-m * gvy<ID>(v));
+    const float mag2 = nlx * nlx + nly * nly;
+    if (mag2 > Llin * Llin) {
+        const float scl = Llin / sqrtf(mag2);
+        nlx = nlx * scl; nly = nly * scl;
+    }
+    float nla = f.la + (-I * gw<ID>(v));
+    if constexpr (ID == BOXB) {
+        v.bvx += sc.invm_b * (nlx - f.lx);
+        v.bvy += sc.invm_b * (nly - f.ly);
+    } else {
+        v.dvx += sc.invm_d * (nlx - f.lx);
+        v.dvy += sc.invm_d * (nly - f.ly);
+    }
+    f.lx = nlx; f.ly = nly;
+    if (nla > Lang) nla = Lang;
+    if (nla < -Lang) nla = -Lang;
+    if constexpr (ID == BOXB) v.bw += sc.invI_b * (nla - f.la);
+    else v.dw += sc.invI_d * (nla - f.la);
+    f.la = nla;
+}
+
+__device__ __forceinline__ void integrate_box(Box& X, float h) {
+    X.x = X.x + h * X.vx;
+    X.y = X.y + h * X.vy;
+    const float a = 0.5f * (h * X.w);
+    const float a2 = a * a;
+    const float den = 1.0f + a2;
+    const float cd = (1.0f - a2) / den;
+    const float sd = (2.0f * a) / den;
+    const float c = X.c * cd - X.s * sd;
+    const float s = X.s * cd + X.c * sd;
+    const float nrm = sqrtf(c * c + s * s);
+    X.c = c / nrm;
+    X.s = s / nrm;
+}
+
+// impulse of slot c on its body b (+) / a (-), accumulated in slot order like the oracle
+#define M3_ACC(fx, fy, c, sign)                                   \
+    if ((c).on) {                                                 \
+        const float ix_ = (c).ln * (c).nx + (c).lt * (-(c).ny);   \
+        const float iy_ = (c).ln * (c).ny + (c).lt * (c).nx;      \
+        if ((sign) > 0) { fx += ix_; fy += iy_; }                 \
+        else { fx -= ix_; fy -= iy_; }                            \
+    }
+
+// one sim.step(): substeps x (forces, detect, solve, integrate)
+template <bool ALL_FORCES>
+__device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, float ux, float uy) {
+    const float h = sc.h;
+    for (int sub = 0; sub < sc.substeps; ++sub) {
+        // 1. external forces
+        w.rvx = w.rvx + (h * w.fRx) * sc.invm_r;
+        w.rvy = w.rvy + (h * w.fRy) * sc.invm_r;
+        w.B.vx = w.B.vx + (h * w.fBx) * sc.invm_b;
+        w.B.vy = w.B.vy + (h * w.fBy) * sc.invm_b;
+
+        // 2. contacts (static slots)
+        Slot s_rb, s_rd, s_ro, s_rwx, s_rwy;
+        Slot s_bx1, s_bx2, s_by1, s_by2, s_dx1, s_dx2, s_dy1, s_dy2;
+        Slot s_bd1, s_bd2, s_bo1, s_bo2, s_do1, s_do2;
+        detect_disc_box<BOXB>(sc, s_rb, w.rx, w.ry, w.B.x, w.B.y, w.B.c, w.B.s, sc.box_hx,
+                              sc.box_hy, sc.rad_b);
+        detect_disc_box<BOXD>(sc, s_rd, w.rx, w.ry, w.D.x, w.D.y, w.D.c, w.D.s, sc.dyn_hx,
+                              sc.dyn_hy, sc.rad_d);
+        detect_disc_box<STATIC>(sc, s_ro, w.rx, w.ry, sc.obs_x, sc.obs_y, 1.0f, 0.0f, sc.obs_hx,
+                                sc.obs_hy, sc.rad_o);
+        detect_disc_walls(sc, s_rwx, s_rwy, w.rx, w.ry);
+        detect_box_walls<BOXB>(sc, s_bx1, s_bx2, s_by1, s_by2, w.B, sc.box_hx, sc.box_hy, sc.rad_b);
+        detect_box_walls<BOXD>(sc, s_dx1, s_dx2, s_dy1, s_dy2, w.D, sc.dyn_hx, sc.dyn_hy, sc.rad_d);
+        detect_box_box<BOXB, BOXD>(sc, s_bd1, s_bd2, w.B.x, w.B.y, w.B.c, w.B.s, sc.box_hx,
+                                   sc.box_hy, sc.rad_b, w.D.x, w.D.y, w.D.c, w.D.s, sc.dyn_hx,
+                                   sc.dyn_hy, sc.rad_d);
+        detect_box_box<BOXB, STATIC>(sc, s_bo1, s_bo2, w.B.x, w.B.y, w.B.c, w.B.s, sc.box_hx,
+                                     sc.box_hy, sc.rad_b, sc.obs_x, sc.obs_y, 1.0f, 0.0f,
+                                     sc.obs_hx, sc.obs_hy, sc.rad_o);
+        detect_box_box<BOXD, STATIC>(sc, s_do1, s_do2, w.D.x, w.D.y, w.D.c, w.D.s, sc.dyn_hx,
+                                     sc.dyn_hy, sc.rad_d, sc.obs_x, sc.obs_y, 1.0f, 0.0f,
+                                     sc.obs_hx, sc.obs_hy, sc.rad_o);
+
+        // 3. velocity solve
+        Vel v = {w.rvx, w.rvy, w.B.vx, w.B.vy, w.B.w, w.D.vx, w.D.vy, w.D.w};
+        float ldx = 0.0f, ldy = 0.0f;
+        Fric fB = {0.f, 0.f, 0.f}, fD = {0.f, 0.f, 0.f};
+        for (int it = 0; it < sc.iters; ++it) {
+            {
+                float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
+                float l1 = ldx + dl;
+                if (l1 > sc.dmax) l1 = sc.dmax;
+                if (l1 < -sc.dmax) l1 = -sc.dmax;
+                v.rvx += sc.invm_r * (l1 - ldx);
+                ldx = l1;
+                dl = -(((v.rvy - uy) + sc.gam * ldy) * sc.md);
+                l1 = ldy + dl;
+                if (l1 > sc.dmax) l1 = sc.dmax;
+                if (l1 < -sc.dmax) l1 = -sc.dmax;
+                v.rvy += sc.invm_r * (l1 - ldy);
+                ldy = l1;
+            }
+            solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
+            solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
+            if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
+            if (s_rd.on) solve<ROBOT, BOXD>(sc, v, s_rd, sc.mu_rd);
+            if (s_ro.on) solve<ROBOT, STATIC>(sc, v, s_ro, sc.mu_ro);
+            if (s_rwx.on) solve<ROBOT, STATIC>(sc, v, s_rwx, sc.mu_rw);
+            if (s_rwy.on) solve<ROBOT, STATIC>(sc, v, s_rwy, sc.mu_rw);
+            if (s_bx1.on) solve<BOXB, STATIC>(sc, v, s_bx1, sc.mu_bw);
+            if (s_bx2.on) solve<BOXB, STATIC>(sc, v, s_bx2, sc.mu_bw);
+            if (s_by1.on) solve<BOXB, STATIC>(sc, v, s_by1, sc.mu_bw);
+            if (s_by2.on) solve<BOXB, STATIC>(sc, v, s_by2, sc.mu_bw);
+            if (s_dx1.on) solve<BOXD, STATIC>(sc, v, s_dx1, sc.mu_dw);
+            if (s_dx2.on) solve<BOXD, STATIC>(sc, v, s_dx2, sc.mu_dw);
+            if (s_dy1.on) solve<BOXD, STATIC>(sc, v, s_dy1, sc.mu_dw);
+            if (s_dy2.on) solve<BOXD, STATIC>(sc, v, s_dy2, sc.mu_dw);
+            if (s_bd1.on) solve<BOXB, BOXD>(sc, v, s_bd1, sc.mu_bd);
+            if (s_bd2.on) solve<BOXB, BOXD>(sc, v, s_bd2, sc.mu_bd);
+            if (s_bo1.on) solve<BOXB, STATIC>(sc, v, s_bo1, sc.mu_bo);
+            if (s_bo2.on) solve<BOXB, STATIC>(sc, v, s_bo2, sc.mu_bo);
+            if (s_do1.on) solve<BOXD, STATIC>(sc, v, s_do1, sc.mu_do);
+            if (s_do2.on) solve<BOXD, STATIC>(sc, v, s_do2, sc.mu_do);
+        }
+        w.rvx = v.rvx; w.rvy = v.rvy;
+        w.B.vx = v.bvx; w.B.vy = v.bvy; w.B.w = v.bw;
+        w.D.vx = v.dvx; w.D.vy = v.dvy; w.D.w = v.dw;
+
+        // net contact force on the dyn-obs (get_motion_cost reads it), slot order
+        {
+            float fx = 0.0f, fy = 0.0f;
+            M3_ACC(fx, fy, s_rd, +1)
+            M3_ACC(fx, fy, s_dx1, -1) M3_ACC(fx, fy, s_dx2, -1)
+            M3_ACC(fx, fy, s_dy1, -1) M3_ACC(fx, fy, s_dy2, -1)
+            M3_ACC(fx, fy, s_bd1, +1) M3_ACC(fx, fy, s_bd2, +1)
+            M3_ACC(fx, fy, s_do1, -1) M3_ACC(fx, fy, s_do2, -1)
+            fx += fD.lx; fy += fD.ly;
+            w.fcDx = fx / h; w.fcDy = fy / h;
+        }
+        if constexpr (ALL_FORCES) {
+            float fx = 0.0f, fy = 0.0f;
+            M3_ACC(fx, fy, s_rb, +1)
+            M3_ACC(fx, fy, s_bx1, -1) M3_ACC(fx, fy, s_bx2, -1)
+            M3_ACC(fx, fy, s_by1, -1) M3_ACC(fx, fy, s_by2, -1)
+            M3_ACC(fx, fy, s_bd1, -1) M3_ACC(fx, fy, s_bd2, -1)
+            M3_ACC(fx, fy, s_bo1, -1) M3_ACC(fx, fy, s_bo2, -1)
+            fx += fB.lx; fy += fB.ly;
+            w.fcBx = fx / h; w.fcBy = fy / h;
+            fx = 0.0f; fy = 0.0f;
+            M3_ACC(fx, fy, s_rb, -1) M3_ACC(fx, fy, s_rd, -1) M3_ACC(fx, fy, s_ro, -1)
+            M3_ACC(fx, fy, s_rwx, -1) M3_ACC(fx, fy, s_rwy, -1)
+            w.fcRx = fx / h; w.fcRy = fy / h;
+        }
+
+        // 4. integrate
+        w.rx = w.rx + h * w.rvx;
+        w.ry = w.ry + h * w.rvy;
+        integrate_box(w.B, h);
+        integrate_box(w.D, h);
+    }
+    w.fRx = 0.0f; w.fRy = 0.0f; w.fBx = 0.0f; w.fBy = 0.0f;
+}
+
+}  // namespace m3

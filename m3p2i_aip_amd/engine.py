@@ -1,0 +1,250 @@
+"""HipEngine: thin object over one ``m3_handle`` of libm3p2i_hip.so.
+
+PyTorch is plumbing here: it provides the HIP stream and wraps the library-owned device
+buffers as zero-copy tensors (``__cuda_array_interface__``).  All arithmetic of the hot
+path happens inside the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier for a library-owned device pointer."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+        self._owner = owner  # keeps the handle alive while views exist
+
+
+def make_config(K, T, nu=2, env_type="point_env", multi_modal=False, mode_simple=False,
+                sampling_random=False, sample_null_action=True, filter_u=True,
+                u_per_command=None, u_min=None, u_max=None, noise_sigma_diag=None, u_scale=1.0,
+                gamma=0.95, lambda_=1.0, kp_suction=400.0, pre_height_diff=0.05, dt=None,
+                substeps=2, solver_iters=6, seed=0, device=0, K_local=None, k_offset=0,
+                cube_on_shelf=False) -> L.Config:
+    lib = L.load()
+    c = L.Config()
+    env = L.ENV_POINT if env_type in ("point_env", 0) else L.ENV_PANDA
+    lib.m3_default_config(C.byref(c), env)
+    c.device = int(device)
+    c.K_global = int(K)
+    c.K_local = int(K if K_local is None else K_local)
+    c.k_offset = int(k_offset)
+    c.T, c.nu = int(T), int(nu)
+    c.multi_modal = int(bool(multi_modal))
+    c.mode_simple = int(bool(mode_simple))
+    c.sampling_random = int(bool(sampling_random))
+    c.sample_null_action = int(bool(sample_null_action))
+    c.filter_u = int(bool(filter_u))
+    c.u_per_command = int(T if u_per_command is None else u_per_command)
+    for name, vals in (("u_min", u_min), ("u_max", u_max), ("noise_sigma_diag", noise_sigma_diag)):
+        if vals is not None:
+            arr = getattr(c, name)
+            for j in range(nu):
+                arr[j] = float(vals[j])
+    c.u_scale, c.gamma, c.lambda_ = float(u_scale), float(gamma), float(lambda_)
+    c.kp_suction, c.pre_height_diff = float(kp_suction), float(pre_height_diff)
+    if dt is not None:
+        c.dt = float(dt)
+    c.substeps, c.solver_iters = int(substeps), int(solver_iters)
+    c.cube_on_shelf = int(bool(cube_on_shelf))
+    c.seed = int(seed)
+    return c
+
+
+class HipEngine:
+    def __init__(self, cfg: L.Config):
+        if not torch.cuda.is_available():
+            raise L.M3Error("HipEngine needs a HIP device (torch.cuda.is_available() is False); "
+                            "there is no CPU fallback")
+        self.lib = L.load()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        torch.cuda.set_device(cfg.device)
+        torch.zeros(1, device=f"cuda:{cfg.device}")  # make sure the HIP context exists
+        L.check(self.lib.m3_create(C.byref(cfg), C.byref(self._h)))
+        self.device = torch.device(f"cuda:{cfg.device}")
+        self._views = {}
+        self.use_torch_stream()
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._views.clear()
+            self.lib.m3_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        L.check(rc, self._h)
+
+    # ---- configuration ----
+    def use_torch_stream(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._ck(self.lib.m3_set_stream(self._h, C.c_void_p(s.cuda_stream)))
+
+    def enable_timing(self, on=True):
+        self._ck(self.lib.m3_enable_timing(self._h, int(on)))
+
+    def set_noise(self, delta):
+        """delta: [K_local, T, nu] (reference layout), torch (cpu/cuda) or numpy."""
+        c = self.cfg
+        if isinstance(delta, torch.Tensor) and delta.is_cuda:
+            d = delta.to(torch.float32).contiguous()
+            assert tuple(d.shape) == (c.K_local, c.T, c.nu), d.shape
+            self._ck(self.lib.m3_set_noise(self._h, d.data_ptr(), 1))
+            torch.cuda.current_stream(self.device).synchronize()
+        else:
+            d = np.ascontiguousarray(delta.cpu().numpy() if isinstance(delta, torch.Tensor)
+                                     else delta, dtype=np.float32)
+            assert d.shape == (c.K_local, c.T, c.nu), d.shape
+            self._ck(self.lib.m3_set_noise(self._h, d.ctypes.data, 0))
+
+    def set_objective(self, task, goal, gripper_cmd=0):
+        t = L.TASKS[task] if isinstance(task, str) else int(task)
+        g = [float(x) for x in (goal.detach().cpu().reshape(-1).tolist()
+                                if isinstance(goal, torch.Tensor) else np.ravel(goal))]
+        arr = (C.c_float * len(g))(*g)
+        self._ck(self.lib.m3_set_objective(self._h, t, arr, len(g), int(gripper_cmd)))
+
+    def set_plan(self, which, values):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        assert v.shape == (self.cfg.T, self.cfg.nu)
+        self._ck(self.lib.m3_set_plan(self._h, which, v.ctypes.data))
+
+    def reset(self):
+        self._ck(self.lib.m3_reset(self._h))
+
+    def set_world_point(self, robot, box, dyn_obs):
+        w = L.PointWorld()
+        for dst, src, n in ((w.robot, robot, 4), (w.box, box, 7), (w.dyn_obs, dyn_obs, 7)):
+            for i in range(n):
+                dst[i] = float(src[i])
+        self._ck(self.lib.m3_set_world_point(self._h, C.byref(w)))
+
+    def set_world_point_raw(self, w18):
+        arr = (C.c_float * 18)(*[float(x) for x in w18])
+        self._ck(self.lib.m3_set_world_point_raw(self._h, arr))
+
+    def bind_sim_point(self, dof_state, root_state, box_actor, dyn_actor):
+        assert dof_state.is_cuda and root_state.is_cuda and dof_state.dtype == torch.float32
+        self._bound = (dof_state, root_state)  # keep alive
+        self._ck(self.lib.m3_bind_sim_point(self._h, dof_state.data_ptr(), root_state.data_ptr(),
+                                            root_state.shape[-2], box_actor, dyn_actor))
+
+    # ---- the hot path ----
+    def command(self, sync_host=False):
+        """One MPPI iteration.  Returns the device tensor [T, nu] of the filtered plan."""
+        if sync_host:
+            rows = self.cfg.u_per_command if self.cfg.mode_simple else self.cfg.T
+            out = np.zeros((rows, self.cfg.nu), np.float32)
+            self._ck(self.lib.m3_command(self._h, out.ctypes.data))
+            return out
+        self._ck(self.lib.m3_command(self._h, None))
+        return self.buffer(L.BUF_ACTION_OUT)
+
+    def rollout(self):
+        self._ck(self.lib.m3_rollout(self._h))
+
+    def update(self):
+        self._ck(self.lib.m3_update(self._h))
+
+    def finalize(self):
+        self._ck(self.lib.m3_finalize(self._h))
+
+    # ---- views ----
+    def _shape(self, which):
+        c = self.cfg
+        Kl, Kg, T, nu = c.K_local, c.K_global, c.T, c.nu
+        return {
+            L.BUF_STATES: ((T, Kl, 4), "<f4"), L.BUF_ACTIONS: ((T, Kl, nu), "<f4"),
+            L.BUF_COST_HORIZON: ((T, Kl), "<f4"), L.BUF_TRAJ_COST: ((Kl,), "<f4"),
+            L.BUF_TRAJ_COST_ALL: ((Kg,), "<f4"), L.BUF_WEIGHTS: ((Kg,), "<f4"),
+            L.BUF_WEIGHTS_1: ((Kg // 2,), "<f4"), L.BUF_WEIGHTS_2: ((Kg - Kg // 2,), "<f4"),
+            L.BUF_MEAN: ((T, nu), "<f4"), L.BUF_MEAN_1: ((T, nu), "<f4"),
+            L.BUF_MEAN_2: ((T, nu), "<f4"), L.BUF_BEST: ((T, nu), "<f4"),
+            L.BUF_BEST_1: ((T, nu), "<f4"), L.BUF_BEST_2: ((T, nu), "<f4"),
+            L.BUF_ACTION_OUT: ((T, nu), "<f4"), L.BUF_TOP_IDX: ((L.TOPK,), "<i4"),
+            L.BUF_TOP_TRAJS: ((L.TOPK, T, 2), "<f4"),
+            L.BUF_REDUCE: ((self.lib.m3_reduce_len(self._h),), "<f4"),
+            L.BUF_NOISE: ((T, Kl, nu), "<f4"), L.BUF_PENDING_FORCE: ((4, Kl), "<f4"),
+        }[which]
+
+    def buffer(self, which) -> torch.Tensor:
+        """Zero-copy torch view of a library-owned device buffer."""
+        if which in self._views:
+            return self._views[which]
+        p = C.c_void_p()
+        n = C.c_longlong()
+        self._ck(self.lib.m3_get_buffer(self._h, which, C.byref(p), C.byref(n)))
+        shape, typestr = self._shape(which)
+        t = torch.as_tensor(_DevArray(p.value, shape, typestr, self), device=self.device)
+        self._views[which] = t
+        return t
+
+    def info(self) -> L.Info:
+        i = L.Info()
+        self._ck(self.lib.m3_get_info(self._h, C.byref(i)))
+        return i
+
+    def timing(self) -> L.Timing:
+        t = L.Timing()
+        self._ck(self.lib.m3_get_timing(self._h, C.byref(t)))
+        return t
+
+    # reference-layout conveniences ([K, T, c] strided views, no copies)
+    @property
+    def states(self):
+        return self.buffer(L.BUF_STATES).permute(1, 0, 2)
+
+    @property
+    def actions(self):
+        return self.buffer(L.BUF_ACTIONS).permute(1, 0, 2)
+
+    @property
+    def cost_horizon(self):
+        return self.buffer(L.BUF_COST_HORIZON).permute(1, 0)
+
+    # ---- step mode ----
+    def sim_bind_views(self, dof_state, root_state, rigid_body_state, net_contact_force):
+        self._simviews = (dof_state, root_state, rigid_body_state, net_contact_force)
+        self._ck(self.lib.m3_sim_bind_views(
+            self._h, dof_state.data_ptr(), root_state.data_ptr(), rigid_body_state.data_ptr(),
+            net_contact_force.data_ptr(), root_state.shape[1], rigid_body_state.shape[1]))
+
+    def sim_pull_state(self):
+        self._ck(self.lib.m3_sim_pull_state(self._h))
+
+    def sim_push_state(self):
+        self._ck(self.lib.m3_sim_push_state(self._h))
+
+    def sim_set_velocity_target(self, u):
+        u = u.to(torch.float32).contiguous()
+        assert u.is_cuda and tuple(u.shape) == (self.cfg.K_local, self.cfg.nu), u.shape
+        self._ck(self.lib.m3_sim_set_velocity_target(self._h, u.data_ptr()))
+
+    def sim_apply_body_forces(self, f):
+        f = f.to(torch.float32).contiguous()
+        assert f.is_cuda
+        self._ck(self.lib.m3_sim_apply_body_forces(self._h, f.data_ptr()))
+
+    def sim_step(self):
+        self._ck(self.lib.m3_sim_step(self._h))
+
+    def cost(self, out=None):
+        if out is None:
+            out = torch.empty(self.cfg.K_local, device=self.device, dtype=torch.float32)
+        self._ck(self.lib.m3_cost(self._h, out.data_ptr()))
+        return out

@@ -1,0 +1,159 @@
+"""GPU parity tests for the point_env hot path: HIP kernels (through the C-ABI of
+libm3p2i_hip.so) vs the CPU oracle and vs golden traces produced by the reference's own
+planner code (tests/golden/make_golden.py).  Run with ``pytest -m gpu``.
+
+Bars (BASELINE.json north_star): 1e-3 on trajectory cost and control output.  The rollout
+itself is checked far tighter: the dynamics are specified as a fixed sequence of IEEE f32
+operations, so HIP and oracle states must agree bit-for-bit.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _engine(**kw):
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    return HipEngine(make_config(**kw))
+
+
+def raw_world(w31):
+    """oracle world row (31 floats) -> library internal 18 floats."""
+    w = np.asarray(w31, np.float32)
+    return np.concatenate([w[[0, 1, 4, 5]], w[7:14], w[14:21]])
+
+
+G9 = {
+    "push": dict(K=256, T=30, task="push", goal=(-1.0, -1.0)),
+    "pushc": dict(K=256, T=30, task="push", goal=(-1.0, 3.0)),
+    "pull": dict(K=256, T=30, task="pull", goal=(0.0, 0.0)),
+    "hybrid": dict(K=256, T=30, task="push_pull", goal=(-3.75, -3.75), multi_modal=True),
+    "nav": dict(K=100, T=10, task="navigation", goal=(-3.0, 3.0), mode_simple=True,
+                u_per_command=10, lambda_=0.5),
+    "navr": dict(K=128, T=12, task="navigation", goal=(-3.0, 3.0)),
+}
+
+
+def make_pair(oracle, golden, tag, seed=7):
+    """(HIP engine, oracle planner) configured identically for golden trace `tag`."""
+    kw = dict(G9[tag])
+    task, goal = kw.pop("task"), kw.pop("goal")
+    K, T = kw.pop("K"), kw.pop("T")
+    delta = golden[f"g9_{tag}_delta"] if f"g9_{tag}_delta" in golden else None
+    ocfg = oracle.make_cfg(K, T, 2, task=task, goal=goal, **kw)
+    opl = oracle.OraclePointPlanner(ocfg, delta, seed=seed)
+    eng = _engine(K=K, T=T, nu=2, multi_modal=kw.get("multi_modal", False),
+                  mode_simple=kw.get("mode_simple", False), sampling_random=delta is None,
+                  u_per_command=kw.get("u_per_command"), lambda_=kw.get("lambda_", 1.0),
+                  u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3], seed=seed)
+    eng.set_objective(task, goal)
+    if delta is not None:
+        eng.set_noise(delta)
+    return eng, opl
+
+
+@pytest.mark.parametrize("tag", list(G9))
+def test_command_traces_vs_reference_and_oracle(golden, oracle, tag):
+    eng, opl = make_pair(oracle, golden, tag)
+    worlds = golden[f"g9_{tag}_world"]
+    from m3p2i_aip_amd import _lib as L
+    for call in range(worlds.shape[0]):
+        eng.set_world_point_raw(raw_world(worlds[call]))
+        a_hip = eng.command(sync_host=True)
+        a_orc = opl.command(worlds[call])
+        a_ref = golden[f"g9_{tag}_action"][call]
+        rows = a_ref.shape[0]
+        # control output: HIP vs reference-generated golden and vs oracle (bar 1e-3)
+        np.testing.assert_allclose(a_hip[:rows], a_ref, atol=1e-3, err_msg=f"{tag} call {call} vs reference")
+        np.testing.assert_allclose(a_hip[:rows], a_orc, atol=1e-3, err_msg=f"{tag} call {call} vs oracle")
+        w_hip = eng.buffer(L.BUF_WEIGHTS).cpu().numpy()
+        np.testing.assert_allclose(w_hip, golden[f"g9_{tag}_weights"][call], atol=1e-3)
+        if call == 0:
+            # identical inputs on the first call: rollout must be bit-identical to the oracle
+            st = eng.states.cpu().numpy()
+            ac = eng.actions.cpu().numpy()
+            if f"g9_{tag}_delta" in golden:
+                np.testing.assert_array_equal(ac, opl.last["actions"])
+                np.testing.assert_array_equal(st, opl.last["states"])
+                np.testing.assert_array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+                np.testing.assert_array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(),
+                                              opl.last["J"])
+            else:
+                # in-kernel noise: logf/sinf/cosf of the device library and glibc differ in
+                # the last bit, so the sampled actions agree to ~1 ulp, not bit-for-bit
+                np.testing.assert_allclose(ac, opl.last["actions"], atol=2e-6)
+                np.testing.assert_allclose(st, opl.last["states"], atol=1e-4)
+                np.testing.assert_allclose(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"],
+                                           rtol=1e-5, atol=1e-4)
+        info = eng.info()
+        if G9[tag].get("multi_modal"):
+            assert info.pull_preference == int(golden[f"g9_{tag}_pref"][call])
+            oi = opl.last["info"]
+            assert (info.iters_1, info.iters_2, info.iters) == (oi.iters_1, oi.iters_2, oi.iters)
+    eng.close()
+
+
+@pytest.mark.parametrize("task,goal,mm", [("push", (-1, -1), False), ("pull", (0, 0), False),
+                                           ("push_pull", (-3.75, -3.75), True),
+                                           ("navigation", (-3, 3), False)])
+def test_rollout_bit_exact_with_contacts(oracle, task, goal, mm):
+    """Dense-contact stress: robot starts between box, dyn-obs, obstacle and a wall corner;
+    large random controls.  Every state / action / cost must equal the oracle's bit-for-bit."""
+    from m3p2i_aip_amd import _lib as L
+    K, T = 1024, 30
+    rng = np.random.default_rng(11)
+    delta = (rng.standard_normal((K, T, 2)) * 1.5).astype(np.float32)
+    worlds = []
+    w = oracle.init_world(1)[0]
+    worlds.append(w.copy())
+    w2 = w.copy()
+    w2[0:2] = (-1.2, 2.0)            # between box (0,2) and dyn-obs (-2,2)
+    w2[oracle.W_B:oracle.W_B + 2] = (-0.7, 2.05)
+    worlds.append(w2)
+    w3 = w.copy()
+    w3[0:2] = (3.2, 3.2)             # wall corner, obstacle at (2,2) close by
+    w3[oracle.W_B:oracle.W_B + 4] = (3.4, 2.6, np.cos(0.4), np.sin(0.4))
+    w3[oracle.W_D:oracle.W_D + 4] = (2.6, 3.5, np.cos(-0.9), np.sin(-0.9))
+    worlds.append(w3)
+    ocfg = oracle.make_cfg(K, T, 2, task=task, goal=goal, multi_modal=mm)
+    eng = _engine(K=K, T=T, nu=2, multi_modal=mm, u_min=[-3, -3], u_max=[3, 3],
+                  noise_sigma_diag=[3, 3])
+    eng.set_objective(task, goal)
+    eng.set_noise(delta)
+    for w0 in worlds:
+        opl = oracle.OraclePointPlanner(ocfg, delta)
+        eng.reset()
+        eng.set_world_point_raw(raw_world(w0))
+        eng.command(sync_host=True)
+        opl.command(w0)
+        st = eng.states.cpu().numpy()
+        np.testing.assert_array_equal(eng.actions.cpu().numpy(), opl.last["actions"])
+        bad = np.argwhere(st != opl.last["states"])
+        assert bad.size == 0, f"first mismatch at (k,t,c)={bad[0]} of {len(bad)}"
+        np.testing.assert_array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+        np.testing.assert_array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
+        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), opl.last["w"],
+                                   rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(eng.buffer(L.BUF_MEAN).cpu().numpy(), opl.mean, atol=1e-4)
+        np.testing.assert_allclose(eng.buffer(L.BUF_PENDING_FORCE).cpu().numpy().T,
+                                   opl.pend, atol=0)
+    eng.close()
+
+
+def test_api_errors_are_loud(oracle):
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    with pytest.raises(L.M3Error):
+        HipEngine(make_config(K=10, T=30))            # K < 20: topk(20)
+    with pytest.raises(L.M3Error):
+        HipEngine(make_config(K=64, T=8))             # filter window 9 > T
+    eng = HipEngine(make_config(K=64, T=12))
+    with pytest.raises(L.M3Error):
+        eng.command()                                  # no noise set
+    with pytest.raises(L.M3Error):
+        eng.set_objective("push_pull", (0, 0))         # needs multi_modal
+    with pytest.raises(L.M3Error):
+        eng.set_objective("reach", (0, 0))             # not a point_env task
+    eng.close()
