@@ -104,6 +104,9 @@ typedef struct {
     int substeps;           /* isaacgym_wrapper.py:10 */
     int solver_iters;       /* isaacgym_wrapper.py:28 */
     int cube_on_shelf;      /* reactive_tamp.py:29 */
+    int sim_only;           /* 1: handle is used only through m3_sim_* / m3_cost (the wrapper's
+                               environments); planner-shape checks (K >= 20, filter rows) are
+                               skipped and m3_rollout/m3_update are refused */
     unsigned long long seed;
 } m3_config;
 
@@ -155,7 +158,9 @@ typedef enum {
     M3_BUF_NOISE = 18,      /* f32 [T][Kl][nu] delta (time-major copy of m3_set_noise) */
     M3_BUF_PENDING_FORCE = 19, /* f32 [4][Kl] suction force pending for the next step */
     M3_BUF_INFO = 20,       /* device copy of m3_info */
-    M3_BUF_COUNT = 21
+    M3_BUF_SIM_WORLD = 21,  /* f32 [28][Kl] step-mode environments (SoA; rows 18..21 = pending
+                               force in M3_BUF_PENDING_FORCE order); allocated on first use */
+    M3_BUF_COUNT = 22
 } m3_buffer_id;
 
 typedef struct m3_handle m3_handle;
@@ -173,6 +178,9 @@ int m3_enable_timing(m3_handle* h, int on);
  * on_device: 0 host pointer, 1 device pointer. */
 int m3_set_noise(m3_handle* h, const float* delta, int on_device);
 int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd);
+/* Objective.multi_modal (cost_functions.py:9) for a sim_only handle, whose config does not
+ * come from an MPPI object; refused on planner handles (fixed at m3_create) */
+int m3_set_multi_modal(m3_handle* h, int multi_modal);
 /* warm-start state (means, best trajs, U): which = M3_BUF_MEAN.., host pointer [T][nu] */
 int m3_set_plan(m3_handle* h, int which, const float* host_values);
 int m3_reset(m3_handle* h); /* zero means/best/pending forces, beta = 1, call counter = 0 */

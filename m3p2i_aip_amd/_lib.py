@@ -22,7 +22,7 @@ TASKS = {"navigation": 0, "push": 1, "pull": 2, "push_pull": 3, "reach": 4, "pic
 (BUF_STATES, BUF_ACTIONS, BUF_COST_HORIZON, BUF_TRAJ_COST, BUF_TRAJ_COST_ALL, BUF_WEIGHTS,
  BUF_WEIGHTS_1, BUF_WEIGHTS_2, BUF_MEAN, BUF_MEAN_1, BUF_MEAN_2, BUF_BEST, BUF_BEST_1,
  BUF_BEST_2, BUF_ACTION_OUT, BUF_TOP_IDX, BUF_TOP_TRAJS, BUF_REDUCE, BUF_NOISE,
- BUF_PENDING_FORCE, BUF_INFO, BUF_COUNT) = range(22)
+ BUF_PENDING_FORCE, BUF_INFO, BUF_SIM_WORLD, BUF_COUNT) = range(23)
 
 
 class Config(C.Structure):
@@ -36,7 +36,7 @@ class Config(C.Structure):
                 ("gamma", C.c_float), ("lambda_", C.c_float), ("step_size_mean", C.c_float),
                 ("kp_suction", C.c_float), ("pre_height_diff", C.c_float), ("dt", C.c_float),
                 ("substeps", C.c_int), ("solver_iters", C.c_int), ("cube_on_shelf", C.c_int),
-                ("seed", C.c_ulonglong)]
+                ("sim_only", C.c_int), ("seed", C.c_ulonglong)]
 
 
 class PointWorld(C.Structure):
@@ -70,6 +70,7 @@ SYMBOLS = [
     ("m3_enable_timing", C.c_int, [_H, C.c_int]),
     ("m3_set_noise", C.c_int, [_H, _FP, C.c_int]),
     ("m3_set_objective", C.c_int, [_H, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int]),
+    ("m3_set_multi_modal", C.c_int, [_H, C.c_int]),
     ("m3_set_plan", C.c_int, [_H, C.c_int, _FP]),
     ("m3_reset", C.c_int, [_H]),
     ("m3_set_world_point", C.c_int, [_H, C.POINTER(PointWorld)]),

@@ -1,0 +1,65 @@
+"""Objective -- the reference's task-cost plugin, evaluated by the HIP cost kernel.
+
+Mirror of src/m3p2i_aip/planners/motion_planner/cost_functions.py:
+  Objective.__init__           :6-13
+  Objective.update_objective   :15-17
+  Objective.compute_cost       :19-36   (dispatch on task)
+
+In FUSED mode (the planner's default when it recognises this plugin) compute_cost is never
+called: the same device function runs inside the rollout kernel after every physics step.
+In STEP mode (user-supplied dynamics/running_cost callables) compute_cost(sim) launches the
+stand-alone cost kernel (m3_cost) on the wrapper's environments; like the reference's
+get_pull_cost (:76) it also stages the suction force that acts during the next step.
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from . import _lib as L
+
+_LIVE = weakref.WeakSet()
+
+POINT_TASKS = ("navigation", "push", "pull", "push_pull")
+PANDA_TASKS = ("reach", "pick", "place")
+
+
+class Objective(object):
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.multi_modal = cfg.multi_modal
+        self.num_samples = cfg.mppi.num_samples
+        self.half_samples = int(cfg.mppi.num_samples / 2)
+        self.device = cfg.mppi.device
+        self.pre_height_diff = getattr(cfg, "pre_height_diff", 0.0)
+        self.tilt_cos_theta = 0.5
+        self.task = getattr(cfg, "task", None)
+        goal = getattr(cfg, "goal", None)
+        self.goal = None if goal is None else torch.tensor(list(goal), dtype=torch.float32)
+        self.gripper_cmd = 0
+        _LIVE.add(self)
+
+    def update_objective(self, task, goal):
+        self.task = task
+        self.goal = goal if torch.is_tensor(goal) else torch.tensor(goal, device=self.device)
+
+    def goal_list(self):
+        return [float(x) for x in self.goal.detach().reshape(-1).cpu().tolist()]
+
+    def compute_cost(self, sim):
+        eng = getattr(sim, "_engine", None)
+        if eng is None:
+            raise TypeError("Objective.compute_cost needs the HIP-backed IsaacGymWrapper "
+                            "(m3p2i_aip_amd.isaacgym_wrapper); there is no CPU fallback")
+        if self.task is None or self.goal is None:
+            raise RuntimeError("update_objective(task, goal) has not been called")
+        if self.task == "push_pull" and not self.multi_modal:
+            raise L.M3Error("task 'push_pull' needs multi_modal=True (cost_functions.py:27-29)")
+        eng.set_multi_modal(self.multi_modal)  # the wrapper's handle learns it here (:9)
+        eng.set_objective(self.task, self.goal_list(), self.gripper_cmd)
+        return eng.cost()
+
+
+def live_objectives():
+    return list(_LIVE)

@@ -111,11 +111,13 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (c->env_type == M3_ENV_PANDA && c->nu != 9) return fail(nullptr, M3_ERR_SHAPE, "m3_create: panda_env needs nu == 9");
     if (c->env_type != M3_ENV_POINT && c->env_type != M3_ENV_PANDA) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad env_type");
     if (c->env_type == M3_ENV_PANDA) return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: panda_env kernels are not built yet");
-    if (c->K_global < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: K must be >= 20 (torch.topk(weights, 20), mppi.py:248)");
-    if (c->filter_u && (c->mode_simple ? c->u_per_command : c->T) < 9)
-        return fail(nullptr, M3_ERR_SHAPE, "m3_create: filter_u needs >= 9 rows (savgol window, mppi.py:190)");
-    if (c->mode_simple && (c->u_per_command < 1 || c->u_per_command > c->T))
-        return fail(nullptr, M3_ERR_SHAPE, "m3_create: bad u_per_command");
+    if (!c->sim_only) {
+        if (c->K_global < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: K must be >= 20 (torch.topk(weights, 20), mppi.py:248)");
+        if (c->filter_u && (c->mode_simple ? c->u_per_command : c->T) < 9)
+            return fail(nullptr, M3_ERR_SHAPE, "m3_create: filter_u needs >= 9 rows (savgol window, mppi.py:190)");
+        if (c->mode_simple && (c->u_per_command < 1 || c->u_per_command > c->T))
+            return fail(nullptr, M3_ERR_SHAPE, "m3_create: bad u_per_command");
+    }
     if (c->substeps < 1 || c->solver_iters < 1 || !(c->dt > 0.0f)) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad dt/substeps/solver_iters");
     for (int j = 0; j < c->nu; ++j)
         if (!(c->noise_sigma_diag[j] > 0.0f) || !(c->u_max[j] >= c->u_min[j]))
@@ -138,6 +140,13 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     const long long f = sizeof(float);
     int rc = M3_OK;
     auto A = [&](int id, long long bytes) { if (rc == M3_OK) rc = alloc_buf(h, id, bytes); };
+    if (c->sim_only) {
+        A(M3_BUF_INFO, sizeof(m3_info));
+        if (rc != M3_OK) { g_create_err = h->err; m3_destroy(h); return rc; }
+        (void)hipDeviceSynchronize();
+        *out = h;
+        return M3_OK;
+    }
     A(M3_BUF_STATES, T * Kl * 4 * f);
     A(M3_BUF_ACTIONS, T * Kl * nu * f);
     A(M3_BUF_COST_HORIZON, T * Kl * f);
@@ -229,6 +238,14 @@ extern "C" int m3_set_objective(m3_handle* h, int task, const float* goal, int g
     return M3_OK;
 }
 
+extern "C" int m3_set_multi_modal(m3_handle* h, int mm) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->cfg.sim_only && (mm != 0) != (h->cfg.multi_modal != 0))
+        return fail(h, M3_ERR_STATE, "m3_set_multi_modal: fixed at m3_create for planner handles");
+    h->cfg.multi_modal = mm != 0;
+    return M3_OK;
+}
+
 extern "C" int m3_set_plan(m3_handle* h, int which, const float* v) {
     if (!h || !v) return M3_ERR_BAD_ARG;
     if (which < M3_BUF_MEAN || which > M3_BUF_BEST_2) return fail(h, M3_ERR_BAD_ARG, "m3_set_plan: not a plan buffer");
@@ -299,6 +316,7 @@ static void fill_cost_params(const m3_handle* h, CostParams& cp) {
 extern "C" int m3_rollout(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     const m3_config& c = h->cfg;
+    if (c.sim_only) return fail(h, M3_ERR_STATE, "m3_rollout: handle was created sim_only");
     if (!c.sampling_random && !c.mode_simple && !h->have_noise)
         return fail(h, M3_ERR_STATE, "m3_rollout: no noise set (m3_set_noise) and sampling_random == 0");
     if (c.mode_simple && !c.sampling_random && !h->have_noise)
@@ -370,6 +388,7 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
 extern "C" int m3_update(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     const m3_config& c = h->cfg;
+    if (c.sim_only) return fail(h, M3_ERR_STATE, "m3_update: handle was created sim_only");
     if (c.K_local == c.K_global)  // unsharded: the local costs are the global costs
         HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_TRAJ_COST_ALL], h->buf[M3_BUF_TRAJ_COST], (size_t)c.K_global * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     UpdateArgs a;
@@ -408,9 +427,18 @@ extern "C" int m3_command(m3_handle* h, float* action_host) {
     return M3_OK;
 }
 
+static int ensure_sim(m3_handle* h);
 extern "C" int m3_get_buffer(m3_handle* h, int which, void** p, long long* nbytes) {
     if (!h || !p) return M3_ERR_BAD_ARG;
     if (which < 0 || which >= M3_BUF_COUNT) return fail(h, M3_ERR_BAD_ARG, "m3_get_buffer: unknown buffer id");
+    if (which == M3_BUF_SIM_WORLD) {
+        int rc = ensure_sim(h);
+        if (rc != M3_OK) return rc;
+        *p = h->sim_world;
+        if (nbytes) *nbytes = (long long)NW * h->cfg.K_local * sizeof(float);
+        return M3_OK;
+    }
+    if (!h->buf[which]) return fail(h, M3_ERR_STATE, "m3_get_buffer: buffer not allocated for this handle");
     *p = h->buf[which];
     if (nbytes) *nbytes = h->nbytes[which];
     return M3_OK;

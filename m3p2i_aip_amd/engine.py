@@ -28,7 +28,7 @@ def make_config(K, T, nu=2, env_type="point_env", multi_modal=False, mode_simple
                 u_per_command=None, u_min=None, u_max=None, noise_sigma_diag=None, u_scale=1.0,
                 gamma=0.95, lambda_=1.0, kp_suction=400.0, pre_height_diff=0.05, dt=None,
                 substeps=2, solver_iters=6, seed=0, device=0, K_local=None, k_offset=0,
-                cube_on_shelf=False) -> L.Config:
+                cube_on_shelf=False, sim_only=False) -> L.Config:
     lib = L.load()
     c = L.Config()
     env = L.ENV_POINT if env_type in ("point_env", 0) else L.ENV_PANDA
@@ -55,6 +55,7 @@ def make_config(K, T, nu=2, env_type="point_env", multi_modal=False, mode_simple
         c.dt = float(dt)
     c.substeps, c.solver_iters = int(substeps), int(solver_iters)
     c.cube_on_shelf = int(bool(cube_on_shelf))
+    c.sim_only = int(bool(sim_only))
     c.seed = int(seed)
     return c
 
@@ -119,6 +120,9 @@ class HipEngine:
         arr = (C.c_float * len(g))(*g)
         self._ck(self.lib.m3_set_objective(self._h, t, arr, len(g), int(gripper_cmd)))
 
+    def set_multi_modal(self, mm):
+        self._ck(self.lib.m3_set_multi_modal(self._h, int(bool(mm))))
+
     def set_plan(self, which, values):
         v = np.ascontiguousarray(values, dtype=np.float32)
         assert v.shape == (self.cfg.T, self.cfg.nu)
@@ -180,6 +184,7 @@ class HipEngine:
             L.BUF_TOP_TRAJS: ((L.TOPK, T, 2), "<f4"),
             L.BUF_REDUCE: ((self.lib.m3_reduce_len(self._h),), "<f4"),
             L.BUF_NOISE: ((T, Kl, nu), "<f4"), L.BUF_PENDING_FORCE: ((4, Kl), "<f4"),
+            L.BUF_SIM_WORLD: ((28, Kl), "<f4"),
         }[which]
 
     def buffer(self, which) -> torch.Tensor:

@@ -1,0 +1,417 @@
+"""MPPI / M3P2I with the reference's constructor and command() API on the HIP engine.
+
+Mirror of
+  src/m3p2i_aip/planners/motion_planner/mppi.py    MPPIConfig :9-59, MPPI :61-517
+  src/m3p2i_aip/planners/motion_planner/m3p2i.py   M3P2I :5-92
+
+    M3P2I(cfg, dynamics=callable, running_cost=callable).command(state) -> Tensor[T, nu]
+
+Two execution modes behind the same API:
+
+* FUSED   one C call: rollout+cost kernel, weight kernel, weighted-sum kernel, finalize
+          kernel.  The Python callbacks are never invoked.  Used when the callbacks are the
+          standard plugin of scripts/reactive_tamp.py:63-73 (step the wrapper, return
+          Objective.compute_cost) -- which the planner CHECKS, not assumes: on the first
+          command it runs both modes from the same state and keeps the fused path only if
+          the trajectory costs agree (``cfg.mppi.fused`` = True/False overrides the probe).
+* STEP    the reference's per-t loop (mppi.py:296-315) through the user's callables, with
+          the wrapper's step()/getters backed by single-step kernels; the importance-weight
+          update still runs in the HIP update kernels.
+
+Quirks of the reference that change numbers are kept (bug-compatible) and listed in
+DESIGN.md: Q1 cost_total aliasing, Q2 lambda_ unused in halton mode, Q3 multi-modal beta
+restarts at 1, Q4 double noise scaling for halton-spline+random, Q5 suction acts one step
+late, Q6 null action on the zero-noise sample, Q7 push_pull evaluates both costs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import sampling, scenes
+from .engine import HipEngine, make_config
+
+
+@dataclass
+class MPPIConfig(object):
+    """Same fields and defaults as the reference's MPPIConfig (mppi.py:9-59); the last three
+    are additions of this build (None = automatic)."""
+    num_samples: int = 200
+    horizon: int = 12
+    nx: int = 4
+    mppi_mode: str = 'halton-spline'
+    sampling_method: str = "halton"
+    noise_sigma: Optional[List[List[float]]] = None
+    noise_mu: Optional[List[float]] = None
+    device: str = "cuda:0"
+    lambda_: float = 1.0
+    update_lambda: bool = False
+    update_cov: bool = False
+    u_min: Optional[List[float]] = None
+    u_max: Optional[List[float]] = None
+    u_init: float = 0.0
+    U_init: Optional[List[List[float]]] = None
+    u_scale: float = 1
+    u_per_command: int = 1
+    rollout_var_discount: float = 0.95
+    sample_null_action: bool = False
+    sample_previous_plan: bool = True
+    sample_other_priors: bool = False
+    noise_abs_cost: bool = False
+    filter_u: bool = False
+    use_priors: bool = False
+    seed_val: int = 0
+    eta_u_bound: int = 10
+    eta_l_bound: int = 5
+    # --- additions ---
+    fused: Optional[bool] = None      # None: probe the callbacks on the first command
+    rank: int = 0                     # sample sharding: this process owns
+    world_size: int = 1               #   num_samples/world_size consecutive samples
+
+
+def _get(cfg, name, default=None):
+    try:
+        return getattr(cfg, name)
+    except Exception:
+        return default
+
+
+class MPPI():
+    def __init__(self, cfg, dynamics: Callable = None, running_cost: Callable = None):
+        self.env_type = cfg.env_type
+        self.multi_modal = bool(cfg.multi_modal)
+        self._top_cfg = cfg
+        m = cfg.mppi
+        self.mppi_mode = m.mppi_mode
+        self.sampling_method = m.sampling_method
+        if self.mppi_mode not in ("simple", "halton-spline"):
+            raise ValueError(f"unknown mppi_mode {self.mppi_mode!r}")
+        if self.sampling_method not in ("halton", "random"):
+            raise ValueError(f"unknown sampling_method {self.sampling_method!r}")
+        if _get(m, "update_cov", False):
+            raise NotImplementedError("update_cov=True (flagged '!! weird' in mppi.py:199) is not supported")
+        if _get(m, "noise_abs_cost", False):
+            raise NotImplementedError("noise_abs_cost=True is not supported")
+
+        self.K = int(m.num_samples)
+        self.half_K = int(self.K / 2)
+        self.T = int(m.horizon)
+        self.filter_u = bool(m.filter_u)
+        self.lambda_ = float(m.lambda_)
+        self.sample_null_action = bool(m.sample_null_action)
+        self.u_per_command = int(m.u_per_command)
+        self.device = m.device
+        self.tensor_args = {'device': m.device, 'dtype': torch.float32}
+        self.nx = int(m.nx)
+
+        noise_sigma = m.noise_sigma
+        if not noise_sigma:
+            noise_sigma = np.identity(int(m.nx / 2)).tolist()
+        noise_sigma = [list(map(float, r)) for r in noise_sigma]
+        self.nu = len(noise_sigma)
+        sig = torch.tensor(noise_sigma, dtype=torch.float32)
+        if not torch.equal(sig, torch.diag(torch.diagonal(sig))):
+            raise NotImplementedError("only diagonal noise_sigma is supported (all reference configs are diagonal)")
+        u_max, u_min = m.u_max, m.u_min
+        if u_max and not u_min:
+            u_min = [-float(x) for x in u_max]
+        if u_min and not u_max:
+            u_max = [-float(x) for x in u_min]
+        if not u_max:
+            raise ValueError("u_min/u_max are required (mppi.py:135-136)")
+        self.noise_sigma = sig.to(m.device)
+        self.noise_mu = torch.zeros(self.nu, device=m.device)
+        self.noise_sigma_inv = torch.inverse(sig).to(m.device)
+        self.u_max = torch.tensor(list(map(float, u_max)), device=m.device)
+        self.u_min = torch.tensor(list(map(float, u_min)), device=m.device)
+        self.u_scale = float(m.u_scale)
+        self.cov_action = torch.diagonal(self.noise_sigma, 0)
+        self.scale_tril = torch.sqrt(self.cov_action)
+        self.knot_scale, self.degree, self.seed_val = 4, 2, int(_get(m, "seed_val", 0) or 0)
+        self.n_knots = self.T // self.knot_scale
+        self.step_size_mean = 0.98
+        self.gamma = float(m.rollout_var_discount)
+        self.gamma_seq = torch.cumprod(torch.tensor([1.0] + [self.gamma] * (self.T - 1)), dim=0
+                                       ).reshape(1, self.T).to(**self.tensor_args)
+        self.sgf_window, self.sgf_order = 9, 2
+
+        self.F = dynamics
+        self.running_cost = running_cost
+        self.terminal_state_cost = None
+        self.state = None
+        self.delta = None
+        self.ee_states = 'None'
+
+        rank, world = int(_get(m, "rank", 0) or 0), int(_get(m, "world_size", 1) or 1)
+        if self.K % world:
+            raise ValueError("num_samples must be divisible by world_size")
+        self.rank, self.world_size = rank, world
+        self.K_local = self.K // world
+        self.k_offset = rank * self.K_local
+        dev = torch.device(m.device)
+        isaac = _get(cfg, "isaacgym", None)
+        self._engine = HipEngine(make_config(
+            K=self.K, K_local=self.K_local, k_offset=self.k_offset, T=self.T, nu=self.nu,
+            env_type=self.env_type, multi_modal=self.multi_modal,
+            mode_simple=self.mppi_mode == "simple",
+            sampling_random=self.sampling_method == "random" or self.mppi_mode == "simple",
+            sample_null_action=self.sample_null_action, filter_u=self.filter_u,
+            u_per_command=self.u_per_command, u_min=list(map(float, u_min)),
+            u_max=list(map(float, u_max)), noise_sigma_diag=[noise_sigma[j][j] for j in range(self.nu)],
+            u_scale=self.u_scale, gamma=self.gamma, lambda_=self.lambda_,
+            kp_suction=float(_get(cfg, "kp_suction", 0) or 0),
+            pre_height_diff=float(_get(cfg, "pre_height_diff", 0) or 0),
+            dt=float(_get(isaac, "dt", 0.05 if self.env_type == "point_env" else 0.01)),
+            substeps=int(_get(isaac, "substeps", 2)), seed=self.seed_val, device=dev.index or 0,
+            cube_on_shelf=bool(_get(cfg, "cube_on_shelf", False))))
+        self._fused = _get(m, "fused", None)
+        self._sim = None
+        self._objective = None
+        self._discover_plugin()
+        self.gripper_command = None
+        self.collective = None  # set by m3p2i_aip_amd.distributed for world_size > 1
+
+    # ------------------------------------------------------------------ plugin discovery
+    def _discover_plugin(self):
+        """Find the wrapper + Objective behind the callbacks (reactive_tamp.py keeps them as
+        attributes of the object whose bound methods it passes in)."""
+        from .cost_functions import Objective, live_objectives
+        from .isaacgym_wrapper import IsaacGymWrapper, live_wrappers
+        owners = [getattr(f, "__self__", None) for f in (self.F, self.running_cost)]
+        for o in owners:
+            if o is None:
+                continue
+            for v in list(vars(o).values()) if hasattr(o, "__dict__") else []:
+                if isinstance(v, IsaacGymWrapper) and self._sim is None:
+                    self._sim = v
+                if isinstance(v, Objective) and self._objective is None:
+                    self._objective = v
+        if self._sim is None:
+            c = [w for w in live_wrappers() if w.num_envs == self.K_local and w.env_type == self.env_type]
+            if len(c) == 1:
+                self._sim = c[0]
+        if self._objective is None:
+            c = [o for o in live_objectives() if o.num_samples == self.K]
+            if len(c) == 1:
+                self._objective = c[0]
+
+    def attach(self, sim=None, objective=None):
+        """Explicitly name the simulator wrapper / Objective used by the fused path."""
+        if sim is not None:
+            self._sim = sim
+        if objective is not None:
+            self._objective = objective
+        return self
+
+    # ------------------------------------------------------------------ reference attributes
+    def _buf(self, which):
+        return self._engine.buffer(which)
+
+    mean_action = property(lambda s: s._buf(L.BUF_MEAN), lambda s, v: s._buf(L.BUF_MEAN).copy_(v))
+    mean_action_1 = property(lambda s: s._buf(L.BUF_MEAN_1), lambda s, v: s._buf(L.BUF_MEAN_1).copy_(v))
+    mean_action_2 = property(lambda s: s._buf(L.BUF_MEAN_2), lambda s, v: s._buf(L.BUF_MEAN_2).copy_(v))
+    best_traj = property(lambda s: s._buf(L.BUF_BEST), lambda s, v: s._buf(L.BUF_BEST).copy_(v))
+    best_traj_1 = property(lambda s: s._buf(L.BUF_BEST_1), lambda s, v: s._buf(L.BUF_BEST_1).copy_(v))
+    best_traj_2 = property(lambda s: s._buf(L.BUF_BEST_2), lambda s, v: s._buf(L.BUF_BEST_2).copy_(v))
+    U = property(lambda s: s._buf(L.BUF_MEAN), lambda s, v: s._buf(L.BUF_MEAN).copy_(v))
+    weights = property(lambda s: s._buf(L.BUF_WEIGHTS))
+    weights_1 = property(lambda s: s._buf(L.BUF_WEIGHTS_1))
+    weights_2 = property(lambda s: s._buf(L.BUF_WEIGHTS_2))
+    states = property(lambda s: s._engine.states)        # [K_local, T, 4] strided view
+    actions = property(lambda s: s._engine.actions)      # [K_local, T, nu]
+    top_trajs = property(lambda s: s._buf(L.BUF_TOP_TRAJS))
+    top_idx = property(lambda s: s._buf(L.BUF_TOP_IDX).to(torch.int64))
+    top_values = property(lambda s: s.weights[s.top_idx])
+    cost_total = property(lambda s: s._buf(L.BUF_TRAJ_COST))
+
+    @property
+    def beta(self):
+        return self._engine.info().beta
+
+    @property
+    def total_costs(self):
+        J = self._buf(L.BUF_TRAJ_COST_ALL)
+        return J - J.min()
+
+    # ------------------------------------------------------------------ command
+    def _dynamics(self, state, u, t=None):
+        return self.F(state, u, t=None)
+
+    def _running_cost(self, state):
+        return self.running_cost(state)
+
+    def _ensure_noise(self):
+        if self.mppi_mode == "simple" or self.sampling_method == "random":
+            return
+        if self.delta is None:
+            d = sampling.halton_spline_delta(self.K, self.T, self.nu, self.knot_scale, self.degree,
+                                             self.k_offset, self.k_offset + self.K_local)
+            self.delta = d.to(self.device)
+            self._engine.set_noise(self.delta)
+
+    def _push_objective(self):
+        o = self._objective
+        if o is None or o.task is None or o.goal is None:
+            raise RuntimeError("fused command() needs an Objective with update_objective(task, goal) done; "
+                               "use planner.attach(sim, objective)")
+        grip = {"open": 1, "close": 2}.get(self.gripper_command, 0)
+        self._engine.set_objective(o.task, o.goal_list(), grip)
+
+    def _bind_world(self):
+        s = self._sim
+        if s is None:
+            raise RuntimeError("fused command() needs the HIP IsaacGymWrapper; use planner.attach(sim, objective)")
+        if getattr(self, "_bound_sim", None) is not s:
+            self._engine.bind_sim_point(s._dof_state, s._root_state,
+                                        scenes.actor_index(self.env_type, "box"),
+                                        scenes.actor_index(self.env_type, "dyn-obs"))
+            self._bound_sim = s
+
+    def _exchange(self, phase):
+        if self.collective is not None:
+            self.collective(self, phase)
+
+    def _command_fused(self):
+        self._push_objective()
+        self._bind_world()
+        e = self._engine
+        if self.world_size == 1:
+            e.command()
+        else:
+            e.rollout()
+            self._exchange("gather")
+            e.update()
+            self._exchange("reduce")
+            e.finalize()
+        out = self._buf(L.BUF_ACTION_OUT)
+        rows = self.u_per_command if self.mppi_mode == "simple" else self.T
+        return out[:rows].clone()
+
+    def _assemble_torch(self):
+        """mppi.py:381-416 / :335-347 in torch ops (STEP mode only; the fused kernel does this
+        in registers).  Same f32 operations in the same order => identical bits."""
+        T, nu, Kl, k0 = self.T, self.nu, self.K_local, self.k_offset
+        e = self._engine
+        ks = torch.arange(k0, k0 + Kl, device=self.device)
+        if self.mppi_mode == "simple" or self.sampling_method == "random":
+            raise NotImplementedError("STEP mode with in-kernel random sampling: set the noise explicitly "
+                                      "(planner.set_noise) or use the fused path")
+        delta = self.delta.clone()
+        delta[ks == self.K - 1] = 0.0
+        shift = torch.clamp(torch.arange(1, T + 1, device=self.device), max=T - 1)
+        scaled = delta * self.scale_tril.view(1, 1, nu)
+        if self.multi_modal:
+            m1, m2 = self.mean_action_1[shift], self.mean_action_2[shift]
+            first = (ks < self.half_K).view(Kl, 1, 1)
+            act = torch.where(first, m1.unsqueeze(0) + scaled, m2.unsqueeze(0) + scaled)
+        else:
+            act = self.mean_action[shift].unsqueeze(0) + scaled
+        act = torch.max(torch.min(act, self.u_max), self.u_min)
+        if self.multi_modal:
+            act[ks == 0] = self.best_traj_1[shift]
+            act[ks == self.half_K] = self.best_traj_2[shift]
+        if self.env_type == "panda_env":
+            if self.gripper_command == "open":
+                act[:, :, 7:] = 1.5
+            elif self.gripper_command == "close":
+                act[:, :, 7:] = -1.5
+        return act
+
+    def _command_step(self):
+        """mppi.py:275-332 through the user's callables."""
+        e = self._engine
+        T, Kl = self.T, self.K_local
+        act = self._assemble_torch()
+        self.perturbed_action = act
+        A, S, C = self._buf(L.BUF_ACTIONS), self._buf(L.BUF_STATES), self._buf(L.BUF_COST_HORIZON)
+        state = self.state.view(1, -1).repeat(Kl, 1) if self.state.shape != (Kl, self.nx) else self.state
+        J = torch.zeros(Kl, **self.tensor_args)
+        g = 1.0
+        gs = torch.ones((), **self.tensor_args)
+        last = self.K - 1 - self.k_offset
+        for t in range(T):
+            u = self.u_scale * act[:, t]
+            if self.sample_null_action and 0 <= last < Kl:
+                u[last] = 0.0
+            state, u = self._dynamics(state, u, t)
+            c = self._running_cost(state)
+            A[t].copy_(u / self.u_scale)
+            S[t].copy_(state[:, :4])
+            C[t].copy_(c)
+            J = J + gs * c
+            gs = gs * self.gamma
+        self._buf(L.BUF_TRAJ_COST).copy_(J)
+        self._exchange("gather")
+        e.update()
+        self._exchange("reduce")
+        e.finalize()
+        return self._buf(L.BUF_ACTION_OUT)[:T].clone()
+
+    def command(self, state):
+        if not torch.is_tensor(state):
+            state = torch.tensor(state)
+        self.state = state.to(**self.tensor_args)
+        self._engine.use_torch_stream()
+        self._ensure_noise()
+        if self._fused is None:
+            return self._probe_and_command()
+        return self._command_fused() if self._fused else self._command_step()
+
+    def _probe_and_command(self):
+        """First call with fused='auto': run the fused path, rewind, run the step path through
+        the user's callbacks, and keep the fused path only if both produced the same costs."""
+        can_fuse = (self._sim is not None and self._objective is not None and self.F is not None
+                    and self.running_cost is not None and self._objective.task is not None)
+        can_step = self.F is not None and self.running_cost is not None and \
+            self.mppi_mode != "simple" and self.sampling_method != "random"
+        if can_fuse and not can_step:
+            self._fused = True
+            return self._command_fused()
+        if not can_fuse:
+            self._fused = False
+            return self._command_step()
+        self._command_fused()
+        Jf = self._buf(L.BUF_TRAJ_COST).clone()
+        self._engine.reset()
+        out = self._command_step()
+        Js = self._buf(L.BUF_TRAJ_COST)
+        same = bool(torch.allclose(Jf, Js, rtol=1e-5, atol=1e-4))
+        self._fused = same
+        self.probe_result = dict(fused=same, max_abs_diff=float((Jf - Js).abs().max()))
+        if same:  # carry the suction force staged by the last cost evaluation into the fused state
+            simw = self._sim._engine.buffer(L.BUF_SIM_WORLD)
+            self._buf(L.BUF_PENDING_FORCE).copy_(simw[18:22])
+        return out
+
+    def set_noise(self, delta):
+        """Explicit noise [K_local, T, nu] (e.g. a recorded sample set)."""
+        self.delta = torch.as_tensor(delta, dtype=torch.float32).to(self.device)
+        self._engine.set_noise(self.delta)
+
+    def _shift_action(self, action_seq):
+        saved = action_seq[-1].clone()
+        action_seq = torch.roll(action_seq, -1, dims=0)
+        action_seq[-1] = saved
+        return action_seq
+
+
+class M3P2I(MPPI):
+    def __init__(self, cfg, dynamics=None, running_cost=None):
+        super().__init__(cfg, dynamics, running_cost)
+        self.suction_active = _get(cfg, "suction_active", False)
+
+    def update_gripper_command(self, task):
+        if task in ["reach", "place"]:
+            self.gripper_command = "open"
+        elif task == "pick":
+            self.gripper_command = "close"
+
+    def get_pull_preference(self):
+        if self.multi_modal:
+            i = self._engine.info()   # one host sync, like the reference's two .item() calls
+            return int(i.wsum_pull > i.wsum_push)
+        return self.suction_active

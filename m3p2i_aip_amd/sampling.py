@@ -1,0 +1,84 @@
+"""Init-time noise sampler: Halton knots -> Gaussian -> quadratic smoothing spline.
+
+Mirrors what the reference does ONCE at the first command() and then caches
+(MPPI.get_samples, mppi.py:458-483):
+  * quasi-random knots  generate_halton_samples      mppi_utils.py:80-96
+  * Gaussianisation     sqrt(2) * erfinv(2u - 1)     mppi_utils.py:99-104
+  * per (sample, dof) smoothing spline through n_knots = T//4 knots evaluated at T
+    points                                            skill_utils.py:9-22
+
+The reference takes its Halton points from the third-party ``ghalton`` package
+(GeneralizedHalton with EA_PERMS, unpinned in pyproject.toml:15), which is not available
+here: PARITY UNPINNED for the sample VALUES.  This build uses the reference's own in-tree
+alternative branch (van der Corput radical inverse on the first primes, mppi_utils.py:81-87)
+which is restatable and pinned by golden group G8.  The spline is SciPy FITPACK
+(splrep k=2 s=0.5 / splev ext=3), the same library call the reference makes.
+
+Not on the hot path (runs once; the result is uploaded with m3_set_noise).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def first_primes(n: int):
+    """First n primes (2, 3, 5, ...): the bases of mppi_utils.py:50-67."""
+    out, cand = [], 2
+    while len(out) < n:
+        if all(cand % p for p in out if p * p <= cand):
+            out.append(cand)
+        cand += 1 if cand == 2 else 2
+    return out
+
+
+def radical_inverse(idx: torch.Tensor, base: int) -> torch.Tensor:
+    """van der Corput radical inverse of the integers `idx` in `base`, accumulated in f32
+    digit by digit from the least significant one (same arithmetic as mppi_utils.py:69-78)."""
+    acc = torch.zeros(idx.shape[0], dtype=torch.float32)
+    rem = idx.clone()
+    scale = 1.0
+    while bool((rem > 0).any()):
+        scale /= float(base)
+        acc += scale * (rem % base)
+        rem = rem // base
+    return acc
+
+
+def halton_uniform(num_samples: int, ndims: int) -> torch.Tensor:
+    idx = torch.arange(1, num_samples + 1)
+    cols = [radical_inverse(idx, b) for b in first_primes(ndims)]
+    return torch.stack(cols, dim=1)
+
+
+def halton_gaussian(num_samples: int, ndims: int) -> torch.Tensor:
+    u = halton_uniform(num_samples, ndims)
+    return torch.sqrt(torch.tensor([2.0], dtype=torch.float32)) * torch.erfinv(2 * u - 1)
+
+
+def smoothing_spline(knots: np.ndarray, n_out: int, degree: int = 2) -> np.ndarray:
+    """FITPACK smoothing spline (s = 0.5) through `knots` placed on linspace(0, n, n),
+    evaluated on linspace(0, n, n_out) with ext=3 (clamp outside) -- skill_utils.py:9-22."""
+    import scipy.interpolate as si
+    n = knots.shape[0]
+    x = np.linspace(0, n, n)
+    tck = si.splrep(x, knots, k=degree, s=0.5)
+    return si.splev(np.linspace(0, n, n_out), tck, ext=3)
+
+
+def halton_spline_delta(K: int, T: int, nu: int, knot_scale: int = 4, degree: int = 2,
+                        k0: int = 0, k1: int | None = None) -> torch.Tensor:
+    """delta[K, T, nu] (rows k0..k1 only if given).  n_knots = T // knot_scale must be >= 3
+    for a degree-2 spline ("At least 12 for Halton Sampling", mppi/point.yaml:7)."""
+    n_knots = T // knot_scale
+    if n_knots <= degree:
+        raise ValueError(f"horizon T={T} gives n_knots={n_knots}; the degree-{degree} spline "
+                         f"needs T >= {knot_scale * (degree + 1)} (reference: splrep raises "
+                         "'m > k must hold'); use sampling_method='random' or mppi_mode='simple'")
+    k1 = K if k1 is None else k1
+    g = halton_gaussian(K, n_knots * nu).view(K, nu, n_knots).numpy()
+    out = np.zeros((k1 - k0, T, nu), np.float32)
+    for i in range(k0, k1):
+        for j in range(nu):
+            out[i - k0, :, j] = smoothing_spline(g[i, j].astype(np.float32), T, degree)
+    return torch.from_numpy(out)
