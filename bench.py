@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- the MPPI/M3P2I command() hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config push|hybrid|northstar]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full MPPI iteration (M3P2I.command(): rollout of every sample over the
+horizon through the contact dynamics + per-step task cost, softmin weights, mean update,
+top-k, filter) on synthetic input: the reference's initial point_env scene.
+
+Workload at N=1 (BASELINE.json configs[1], the config the metric is quoted on):
+task=push goal=[-1,-1], K=2000 samples, T=30 horizon, single-mode, halton-spline noise.
+For N>1 every rank keeps 2000 samples (weak scaling, K_global = 2000*N); the ranks exchange
+the K_global trajectory costs (all-gather) and one packed buffer of weighted sums
+(all-reduce) per step over RCCL.
+
+Prints ONE JSON line (rank 0).  `value` = K_global*T*steps / wall time (state-steps/s) with
+inputs resident in HBM.  `roofline` is for the dominant kernel (k_rollout_point): algorithmic
+bytes per launch (36 B per state-step) / its average duration measured with HIP
+events on the launch stream.  `cpu_baseline` times the CPU oracle (a C port of the same
+algorithm, oracle/) on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (task, goal, multi_modal, K per GPU, T)
+    "push": ("push", (-1.0, -1.0), False, 2000, 30),          # BASELINE configs[1]
+    "hybrid": ("push_pull", (-3.75, -3.75), True, 4000, 30),  # BASELINE configs[2]
+    "northstar": ("push", (-1.0, -1.0), False, 10000, 30),    # north_star target point
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_STATE_STEP_ROLLOUT = 36   # delta 8 B read; state 16 + action 8 + cost 4 B written
+
+
+def build_tamp(task, goal, multi_modal, K_global, K_local, rank, world, T, device):
+    from m3p2i_aip_amd import isaacgym_wrapper as wrapper
+    from m3p2i_aip_amd.cost_functions import Objective
+    from m3p2i_aip_amd.planner import M3P2I, MPPIConfig
+    m = MPPIConfig(num_samples=K_global, horizon=T, nx=4, mppi_mode="halton-spline",
+                   sampling_method="halton", device=device, lambda_=0.5, u_min=[-3.0, -3.0],
+                   u_max=[3.0, 3.0], noise_sigma=[[3.0, 0.0], [0.0, 3.0]], u_per_command=T,
+                   sample_null_action=True, filter_u=True, fused=True, rank=rank, world_size=world)
+    cfg = SimpleNamespace(env_type="point_env", multi_modal=multi_modal, suction_active=True,
+                          kp_suction=400, pre_height_diff=0.0, task=task, goal=list(goal),
+                          cube_on_shelf=False, mppi=m, isaacgym=wrapper.IsaacGymConfig(dt=0.05))
+    # the wrapper only supplies the world state (env 0) to the fused planner: 64 envs suffice
+    sim = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=64, device=device)
+    obj = Objective(cfg)
+    obj.update_objective(task, list(goal))
+    pl = M3P2I(cfg).attach(sim, obj)
+    return pl, sim, obj
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(task, goal, multi_modal, K, T, delta):
+    """Oracle (kind='port') on the host cores: bounded sample of the same workload."""
+    import oracle as O
+    O.load()
+    cfg = O.make_cfg(K, T, 2, task=task, goal=goal, multi_modal=multi_modal)
+    w0 = O.init_world(1)[0]
+    out = {}
+    ncpu = usable_cores()
+    for label, threads, budget in (("all", ncpu, 8.0), ("one", 1, 8.0)):
+        O.load().m3o_set_threads(threads)
+        pl = O.OraclePointPlanner(cfg, delta)
+        pl.command(w0)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget and n < 400:
+            pl.command(w0)
+            n += 1
+        dt = time.perf_counter() - t0
+        out[label] = dict(threads=threads, calls=n, ms=dt / n * 1e3, value=K * T * n / dt)
+    best = max(out.values(), key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "state-steps/s", "cores": best["threads"],
+            "kind": "port", "ms_per_command": best["ms"],
+            "single_thread_value": out["one"]["value"], "host_cores": ncpu,
+            "sample": f"{best['calls']} command() calls of the same K={K},T={T} {task} workload "
+                      f"(oracle/: C port of planner + dynamics spec, OpenMP over samples)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="push", choices=list(CONFIGS))
+    ap.add_argument("--samples-per-gpu", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    task, goal, multi_modal, K_local, T = CONFIGS[args.config]
+    if args.samples_per_gpu:
+        K_local = args.samples_per_gpu
+    K_global = K_local * world
+
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd import sampling
+    pl, sim, obj = build_tamp(task, goal, multi_modal, K_global, K_local, rank, world, T, device)
+    # synthetic noise: the build's Halton-spline sampler for the first 2000 global samples,
+    # tiled for larger K (the FITPACK init costs ~0.15 ms per spline and is not the hot path)
+    base = sampling.halton_spline_delta(min(K_global, 2000), T, 2)
+    idx = torch.arange(rank * K_local, (rank + 1) * K_local) % base.shape[0]
+    delta_local = base[idx].contiguous()
+    pl.set_noise(delta_local)
+    if world > 1:
+        from m3p2i_aip_amd.distributed import attach_collectives
+        attach_collectives(pl)
+    eng = pl._engine
+    state = sim._dof_state[0]
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pl.command(state)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pl.command(state)
+    sync()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tw = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+
+    # dominant kernel: average duration from HIP events recorded by the library on its stream
+    eng.enable_timing(True)
+    tr, tu, tf = [], [], []
+    for _ in range(min(args.steps, 50)):
+        pl.command(state)
+        t = eng.timing()
+        tr.append(t.rollout_ms)
+        tu.append(t.update_ms)
+        tf.append(t.finalize_ms)
+    eng.enable_timing(False)
+    rollout_ms = float(np.mean(tr))
+    alg_bytes = BYTES_PER_STATE_STEP_ROLLOUT * K_local * T
+    achieved = alg_bytes / (rollout_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        value = K_global * T * args.steps / wall
+        line = {
+            "metric": "mppi_state_steps_per_sec (K x T per command(), push task)",
+            "value": value, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"task={task} goal={list(goal)} K={K_global} ({K_local}/GPU) T={T} "
+                                   f"{'multi-modal' if multi_modal else 'single-mode'} halton-spline, "
+                                   "point_env initial scene, open loop (fixed world, warm-started plan)",
+                       "name": args.config, "command_hz": args.steps / wall,
+                       "parallelism": f"samples sharded x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_rollout_point", "kernel_ms": rollout_ms,
+                         "bytes_per_launch": alg_bytes,
+                         "note": "latency-bound at this K (sequential T x substeps x solver "
+                                 "iterations chain); see DESIGN.md K-sweep"},
+            "kernel_ms": {"rollout": rollout_ms, "update": float(np.mean(tu)), "finalize": float(np.mean(tf))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(task, goal, multi_modal, K_local, T, delta_local.numpy())
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

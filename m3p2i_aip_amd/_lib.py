@@ -108,8 +108,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise M3Error(f"{LIB_PATH} not found: build it with `python -m m3p2i_aip_amd.build` "
                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    # torch (if imported) has already mapped its bundled libamdhip64.so.7; our NEEDED entry
-    # resolves to that same runtime, so device pointers and streams are interchangeable.
+    # torch must be imported FIRST: it maps its bundled libamdhip64.so.7, and our NEEDED entry
+    # then resolves to that same runtime (one HIP runtime per process), so device pointers
+    # and streams are interchangeable between torch and the library.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the export is missing

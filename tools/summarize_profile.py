@@ -1,0 +1,41 @@
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into a small text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def find(sub, pat):
+    r = glob.glob(os.path.join(root, sub, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+ks = find("trace", "*kernel_stats.csv")
+if ks:
+    print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+    rows = list(csv.DictReader(open(ks)))
+    for r in rows:
+        print("{:<60s} calls={:>6s} total_ns={:>12s} avg_ns={:>10s} pct={:>6s}".format(
+            r["Name"][:60], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
+kt = find("trace", "*kernel_trace.csv")
+if kt:
+    rows = list(csv.DictReader(open(kt)))
+    r = [x for x in rows if "k_rollout" in x["Kernel_Name"]]
+    if r:
+        x = r[-1]
+        print("rollout dispatch: grid", x.get("Grid_Size_X"), "wg", x.get("Workgroup_Size_X"),
+              "VGPR", x.get("VGPR_Count"), "accum", x.get("Accum_VGPR_Count"), "SGPR", x.get("SGPR_Count"),
+              "LDS", x.get("LDS_Block_Size"), "scratch", x.get("Scratch_Size"))
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    f = find(sub, "*counter_collection.csv")
+    if not f:
+        continue
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0][:50]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print(f"== PMC {sub} (per-dispatch mean) ==")
+    for k, cs in acc.items():
+        print("  ", k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
