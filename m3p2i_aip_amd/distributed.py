@@ -36,8 +36,11 @@ def attach_collectives(planner, group=None):
     def exchange(pl, phase):
         e = pl._engine
         if phase == "gather":
-            dist.all_gather_into_tensor(e.buffer(L.BUF_TRAJ_COST_ALL), e.buffer(L.BUF_TRAJ_COST),
-                                        group=group)
+            out, loc = e.buffer(L.BUF_TRAJ_COST_ALL), e.buffer(L.BUF_TRAJ_COST)
+            try:
+                dist.all_gather_into_tensor(out, loc, group=group)
+            except (RuntimeError, NotImplementedError):  # backends without the flat variant
+                dist.all_gather(list(out.chunk(pl.world_size)), loc, group=group)
         elif phase == "reduce":
             dist.all_reduce(e.buffer(L.BUF_REDUCE), op=dist.ReduceOp.SUM, group=group)
         else:

@@ -35,6 +35,11 @@ from . import _lib as L
 from . import sampling, scenes
 from .engine import HipEngine, make_config
 
+# The engine class the planner instantiates.  The product always uses HipEngine (HIP kernels,
+# no fallback); the world_size-2 gloo tests substitute an oracle-backed stand-in to exercise
+# the host-side sharding logic on a machine without a GPU (tests/oracle_engine.py).
+ENGINE_CLS = HipEngine
+
 
 @dataclass
 class MPPIConfig(object):
@@ -154,7 +159,7 @@ class MPPI():
         self.k_offset = rank * self.K_local
         dev = torch.device(m.device)
         isaac = _get(cfg, "isaacgym", None)
-        self._engine = HipEngine(make_config(
+        self._engine = ENGINE_CLS(make_config(
             K=self.K, K_local=self.K_local, k_offset=self.k_offset, T=self.T, nu=self.nu,
             env_type=self.env_type, multi_modal=self.multi_modal,
             mode_simple=self.mppi_mode == "simple",

@@ -1,0 +1,172 @@
+"""Test infrastructure: an object with the HipEngine phase interface (rollout / update /
+finalize + buffers) whose arithmetic is the CPU oracle.  It lets the world_size-2 gloo tests
+exercise the HOST-side sharding logic (planner.py, distributed.py: sample offsets, the
+all-gather of trajectory costs, the packed all-reduce, owner-only rows) on a machine without
+a GPU.  It is never importable from the product package."""
+import numpy as np
+import torch
+
+import oracle as O
+from m3p2i_aip_amd import _lib as L
+
+
+def _t(a):
+    return torch.from_numpy(a)
+
+
+class OracleEngine:
+    def __init__(self, cfg: L.Config):
+        self.cfg = cfg
+        c = cfg
+        self.Kg, self.Kl, self.k0, self.T, self.nu = c.K_global, c.K_local, c.k_offset, c.T, c.nu
+        T, nu, Kl, Kg = self.T, self.nu, self.Kl, self.Kg
+        f = np.float32
+        self.np = {
+            L.BUF_STATES: np.zeros((T, Kl, 4), f), L.BUF_ACTIONS: np.zeros((T, Kl, nu), f),
+            L.BUF_COST_HORIZON: np.zeros((T, Kl), f), L.BUF_TRAJ_COST: np.zeros(Kl, f),
+            L.BUF_TRAJ_COST_ALL: np.zeros(Kg, f), L.BUF_WEIGHTS: np.zeros(Kg, f),
+            L.BUF_WEIGHTS_1: np.zeros(Kg // 2, f), L.BUF_WEIGHTS_2: np.zeros(Kg - Kg // 2, f),
+            L.BUF_TOP_IDX: np.zeros(L.TOPK, np.int32), L.BUF_TOP_TRAJS: np.zeros((L.TOPK, T, 2), f),
+            L.BUF_REDUCE: np.zeros(6 * T * nu + L.TOPK * T * 2, f),
+            L.BUF_PENDING_FORCE: np.zeros((4, Kl), f),
+        }
+        for b in range(L.BUF_MEAN, L.BUF_ACTION_OUT + 1):
+            self.np[b] = np.zeros((T, nu), f)
+        self.t = {k: _t(v) for k, v in self.np.items()}
+        self.sc = O.default_scene()
+        self.device = torch.device("cpu")
+        self.delta = None
+        self.beta = 1.0
+        self._info = None
+        self.task, self.goal, self.grip = "push", (0.0, 0.0), 0
+        self.bound = None
+        self.calls = 0
+
+    # ---- interface used by planner.py / distributed.py ----
+    def use_torch_stream(self, stream=None):
+        pass
+
+    def buffer(self, which):
+        return self.t[which]
+
+    def set_noise(self, delta):
+        self.delta = np.ascontiguousarray(delta.cpu().numpy() if torch.is_tensor(delta) else delta,
+                                          dtype=np.float32)
+        assert self.delta.shape == (self.Kl, self.T, self.nu)
+
+    def set_objective(self, task, goal, gripper_cmd=0):
+        self.task, self.goal, self.grip = task, tuple(goal), gripper_cmd
+
+    def bind_sim_point(self, dof, root, box_actor, dyn_actor):
+        self.bound = (dof, root, box_actor, dyn_actor)
+
+    def reset(self):
+        for b in list(range(L.BUF_MEAN, L.BUF_ACTION_OUT + 1)) + [L.BUF_PENDING_FORCE]:
+            self.np[b][...] = 0
+        self.beta, self.calls = 1.0, 0
+
+    def _ocfg(self):
+        c = self.cfg
+        return O.make_cfg(self.Kg, self.T, self.nu, multi_modal=bool(c.multi_modal), task=self.task,
+                          goal=self.goal, u_min=list(c.u_min)[:self.nu], u_max=list(c.u_max)[:self.nu],
+                          noise_sigma_diag=list(c.noise_sigma_diag)[:self.nu], u_scale=c.u_scale,
+                          gamma=c.gamma, lambda_=c.lambda_, sample_null_action=bool(c.sample_null_action),
+                          filter_u=bool(c.filter_u), kp_suction=c.kp_suction)
+
+    def _world0(self):
+        dof, root, bi, di = self.bound
+        d, r = dof[0].numpy(), root[0].numpy()
+        w = O.init_world(1)[0]
+        w[0], w[1], w[4], w[5] = d[0], d[2], d[1], d[3]
+        for base, a in ((O.W_B, bi), (O.W_D, di)):
+            qz, qw = r[a, 5], r[a, 6]
+            w[base:base + 7] = (r[a, 0], r[a, 1], 1 - 2 * qz * qz, 2 * qz * qw, r[a, 7], r[a, 8], r[a, 12])
+        return w
+
+    def rollout(self):
+        cfg = self._ocfg()
+        k0, k1, T, nu = self.k0, self.k0 + self.Kl, self.T, self.nu
+        full = np.zeros((self.Kg, T, nu), np.float32)
+        full[k0:k1] = self.delta
+        sh = np.minimum(np.arange(1, T + 1), T - 1)
+        n = self.np
+        act = O.assemble_actions(cfg, full, n[L.BUF_MEAN][sh], n[L.BUF_MEAN_1][sh], n[L.BUF_MEAN_2][sh],
+                                 n[L.BUF_BEST_1][sh], n[L.BUF_BEST_2][sh], k0, k1)
+        pend = np.ascontiguousarray(n[L.BUF_PENDING_FORCE].T)
+        r = O.point_rollout(cfg, self.sc, self._world0(), act, pend, k0, k1)
+        n[L.BUF_PENDING_FORCE][...] = pend.T
+        n[L.BUF_STATES][...] = r["states"].transpose(1, 0, 2)
+        n[L.BUF_ACTIONS][...] = r["actions"].transpose(1, 0, 2)
+        n[L.BUF_COST_HORIZON][...] = r["cost_h"].T
+        n[L.BUF_TRAJ_COST][...] = r["J"]
+
+    def update(self):
+        cfg = self._ocfg()
+        n = self.np
+        if self.Kl == self.Kg:
+            n[L.BUF_TRAJ_COST_ALL][...] = n[L.BUF_TRAJ_COST]
+        J = n[L.BUF_TRAJ_COST_ALL]
+        w, w1, w2, info = O.update_weights(cfg, J, self.beta)
+        self.beta = info.beta
+        n[L.BUF_WEIGHTS][...], n[L.BUF_WEIGHTS_1][...], n[L.BUF_WEIGHTS_2][...] = w, w1, w2
+        k0, k1, T, nu = self.k0, self.k0 + self.Kl, self.T, self.nu
+        actions = np.ascontiguousarray(n[L.BUF_ACTIONS].transpose(1, 0, 2))
+        ps = O.partial_sums(cfg, w, w1, w2, actions, k0, k1)
+        red = n[L.BUF_REDUCE]
+        red[...] = 0
+        red[:3 * T * nu] = ps.reshape(-1)
+        best = [info.best_idx, info.best_idx_1, self.Kg // 2 + info.best_idx_2] if cfg.multi_modal \
+            else [info.best_idx, -1, -1]
+        for i, g in enumerate(best):
+            if k0 <= g < k1:
+                red[(3 + i) * T * nu:(4 + i) * T * nu] = actions[g - k0].reshape(-1)
+        order = np.lexsort((np.arange(self.Kg), J))[:L.TOPK]
+        n[L.BUF_TOP_IDX][...] = order
+        top = red[6 * T * nu:].reshape(L.TOPK, T, 2)
+        for r_, g in enumerate(order):
+            if k0 <= g < k1:
+                top[r_] = n[L.BUF_STATES][:, g - k0, :][:, [0, 2]]
+        self._info = info
+
+    def finalize(self):
+        cfg = self._ocfg()
+        n, T, nu = self.np, self.T, self.nu
+        red = n[L.BUF_REDUCE]
+        sh = np.minimum(np.arange(1, T + 1), T - 1)
+        ps = red[:3 * T * nu].reshape(3, T, nu)
+        n[L.BUF_MEAN][...] = O.mean_update(cfg, n[L.BUF_MEAN][sh], ps[0])
+        if cfg.multi_modal:
+            n[L.BUF_MEAN_1][...], n[L.BUF_MEAN_2][...] = ps[1], ps[2]
+            n[L.BUF_BEST_1][...] = red[4 * T * nu:5 * T * nu].reshape(T, nu)
+            n[L.BUF_BEST_2][...] = red[5 * T * nu:6 * T * nu].reshape(T, nu)
+        else:
+            n[L.BUF_BEST][...] = red[3 * T * nu:4 * T * nu].reshape(T, nu)
+        a = n[L.BUF_MEAN].copy()
+        n[L.BUF_ACTION_OUT][...] = O.savgol9(a) if cfg.filter_u else a
+        n[L.BUF_TOP_TRAJS][...] = red[6 * T * nu:].reshape(L.TOPK, T, 2)
+        self.calls += 1
+
+    def command(self, sync_host=False):
+        self.rollout()
+        self.update()
+        self.finalize()
+        return self.t[L.BUF_ACTION_OUT]
+
+    def info(self):
+        i = L.Info()
+        s = self._info
+        if s is not None:
+            i.wsum_push, i.wsum_pull, i.beta = s.wsum_push, s.wsum_pull, s.beta
+            i.pull_preference = int(s.wsum_pull > s.wsum_push)
+        return i
+
+    @property
+    def states(self):
+        return self.t[L.BUF_STATES].permute(1, 0, 2)
+
+    @property
+    def actions(self):
+        return self.t[L.BUF_ACTIONS].permute(1, 0, 2)
+
+    def close(self):
+        pass

@@ -1,0 +1,82 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the
+header declares, the init-time sampler reproduces the reference's values, scene tables."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd import build
+    build.build()
+    hdr = open(os.path.join(ROOT, "include", "m3p2i_hip.h")).read()
+    declared = set(re.findall(r"\b(m3_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"m3_status", "m3_env", "m3_task"}
+    lib = L.load()            # raises if the .so is missing -- no fallback
+    bound = {n for n, _, _ in L.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    raw = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.m3_abi_version() == L.ABI_VERSION
+
+
+def test_config_struct_layout_matches_header():
+    """ctypes mirror of m3_config vs the C definition: defaults written by the library land in
+    the right Python fields (no GPU needed: m3_default_config is host-only)."""
+    from m3p2i_aip_amd import _lib as L
+    lib = L.load()
+    c = L.Config()
+    lib.m3_default_config(ctypes.byref(c), L.ENV_POINT)
+    assert (c.nu, c.T, c.K_global, c.substeps, c.solver_iters) == (2, 15, 200, 2, 6)
+    assert c.dt == pytest.approx(0.05) and c.kp_suction == 400 and c.step_size_mean == pytest.approx(0.98)
+    assert list(c.u_max)[:2] == [3.0, 3.0] and list(c.noise_sigma_diag)[:2] == [3.0, 3.0]
+    lib.m3_default_config(ctypes.byref(c), L.ENV_PANDA)
+    assert (c.nu, c.T) == (9, 12) and c.dt == pytest.approx(0.01)
+    assert list(c.u_max)[6:9] == [2.0, 1.5, 1.5] and c.noise_sigma_diag[7] == pytest.approx(0.8)
+    assert c.sim_only == 0 and c.seed == 0
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    with pytest.raises(L.M3Error):
+        HipEngine(make_config(K=64, T=12))
+
+
+@pytest.mark.parametrize("shape", [(64, 12, 2), (64, 30, 2), (64, 20, 9)])
+def test_g8_sampler_reproduces_reference_values(golden, shape):
+    from m3p2i_aip_amd import sampling as S
+    K, T, nu = shape
+    kn = S.halton_gaussian(K, (T // 4) * nu).numpy()
+    np.testing.assert_array_equal(kn, golden[f"g8_knots_{K}_{T}_{nu}"])
+    d = S.halton_spline_delta(K, T, nu).numpy()
+    np.testing.assert_allclose(d, golden[f"g8_delta_{K}_{T}_{nu}"], atol=1e-6)
+    # sharded generation = rows of the global set
+    np.testing.assert_array_equal(S.halton_spline_delta(K, T, nu, k0=16, k1=32).numpy(), d[16:32])
+    assert S.first_primes(20) == list(golden["g8_primes"])
+
+
+def test_sampler_rejects_short_horizon():
+    from m3p2i_aip_amd import sampling as S
+    with pytest.raises(ValueError):
+        S.halton_spline_delta(8, 10, 2)   # n_knots = 2 <= degree (reference: splrep raises)
+
+
+def test_scene_tables():
+    from m3p2i_aip_amd import scenes
+    assert len(scenes.POINT_ENV) == 11 and scenes.num_bodies("point_env") == 13
+    assert len(scenes.PANDA_ENV) == 7 and scenes.num_bodies("panda_env") == 17
+    assert scenes.POINT_ENV[-1].type == "robot"       # skill_utils.py:89-90 needs robot last
+    assert scenes.body_index("point_env", "point_robot", "link_y") == 12
+    assert scenes.body_index("point_env", "box", "box") == scenes.actor_index("point_env", "box") == 6
+    assert scenes.body_index("panda_env", "panda", "panda_leftfinger") == 15
+    assert scenes.body_index("panda_env", "cubeA", "box") == 4
