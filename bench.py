@@ -135,11 +135,11 @@ def main():
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd import sampling
     pl, sim, obj = build_tamp(task, goal, multi_modal, K_global, K_local, rank, world, T, device)
-    # synthetic noise: the build's Halton-spline sampler for the first 2000 global samples,
-    # tiled for larger K (the FITPACK init costs ~0.15 ms per spline and is not the hot path)
-    base = sampling.halton_spline_delta(min(K_global, 2000), T, 2)
-    idx = torch.arange(rank * K_local, (rank + 1) * K_local) % base.shape[0]
-    delta_local = base[idx].contiguous()
+    # synthetic noise: the build's Halton-spline sampler, this rank's rows of the global set
+    # (init only, not the hot path; NOT tiled -- duplicated samples would make the reference's
+    # beta search non-terminating: eta >= number of copies of the best sample)
+    delta_local = sampling.halton_spline_delta(K_global, T, 2, k0=rank * K_local,
+                                               k1=(rank + 1) * K_local).contiguous()
     pl.set_noise(delta_local)
     if world > 1:
         from m3p2i_aip_amd.distributed import attach_collectives

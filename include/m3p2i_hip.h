@@ -173,6 +173,10 @@ int m3_create(const m3_config* cfg, m3_handle** out);
 void m3_destroy(m3_handle* h);
 int m3_set_stream(m3_handle* h, void* hip_stream);
 int m3_enable_timing(m3_handle* h, int on);
+/* launch geometry of the rollout kernel: samples (active lanes) per 64-wide wavefront,
+ * a power of two in 1..64, or 0 = choose from K_local so that the waves fill the chip
+ * (DESIGN.md "Lanes per wavefront").  Results do not depend on it. */
+int m3_set_rollout_lanes(m3_handle* h, int lanes);
 
 /* delta: [K_local][T][nu] row-major (the reference's layout, rows of THIS shard).
  * on_device: 0 host pointer, 1 device pointer. */

@@ -68,6 +68,7 @@ SYMBOLS = [
     ("m3_destroy", None, [_H]),
     ("m3_set_stream", C.c_int, [_H, C.c_void_p]),
     ("m3_enable_timing", C.c_int, [_H, C.c_int]),
+    ("m3_set_rollout_lanes", C.c_int, [_H, C.c_int]),
     ("m3_set_noise", C.c_int, [_H, _FP, C.c_int]),
     ("m3_set_objective", C.c_int, [_H, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int]),
     ("m3_set_multi_modal", C.c_int, [_H, C.c_int]),

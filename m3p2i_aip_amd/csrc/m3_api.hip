@@ -163,6 +163,7 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     A(M3_BUF_PENDING_FORCE, 4 * Kl * f);
     A(M3_BUF_INFO, sizeof(m3_info));
     if (rc == M3_OK && hipMalloc((void**)&h->world0_dev, 18 * f) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->topk_cand, (size_t)topk_workgroups((int)Kg) * M3_TOPK * sizeof(VI)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK) {
         m3_info init;
         std::memset(&init, 0, sizeof(init));
@@ -184,6 +185,7 @@ extern "C" void m3_destroy(m3_handle* h) {
     for (int i = 0; i < M3_BUF_COUNT; ++i)
         if (h->buf[i]) (void)hipFree(h->buf[i]);
     if (h->world0_dev) (void)hipFree(h->world0_dev);
+    if (h->topk_cand) (void)hipFree(h->topk_cand);
     if (h->sim_world) (void)hipFree(h->sim_world);
     if (h->sim_u) (void)hipFree(h->sim_u);
     if (h->noise_stage) (void)hipFree(h->noise_stage);
@@ -195,6 +197,14 @@ extern "C" void m3_destroy(m3_handle* h) {
 extern "C" int m3_set_stream(m3_handle* h, void* s) {
     if (!h) return M3_ERR_BAD_ARG;
     h->stream = (hipStream_t)s;
+    return M3_OK;
+}
+
+extern "C" int m3_set_rollout_lanes(m3_handle* h, int lanes) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (lanes != 0 && (lanes < 1 || lanes > 64 || (lanes & (lanes - 1)) != 0))
+        return fail(h, M3_ERR_BAD_ARG, "m3_set_rollout_lanes: lanes must be 0 (auto) or a power of two in 1..64");
+    h->lanes_override = lanes;
     return M3_OK;
 }
 
@@ -338,9 +348,10 @@ extern "C" int m3_rollout(m3_handle* h) {
     fill_cost_params(h, a.cp);
     std::memcpy(a.world0, h->world0, sizeof(a.world0));
     if (h->bind_dof) {
-        launch_world_from_sim(h->bind_dof, h->bind_root, h->bind_nact, h->bind_box, h->bind_dyn, h->world0_dev, h->stream);
-        a.world0_dev = h->world0_dev;
+        a.sim_dof = h->bind_dof; a.sim_root = h->bind_root;
+        a.sim_box = h->bind_box; a.sim_dyn = h->bind_dyn;
     }
+    a.lanes = h->lanes_override > 0 ? h->lanes_override : rollout_lanes_for(c.K_local);
     a.delta = (const float*)h->buf[M3_BUF_NOISE];
     a.mean = (const float*)h->buf[M3_BUF_MEAN];
     a.mean1 = (const float*)h->buf[M3_BUF_MEAN_1];
@@ -366,6 +377,8 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.multi_modal = c.multi_modal; a.mode_simple = c.mode_simple; a.env_type = c.env_type;
     a.filter_u = c.filter_u; a.u_per_command = c.u_per_command;
     a.lambda_ = c.lambda_; a.step_size_mean = c.step_size_mean;
+    a.cand = h->topk_cand;
+    a.n_cand = topk_workgroups(c.K_global);
     a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST_ALL];
     a.w = (float*)h->buf[M3_BUF_WEIGHTS];
     a.w1 = (float*)h->buf[M3_BUF_WEIGHTS_1];
@@ -389,10 +402,10 @@ extern "C" int m3_update(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     const m3_config& c = h->cfg;
     if (c.sim_only) return fail(h, M3_ERR_STATE, "m3_update: handle was created sim_only");
-    if (c.K_local == c.K_global)  // unsharded: the local costs are the global costs
-        HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_TRAJ_COST_ALL], h->buf[M3_BUF_TRAJ_COST], (size_t)c.K_global * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     UpdateArgs a;
     fill_update_args(h, a);
+    if (c.K_local == c.K_global)  // unsharded: the local costs ARE the global costs (no copy)
+        a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST];
     launch_weights(a, h->stream);
     launch_wsum(a, h->stream);
     HIPCHK(h, hipGetLastError());
@@ -438,6 +451,8 @@ extern "C" int m3_get_buffer(m3_handle* h, int which, void** p, long long* nbyte
         if (nbytes) *nbytes = (long long)NW * h->cfg.K_local * sizeof(float);
         return M3_OK;
     }
+    if (which == M3_BUF_TRAJ_COST_ALL && !h->cfg.sim_only && h->cfg.K_local == h->cfg.K_global)
+        which = M3_BUF_TRAJ_COST;  // unsharded: the local costs are the global costs
     if (!h->buf[which]) return fail(h, M3_ERR_STATE, "m3_get_buffer: buffer not allocated for this handle");
     *p = h->buf[which];
     if (nbytes) *nbytes = h->nbytes[which];

@@ -20,8 +20,13 @@ struct RolloutArgs {
     unsigned long long seed;
     unsigned call;
     CostParams cp;
+    int lanes;                // active lanes (= samples) per 64-wide wavefront: 1..64
     float world0[18];         // rx ry rvx rvy | B: x y c s vx vy w | D: x y c s vx vy w
-    const float* world0_dev;  // if non-null, read the 18 floats from device memory instead
+    // if sim_dof != null the initial world is read from env 0 of the wrapper's tensors
+    // (dof_state [*,4], root_state [*,nA,13]) inside the kernel: no upload, no extra launch
+    const float* sim_dof;
+    const float* sim_root;
+    int sim_box, sim_dyn;
     const float* delta;       // [T][Kl][nu]
     const float* mean;        // [T][nu] (U in simple mode)
     const float* mean1;
@@ -35,7 +40,14 @@ struct RolloutArgs {
     float* J;                 // [Kl]
 };
 
+struct VI {  // (cost, global sample index) candidate of the top-k selection
+    float v;
+    int i;
+};
+
 struct UpdateArgs {
+    VI* cand;    // [n_cand][M3_TOPK] per-workgroup top-k candidates (k_weights -> k_wsum)
+    int n_cand;
     int Kg, Kl, k0, T, nu;
     int multi_modal, mode_simple, env_type, filter_u, u_per_command;
     float lambda_, step_size_mean;
@@ -72,8 +84,8 @@ void launch_transpose_noise(const float* src_ktn, float* dst_tkn, int K, int T, 
 void launch_weights(const UpdateArgs& a, hipStream_t s);
 void launch_wsum(const UpdateArgs& a, hipStream_t s);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);
-void launch_world_from_sim(const float* dof_state, const float* root_state, int n_actors,
-                           int box_actor, int dyn_actor, float* world0_dev, hipStream_t s);
+int rollout_lanes_for(int Kl);
+int topk_workgroups(int Kg);
 
 // step mode
 struct SimViews {
@@ -115,10 +127,12 @@ struct m3_handle {
     int bind_nact = 0, bind_box = 0, bind_dyn = 0;
     bool have_noise = false;
     unsigned calls = 0;
+    int lanes_override = 0;  // 0 = automatic (rollout_lanes_for)
     // device buffers
     void* buf[M3_BUF_COUNT] = {};
     long long nbytes[M3_BUF_COUNT] = {};
     float* world0_dev = nullptr;
+    m3::VI* topk_cand = nullptr;
     float* sim_world = nullptr;  // step mode SoA [NW][Kl]
     float* sim_u = nullptr;      // [Kl][nu]
     float* noise_stage = nullptr;

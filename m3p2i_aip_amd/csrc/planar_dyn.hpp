@@ -367,6 +367,8 @@ struct Fric {
 template <int ID>
 __device__ __forceinline__ void solve_ground_friction(const PointScene& sc, Vel& v, Fric& f,
                                                       float m, float I, float Llin, float Lang) {
+    // spec: a body at rest (v = 0 and w = 0) has no friction row in this pass
+    if (gvx<ID>(v) == 0.0f && gvy<ID>(v) == 0.0f && gw<ID>(v) == 0.0f) return;
     float nlx = f.lx + (-m * gvx<ID>(v));
     float nly = f.ly + (-m * gvy<ID>(v));
     const float mag2 = nlx * nlx + nly * nly;
@@ -393,6 +395,7 @@ __device__ __forceinline__ void solve_ground_friction(const PointScene& sc, Vel&
 __device__ __forceinline__ void integrate_box(Box& X, float h) {
     X.x = X.x + h * X.vx;
     X.y = X.y + h * X.vy;
+    if (X.w == 0.0f) return;  // spec: orientation is only touched when w != 0
     const float a = 0.5f * (h * X.w);
     const float a2 = a * a;
     const float den = 1.0f + a2;
@@ -448,6 +451,10 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
                                      sc.dyn_hy, sc.rad_d, sc.obs_x, sc.obs_y, 1.0f, 0.0f,
                                      sc.obs_hx, sc.obs_hy, sc.rad_o);
 
+        const bool on_walls = s_rwx.on | s_rwy.on | s_bx1.on | s_bx2.on | s_by1.on | s_by2.on |
+                              s_dx1.on | s_dx2.on | s_dy1.on | s_dy2.on;
+        const bool on_boxes = s_bd1.on | s_bd2.on | s_bo1.on | s_bo2.on | s_do1.on | s_do2.on;
+
         // 3. velocity solve
         Vel v = {w.rvx, w.rvy, w.B.vx, w.B.vy, w.B.w, w.D.vx, w.D.vy, w.D.w};
         float ldx = 0.0f, ldy = 0.0f;
@@ -472,22 +479,29 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
             if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
             if (s_rd.on) solve<ROBOT, BOXD>(sc, v, s_rd, sc.mu_rd);
             if (s_ro.on) solve<ROBOT, STATIC>(sc, v, s_ro, sc.mu_ro);
-            if (s_rwx.on) solve<ROBOT, STATIC>(sc, v, s_rwx, sc.mu_rw);
-            if (s_rwy.on) solve<ROBOT, STATIC>(sc, v, s_rwy, sc.mu_rw);
-            if (s_bx1.on) solve<BOXB, STATIC>(sc, v, s_bx1, sc.mu_bw);
-            if (s_bx2.on) solve<BOXB, STATIC>(sc, v, s_bx2, sc.mu_bw);
-            if (s_by1.on) solve<BOXB, STATIC>(sc, v, s_by1, sc.mu_bw);
-            if (s_by2.on) solve<BOXB, STATIC>(sc, v, s_by2, sc.mu_bw);
-            if (s_dx1.on) solve<BOXD, STATIC>(sc, v, s_dx1, sc.mu_dw);
-            if (s_dx2.on) solve<BOXD, STATIC>(sc, v, s_dx2, sc.mu_dw);
-            if (s_dy1.on) solve<BOXD, STATIC>(sc, v, s_dy1, sc.mu_dw);
-            if (s_dy2.on) solve<BOXD, STATIC>(sc, v, s_dy2, sc.mu_dw);
-            if (s_bd1.on) solve<BOXB, BOXD>(sc, v, s_bd1, sc.mu_bd);
-            if (s_bd2.on) solve<BOXB, BOXD>(sc, v, s_bd2, sc.mu_bd);
-            if (s_bo1.on) solve<BOXB, STATIC>(sc, v, s_bo1, sc.mu_bo);
-            if (s_bo2.on) solve<BOXB, STATIC>(sc, v, s_bo2, sc.mu_bo);
-            if (s_do1.on) solve<BOXD, STATIC>(sc, v, s_do1, sc.mu_do);
-            if (s_do2.on) solve<BOXD, STATIC>(sc, v, s_do2, sc.mu_do);
+            // the 16 rarely-active slots sit behind two group flags: when no lane of the wave
+            // touches a wall / has a box-box contact the whole group is ONE skipped branch
+            // instead of one exec-mask test per slot per pass (same solve order as the spec)
+            if (on_walls) {
+                if (s_rwx.on) solve<ROBOT, STATIC>(sc, v, s_rwx, sc.mu_rw);
+                if (s_rwy.on) solve<ROBOT, STATIC>(sc, v, s_rwy, sc.mu_rw);
+                if (s_bx1.on) solve<BOXB, STATIC>(sc, v, s_bx1, sc.mu_bw);
+                if (s_bx2.on) solve<BOXB, STATIC>(sc, v, s_bx2, sc.mu_bw);
+                if (s_by1.on) solve<BOXB, STATIC>(sc, v, s_by1, sc.mu_bw);
+                if (s_by2.on) solve<BOXB, STATIC>(sc, v, s_by2, sc.mu_bw);
+                if (s_dx1.on) solve<BOXD, STATIC>(sc, v, s_dx1, sc.mu_dw);
+                if (s_dx2.on) solve<BOXD, STATIC>(sc, v, s_dx2, sc.mu_dw);
+                if (s_dy1.on) solve<BOXD, STATIC>(sc, v, s_dy1, sc.mu_dw);
+                if (s_dy2.on) solve<BOXD, STATIC>(sc, v, s_dy2, sc.mu_dw);
+            }
+            if (on_boxes) {
+                if (s_bd1.on) solve<BOXB, BOXD>(sc, v, s_bd1, sc.mu_bd);
+                if (s_bd2.on) solve<BOXB, BOXD>(sc, v, s_bd2, sc.mu_bd);
+                if (s_bo1.on) solve<BOXB, STATIC>(sc, v, s_bo1, sc.mu_bo);
+                if (s_bo2.on) solve<BOXB, STATIC>(sc, v, s_bo2, sc.mu_bo);
+                if (s_do1.on) solve<BOXD, STATIC>(sc, v, s_do1, sc.mu_do);
+                if (s_do2.on) solve<BOXD, STATIC>(sc, v, s_do2, sc.mu_do);
+            }
         }
         w.rvx = v.rvx; w.rvy = v.rvy;
         w.B.vx = v.bvx; w.B.vy = v.bvy; w.B.w = v.bw;
@@ -497,10 +511,14 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
         {
             float fx = 0.0f, fy = 0.0f;
             M3_ACC(fx, fy, s_rd, +1)
-            M3_ACC(fx, fy, s_dx1, -1) M3_ACC(fx, fy, s_dx2, -1)
-            M3_ACC(fx, fy, s_dy1, -1) M3_ACC(fx, fy, s_dy2, -1)
-            M3_ACC(fx, fy, s_bd1, +1) M3_ACC(fx, fy, s_bd2, +1)
-            M3_ACC(fx, fy, s_do1, -1) M3_ACC(fx, fy, s_do2, -1)
+            if (on_walls) {
+                M3_ACC(fx, fy, s_dx1, -1) M3_ACC(fx, fy, s_dx2, -1)
+                M3_ACC(fx, fy, s_dy1, -1) M3_ACC(fx, fy, s_dy2, -1)
+            }
+            if (on_boxes) {
+                M3_ACC(fx, fy, s_bd1, +1) M3_ACC(fx, fy, s_bd2, +1)
+                M3_ACC(fx, fy, s_do1, -1) M3_ACC(fx, fy, s_do2, -1)
+            }
             fx += fD.lx; fy += fD.ly;
             w.fcDx = fx / h; w.fcDy = fy / h;
         }

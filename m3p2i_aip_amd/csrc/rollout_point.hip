@@ -55,13 +55,32 @@ __device__ __forceinline__ void load_world(const float* p, PointWorld& w) {
     w.fcDx = w.fcDy = w.fcBx = w.fcBy = w.fcRx = w.fcRy = 0.0f;
 }
 
+// env 0 of the wrapper's tensors -> world (yaw from the (0,0,qz,qw) quaternion);
+// dof_state row = [x, vx, y, vy] (isaacgym_wrapper.py:120-126), root row = pos3 quat4 vel3 ang3
+__device__ __forceinline__ void load_world_from_sim(const float* dof, const float* root, int box,
+                                                    int dyn, PointWorld& w) {
+    w.rx = dof[0]; w.ry = dof[2]; w.rvx = dof[1]; w.rvy = dof[3];
+    const float* r = root + (size_t)box * 13;
+    float qz = r[5], qw = r[6];
+    w.B.x = r[0]; w.B.y = r[1]; w.B.c = 1.0f - 2.0f * (qz * qz); w.B.s = 2.0f * (qz * qw);
+    w.B.vx = r[7]; w.B.vy = r[8]; w.B.w = r[12];
+    r = root + (size_t)dyn * 13;
+    qz = r[5]; qw = r[6];
+    w.D.x = r[0]; w.D.y = r[1]; w.D.c = 1.0f - 2.0f * (qz * qz); w.D.s = 2.0f * (qz * qw);
+    w.D.vx = r[7]; w.D.vy = r[8]; w.D.w = r[12];
+    w.fcDx = w.fcDy = w.fcBx = w.fcBy = w.fcRx = w.fcRy = 0.0f;
+}
+
+// Launch geometry: 64-thread workgroups (one wavefront) of which `lanes` are active
+// (default 64 = one lane per sample; lanes = 1 is the north_star's literal "one wavefront
+// per sample" and was measured 2-9x slower, see rollout_lanes_for below).
 __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const PointScene sc) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.Kl) return;
+    const int i = blockIdx.x * a.lanes + threadIdx.x;
+    if ((int)threadIdx.x >= a.lanes || i >= a.Kl) return;
     const int Kl = a.Kl, T = a.T;
     const int k = a.k0 + i;  // global sample index
     PointWorld w;
-    if (a.world0_dev) load_world(a.world0_dev, w);
+    if (a.sim_dof) load_world_from_sim(a.sim_dof, a.sim_root, a.sim_box, a.sim_dyn, w);
     else load_world(a.world0, w);
     w.fRx = a.pend[0 * Kl + i]; w.fRy = a.pend[1 * Kl + i];
     w.fBx = a.pend[2 * Kl + i]; w.fBy = a.pend[3 * Kl + i];
@@ -127,8 +146,19 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const
     a.pend[2 * Kl + i] = w.fBx; a.pend[3 * Kl + i] = w.fBy;
 }
 
+// lanes per wavefront.  MEASURED on MI355X (tools/lanes_sweep.py, DESIGN.md "Lanes per
+// wavefront"): full 64-lane waves are never slower -- K=2000: 0.38 ms at 64 lanes vs 0.83 ms
+// at 1 lane (2000 waves), K=10000: 0.36 ms vs 3.3 ms.  Narrow waves do execute ~2x fewer
+// instructions each (no divergence), but the kernel ends with its SLOWEST wave, whose
+// contact-heavy sample runs the same long path either way, and co-resident waves on a CU
+// slow each other down.  So the automatic choice is 64; the knob stays for experiments.
+int rollout_lanes_for(int Kl) {
+    (void)Kl;
+    return 64;
+}
+
 void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s) {
-    const int blocks = (a.Kl + 63) / 64;
+    const int blocks = (a.Kl + a.lanes - 1) / a.lanes;
     hipLaunchKernelGGL(k_rollout_point, dim3(blocks), dim3(64), 0, s, a, sc);
 }
 
@@ -150,27 +180,6 @@ void launch_transpose_noise(const float* src, float* dst, int K, int T, int nu, 
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_transpose_noise, dim3(blocks), dim3(256), 0, s, src, dst, K, T, nu);
-}
-
-// env 0 of the wrapper's tensors -> the 18-float internal world (yaw from quaternion z,w)
-__global__ void k_world_from_sim(const float* dof, const float* root, int nact, int box, int dyn,
-                                 float* out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    out[0] = dof[0]; out[1] = dof[2]; out[2] = dof[1]; out[3] = dof[3];
-    for (int b = 0; b < 2; ++b) {
-        const float* r = root + (size_t)(b == 0 ? box : dyn) * 13;
-        float* o = out + 4 + b * 7;
-        const float qz = r[5], qw = r[6];
-        o[0] = r[0]; o[1] = r[1];
-        o[2] = 1.0f - 2.0f * (qz * qz);
-        o[3] = 2.0f * (qz * qw);
-        o[4] = r[7]; o[5] = r[8]; o[6] = r[12];
-    }
-    (void)nact;
-}
-void launch_world_from_sim(const float* dof, const float* root, int nact, int box, int dyn,
-                           float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_world_from_sim, dim3(1), dim3(64), 0, s, dof, root, nact, box, dyn, out);
 }
 
 // ======================= step mode (IsaacGymWrapper-like surface) =======================

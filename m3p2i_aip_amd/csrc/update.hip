@@ -15,21 +15,61 @@
 // (10-25 passes x 3 searches per command); here the searches stay on the device in one
 // workgroup.  No MFMA: there is no dense contraction in this path (K x T*nu weighted sums
 // are K-long dot products against ONE weight vector -> bandwidth-bound reductions).
+#include <cstdlib>
 #include "m3_internal.hpp"
 
 namespace m3 {
 
-constexpr int WT = 1024;  // threads of k_weights (16 wavefronts)
+constexpr int WT_MAX = 1024;  // max threads of k_weights (16 wavefronts); 256 for small K
+
+// exp for the softmin weights: v_exp_f32 on x*log2(e) (2 instructions, ~2 ulp + the argument
+// rounding, i.e. <= ~5e-6 relative at |x| = 88) instead of the ~40-instruction correctly
+// rounded expf.  The bar on the weights is 1e-3 and the same function is used for eta and
+// for the weights, so they still sum to one.
+__device__ __forceinline__ float m3_exp(float x) { return __expf(x); }
+
+// ---- wavefront (64-lane) reductions on the DPP cross-lane path ---------------------------
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~100+ cycles each, six
+// dependent steps per reduction); the update kernels are nothing but chains of such
+// reductions (20+20 top-k rounds, up to ~25 beta-search passes), so they were latency-bound
+// on it.  DPP row operations are ordinary VALU instructions: butterfly inside each 16-lane
+// row with quad_perm / row_half_mirror / row_mirror, then row_bcast:15 / row_bcast:31 fold
+// the four rows into lane 63, which v_readlane broadcasts.
+#define M3_DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define M3_DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define M3_DPP_HALF_MIRROR 0x141
+#define M3_DPP_MIRROR 0x140
+#define M3_DPP_BCAST15 0x142
+#define M3_DPP_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL,
+                                                       ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u(unsigned old, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<M3_DPP_XOR1, 0xF>(0.0f, v);
+    v += dpp_f<M3_DPP_XOR2, 0xF>(0.0f, v);
+    v += dpp_f<M3_DPP_HALF_MIRROR, 0xF>(0.0f, v);
+    v += dpp_f<M3_DPP_MIRROR, 0xF>(0.0f, v);
+    v += dpp_f<M3_DPP_BCAST15, 0xA>(0.0f, v);
+    v += dpp_f<M3_DPP_BCAST31, 0xC>(0.0f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    const float INF = __builtin_inff();
+    v = fminf(v, dpp_f<M3_DPP_XOR1, 0xF>(INF, v));
+    v = fminf(v, dpp_f<M3_DPP_XOR2, 0xF>(INF, v));
+    v = fminf(v, dpp_f<M3_DPP_HALF_MIRROR, 0xF>(INF, v));
+    v = fminf(v, dpp_f<M3_DPP_MIRROR, 0xF>(INF, v));
+    v = fminf(v, dpp_f<M3_DPP_BCAST15, 0xA>(INF, v));
+    v = fminf(v, dpp_f<M3_DPP_BCAST31, 0xC>(INF, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // block-wide reductions of up to 3 values at once; result broadcast to every thread
@@ -68,18 +108,46 @@ __device__ __forceinline__ void block_min(float (&v)[N], float* lds) {
 
 // lexicographic (value, index) argmin over the block; "greater than (pv,pi)" filter gives
 // the next-smallest element each round (no exclusion list).
-struct VI { float v; int i; };
+constexpr int TOPK_RPT = 8;  // costs per thread held in registers by a top-k workgroup
+constexpr int WEIGHTS_LDS_MAX = 15000;  // costs staged in LDS by k_weights (60 KB, within the
+                                        // 64 KB a launch gets without a function attribute)
+int weights_lds_floats(int Kg) { return Kg < WEIGHTS_LDS_MAX ? Kg : WEIGHTS_LDS_MAX; }
 __device__ __forceinline__ bool vi_less(float av, int ai, float bv, int bi) {
     return (av < bv) || (av == bv && ai < bi);
 }
+// (value, index) argmin as a min over 64-bit keys: the float is mapped to an order-preserving
+// unsigned (sign flip) in the high word, the index sits in the low word, so one unsigned
+// 64-bit min is the lexicographic (value, index) min.  Same DPP butterfly as wave_sum.
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = (unsigned)__float_as_int(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __int_as_float((int)((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void key_min_step(unsigned& hi, unsigned& lo) {
+    const unsigned ohi = dpp_u<CTRL, ROW_MASK>(0xffffffffu, hi);
+    const unsigned olo = dpp_u<CTRL, ROW_MASK>(0xffffffffu, lo);
+    const bool take = (ohi < hi) || (ohi == hi && olo < lo);
+    hi = take ? ohi : hi;
+    lo = take ? olo : lo;
+}
+__device__ __forceinline__ VI wave_argmin(VI x) {
+    unsigned hi = f2ord(x.v), lo = (unsigned)x.i;
+    key_min_step<M3_DPP_XOR1, 0xF>(hi, lo);
+    key_min_step<M3_DPP_XOR2, 0xF>(hi, lo);
+    key_min_step<M3_DPP_HALF_MIRROR, 0xF>(hi, lo);
+    key_min_step<M3_DPP_MIRROR, 0xF>(hi, lo);
+    key_min_step<M3_DPP_BCAST15, 0xA>(hi, lo);
+    key_min_step<M3_DPP_BCAST31, 0xC>(hi, lo);
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    return VI{ord2f(hi), (int)lo};
+}
 __device__ __forceinline__ VI block_argmin(VI x, VI* lds) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(x.v, o, 64);
-        const int oi = __shfl_xor(x.i, o, 64);
-        if (vi_less(ov, oi, x.v, x.i)) { x.v = ov; x.i = oi; }
-    }
+    x = wave_argmin(x);
     __syncthreads();
     if (lane == 0) lds[wv] = x;
     __syncthreads();
@@ -90,40 +158,80 @@ __device__ __forceinline__ VI block_argmin(VI x, VI* lds) {
 }
 
 // grid = 2 workgroups: 0 -> weights/info, 1 -> top-k (independent, runs concurrently)
-__global__ __launch_bounds__(WT) void k_weights(const UpdateArgs a) {
+__global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
     __shared__ float red[3 * 16];
     __shared__ VI redvi[16];
     __shared__ float s_beta[3];
     __shared__ int s_done[3];
     const int Kg = a.Kg, half = Kg / 2;
     const int tid = threadIdx.x;
+    const int WT = blockDim.x;
     const float* J = a.Jall;
     const float INF = __builtin_inff();
 
-    if (blockIdx.x == 1) {
-        // top-k weights == k smallest trajectory costs (weights are monotone in J);
-        // ties resolved towards the lower sample index.
-        float pv = -INF;
-        int pi = -1;
-        const int n = (Kg < M3_TOPK) ? Kg : M3_TOPK;
+    if (blockIdx.x >= 1) {
+        // top-k weights == k smallest trajectory costs (weights are monotone in J); ties
+        // resolved towards the lower sample index.  Stage A (these workgroups, running beside
+        // workgroup 0): each workgroup owns TOPK_RPT*blockDim consecutive costs, held in
+        // REGISTERS (re-reading J from L2 every round costs ~1 us per round: measured 47 us
+        // for K = 2000); every wave extracts the sorted top-k of its registers with shuffles
+        // only, wave 0 merges the waves' candidates and writes the workgroup's k candidates.
+        // Stage B (merge across workgroups) runs in k_wsum.
+        __shared__ VI cand[16 * M3_TOPK];
+        const int lane = tid & 63, wv = tid >> 6, nw = WT >> 6;
+        const int base = (blockIdx.x - 1) * WT * TOPK_RPT;
+        float rv[TOPK_RPT];
+#pragma unroll
+        for (int e = 0; e < TOPK_RPT; ++e) {
+            const int k = base + e * WT + tid;
+            rv[e] = (k < Kg) ? J[k] : INF;
+        }
+        unsigned used = 0u;
         for (int r = 0; r < M3_TOPK; ++r) {
-            if (r >= n) { if (tid == 0) a.top_idx[r] = a.top_idx[n - 1]; continue; }
             VI best = {INF, 0x7fffffff};
-            for (int k = tid; k < Kg; k += WT) {
-                const float v = J[k];
-                if (vi_less(pv, pi, v, k) && vi_less(v, k, best.v, best.i)) { best.v = v; best.i = k; }
+            int be = -1;
+#pragma unroll
+            for (int e = 0; e < TOPK_RPT; ++e) {
+                const int k = base + e * WT + tid;
+                if (!((used >> e) & 1u) && k < Kg && vi_less(rv[e], k, best.v, best.i)) {
+                    best.v = rv[e]; best.i = k; be = e;
+                }
             }
-            best = block_argmin(best, redvi);
-            pv = best.v; pi = best.i;
-            if (tid == 0) a.top_idx[r] = best.i;
+            const VI win = wave_argmin(best);
+            if (be >= 0 && win.i == best.i) used |= 1u << be;
+            if (lane == 0) cand[wv * M3_TOPK + r] = win;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            float pv = -INF;
+            int pi = -1;
+            for (int r = 0; r < M3_TOPK; ++r) {
+                VI best = {INF, 0x7fffffff};
+                for (int c = lane; c < nw * M3_TOPK; c += 64) {
+                    const VI x = cand[c];
+                    if (vi_less(pv, pi, x.v, x.i) && vi_less(x.v, x.i, best.v, best.i)) best = x;
+                }
+                best = wave_argmin(best);
+                pv = best.v; pi = best.i;
+                if (lane == 0) a.cand[(blockIdx.x - 1) * M3_TOPK + r] = best;
+            }
         }
         return;
     }
 
+    // stage the costs in LDS once: every later pass (min, up to ~25 beta-search passes x 3
+    // searches, final weights) then reads LDS at stride blockDim (conflict-free) instead of
+    // paying an L2 round trip per element per pass
+    extern __shared__ __attribute__((aligned(16))) float sJ[];
+    const int n_lds = (Kg < WEIGHTS_LDS_MAX) ? Kg : WEIGHTS_LDS_MAX;
+    for (int k = tid; k < n_lds; k += WT) sJ[k] = J[k];
+    __syncthreads();
+#define LDJ(k) (((k) < n_lds) ? sJ[(k)] : J[(k)])
+
     // ---- minima (all, first half, second half) ----
     float mn[3] = {INF, INF, INF};
     for (int k = tid; k < Kg; k += WT) {
-        const float v = J[k];
+        const float v = LDJ(k);
         mn[0] = fminf(mn[0], v);
         if (k < half) mn[1] = fminf(mn[1], v); else mn[2] = fminf(mn[2], v);
     }
@@ -136,7 +244,7 @@ __global__ __launch_bounds__(WT) void k_weights(const UpdateArgs a) {
         const float b = a.mode_simple ? a.lambda_ : a.info->beta;
         float e[1] = {0.0f};
         const float nib = -1.0f / b;
-        for (int k = tid; k < Kg; k += WT) e[0] += expf(nib * (J[k] - mn[0]));
+        for (int k = tid; k < Kg; k += WT) e[0] += m3_exp(nib * (LDJ(k) - mn[0]));
         block_sum<1>(e, red);
         beta[0] = b; eta[0] = e[0];
         beta[1] = beta[2] = 1.0f; eta[1] = eta[2] = 0.0f;
@@ -153,10 +261,10 @@ __global__ __launch_bounds__(WT) void k_weights(const UpdateArgs a) {
             float e[3] = {0.0f, 0.0f, 0.0f};
             const float n0 = -1.0f / b0, n1 = -1.0f / b1, n2 = -1.0f / b2;
             for (int k = tid; k < Kg; k += WT) {
-                const float v = J[k];
-                if (!d0) e[0] += expf(n0 * (v - mn[0]));
-                if (k < half) { if (!d1) e[1] += expf(n1 * (v - mn[1])); }
-                else { if (!d2) e[2] += expf(n2 * (v - mn[2])); }
+                const float v = LDJ(k);
+                if (!d0) e[0] += m3_exp(n0 * (v - mn[0]));
+                if (k < half) { if (!d1) e[1] += m3_exp(n1 * (v - mn[1])); }
+                else { if (!d2) e[2] += m3_exp(n2 * (v - mn[2])); }
             }
             block_sum<3>(e, red);
             __syncthreads();
@@ -183,19 +291,19 @@ __global__ __launch_bounds__(WT) void k_weights(const UpdateArgs a) {
     float hs[2] = {0.0f, 0.0f};
     VI b0 = {INF, 0x7fffffff}, b1 = {INF, 0x7fffffff}, b2 = {INF, 0x7fffffff};
     for (int k = tid; k < Kg; k += WT) {
-        const float v = J[k];
-        const float wk = i0 * expf(n0 * (v - mn[0]));
+        const float v = LDJ(k);
+        const float wk = i0 * m3_exp(n0 * (v - mn[0]));
         a.w[k] = wk;
         if (k < half) hs[0] += wk; else hs[1] += wk;
         // argmax of the weights, first index on ties (torch.argmax on CPU): key = -w
         if (vi_less(-wk, k, b0.v, b0.i)) { b0.v = -wk; b0.i = k; }
         if (a.multi_modal && !a.mode_simple) {
             if (k < half) {
-                const float w1k = (1.0f / eta[1]) * expf((-1.0f / beta[1]) * (v - mn[1]));
+                const float w1k = (1.0f / eta[1]) * m3_exp((-1.0f / beta[1]) * (v - mn[1]));
                 a.w1[k] = w1k;
                 if (vi_less(-w1k, k, b1.v, b1.i)) { b1.v = -w1k; b1.i = k; }
             } else {
-                const float w2k = (1.0f / eta[2]) * expf((-1.0f / beta[2]) * (v - mn[2]));
+                const float w2k = (1.0f / eta[2]) * m3_exp((-1.0f / beta[2]) * (v - mn[2]));
                 a.w2[k - half] = w2k;
                 if (vi_less(-w2k, k, b2.v, b2.i)) { b2.v = -w2k; b2.i = k; }
             }
@@ -227,8 +335,17 @@ __global__ __launch_bounds__(WT) void k_weights(const UpdateArgs a) {
     }
 }
 
+int weights_threads(int Kg) { return Kg <= 8192 ? 256 : WT_MAX; }
+int topk_workgroups(int Kg) {
+    const int per = weights_threads(Kg) * TOPK_RPT;
+    return (Kg + per - 1) / per;
+}
+
 void launch_weights(const UpdateArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_weights, dim3(2), dim3(WT), 0, s, a);
+    // few waves for small K: the block-wide reductions (2 barriers + a serial pass over the
+    // waves' partials) dominate, not the K/threads elements per thread
+    const int threads = weights_threads(a.Kg);
+    hipLaunchKernelGGL(k_weights, dim3(1 + a.n_cand), dim3(threads), weights_lds_floats(a.Kg) * sizeof(float), s, a);
 }
 
 // one workgroup per time step t: sum_k w_k * actions[t][k][:] over the local shard, for the
@@ -236,10 +353,49 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
 constexpr int ST = 256;
 __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     __shared__ float red[3 * 16];
+    __shared__ int s_top[M3_TOPK];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int Kl = a.Kl, k0 = a.k0, nu = a.nu, T = a.T, half = a.Kg / 2;
     const bool multi = a.multi_modal && !a.mode_simple;
     const float* act = a.actions + (size_t)t * Kl * nu;
+    // workgroup T: top-k stage B.  Wave 0 merges the stage-A candidates (registers + DPP
+    // argmin rounds), then the whole workgroup gathers the top-k trajectories for every t
+    // (mppi.py:252-254) -- in parallel with the T weighted-sum workgroups.
+    if (t == T) {
+        if (tid < 64) {
+            const int lane = tid, nc = a.n_cand * M3_TOPK;
+            VI rc[4];  // first 256 candidates in registers (covers K <= 98304)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = lane + 64 * e;
+                rc[e] = (c < nc) ? a.cand[c] : VI{__builtin_inff(), 0x7fffffff};
+            }
+            float pv = -__builtin_inff();
+            int pi = -1;
+            for (int r = 0; r < M3_TOPK; ++r) {
+                VI best = {__builtin_inff(), 0x7fffffff};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (vi_less(pv, pi, rc[e].v, rc[e].i) && vi_less(rc[e].v, rc[e].i, best.v, best.i)) best = rc[e];
+                for (int c = lane + 256; c < nc; c += 64) {
+                    const VI x = a.cand[c];
+                    if (vi_less(pv, pi, x.v, x.i) && vi_less(x.v, x.i, best.v, best.i)) best = x;
+                }
+                best = wave_argmin(best);
+                pv = best.v; pi = best.i;
+                if (lane == 0) { s_top[r] = best.i; a.top_idx[r] = best.i; }
+            }
+        }
+        __syncthreads();
+        for (int o = tid; o < M3_TOPK * T * 2; o += ST) {
+            const int c = o & 1, tt = (o >> 1) % T, r = (o >> 1) / T;
+            const int li = s_top[r] - k0;
+            float v = 0.0f;  // zero unless this rank owns the sample (summed by the all-reduce)
+            if (li >= 0 && li < Kl) v = a.states[((size_t)tt * Kl + li) * 4 + (c ? 2 : 0)];  // [0, 2]
+            a.reduce[reduce_off_top(T, nu) + o] = v;
+        }
+        return;
+    }
     for (int j0 = 0; j0 < nu; ++j0) {
         float acc[3] = {0.0f, 0.0f, 0.0f};
         for (int i = tid; i < Kl; i += ST) {
@@ -268,16 +424,9 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         if (gi >= 0 && li >= 0 && li < Kl) v = act[(size_t)li * nu + j];
         a.reduce[reduce_off_best(which, T, nu) + t * nu + j] = v;
     }
-    if (tid >= 64 && tid < 64 + M3_TOPK * 2) {
-        const int r = (tid - 64) >> 1, c = (tid - 64) & 1;
-        const int li = a.top_idx[r] - k0;
-        float v = 0.0f;
-        if (li >= 0 && li < Kl) v = a.states[((size_t)t * Kl + li) * 4 + (c ? 2 : 0)];  // [0, 2]: mppi.py:253
-        a.reduce[reduce_off_top(T, nu) + (r * T + t) * 2 + c] = v;
-    }
 }
 void launch_wsum(const UpdateArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_wsum, dim3(a.T), dim3(ST), 0, s, a);
+    hipLaunchKernelGGL(k_wsum, dim3(a.T + 1), dim3(ST), 0, s, a);
 }
 
 // Savitzky-Golay(9, 2, 'interp') as a fixed linear map: value at window position p of the

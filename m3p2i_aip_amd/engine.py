@@ -96,6 +96,9 @@ class HipEngine:
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         self._ck(self.lib.m3_set_stream(self._h, C.c_void_p(s.cuda_stream)))
 
+    def set_rollout_lanes(self, lanes=0):
+        self._ck(self.lib.m3_set_rollout_lanes(self._h, int(lanes)))
+
     def enable_timing(self, on=True):
         self._ck(self.lib.m3_enable_timing(self._h, int(on)))
 

@@ -67,7 +67,7 @@ def smoothing_spline(knots: np.ndarray, n_out: int, degree: int = 2) -> np.ndarr
 
 
 def halton_spline_delta(K: int, T: int, nu: int, knot_scale: int = 4, degree: int = 2,
-                        k0: int = 0, k1: int | None = None) -> torch.Tensor:
+                        k0: int = 0, k1: int | None = None, workers: int | None = None) -> torch.Tensor:
     """delta[K, T, nu] (rows k0..k1 only if given).  n_knots = T // knot_scale must be >= 3
     for a degree-2 spline ("At least 12 for Halton Sampling", mppi/point.yaml:7)."""
     n_knots = T // knot_scale
@@ -77,8 +77,35 @@ def halton_spline_delta(K: int, T: int, nu: int, knot_scale: int = 4, degree: in
                          "'m > k must hold'); use sampling_method='random' or mppi_mode='simple'")
     k1 = K if k1 is None else k1
     g = halton_gaussian(K, n_knots * nu).view(K, nu, n_knots).numpy()
-    out = np.zeros((k1 - k0, T, nu), np.float32)
-    for i in range(k0, k1):
-        for j in range(nu):
-            out[i - k0, :, j] = smoothing_spline(g[i, j].astype(np.float32), T, degree)
+    rows = g[k0:k1].astype(np.float32)
+    if workers is None:
+        workers = min(_usable_cores(), 32) if (k1 - k0) * nu >= 8192 else 1
+    if workers > 1:
+        import multiprocessing as mp
+        chunks = np.array_split(rows, workers * 4)
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.starmap(_spline_rows, [(c, T, degree) for c in chunks if len(c)])
+        out = np.concatenate(parts, axis=0)
+    else:
+        out = _spline_rows(rows, T, degree)
     return torch.from_numpy(out)
+
+
+def _spline_rows(rows: np.ndarray, T: int, degree: int) -> np.ndarray:
+    out = np.zeros((rows.shape[0], T, rows.shape[1]), np.float32)
+    for i in range(rows.shape[0]):
+        for j in range(rows.shape[1]):
+            out[i, :, j] = smoothing_spline(rows[i, j], T, degree)
+    return out
+
+
+def _usable_cores() -> int:
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n

@@ -325,6 +325,8 @@ typedef struct { float lx, ly, la; } fric_acc;
 
 static void solve_ground_friction(solver_t* s, int b, float m, float I, float Llin, float Lang,
                                   fric_acc* f) {
+    /* spec: a body at rest (v = 0 and w = 0) has no friction row in this pass */
+    if (s->vx[b] == 0.0f && s->vy[b] == 0.0f && s->w[b] == 0.0f) return;
     float nlx = f->lx + (-m * s->vx[b]);
     float nly = f->ly + (-m * s->vy[b]);
     float mag2 = nlx * nlx + nly * nly;
@@ -345,7 +347,7 @@ static void solve_ground_friction(solver_t* s, int b, float m, float I, float Ll
 static void integrate_body(m3o_body* X, float h, int rotate) {
     X->x = X->x + h * X->vx;
     X->y = X->y + h * X->vy;
-    if (rotate) {
+    if (rotate && X->w != 0.0f) { /* spec: orientation is only touched when w != 0 */
         float a = 0.5f * (h * X->w);
         float a2 = a * a;
         float den = 1.0f + a2;

@@ -157,3 +157,50 @@ def test_api_errors_are_loud(oracle):
     with pytest.raises(L.M3Error):
         eng.set_objective("reach", (0, 0))             # not a point_env task
     eng.close()
+
+
+@pytest.mark.parametrize("task,goal,mm", [("push", (-1, -1), False), ("push_pull", (-3.75, -3.75), True)])
+def test_sharded_handles_equal_unsharded(golden, oracle, task, goal, mm):
+    """Two shard handles (rank 0 / rank 1 of world_size 2) on ONE GPU with the two collectives
+    done by hand (concatenate J, add the REDUCE buffers) must reproduce the unsharded handle:
+    checks the kernels' global-index logic (k_offset, specials at k=0, K/2, K-1, owner-only
+    rows) that the RCCL path relies on."""
+    from m3p2i_aip_amd import _lib as L
+    K, T = 256, 30
+    delta = golden["g9_push_delta"]
+    kw = dict(T=T, nu=2, multi_modal=mm, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+    full = _engine(K=K, **kw)
+    shards = [_engine(K=K, K_local=K // 2, k_offset=r * (K // 2), **kw) for r in range(2)]
+    w0 = oracle.init_world(1)[0]
+    w0[0:2] = (0.0, 1.5)
+    for e, d in [(full, delta)] + [(shards[r], delta[r * 128:(r + 1) * 128]) for r in range(2)]:
+        e.set_objective(task, goal)
+        e.set_noise(d)
+        e.set_world_point_raw(raw_world(w0))
+    for call in range(4):
+        full.command()
+        for e in shards:
+            e.rollout()
+        J = torch.cat([e.buffer(L.BUF_TRAJ_COST) for e in shards])           # all_gather
+        for e in shards:
+            e.buffer(L.BUF_TRAJ_COST_ALL).copy_(J)
+            e.update()
+        red = shards[0].buffer(L.BUF_REDUCE) + shards[1].buffer(L.BUF_REDUCE)  # all_reduce(sum)
+        for e in shards:
+            e.buffer(L.BUF_REDUCE).copy_(red)
+            e.finalize()
+        torch.cuda.synchronize()
+        for e in shards:
+            for b in (L.BUF_ACTION_OUT, L.BUF_MEAN, L.BUF_MEAN_1, L.BUF_MEAN_2, L.BUF_BEST,
+                      L.BUF_BEST_1, L.BUF_BEST_2, L.BUF_TOP_TRAJS):
+                np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(),
+                                           atol=2e-5, err_msg=f"call {call} buffer {b}")
+            np.testing.assert_allclose(e.buffer(L.BUF_WEIGHTS).cpu().numpy(),
+                                       full.buffer(L.BUF_WEIGHTS).cpu().numpy(), rtol=1e-3, atol=1e-8)
+            np.testing.assert_array_equal(e.buffer(L.BUF_TOP_IDX).cpu().numpy(),
+                                          full.buffer(L.BUF_TOP_IDX).cpu().numpy())
+        st = torch.cat([e.states for e in shards]).cpu().numpy()
+        np.testing.assert_allclose(st, full.states.cpu().numpy(), atol=1e-4)
+        assert shards[0].info().pull_preference == full.info().pull_preference
+    for e in shards + [full]:
+        e.close()
