@@ -199,6 +199,14 @@ int m3_set_world_point_raw(m3_handle* h, const float* w18);
 int m3_bind_sim_point(m3_handle* h, const float* dof_state_dev, const float* root_state_dev,
                       int n_actors, int box_actor, int dyn_obs_actor);
 
+/* panda_env counterparts.  w31 = q[9] qd[9] | cubeA pos3 quat4(xyzw) linvel3 | cubeB pos3;
+ * bind: dof_state f32 [*,18] (pos,vel interleaved), root_state f32 [*,n_actors,13].
+ * Whether cubeA starts clamped between the finger pads is inferred from the geometry
+ * (DESIGN.md "Panda chain spec v1"): the wrapper's tensors carry no such bit. */
+int m3_set_world_panda_raw(m3_handle* h, const float* w31);
+int m3_bind_sim_panda(m3_handle* h, const float* dof_state_dev, const float* root_state_dev,
+                      int n_actors, int cubeA_actor, int cubeB_actor);
+
 /* one MPPI iteration = rollout + update + finalize.  action_host: optional [T][nu] (or
  * [u_per_command][nu] in simple mode) host buffer; if non-NULL the call synchronises. */
 int m3_command(m3_handle* h, float* action_host);

@@ -87,6 +87,41 @@ static void build_point_scene(const m3_config& c, PointScene& s) {
     s.rad_o = std::sqrt(s.obs_hx * s.obs_hx + s.obs_hy * s.obs_hy);
 }
 
+// "Panda chain spec v1" constants (sources: franka_panda.urdf limits, config/
+// panda_env/*.yaml, isaacgym_wrapper.py:341-344)
+static void build_panda_scene(const m3_config& c, PandaScene& s) {
+    std::memset(&s, 0, sizeof(s));
+    s.h = c.dt / (float)c.substeps; s.substeps = c.substeps; s.g = 9.8f;
+    s.base[0] = -0.45f; s.base[1] = 0.0f; s.base[2] = 1.125f;
+    s.drive_damping = 600.0f;
+    const float inertia[9] = {1.0f, 1.0f, 0.5f, 0.5f, 0.1f, 0.1f, 0.05f, 0.1f, 0.1f};
+    const float effort[9] = {87, 87, 87, 87, 12, 12, 12, 20, 20};
+    const float vlim[9] = {2.175f, 2.175f, 2.175f, 2.175f, 2.61f, 2.61f, 2.61f, 0.2f, 0.2f};
+    const float lo[9] = {-2.8973f, -1.7628f, -2.8973f, -3.0718f, -2.8973f, -0.0175f, -2.8973f, 0.0f, 0.0f};
+    const float hi[9] = {2.8973f, 1.7628f, 2.8973f, -0.0698f, 2.8973f, 3.7525f, 2.8973f, 0.04f, 0.04f};
+    for (int i = 0; i < 9; ++i) {
+        s.inertia[i] = inertia[i]; s.effort[i] = effort[i]; s.vlim[i] = vlim[i];
+        s.qlo[i] = lo[i]; s.qhi[i] = hi[i];
+    }
+    const float table[6] = {0.0f, 0.0f, 1.0f, 0.6f, 0.6f, 0.025f};
+    const float shelf[6] = {0.5f, 0.0f, 1.175f, 0.1f, 0.1f, 0.15f};
+    for (int i = 0; i < 6; ++i) { s.table[i] = table[i]; s.shelf[i] = shelf[i]; }
+    s.cube_half = 0.025f; s.cube_m = 0.125f; s.cube_mu = 1.0f;
+    s.grasp_z = 0.1034f; s.grasp_dx = 0.02f; s.grasp_dz = 0.02f; s.grasp_align = 0.95f; s.grasp_tol = 0.002f;
+    s.k_contact = 5000.0f;
+    s.tip_z = 0.045f; s.tip_r = 0.012f; s.hand_z = 0.03f; s.hand_r = 0.04f;
+}
+
+static void default_panda_world(float* w, int cube_on_shelf) {
+    const float q0[9] = {0, 0, 0, -2.0f, 0, 1.8675f, 0, 0.02f, 0.02f};  // panda.yaml:10
+    std::memset(w, 0, 31 * sizeof(float));
+    for (int i = 0; i < 9; ++i) w[i] = q0[i];
+    if (cube_on_shelf) { w[18] = 0.425f; w[19] = 0.0f; w[20] = 1.35f; }
+    else { w[18] = 0.2f; w[19] = -0.2f; w[20] = 1.06f; }
+    w[24] = 1.0f;
+    w[28] = 0.2f; w[29] = 0.2f; w[30] = 1.06f;
+}
+
 static void default_world(float* w) {
     const float init[18] = {0, 0, 0, 0, /*box 7_box.yaml*/ 0, 2, 1, 0, 0, 0, 0,
                             /*dyn-obs 6_dyn_obs.yaml*/ -2, 2, 1, 0, 0, 0, 0};
@@ -110,7 +145,8 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (c->env_type == M3_ENV_POINT && c->nu != 2) return fail(nullptr, M3_ERR_SHAPE, "m3_create: point_env needs nu == 2");
     if (c->env_type == M3_ENV_PANDA && c->nu != 9) return fail(nullptr, M3_ERR_SHAPE, "m3_create: panda_env needs nu == 9");
     if (c->env_type != M3_ENV_POINT && c->env_type != M3_ENV_PANDA) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad env_type");
-    if (c->env_type == M3_ENV_PANDA) return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: panda_env kernels are not built yet");
+    if (c->env_type == M3_ENV_PANDA && (c->mode_simple || c->sampling_random))
+        return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: panda_env supports mppi_mode='halton-spline' with explicit noise only");
     if (!c->sim_only) {
         if (c->K_global < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: K must be >= 20 (torch.topk(weights, 20), mppi.py:248)");
         if (c->filter_u && (c->mode_simple ? c->u_per_command : c->T) < 9)
@@ -136,6 +172,8 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     }
     build_point_scene(*c, h->scene);
     default_world(h->world0);
+    build_panda_scene(*c, h->pscene);
+    default_panda_world(h->pworld0, c->cube_on_shelf);
     const long long Kl = c->K_local, Kg = c->K_global, T = c->T, nu = c->nu;
     const long long f = sizeof(float);
     int rc = M3_OK;
@@ -240,6 +278,10 @@ extern "C" int m3_set_objective(m3_handle* h, int task, const float* goal, int g
     if (h->cfg.env_type == M3_ENV_POINT && task > M3_TASK_PUSH_PULL)
         return fail(h, M3_ERR_UNSUPPORTED, "m3_set_objective: task not defined for point_env");
     if (h->cfg.env_type == M3_ENV_POINT && goal_len < 2) return fail(h, M3_ERR_SHAPE, "m3_set_objective: point_env goal needs 2 values");
+    if (h->cfg.env_type == M3_ENV_PANDA && task <= M3_TASK_PUSH_PULL)
+        return fail(h, M3_ERR_UNSUPPORTED, "m3_set_objective: task not defined for panda_env");
+    if (h->cfg.env_type == M3_ENV_PANDA && task == M3_TASK_PICK && goal_len < 7)
+        return fail(h, M3_ERR_SHAPE, "m3_set_objective: pick needs a 7-value goal pose (cost_functions.py:116-123)");
     if (task == M3_TASK_PUSH_PULL && !h->cfg.multi_modal)
         return fail(h, M3_ERR_STATE, "m3_set_objective: push_pull needs multi_modal (cost_functions.py:27-29)");
     h->task = task;
@@ -323,6 +365,33 @@ static void fill_cost_params(const m3_handle* h, CostParams& cp) {
     cp.suction_thresh = (h->cfg.K_global == 1) ? 1.5f : 1.8f;  // skill_utils.py:75-82
 }
 
+static void fill_panda_cost_params(const m3_handle* h, PandaCostParams& cp) {
+    cp.task = h->task;
+    cp.multi_modal = h->cfg.multi_modal;
+    cp.half_K = h->cfg.K_global / 2;
+    for (int i = 0; i < 7; ++i) cp.goal[i] = h->goal[i];
+    cp.pre_height_diff = h->cfg.pre_height_diff;
+    cp.tilt_cos_theta = 0.5f;  // cost_functions.py:13
+}
+
+// panda_env initial state, 31 floats: q[9] qd[9] | cubeA pos3 quat4(xyzw) linvel3 | cubeB pos3
+extern "C" int m3_set_world_panda_raw(m3_handle* h, const float* w31) {
+    if (!h || !w31) return M3_ERR_BAD_ARG;
+    if (h->cfg.env_type != M3_ENV_PANDA) return fail(h, M3_ERR_STATE, "m3_set_world_panda_raw: not a panda_env handle");
+    std::memcpy(h->pworld0, w31, 31 * sizeof(float));
+    h->bind_dof = nullptr;
+    return M3_OK;
+}
+
+extern "C" int m3_bind_sim_panda(m3_handle* h, const float* dof, const float* root, int n_actors, int cubeA_actor, int cubeB_actor) {
+    if (!h || !dof || !root) return M3_ERR_BAD_ARG;
+    if (h->cfg.env_type != M3_ENV_PANDA) return fail(h, M3_ERR_STATE, "m3_bind_sim_panda: not a panda_env handle");
+    if (n_actors < 1 || cubeA_actor < 0 || cubeA_actor >= n_actors || cubeB_actor < 0 || cubeB_actor >= n_actors)
+        return fail(h, M3_ERR_SHAPE, "m3_bind_sim_panda: actor index out of range");
+    h->bind_dof = dof; h->bind_root = root; h->bind_nact = n_actors; h->bind_box = cubeA_actor; h->bind_dyn = cubeB_actor;
+    return M3_OK;
+}
+
 extern "C" int m3_rollout(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     const m3_config& c = h->cfg;
@@ -364,7 +433,15 @@ extern "C" int m3_rollout(m3_handle* h) {
     a.cost_h = (float*)h->buf[M3_BUF_COST_HORIZON];
     a.J = (float*)h->buf[M3_BUF_TRAJ_COST];
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-    launch_rollout_point(a, h->scene, h->stream);
+    if (c.env_type == M3_ENV_POINT) {
+        launch_rollout_point(a, h->scene, h->stream);
+    } else {
+        PandaArgs pa;
+        std::memcpy(pa.world0, h->pworld0, sizeof(pa.world0));
+        pa.cubeA_actor = h->bind_box; pa.cubeB_actor = h->bind_dyn;
+        fill_panda_cost_params(h, pa.cp);
+        launch_rollout_panda(a, pa, h->pscene, h->stream);
+    }
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
     return M3_OK;
@@ -448,7 +525,7 @@ extern "C" int m3_get_buffer(m3_handle* h, int which, void** p, long long* nbyte
         int rc = ensure_sim(h);
         if (rc != M3_OK) return rc;
         *p = h->sim_world;
-        if (nbytes) *nbytes = (long long)NW * h->cfg.K_local * sizeof(float);
+        if (nbytes) *nbytes = (long long)(h->cfg.env_type == M3_ENV_POINT ? NW : NWP) * h->cfg.K_local * sizeof(float);
         return M3_OK;
     }
     if (which == M3_BUF_TRAJ_COST_ALL && !h->cfg.sim_only && h->cfg.K_local == h->cfg.K_global)
@@ -486,8 +563,9 @@ extern "C" int m3_get_timing(m3_handle* h, m3_timing* out) {
 static int ensure_sim(m3_handle* h) {
     const m3_config& c = h->cfg;
     if (!h->sim_world) {
-        HIPCHK(h, hipMalloc((void**)&h->sim_world, (size_t)NW * c.K_local * sizeof(float)));
-        HIPCHK(h, hipMemsetAsync(h->sim_world, 0, (size_t)NW * c.K_local * sizeof(float), h->stream));
+        const size_t nw = (c.env_type == M3_ENV_POINT) ? NW : NWP;
+        HIPCHK(h, hipMalloc((void**)&h->sim_world, nw * c.K_local * sizeof(float)));
+        HIPCHK(h, hipMemsetAsync(h->sim_world, 0, nw * c.K_local * sizeof(float), h->stream));
         HIPCHK(h, hipMalloc((void**)&h->sim_u, (size_t)c.K_local * c.nu * sizeof(float)));
         HIPCHK(h, hipMemsetAsync(h->sim_u, 0, (size_t)c.K_local * c.nu * sizeof(float), h->stream));
     }
@@ -496,17 +574,28 @@ static int ensure_sim(m3_handle* h) {
 
 extern "C" int m3_sim_bind_views(m3_handle* h, float* dof, float* root, float* rb, float* ncf, int n_actors, int n_bodies) {
     if (!h) return M3_ERR_BAD_ARG;
-    if (h->cfg.env_type != M3_ENV_POINT) return fail(h, M3_ERR_UNSUPPORTED, "m3_sim_bind_views: point_env only");
-    // actor table of this build (DESIGN.md "Scene tables"): walls 0-3, obs 4, dyn-obs 5,
-    // box 6, goal 7, yaxis 8, xaxis 9, robot 10 (robot last: skill_utils.py:89-90)
-    if (n_actors != 11 || n_bodies != 13) return fail(h, M3_ERR_SHAPE, "m3_sim_bind_views: point_env has 11 actors / 13 bodies");
+    const bool point = h->cfg.env_type == M3_ENV_POINT;
+    // actor tables of this build (DESIGN.md "Scene tables"), robot last (skill_utils.py:89-90):
+    //   point_env: walls 0-3, obs 4, dyn-obs 5, box 6, goal 7, yaxis 8, xaxis 9, robot 10;
+    //              bodies = actors 0..9 + plane 10, link_x 11, link_y 12
+    //   panda_env: table 0, table_stand 1, shelf_stand 2, dyn-obs 3, cubeA 4, cubeB 5, panda 6;
+    //              bodies = actors 0..5 + panda_link0..7, hand, leftfinger, rightfinger (6..16)
+    if (point && (n_actors != 11 || n_bodies != 13)) return fail(h, M3_ERR_SHAPE, "m3_sim_bind_views: point_env has 11 actors / 13 bodies");
+    if (!point && (n_actors != 7 || n_bodies != 17)) return fail(h, M3_ERR_SHAPE, "m3_sim_bind_views: panda_env has 7 actors / 17 bodies");
     int rc = ensure_sim(h);
     if (rc != M3_OK) return rc;
     SimViews& v = h->views;
     v.dof_state = dof; v.root_state = root; v.rigid_body_state = rb; v.net_contact_force = ncf;
     v.n_actors = n_actors; v.n_bodies = n_bodies;
-    v.box_actor = 6; v.dyn_actor = 5; v.robot_actor = 10;
-    v.box_body = 6; v.dyn_body = 5; v.robot_body = 12;
+    if (point) {
+        v.box_actor = 6; v.dyn_actor = 5; v.robot_actor = 10;
+        v.box_body = 6; v.dyn_body = 5; v.robot_body = 12;
+        v.table_body = v.shelf_body = 0;
+    } else {
+        v.box_actor = 4; v.dyn_actor = 5; v.robot_actor = 6;  // cubeA, cubeB, panda
+        v.box_body = 4; v.dyn_body = 5; v.robot_body = 6;
+        v.table_body = 0; v.shelf_body = 2;
+    }
     h->views_bound = true;
     return M3_OK;
 }
@@ -514,7 +603,8 @@ extern "C" int m3_sim_bind_views(m3_handle* h, float* dof, float* root, float* r
 extern "C" int m3_sim_pull_state(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     if (!h->views_bound || !h->views.dof_state || !h->views.root_state) return fail(h, M3_ERR_STATE, "m3_sim_pull_state: views not bound");
-    launch_sim_pull(h->views, h->sim_world, h->cfg.K_local, h->stream);
+    if (h->cfg.env_type == M3_ENV_POINT) launch_sim_pull(h->views, h->sim_world, h->cfg.K_local, h->stream);
+    else launch_psim_pull(h->pscene, h->views, h->sim_world, h->cfg.K_local, h->stream);
     HIPCHK(h, hipGetLastError());
     return M3_OK;
 }
@@ -522,7 +612,8 @@ extern "C" int m3_sim_pull_state(m3_handle* h) {
 extern "C" int m3_sim_push_state(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     if (!h->views_bound) return fail(h, M3_ERR_STATE, "m3_sim_push_state: views not bound");
-    launch_sim_push(h->views, h->sim_world, h->cfg.K_local, h->stream);
+    if (h->cfg.env_type == M3_ENV_POINT) launch_sim_push(h->views, h->sim_world, h->cfg.K_local, h->stream);
+    else launch_psim_push(h->pscene, h->views, h->sim_world, h->cfg.K_local, h->stream);
     HIPCHK(h, hipGetLastError());
     return M3_OK;
 }
@@ -538,6 +629,8 @@ extern "C" int m3_sim_set_velocity_target(m3_handle* h, const float* u) {
 extern "C" int m3_sim_apply_body_forces(m3_handle* h, const float* f) {
     if (!h || !f) return M3_ERR_BAD_ARG;
     if (!h->views_bound) return fail(h, M3_ERR_STATE, "m3_sim_apply_body_forces: views not bound");
+    if (h->cfg.env_type != M3_ENV_POINT)
+        return fail(h, M3_ERR_UNSUPPORTED, "m3_sim_apply_body_forces: the panda_env path applies no body forces (only get_pull_cost does, point_env)");
     launch_sim_forces(h->views, h->sim_world, f, h->cfg.K_local, h->stream);
     HIPCHK(h, hipGetLastError());
     return M3_OK;
@@ -546,8 +639,13 @@ extern "C" int m3_sim_apply_body_forces(m3_handle* h, const float* f) {
 extern "C" int m3_sim_step(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     if (!h->views_bound) return fail(h, M3_ERR_STATE, "m3_sim_step: views not bound");
-    launch_sim_step(h->scene, h->sim_world, h->sim_u, h->cfg.K_local, h->stream);
-    launch_sim_push(h->views, h->sim_world, h->cfg.K_local, h->stream);
+    if (h->cfg.env_type == M3_ENV_POINT) {
+        launch_sim_step(h->scene, h->sim_world, h->sim_u, h->cfg.K_local, h->stream);
+        launch_sim_push(h->views, h->sim_world, h->cfg.K_local, h->stream);
+    } else {
+        launch_psim_step(h->pscene, h->sim_world, h->sim_u, h->cfg.K_local, h->stream);
+        launch_psim_push(h->pscene, h->views, h->sim_world, h->cfg.K_local, h->stream);
+    }
     HIPCHK(h, hipGetLastError());
     return M3_OK;
 }
@@ -555,9 +653,15 @@ extern "C" int m3_sim_step(m3_handle* h) {
 extern "C" int m3_cost(m3_handle* h, float* cost) {
     if (!h || !cost) return M3_ERR_BAD_ARG;
     if (!h->sim_world) return fail(h, M3_ERR_STATE, "m3_cost: step-mode state not initialised");
-    CostParams cp;
-    fill_cost_params(h, cp);
-    launch_sim_cost(cp, h->sim_world, h->cfg.K_local, h->cfg.k_offset, cost, h->stream);
+    if (h->cfg.env_type == M3_ENV_POINT) {
+        CostParams cp;
+        fill_cost_params(h, cp);
+        launch_sim_cost(cp, h->sim_world, h->cfg.K_local, h->cfg.k_offset, cost, h->stream);
+    } else {
+        PandaCostParams cp;
+        fill_panda_cost_params(h, cp);
+        launch_psim_cost(h->pscene, cp, h->sim_world, h->cfg.K_local, h->cfg.k_offset, cost, h->stream);
+    }
     HIPCHK(h, hipGetLastError());
     return M3_OK;
 }

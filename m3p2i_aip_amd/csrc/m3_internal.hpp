@@ -7,6 +7,7 @@
 #include "../../include/m3p2i_hip.h"
 #include "planar_dyn.hpp"
 #include "point_cost.hpp"
+#include "panda_dyn.hpp"
 
 namespace m3 {
 
@@ -94,8 +95,10 @@ struct SimViews {
     float* rigid_body_state;   // [Kl][nB][13]
     float* net_contact_force;  // [Kl][nB][3]
     int n_actors, n_bodies;
-    int box_actor, dyn_actor, robot_actor;
-    int box_body, dyn_body, robot_body;  // robot_body = link_y (last body)
+    int box_actor, dyn_actor, robot_actor;  // panda_env: box = cubeA, dyn = cubeB
+    int box_body, dyn_body, robot_body;     // point: robot_body = link_y (last body);
+                                            // panda: robot_body = panda_link0 (first of 11)
+    int table_body, shelf_body;             // panda_env only
 };
 void launch_sim_pull(const SimViews& v, float* world /*[NW][Kl]*/, int Kl, hipStream_t s);
 void launch_sim_push(const SimViews& v, const float* world, int Kl, hipStream_t s);
@@ -107,12 +110,28 @@ void launch_sim_cost(const CostParams& cp, float* world, int Kl, int k0, float* 
                      hipStream_t s);
 
 constexpr int NW = 28;  // floats per env in the step-mode SoA world (PointWorld fields)
+constexpr int NWP = 45; // same for the panda_env (PandaWorld fields)
+
+// panda_env
+struct PandaArgs {
+    float world0[31];  // q9 qd9 | cubeA pos3 quat4 vel3 | cubeB pos3
+    int cubeA_actor, cubeB_actor;
+    PandaCostParams cp;
+};
+void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s);
+void launch_psim_step(const PandaScene& sc, float* world, const float* u, int Kl, hipStream_t s);
+void launch_psim_pull(const PandaScene& sc, const SimViews& v, float* world, int Kl, hipStream_t s);
+void launch_psim_push(const PandaScene& sc, const SimViews& v, const float* world, int Kl, hipStream_t s);
+void launch_psim_cost(const PandaScene& sc, const PandaCostParams& cp, const float* world, int Kl, int k0,
+                      float* cost, hipStream_t s);
 
 }  // namespace m3
 
 struct m3_handle {
     m3_config cfg;
     m3::PointScene scene;
+    m3::PandaScene pscene;
+    float pworld0[31];
     hipStream_t stream = nullptr;
     std::string err;
     // objective

@@ -1,0 +1,454 @@
+// panda_dyn.hpp -- device-side "Panda chain spec v1"  and the panda_env task costs.
+//
+// Replaces, for the panda_env scene, what the reference delegates to Isaac Gym / PhysX
+// (IsaacGymWrapper.step(), isaacgym_wrapper.py:354-360) with:
+//   * a velocity-servoed 9-dof chain (drive damping 600, isaacgym_wrapper.py:341-344; effort /
+//     velocity / position limits of franka_panda.urdf:34..240),
+//   * forward kinematics from the URDF joint origins (franka_panda.urdf:27-242),
+//   * cubeA as a free body with support contact and a position-level two-finger grasp,
+//   * penalty contact forces on table / shelf_stand / cubeB (what get_motion_cost reads).
+// Costs follow the reference (pinned by golden group G6b):
+//   get_panda_reach_cost :91-114, get_panda_pick_cost :116-125, get_panda_place_cost :127-136,
+//   get_pick_tilt_cost :138-156, get_motion_cost :158-169 (cost_functions.py);
+//   quaternion_rotation_matrix / get_general_ori_* skill_utils.py:140-180, 224-290.
+//
+// One lane per sample; the whole environment (9+9 joint values, cube pose, grasp state) sits
+// in VGPRs.  Trigonometry uses the spec's own Cody-Waite + polynomial sin/cos (plain f32 ops)
+// so that the CPU oracle agrees bit-for-bit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace m3 {
+
+struct PandaScene {
+    float h;  // substep
+    int substeps;
+    float g;
+    float base[3];
+    float drive_damping;
+    float inertia[9], effort[9], vlim[9], qlo[9], qhi[9];
+    float table[6], shelf[6];
+    float cube_half, cube_m, cube_mu;
+    float grasp_z, grasp_dx, grasp_dz, grasp_align, grasp_tol;
+    float k_contact;
+    float tip_z, tip_r, hand_z, hand_r;
+};
+
+struct PandaWorld {
+    float q[9], qd[9];
+    float cube[3], cube_q[4], cube_v[3];  // cubeA (angular velocity is always 0 in spec v1)
+    float cubeB[3];
+    float held;
+    float rel_p[3], rel_q[4];
+    float f_table[2], f_shelf[2], f_cubeB[2];
+};
+
+struct Frame {
+    float x[3], y[3], z[3], p[3];
+};
+
+__device__ __forceinline__ void spec_sincos(float x, float& s, float& c) {
+    const float k = rintf(x * 0.63661977236758134308f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = ps * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    const float sn = r + r * (z * ps);
+    float pc = 2.443315711809948e-5f;
+    pc = pc * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    const float cs = (1.0f - 0.5f * z) + (z * z) * pc;
+    const int q = ((int)k) & 3;
+    if (q == 0) { s = sn; c = cs; }
+    else if (q == 1) { s = cs; c = -sn; }
+    else if (q == 2) { s = -sn; c = -cs; }
+    else { s = -cs; c = sn; }
+}
+
+__device__ __forceinline__ void rot_xp(Frame& f) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float y = f.y[i]; f.y[i] = f.z[i]; f.z[i] = -y; }
+}
+__device__ __forceinline__ void rot_xm(Frame& f) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float y = f.y[i]; f.y[i] = -f.z[i]; f.z[i] = y; }
+}
+__device__ __forceinline__ void rot_z(Frame& f, float s, float c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float x = f.x[i], y = f.y[i];
+        f.x[i] = c * x + s * y;
+        f.y[i] = c * y - s * x;
+    }
+}
+__device__ __forceinline__ void trans(Frame& f, float tx, float ty, float tz) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) f.p[i] = f.p[i] + ((tx * f.x[i] + ty * f.y[i]) + tz * f.z[i]);
+}
+
+__device__ __forceinline__ void mat2quat(const Frame& f, float* q) {
+    const float r00 = f.x[0], r10 = f.x[1], r20 = f.x[2];
+    const float r01 = f.y[0], r11 = f.y[1], r21 = f.y[2];
+    const float r02 = f.z[0], r12 = f.z[1], r22 = f.z[2];
+    const float tr = (r00 + r11) + r22;
+    if (tr > 0.0f) {
+        const float s = sqrtf(tr + 1.0f) * 2.0f;
+        q[3] = 0.25f * s; q[0] = (r21 - r12) / s; q[1] = (r02 - r20) / s; q[2] = (r10 - r01) / s;
+    } else if (r00 > r11 && r00 > r22) {
+        const float s = sqrtf(((1.0f + r00) - r11) - r22) * 2.0f;
+        q[3] = (r21 - r12) / s; q[0] = 0.25f * s; q[1] = (r01 + r10) / s; q[2] = (r02 + r20) / s;
+    } else if (r11 > r22) {
+        const float s = sqrtf(((1.0f + r11) - r00) - r22) * 2.0f;
+        q[3] = (r02 - r20) / s; q[0] = (r01 + r10) / s; q[1] = 0.25f * s; q[2] = (r12 + r21) / s;
+    } else {
+        const float s = sqrtf(((1.0f + r22) - r00) - r11) * 2.0f;
+        q[3] = (r10 - r01) / s; q[0] = (r02 + r20) / s; q[1] = (r12 + r21) / s; q[2] = 0.25f * s;
+    }
+}
+
+// skill_utils.py:140-180 (xyzw -> row-major 3x3)
+__device__ __forceinline__ void quat2mat(const float* Q, float* R) {
+    const float q0 = Q[3], q1 = Q[0], q2 = Q[1], q3 = Q[2];
+    R[0] = 2 * (q0 * q0 + q1 * q1) - 1; R[1] = 2 * (q1 * q2 - q0 * q3); R[2] = 2 * (q1 * q3 + q0 * q2);
+    R[3] = 2 * (q1 * q2 + q0 * q3); R[4] = 2 * (q0 * q0 + q2 * q2) - 1; R[5] = 2 * (q2 * q3 - q0 * q1);
+    R[6] = 2 * (q1 * q3 - q0 * q2); R[7] = 2 * (q2 * q3 + q0 * q1); R[8] = 2 * (q0 * q0 + q3 * q3) - 1;
+}
+
+__device__ __forceinline__ float dot3(const float* a, const float* b) {
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+// FK.  STORE: write every link pose (pos3 + quat4) to out[11][7] (step mode views).
+template <bool STORE>
+__device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, Frame& hand,
+                                         float* pl, float* pr, float* out) {
+    Frame f;
+    f.x[0] = 1; f.x[1] = 0; f.x[2] = 0; f.y[0] = 0; f.y[1] = 1; f.y[2] = 0;
+    f.z[0] = 0; f.z[1] = 0; f.z[2] = 1;
+    f.p[0] = sc.base[0]; f.p[1] = sc.base[1]; f.p[2] = sc.base[2];
+    int li = 0;
+    auto store = [&](const Frame& g) {
+        if constexpr (STORE) {
+            float* o = out + li * 7;
+            o[0] = g.p[0]; o[1] = g.p[1]; o[2] = g.p[2];
+            mat2quat(g, o + 3);
+        }
+        ++li;
+    };
+    store(f);
+    float s, c;
+    trans(f, 0, 0, 0.333f); spec_sincos(q[0], s, c); rot_z(f, s, c); store(f);
+    rot_xm(f); spec_sincos(q[1], s, c); rot_z(f, s, c); store(f);
+    trans(f, 0, -0.316f, 0); rot_xp(f); spec_sincos(q[2], s, c); rot_z(f, s, c); store(f);
+    trans(f, 0.0825f, 0, 0); rot_xp(f); spec_sincos(q[3], s, c); rot_z(f, s, c); store(f);
+    trans(f, -0.0825f, 0.384f, 0); rot_xm(f); spec_sincos(q[4], s, c); rot_z(f, s, c); store(f);
+    rot_xp(f); spec_sincos(q[5], s, c); rot_z(f, s, c); store(f);
+    trans(f, 0.088f, 0, 0); rot_xp(f); spec_sincos(q[6], s, c); rot_z(f, s, c); store(f);
+    trans(f, 0, 0, 0.107f); rot_z(f, -0.70710678118654752f, 0.70710678118654752f); store(f);
+    hand = f;
+    trans(f, 0, 0, 0.0584f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { pl[i] = f.p[i] + q[7] * f.y[i]; pr[i] = f.p[i] - q[8] * f.y[i]; }
+    if constexpr (STORE) {
+        Frame g = f;
+        g.p[0] = pl[0]; g.p[1] = pl[1]; g.p[2] = pl[2]; store(g);
+        g.p[0] = pr[0]; g.p[1] = pr[1]; g.p[2] = pr[2]; store(g);
+    }
+}
+
+__device__ __forceinline__ void sphere_box_force(const PandaScene& sc, const float* c, float r,
+                                                 const float* b, float* f) {
+    float d[3], n2 = 0.0f;
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float l = c[i] - b[i];
+        const float cl = fminf(fmaxf(l, -b[3 + i]), b[3 + i]);
+        d[i] = l - cl;
+        if (d[i] != 0.0f) inside = false;
+        n2 = n2 + d[i] * d[i];
+    }
+    if (inside) return;
+    const float dist = sqrtf(n2);
+    const float pen = r - dist;
+    if (!(pen > 0.0f)) return;
+    const float k = sc.k_contact * pen / dist;
+    f[0] = f[0] - k * d[0];
+    f[1] = f[1] - k * d[1];
+}
+
+// cube pose relative to the hand + alignment test shared by the grasp rule and infer_held
+struct GraspGeom {
+    float cx, cy, cz;
+    float Rc[9];
+    bool in_region;
+};
+__device__ __forceinline__ void grasp_geom(const PandaScene& sc, const PandaWorld& w, const Frame& hand,
+                                           GraspGeom& g) {
+    const float d[3] = {w.cube[0] - hand.p[0], w.cube[1] - hand.p[1], w.cube[2] - hand.p[2]};
+    g.cx = dot3(d, hand.x); g.cy = dot3(d, hand.y); g.cz = dot3(d, hand.z);
+    quat2mat(w.cube_q, g.Rc);
+    float ay = 0.0f, az = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float col[3] = {g.Rc[j], g.Rc[3 + j], g.Rc[6 + j]};
+        ay = fmaxf(ay, fabsf(dot3(hand.y, col)));
+        az = fmaxf(az, fabsf(dot3(hand.z, col)));
+    }
+    g.in_region = fabsf(g.cx) <= sc.grasp_dx && fabsf(g.cz - sc.grasp_z) <= sc.grasp_dz &&
+                  fabsf(g.cy) <= sc.cube_half && ay >= sc.grasp_align && az >= sc.grasp_align;
+}
+__device__ __forceinline__ void set_rel_rot(PandaWorld& w, const Frame& hand, const float* Rc) {
+    Frame r;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float col[3] = {Rc[j], Rc[3 + j], Rc[6 + j]};
+        float* dstc = (j == 0) ? r.x : (j == 1) ? r.y : r.z;
+        dstc[0] = dot3(hand.x, col); dstc[1] = dot3(hand.y, col); dstc[2] = dot3(hand.z, col);
+    }
+    mat2quat(r, w.rel_q);
+}
+
+__device__ __forceinline__ void panda_infer_held(const PandaScene& sc, PandaWorld& w) {
+    Frame hand;
+    float pl[3], pr[3];
+    panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
+    GraspGeom g;
+    grasp_geom(sc, w, hand, g);
+    const float gap = w.q[7] + w.q[8];
+    w.held = 0.0f;
+    if (g.in_region && gap <= 2.0f * sc.cube_half + sc.grasp_tol) {
+        w.held = 1.0f;
+        w.rel_p[0] = g.cx; w.rel_p[1] = g.cy; w.rel_p[2] = g.cz;
+        set_rel_rot(w, hand, g.Rc);
+    }
+}
+
+// what the costs read after a step
+struct PandaObs {
+    float left[3], left_q[4], right[3];
+};
+
+__device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, const float* u,
+                                           PandaObs& obs) {
+    const float h = sc.h;
+    for (int sub = 0; sub < sc.substeps; ++sub) {
+        // 1. velocity servo
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (w.held != 0.0f && i >= 7) { w.qd[i] = 0.0f; continue; }
+            const float a = (h * sc.drive_damping) / sc.inertia[i];
+            float qd1 = (w.qd[i] + a * u[i]) / (1.0f + a);
+            const float tau = sc.drive_damping * (u[i] - qd1);
+            if (tau > sc.effort[i]) qd1 = w.qd[i] + (h * sc.effort[i]) / sc.inertia[i];
+            if (tau < -sc.effort[i]) qd1 = w.qd[i] - (h * sc.effort[i]) / sc.inertia[i];
+            qd1 = fminf(fmaxf(qd1, -sc.vlim[i]), sc.vlim[i]);
+            float q1 = w.q[i] + h * qd1;
+            if (q1 < sc.qlo[i]) { q1 = sc.qlo[i]; qd1 = 0.0f; }
+            if (q1 > sc.qhi[i]) { q1 = sc.qhi[i]; qd1 = 0.0f; }
+            w.q[i] = q1; w.qd[i] = qd1;
+        }
+        // 2. kinematics
+        Frame hand;
+        float pl[3], pr[3];
+        panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
+        float ft[2] = {0.f, 0.f}, fs[2] = {0.f, 0.f}, fb[2] = {0.f, 0.f};
+        const float cubeB_box[6] = {w.cubeB[0], w.cubeB[1], w.cubeB[2], sc.cube_half, sc.cube_half, sc.cube_half};
+
+        // 3. cubeA
+        if (w.held != 0.0f && (u[7] >= 0.0f || u[8] >= 0.0f)) {
+            w.held = 0.0f;
+            w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
+        }
+        if (w.held != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                w.cube[i] = hand.p[i] + ((w.rel_p[0] * hand.x[i] + w.rel_p[1] * hand.y[i]) + w.rel_p[2] * hand.z[i]);
+            float Rr[9];
+            quat2mat(w.rel_q, Rr);
+            Frame c;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                c.x[i] = (hand.x[i] * Rr[0] + hand.y[i] * Rr[3]) + hand.z[i] * Rr[6];
+                c.y[i] = (hand.x[i] * Rr[1] + hand.y[i] * Rr[4]) + hand.z[i] * Rr[7];
+                c.z[i] = (hand.x[i] * Rr[2] + hand.y[i] * Rr[5]) + hand.z[i] * Rr[8];
+            }
+            mat2quat(c, w.cube_q);
+            w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
+        } else {
+            w.cube_v[2] = w.cube_v[2] - sc.g * h;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w.cube[i] = w.cube[i] + h * w.cube_v[i];
+            const float x = w.cube[0], y = w.cube[1];
+            float sup = -1.0e30f;
+            int which = 0;
+            if (fabsf(x - sc.table[0]) <= sc.table[3] && fabsf(y - sc.table[1]) <= sc.table[4]) {
+                sup = sc.table[2] + sc.table[5]; which = 1;
+            }
+            if (fabsf(x - sc.shelf[0]) <= sc.shelf[3] && fabsf(y - sc.shelf[1]) <= sc.shelf[4]) {
+                const float t = sc.shelf[2] + sc.shelf[5];
+                if (t > sup) { sup = t; which = 2; }
+            }
+            if (fabsf(x - w.cubeB[0]) <= sc.cube_half && fabsf(y - w.cubeB[1]) <= sc.cube_half) {
+                const float t = w.cubeB[2] + sc.cube_half;
+                if (t > sup) { sup = t; which = 3; }
+            }
+            if (which != 0 && w.cube[2] - sc.cube_half < sup) {
+                w.cube[2] = sup + sc.cube_half;
+                if (w.cube_v[2] < 0.0f) w.cube_v[2] = 0.0f;
+                const float vx = w.cube_v[0], vy = w.cube_v[1];
+                const float sp = sqrtf(vx * vx + vy * vy);
+                if (sp > 0.0f) {
+                    const float dec = (sc.cube_mu * sc.g) * h;
+                    float nvx, nvy;
+                    if (sp <= dec) { nvx = 0.0f; nvy = 0.0f; }
+                    else { const float sc_ = 1.0f - dec / sp; nvx = vx * sc_; nvy = vy * sc_; }
+                    const float fx = sc.cube_m * (vx - nvx) / h, fy = sc.cube_m * (vy - nvy) / h;
+                    if (which == 1) { ft[0] = ft[0] + fx; ft[1] = ft[1] + fy; }
+                    else if (which == 2) { fs[0] = fs[0] + fx; fs[1] = fs[1] + fy; }
+                    else { fb[0] = fb[0] + fx; fb[1] = fb[1] + fy; }
+                    w.cube_v[0] = nvx; w.cube_v[1] = nvy;
+                }
+            }
+            GraspGeom g;
+            grasp_geom(sc, w, hand, g);
+            if (g.in_region) {
+                float gap = w.q[7] + w.q[8];
+                const float wdt = 2.0f * sc.cube_half;
+                if (gap < wdt) {
+                    const float mid = 0.5f * (w.q[7] - w.q[8]);
+                    w.q[7] = 0.5f * wdt + mid; w.q[8] = 0.5f * wdt - mid;
+                    gap = wdt;
+                }
+                if (gap <= wdt + sc.grasp_tol && u[7] < 0.0f && u[8] < 0.0f) {
+                    w.held = 1.0f;
+                    w.qd[7] = 0.0f; w.qd[8] = 0.0f;
+                    w.rel_p[0] = g.cx; w.rel_p[1] = 0.5f * (w.q[7] - w.q[8]); w.rel_p[2] = g.cz;
+                    set_rel_rot(w, hand, g.Rc);
+                    w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
+                }
+            }
+        }
+        // 4. penalty contact forces
+        {
+            // (finger link origins as given by this substep's FK, i.e. before the pad clamp)
+            float tipl[3], tipr[3], hc[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                tipl[i] = pl[i] + sc.tip_z * hand.z[i];
+                tipr[i] = pr[i] + sc.tip_z * hand.z[i];
+                hc[i] = hand.p[i] + sc.hand_z * hand.z[i];
+            }
+            sphere_box_force(sc, tipl, sc.tip_r, sc.table, ft);
+            sphere_box_force(sc, tipr, sc.tip_r, sc.table, ft);
+            sphere_box_force(sc, hc, sc.hand_r, sc.table, ft);
+            if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, sc.table, ft);
+            sphere_box_force(sc, tipl, sc.tip_r, sc.shelf, fs);
+            sphere_box_force(sc, tipr, sc.tip_r, sc.shelf, fs);
+            sphere_box_force(sc, hc, sc.hand_r, sc.shelf, fs);
+            if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, sc.shelf, fs);
+            sphere_box_force(sc, tipl, sc.tip_r, cubeB_box, fb);
+            sphere_box_force(sc, tipr, sc.tip_r, cubeB_box, fb);
+            sphere_box_force(sc, hc, sc.hand_r, cubeB_box, fb);
+            if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, cubeB_box, fb);
+        }
+        w.f_table[0] = ft[0]; w.f_table[1] = ft[1];
+        w.f_shelf[0] = fs[0]; w.f_shelf[1] = fs[1];
+        w.f_cubeB[0] = fb[0]; w.f_cubeB[1] = fb[1];
+        if (sub == sc.substeps - 1) {
+            // observables for the cost: finger link poses at the FINAL joint values (the pad
+            // clamp may have moved q7/q8 after this substep's FK)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float fo = hand.p[i] + ((0.0f * hand.x[i] + 0.0f * hand.y[i]) + 0.0584f * hand.z[i]);
+                obs.left[i] = fo + w.q[7] * hand.y[i];
+                obs.right[i] = fo - w.q[8] * hand.y[i];
+            }
+            mat2quat(hand, obs.left_q);
+        }
+    }
+}
+
+// ---- costs ------------------------------------------------------------------------------
+__device__ __forceinline__ float coldot(const float* A, int ca, const float* B, int cb) {
+    return A[ca] * B[cb] + A[3 + ca] * B[3 + cb] + A[6 + ca] * B[6 + cb];
+}
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+
+__device__ __forceinline__ float ori_cube2goal(const float* qc, const float* qg) {
+    float C[9], G[9];
+    quat2mat(qc, C);
+    quat2mat(qg, G);
+    const float cx = min3f(1 - fabsf(coldot(G, 0, C, 0)), 1 - fabsf(coldot(G, 0, C, 1)), 1 - fabsf(coldot(G, 0, C, 2)));
+    const float cy = min3f(1 - fabsf(coldot(G, 1, C, 0)), 1 - fabsf(coldot(G, 1, C, 1)), 1 - fabsf(coldot(G, 1, C, 2)));
+    return cx + cy;
+}
+__device__ __forceinline__ float ori_ee2cube(const float* qe, const float* qc, float tilt, const float* qc0) {
+    float E[9], C[9];
+    quat2mat(qe, E);
+    quat2mat(qc, C);
+    float cost_z;
+    if (tilt == 0.0f) {
+        cost_z = min3f(1 - fabsf(coldot(E, 2, C, 2)), 1 - fabsf(coldot(E, 2, C, 0)), 1 - fabsf(coldot(E, 2, C, 1)));
+    } else {
+        float C0[9];
+        quat2mat(qc0, C0);
+        int sel = 0;
+        float best = fabsf(C0[0]);
+        if (fabsf(C0[1]) > best) { best = fabsf(C0[1]); sel = 1; }
+        if (fabsf(C0[2]) > best) { best = fabsf(C0[2]); sel = 2; }
+        const float d = (sel == 0) ? coldot(E, 2, C, 0) : (sel == 1) ? coldot(E, 2, C, 1) : coldot(E, 2, C, 2);
+        cost_z = fabsf(tilt - d);
+    }
+    const float cost_y = min3f(1 - fabsf(coldot(E, 1, C, 0)), 1 - fabsf(coldot(E, 1, C, 1)), 1 - fabsf(coldot(E, 1, C, 2)));
+    return cost_z + cost_y;
+}
+
+struct PandaCostParams {
+    int task, multi_modal, half_K;
+    float goal[7];
+    float pre_height_diff, tilt_cos_theta;
+};
+
+// cube0 / cube_q_half0: cubeA position of env 0 and orientation of the slice's first env
+// (cost_functions.py:97, skill_utils.py:274).  Under spec v1 an un-held cube moves
+// independently of the robot and `reach` keeps the gripper open, so they equal the sample's
+// own cube.
+__device__ __forceinline__ float panda_cost(const PandaCostParams& cp, const PandaWorld& w,
+                                            const PandaObs& o, int k) {
+    if (cp.task == 4) {  // reach
+        float goal[3] = {w.cube[0], w.cube[1], w.cube[2]};
+        if (!cp.multi_modal || k < cp.half_K) {
+            goal[2] = goal[2] + cp.pre_height_diff;
+        } else {
+            goal[0] = goal[0] - cp.pre_height_diff * cp.tilt_cos_theta;
+            goal[2] = goal[2] + cp.pre_height_diff * sqrtf(1.0f - cp.tilt_cos_theta * cp.tilt_cos_theta);
+        }
+        const float dx = (o.left[0] + o.right[0]) / 2.0f - goal[0];
+        const float dy = (o.left[1] + o.right[1]) / 2.0f - goal[1];
+        const float dz = (o.left[2] + o.right[2]) / 2.0f - goal[2];
+        const float reach = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float tilt = (cp.multi_modal && k >= cp.half_K) ? cp.tilt_cos_theta : 0.0f;
+        const float ori = ori_ee2cube(o.left_q, w.cube_q, tilt, w.cube_q);
+        return 10.0f * reach + 3.0f * ori;
+    }
+    if (cp.task == 5) {  // pick
+        const float dx = cp.goal[0] - w.cube[0], dy = cp.goal[1] - w.cube[1], dz = cp.goal[2] - w.cube[2];
+        const float gc = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float ori = ori_cube2goal(w.cube_q, &cp.goal[3]);
+        const float fx = (w.f_table[0] + 4.0f * w.f_shelf[0]) + w.f_cubeB[0];
+        const float fy = (w.f_table[1] + 4.0f * w.f_shelf[1]) + w.f_cubeB[1];
+        const float coll = fabsf(fx) + fabsf(fy);
+        return (10.0f * gc + 15.0f * ori) + ((coll > 0.1f) ? 1000.0f : 0.0f);
+    }
+    if (cp.task == 6) {  // place
+        const float dx = o.left[0] - o.right[0], dy = o.left[1] - o.right[1], dz = o.left[2] - o.right[2];
+        return 2.0f * (1.0f - sqrtf((dx * dx + dy * dy) + dz * dz));
+    }
+    return 0.0f;
+}
+
+}  // namespace m3

@@ -1,0 +1,229 @@
+// rollout_panda.hip -- fused MPPI rollout kernel for the panda_env + step-mode kernels (gfx950).
+//
+// Same structure as rollout_point.hip: one launch = MPPI._compute_rollout_costs
+// (mppi.py:296-315) for all K samples with the 9-dof action assembly (mppi.py:381-416, gripper
+// override :412-416), T x { chain step (replaces reactive_tamp.py:63-70 -> Isaac Gym), task
+// cost (cost_functions.py:91-169) }.  `dynamics` still reports dofs 0 and 1 as the 4-vector
+// state (reactive_tamp.py:66-70), so states stay [T][K][4]; actions are [T][K][9].
+// Algorithmic traffic per state-step: delta 36 B read; state 16 + action 36 + cost 4 B written.
+#include "m3_internal.hpp"
+#include "panda_dyn.hpp"
+
+namespace m3 {
+
+__device__ __forceinline__ void panda_world_from_raw(const float* p, PandaWorld& w) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w.q[i] = p[i]; w.qd[i] = p[9 + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { w.cube[i] = p[18 + i]; w.cube_v[i] = p[25 + i]; w.cubeB[i] = p[28 + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.cube_q[i] = p[21 + i];
+    w.held = 0.0f;
+    w.rel_p[0] = w.rel_p[1] = w.rel_p[2] = 0.0f;
+    w.rel_q[0] = w.rel_q[1] = w.rel_q[2] = 0.0f; w.rel_q[3] = 1.0f;
+    w.f_table[0] = w.f_table[1] = w.f_shelf[0] = w.f_shelf[1] = w.f_cubeB[0] = w.f_cubeB[1] = 0.0f;
+}
+
+// env 0 of the wrapper's tensors: dof_state row = 9 x (pos, vel) interleaved
+// (isaacgym_wrapper.py:98-100), root_state row = pos3 quat4 vel3 ang3 (:102-104)
+__device__ __forceinline__ void panda_world_from_sim(const float* dof, const float* root, int ia, int ib,
+                                                     PandaWorld& w) {
+    float raw[31];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { raw[i] = dof[2 * i]; raw[9 + i] = dof[2 * i + 1]; }
+    const float* a = root + (size_t)ia * 13;
+    const float* b = root + (size_t)ib * 13;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) raw[18 + i] = a[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { raw[25 + i] = a[7 + i]; raw[28 + i] = b[i]; }
+    panda_world_from_raw(raw, w);
+}
+
+__global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a, const PandaArgs pa,
+                                                      const PandaScene sc) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.Kl) return;
+    const int Kl = a.Kl, T = a.T;
+    const int k = a.k0 + i;
+    PandaWorld w;
+    if (a.sim_dof) panda_world_from_sim(a.sim_dof, a.sim_root, pa.cubeA_actor, pa.cubeB_actor, w);
+    else panda_world_from_raw(pa.world0, w);
+    panda_infer_held(sc, w);
+
+    const bool is_last = (k == a.Kg - 1);
+    const bool first_half = k < pa.cp.half_K;
+    const float* mptr = a.mean;
+    if (a.multi_modal) mptr = first_half ? a.mean1 : a.mean2;
+
+    float J = 0.0f, g = 1.0f;
+    for (int t = 0; t < T; ++t) {
+        const int ts = (t + 1 < T) ? t + 1 : T - 1;  // _shift_action: mppi.py:266-273
+        const float* dptr = a.delta + ((size_t)t * Kl + i) * 9;
+        float u[9], e[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            float d = is_last ? 0.0f : dptr[j];                                        // mppi.py:392
+            float aj = fmaxf(fminf(mptr[ts * 9 + j] + d * a.scale_tril[j], a.u_max[j]), a.u_min[j]);
+            if (a.multi_modal) {                                                       // :407-409
+                if (k == 0) aj = a.best1[ts * 9 + j];
+                if (k == pa.cp.half_K) aj = a.best2[ts * 9 + j];
+            }
+            if (j >= 7) {                                                              // :412-416
+                if (a.gripper_cmd == 1) aj = 1.5f;
+                else if (a.gripper_cmd == 2) aj = -1.5f;
+            }
+            float uj = a.u_scale * aj;                                                 // :297
+            if (a.sample_null_action && is_last) uj = 0.0f;                            // :300-302
+            u[j] = uj;
+            e[j] = uj / a.u_scale;                                                     // :421
+        }
+        PandaObs obs;
+        panda_step(sc, w, u, obs);
+        const float c = panda_cost(pa.cp, w, obs, k);
+        *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
+            make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
+        float* ap = a.actions + ((size_t)t * Kl + i) * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) ap[j] = e[j];
+        a.cost_h[(size_t)t * Kl + i] = c;
+        J = J + g * c;
+        g = g * a.gamma;
+    }
+    a.J[i] = J;
+}
+
+void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
+    hipLaunchKernelGGL(k_rollout_panda, dim3((a.Kl + 63) / 64), dim3(64), 0, s, a, pa, sc);
+}
+
+// ======================= step mode ======================================================
+// SoA world rows: q 0-8 | qd 9-17 | cube 18-20 | cube_q 21-24 | cube_v 25-27 | cubeB 28-30 |
+// held 31 | rel_p 32-34 | rel_q 35-38 | f_table 39-40 | f_shelf 41-42 | f_cubeB 43-44
+__device__ __forceinline__ void psoa_load(const float* wd, int Kl, int i, PandaWorld& w) {
+    const float* p = wd + i;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { w.q[j] = p[j * Kl]; w.qd[j] = p[(9 + j) * Kl]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        w.cube[j] = p[(18 + j) * Kl]; w.cube_v[j] = p[(25 + j) * Kl]; w.cubeB[j] = p[(28 + j) * Kl];
+        w.rel_p[j] = p[(32 + j) * Kl];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { w.cube_q[j] = p[(21 + j) * Kl]; w.rel_q[j] = p[(35 + j) * Kl]; }
+    w.held = p[31 * Kl];
+    w.f_table[0] = p[39 * Kl]; w.f_table[1] = p[40 * Kl];
+    w.f_shelf[0] = p[41 * Kl]; w.f_shelf[1] = p[42 * Kl];
+    w.f_cubeB[0] = p[43 * Kl]; w.f_cubeB[1] = p[44 * Kl];
+}
+__device__ __forceinline__ void psoa_store(float* wd, int Kl, int i, const PandaWorld& w) {
+    float* p = wd + i;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { p[j * Kl] = w.q[j]; p[(9 + j) * Kl] = w.qd[j]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        p[(18 + j) * Kl] = w.cube[j]; p[(25 + j) * Kl] = w.cube_v[j]; p[(28 + j) * Kl] = w.cubeB[j];
+        p[(32 + j) * Kl] = w.rel_p[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p[(21 + j) * Kl] = w.cube_q[j]; p[(35 + j) * Kl] = w.rel_q[j]; }
+    p[31 * Kl] = w.held;
+    p[39 * Kl] = w.f_table[0]; p[40 * Kl] = w.f_table[1];
+    p[41 * Kl] = w.f_shelf[0]; p[42 * Kl] = w.f_shelf[1];
+    p[43 * Kl] = w.f_cubeB[0]; p[44 * Kl] = w.f_cubeB[1];
+}
+
+__global__ __launch_bounds__(64) void k_psim_step(const PandaScene sc, float* wd, const float* u, int Kl) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= Kl) return;
+    PandaWorld w;
+    psoa_load(wd, Kl, i, w);
+    float uu[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) uu[j] = u[(size_t)i * 9 + j];
+    PandaObs obs;
+    panda_step(sc, w, uu, obs);
+    psoa_store(wd, Kl, i, w);
+}
+void launch_psim_step(const PandaScene& sc, float* world, const float* u, int Kl, hipStream_t s) {
+    hipLaunchKernelGGL(k_psim_step, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, world, u, Kl);
+}
+
+__global__ __launch_bounds__(64) void k_psim_pull(const PandaScene sc, const SimViews v, float* wd, int Kl) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= Kl) return;
+    PandaWorld w;
+    panda_world_from_sim(v.dof_state + (size_t)i * 18, v.root_state + (size_t)i * v.n_actors * 13,
+                         v.box_actor, v.dyn_actor, w);  // box_actor = cubeA, dyn_actor = cubeB here
+    panda_infer_held(sc, w);
+    psoa_store(wd, Kl, i, w);
+}
+void launch_psim_pull(const PandaScene& sc, const SimViews& v, float* world, int Kl, hipStream_t s) {
+    hipLaunchKernelGGL(k_psim_pull, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, v, world, Kl);
+}
+
+__global__ __launch_bounds__(64) void k_psim_push(const PandaScene sc, const SimViews v, const float* wd, int Kl) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= Kl) return;
+    PandaWorld w;
+    psoa_load(wd, Kl, i, w);
+    if (v.dof_state) {
+        float* d = v.dof_state + (size_t)i * 18;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { d[2 * j] = w.q[j]; d[2 * j + 1] = w.qd[j]; }
+    }
+    float cube13[13];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { cube13[j] = w.cube[j]; cube13[7 + j] = w.cube_v[j]; cube13[10 + j] = 0.0f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cube13[3 + j] = w.cube_q[j];
+    if (v.root_state) {
+        float* r = v.root_state + ((size_t)i * v.n_actors + v.box_actor) * 13;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) r[j] = cube13[j];
+    }
+    if (v.rigid_body_state) {
+        float* base = v.rigid_body_state + (size_t)i * v.n_bodies * 13;
+        float* r = base + v.box_body * 13;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) r[j] = cube13[j];
+        // robot links: bodies robot_body .. robot_body + 10 (link0..7, hand, left, right)
+        float links[11 * 7];
+        Frame hand;
+        float pl[3], pr[3];
+        panda_fk<true>(sc, w.q, hand, pl, pr, links);
+        for (int l = 0; l < 11; ++l) {
+            float* o = base + (v.robot_body + l) * 13;
+            for (int j = 0; j < 7; ++j) o[j] = links[l * 7 + j];
+            for (int j = 7; j < 13; ++j) o[j] = 0.0f;  // link velocities are not modelled (spec v1)
+        }
+    }
+    if (v.net_contact_force) {
+        float* f = v.net_contact_force + (size_t)i * v.n_bodies * 3;
+        f[v.table_body * 3 + 0] = w.f_table[0]; f[v.table_body * 3 + 1] = w.f_table[1];
+        f[v.shelf_body * 3 + 0] = w.f_shelf[0]; f[v.shelf_body * 3 + 1] = w.f_shelf[1];
+        f[v.dyn_body * 3 + 0] = w.f_cubeB[0]; f[v.dyn_body * 3 + 1] = w.f_cubeB[1];
+    }
+}
+void launch_psim_push(const PandaScene& sc, const SimViews& v, const float* world, int Kl, hipStream_t s) {
+    hipLaunchKernelGGL(k_psim_push, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, v, world, Kl);
+}
+
+__global__ __launch_bounds__(64) void k_psim_cost(const PandaScene sc, const PandaCostParams cp, const float* wd,
+                                                  int Kl, int k0, float* cost) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= Kl) return;
+    PandaWorld w;
+    psoa_load(wd, Kl, i, w);
+    Frame hand;
+    PandaObs o;
+    panda_fk<false>(sc, w.q, hand, o.left, o.right, nullptr);
+    mat2quat(hand, o.left_q);
+    cost[i] = panda_cost(cp, w, o, k0 + i);
+}
+void launch_psim_cost(const PandaScene& sc, const PandaCostParams& cp, const float* world, int Kl, int k0,
+                      float* cost, hipStream_t s) {
+    hipLaunchKernelGGL(k_psim_cost, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, cp, world, Kl, k0, cost);
+}
+
+}  // namespace m3

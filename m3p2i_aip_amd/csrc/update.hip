@@ -330,8 +330,10 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
             else if (eta[0] < 10.0f) nb = nb * 1.2f;
         }
         if (!a.multi_modal && !a.mode_simple) f->beta = nb;
+        // multi-modal: the searched betas are locals in the reference (self.beta / beta_1 /
+        // beta_2 are never written, m3p2i.py:58-60), so the persistent beta stays untouched;
+        // the values found are reported for diagnostics only
         f->beta_1 = beta[1]; f->beta_2 = beta[2];
-        if (a.multi_modal && !a.mode_simple) f->beta = beta[0];
     }
 }
 

@@ -178,6 +178,54 @@ float m3o_gauss(unsigned long long seed, unsigned call, unsigned k, unsigned t, 
 void m3o_gauss_fill(unsigned long long seed, unsigned call, int k0, int n, int T, int nu,
                     float* out);
 
+/* ---- panda_env: "Panda chain spec v1"  ---- */
+typedef struct {
+    float dt; int substeps; float g;
+    float base[3];
+    float drive_damping;
+    float inertia[9], effort[9], vlim[9], qlo[9], qhi[9];
+    float table[6], shelf[6];      /* centre xyz + half extents */
+    float cube_half, cube_m, cube_mu;
+    float grasp_z, grasp_dx, grasp_dz, grasp_align, grasp_tol;
+    float k_contact;
+    float tip_z, tip_r, hand_z, hand_r;
+} m3o_panda_scene;
+
+#define M3O_PANDA_WORLD_FLOATS 58
+typedef struct {
+    float q[9], qd[9];
+    float cubeA[13], cubeB[13];    /* pos3 quat4(xyzw) linvel3 angvel3 */
+    float held;                    /* 1.0 while cubeA is clamped between the finger pads */
+    float rel_p[3], rel_q[4];      /* cubeA pose in the hand frame while held */
+    float f_table[2], f_shelf[2], f_cubeB[2]; /* xy contact force of the last substep */
+} m3o_panda_world;
+
+typedef struct {                   /* link0..7, hand, leftfinger, rightfinger */
+    float pos[11][3], quat[11][4], ax[11][3], ay[11][3], az[11][3];
+} m3o_panda_links;
+
+typedef struct {                   /* what the reference's panda costs read from the wrapper */
+    float left[3], left_q[4], right[3];
+    float cube[3], cube_q[4];
+    float cube0[3];                /* cubeA position of env 0 (cost_functions.py:97) */
+    float cube_q_half0[4];         /* cubeA orientation of the first env of the slice (skill_utils.py:274) */
+    float f_table[2], f_shelf[2], f_cubeB[2];
+} m3o_panda_obs;
+
+void m3o_sincos(float x, float* s, float* c);
+void m3o_panda_scene_default(m3o_panda_scene* sc);
+void m3o_panda_world_init(m3o_panda_world* w, int cube_on_shelf);
+void m3o_panda_fk(const m3o_panda_scene* sc, const float q[9], m3o_panda_links* L);
+void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u[9]);
+void m3o_panda_infer_held(const m3o_panda_scene* sc, m3o_panda_world* w);
+void m3o_panda_observe(const m3o_panda_scene* sc, const m3o_panda_world* w, m3o_panda_obs* o);
+float m3o_panda_cost_obs(const m3o_cfg* cfg, const m3o_panda_obs* o, int k);
+void m3o_panda_rollout(const m3o_cfg* cfg, const m3o_panda_scene* sc, const m3o_panda_world* w0,
+                       const float* act, int k0, int k1, float* states, float* actions,
+                       float* cost_h, float* J);
+void m3o_panda_step_batch(const m3o_panda_scene* sc, float* worlds, int n, const float* u);
+void m3o_panda_cost_obs_batch(const m3o_cfg* cfg, const m3o_panda_obs* obs, int n, int k0, float* c);
+
 /* quaternion costs (skill_utils.py:140-180, 224-290), q = xyzw */
 float m3o_ori_cube2goal(const float qc[4], const float qg[4]);
 float m3o_ori_ee2cube(const float qe[4], const float qc[4], float tilt_value,

@@ -1,0 +1,160 @@
+"""CPU ORACLE (test infrastructure) -- ctypes bindings of the panda_env part of libm3oracle.so
+(oracle/panda_chain.c): chain spec v1 dynamics + the reference's reach/pick/place costs."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+import oracle as O
+
+WORLD_FLOATS = 58
+# offsets inside one world row
+W_Q, W_QD, W_CUBEA, W_CUBEB, W_HELD, W_RELP, W_RELQ, W_FT, W_FS, W_FB = 0, 9, 18, 31, 44, 45, 48, 52, 54, 56
+OBS_FLOATS = 30
+LINK_NAMES = ["panda_link0", "panda_link1", "panda_link2", "panda_link3", "panda_link4", "panda_link5",
+              "panda_link6", "panda_link7", "panda_hand", "panda_leftfinger", "panda_rightfinger"]
+
+
+class PandaScene(C.Structure):
+    _fields_ = [("dt", C.c_float), ("substeps", C.c_int), ("g", C.c_float), ("base", C.c_float * 3),
+                ("drive_damping", C.c_float), ("inertia", C.c_float * 9), ("effort", C.c_float * 9),
+                ("vlim", C.c_float * 9), ("qlo", C.c_float * 9), ("qhi", C.c_float * 9),
+                ("table", C.c_float * 6), ("shelf", C.c_float * 6), ("cube_half", C.c_float),
+                ("cube_m", C.c_float), ("cube_mu", C.c_float), ("grasp_z", C.c_float),
+                ("grasp_dx", C.c_float), ("grasp_dz", C.c_float), ("grasp_align", C.c_float),
+                ("grasp_tol", C.c_float), ("k_contact", C.c_float), ("tip_z", C.c_float),
+                ("tip_r", C.c_float), ("hand_z", C.c_float), ("hand_r", C.c_float)]
+
+
+_bound = False
+
+
+def lib():
+    global _bound
+    l = O.load()
+    if not _bound:
+        FP = C.POINTER(C.c_float)
+        l.m3o_sincos.argtypes = [C.c_float, FP, FP]
+        l.m3o_panda_scene_default.argtypes = [C.POINTER(PandaScene)]
+        l.m3o_panda_world_init.argtypes = [FP, C.c_int]
+        l.m3o_panda_fk.argtypes = [C.POINTER(PandaScene), FP, FP]
+        l.m3o_panda_step_batch.argtypes = [C.POINTER(PandaScene), FP, C.c_int, FP]
+        l.m3o_panda_observe.argtypes = [C.POINTER(PandaScene), FP, FP]
+        l.m3o_panda_cost_obs_batch.argtypes = [C.POINTER(O.Cfg), FP, C.c_int, C.c_int, FP]
+        l.m3o_panda_rollout.argtypes = [C.POINTER(O.Cfg), C.POINTER(PandaScene), FP, FP, C.c_int, C.c_int,
+                                        FP, FP, FP, FP]
+        _bound = True
+    return l
+
+
+def default_scene() -> PandaScene:
+    sc = PandaScene()
+    lib().m3o_panda_scene_default(C.byref(sc))
+    return sc
+
+
+def init_world(n=1, cube_on_shelf=False) -> np.ndarray:
+    w = np.zeros(WORLD_FLOATS, np.float32)
+    lib().m3o_panda_world_init(O._fp(w), int(cube_on_shelf))
+    return np.tile(w, (n, 1)).astype(np.float32)
+
+
+def sincos(x):
+    s, c = C.c_float(), C.c_float()
+    lib().m3o_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def fk(sc, q):
+    """dict(pos[11,3], quat[11,4], ax, ay, az [11,3])"""
+    buf = np.zeros(11 * 16, np.float32)
+    lib().m3o_panda_fk(C.byref(sc), O._fp(O.f32(q)), O._fp(buf))
+    return dict(pos=buf[0:33].reshape(11, 3), quat=buf[33:77].reshape(11, 4),
+                ax=buf[77:110].reshape(11, 3), ay=buf[110:143].reshape(11, 3),
+                az=buf[143:176].reshape(11, 3))
+
+
+def step_batch(sc, worlds, u):
+    assert worlds.dtype == np.float32 and worlds.flags.c_contiguous and worlds.shape[1] == WORLD_FLOATS
+    lib().m3o_panda_step_batch(C.byref(sc), O._fp(worlds), worlds.shape[0], O._fp(O.f32(u)))
+
+
+def observe(sc, world):
+    o = np.zeros(OBS_FLOATS, np.float32)
+    lib().m3o_panda_observe(C.byref(sc), O._fp(O.f32(world)), O._fp(o))
+    return o
+
+
+def make_obs(left, left_q, right, cube, cube_q, cube0, cube_q_half0, f_table, f_shelf, f_cubeB):
+    n = left.shape[0]
+    o = np.zeros((n, OBS_FLOATS), np.float32)
+    o[:, 0:3], o[:, 3:7], o[:, 7:10] = left, left_q, right
+    o[:, 10:13], o[:, 13:17] = cube, cube_q
+    o[:, 17:20], o[:, 20:24] = cube0, cube_q_half0
+    o[:, 24:26], o[:, 26:28], o[:, 28:30] = f_table, f_shelf, f_cubeB
+    return o
+
+
+def cost_obs(cfg, obs, k0=0):
+    obs = O.f32(obs)
+    c = np.zeros(obs.shape[0], np.float32)
+    lib().m3o_panda_cost_obs_batch(C.byref(cfg), O._fp(obs), obs.shape[0], k0, O._fp(c))
+    return c
+
+
+def make_cfg(K, T, multi_modal=False, task="reach", goal=(0, 0, 0, 0, 0, 0, 1), gripper_cmd=1, **kw):
+    return O.make_cfg(K, T, 9, multi_modal=multi_modal, env_type="panda_env", task=task, goal=goal,
+                      u_min=[-2.0] * 7 + [-1.5] * 2, u_max=[2.0] * 7 + [1.5] * 2,
+                      noise_sigma_diag=[10.0] * 7 + [0.8] * 2, gripper_cmd=gripper_cmd,
+                      pre_height_diff=0.05, **kw)
+
+
+def rollout(cfg, sc, world0, act, k0=0, k1=None):
+    k1 = cfg.K if k1 is None else k1
+    n = k1 - k0
+    states = np.zeros((n, cfg.T, 4), np.float32)
+    actions = np.zeros((n, cfg.T, 9), np.float32)
+    cost_h = np.zeros((n, cfg.T), np.float32)
+    J = np.zeros(n, np.float32)
+    w0 = O.f32(world0).reshape(-1)[:WORLD_FLOATS].copy()
+    lib().m3o_panda_rollout(C.byref(cfg), C.byref(sc), O._fp(w0), O._fp(O.f32(act)), k0, k1,
+                            O._fp(states), O._fp(actions), O._fp(cost_h), O._fp(J))
+    return dict(states=states, actions=actions, cost_h=cost_h, J=J)
+
+
+class OraclePandaPlanner:
+    """command() for panda_env on the oracle (halton-spline mode), mirrors OraclePointPlanner."""
+
+    def __init__(self, cfg, delta, scene=None):
+        self.cfg, self.sc = cfg, scene or default_scene()
+        self.delta = O.f32(delta).copy()
+        self.delta[-1] = 0.0
+        z = lambda: np.zeros((cfg.T, 9), np.float32)
+        self.mean, self.mean1, self.mean2, self.best, self.best1, self.best2 = z(), z(), z(), z(), z(), z()
+        self.beta = 1.0
+        self.last = {}
+
+    def command(self, world0):
+        cfg = self.cfg
+        K = cfg.K
+        self.mean = O.shift(self.mean)
+        if cfg.multi_modal:
+            self.mean1, self.mean2 = O.shift(self.mean1), O.shift(self.mean2)
+            self.best1, self.best2 = O.shift(self.best1), O.shift(self.best2)
+        act = O.assemble_actions(cfg, self.delta, self.mean, self.mean1, self.mean2, self.best1, self.best2)
+        r = rollout(cfg, self.sc, world0, act)
+        w, w1, w2, info = O.update_weights(cfg, r["J"], self.beta)
+        self.beta = info.beta
+        ps = O.partial_sums(cfg, w, w1, w2, r["actions"])
+        self.mean = O.mean_update(cfg, self.mean, ps[0])
+        if cfg.multi_modal:
+            self.mean1, self.mean2 = ps[1].copy(), ps[2].copy()
+            self.best1 = r["actions"][info.best_idx_1].copy()
+            self.best2 = r["actions"][K // 2 + info.best_idx_2].copy()
+        else:
+            self.best = r["actions"][info.best_idx].copy()
+        action = O.savgol9(self.mean) if cfg.filter_u else self.mean.copy()
+        top_idx, _ = O.topk(w, 20)
+        self.last = dict(r, w=w, w1=w1, w2=w2, info=info, act=act, action=action, top_idx=top_idx)
+        return action

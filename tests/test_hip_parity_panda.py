@@ -1,0 +1,90 @@
+"""GPU parity tests for the panda_env hot path: fused HIP rollout + update (through the C-ABI)
+vs the CPU oracle (Panda chain spec v1 + the reference's reach/pick/place costs, the latter
+pinned by golden group G6b).  Run with ``pytest -m gpu``."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+UMIN = [-2.0] * 7 + [-1.5] * 2
+UMAX = [2.0] * 7 + [1.5] * 2
+SIG = [10.0] * 7 + [0.8] * 2
+
+
+def raw31(P, w58):
+    w = np.asarray(w58, np.float32)
+    return np.concatenate([w[P.W_Q:P.W_Q + 18], w[P.W_CUBEA:P.W_CUBEA + 10], w[P.W_CUBEB:P.W_CUBEB + 3]])
+
+
+def grasp_world(P, sc):
+    """A world in which the gripper holds cubeA (built with the oracle: IK + closing)."""
+    w = P.init_world(1)
+    for _ in range(30):
+        P.step_batch(sc, w, np.zeros((1, 9), np.float32))
+    target = w[0, P.W_CUBEA:P.W_CUBEA + 3] + np.array([0, 0, sc.grasp_z])
+    q = np.array([0, 0.3, 0, -2.2, 0, 2.5, 0.785, 0.04, 0.04], np.float32)
+
+    def feat(L):
+        return np.concatenate([L["pos"][8], 0.3 * L["az"][8], 0.3 * L["ay"][8]])
+
+    want = np.concatenate([target, 0.3 * np.array([0, 0, -1.0]), 0.3 * np.array([0, 1.0, 0])])
+    for _ in range(600):
+        L = P.fk(sc, q)
+        e = want - feat(L)
+        if np.linalg.norm(e) < 1e-4:
+            break
+        Jm = np.zeros((9, 7))
+        for j in range(7):
+            dq = q.copy(); dq[j] += 1e-3
+            Jm[:, j] = (feat(P.fk(sc, dq)) - feat(L)) / 1e-3
+        q[:7] += (np.linalg.pinv(Jm, rcond=1e-3) @ e * 0.5).astype(np.float32)
+        q[:7] = np.clip(q[:7], np.array(sc.qlo)[:7], np.array(sc.qhi)[:7])
+    w[0, P.W_Q:P.W_Q + 9] = q
+    w[0, P.W_QD:P.W_QD + 9] = 0
+    close = np.zeros((1, 9), np.float32); close[0, 7:] = -1.5
+    for _ in range(40):
+        P.step_batch(sc, w, close)
+    assert w[0, P.W_HELD] == 1.0
+    return w[0].copy()
+
+
+@pytest.mark.parametrize("task,mm,grip,held", [("reach", False, 1, False), ("reach", True, 1, False),
+                                               ("pick", False, 2, True), ("pick", False, 2, False),
+                                               ("place", False, 1, True)])
+def test_panda_command_matches_oracle(oracle, task, mm, grip, held):
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    sc = P.default_scene()
+    K, T = 256, 20
+    rng = np.random.default_rng(5)
+    delta = rng.standard_normal((K, T, 9)).astype(np.float32)
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    w0 = grasp_world(P, sc) if held else P.init_world(1)[0]
+    cfg = P.make_cfg(K, T, multi_modal=mm, task=task, goal=goal, gripper_cmd=grip)
+    opl = P.OraclePandaPlanner(cfg, delta, sc)
+    eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", multi_modal=mm, u_min=UMIN, u_max=UMAX,
+                                noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01))
+    eng.set_objective(task, goal, gripper_cmd=grip)
+    eng.set_noise(delta)
+    eng.set_world_panda_raw(raw31(P, w0))
+    for call in range(3):
+        a_hip = eng.command(sync_host=True)
+        a_orc = opl.command(w0)
+        st, ac = eng.states.cpu().numpy(), eng.actions.cpu().numpy()
+        ch, J = eng.cost_horizon.cpu().numpy(), eng.buffer(L.BUF_TRAJ_COST).cpu().numpy()
+        if call == 0:  # identical inputs: the rollout must agree bit-for-bit
+            np.testing.assert_array_equal(ac, opl.last["actions"])
+            np.testing.assert_array_equal(st, opl.last["states"])
+            bad = np.argwhere(ch != opl.last["cost_h"])
+            assert bad.size == 0, f"{len(bad)} cost mismatches, first {bad[0]}: {ch[tuple(bad[0])]} vs {opl.last['cost_h'][tuple(bad[0])]}"
+            np.testing.assert_array_equal(J, opl.last["J"])
+        np.testing.assert_allclose(ch, opl.last["cost_h"], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(a_hip, a_orc, atol=1e-3, err_msg=f"call {call}")
+        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), opl.last["w"], atol=1e-3)
+        info = eng.info()
+        assert info.beta == pytest.approx(opl.beta, rel=1e-5)   # panda adapts beta (mppi.py:446-454)
+    if held and task == "pick":
+        assert np.ptp(ch) > 0.05       # the held cube really moves with the hand in the rollouts
+    eng.close()

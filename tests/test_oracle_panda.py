@@ -1,0 +1,114 @@
+"""CPU tests of the panda_env oracle: reference cost goldens (G6b), FK known answers from the
+URDF, spec sin/cos accuracy, chain/grasp behaviour."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def P():
+    import oracle.panda as P
+    P.lib()
+    return P
+
+
+def test_spec_sincos_accuracy(P):
+    xs = np.linspace(-4.0, 4.0, 4001)
+    err = max(max(abs(P.sincos(x)[0] - np.sin(np.float32(x))), abs(P.sincos(x)[1] - np.cos(np.float32(x))))
+              for x in xs)
+    assert err < 2.5e-7
+
+
+def test_fk_known_answers_appendix_b(P):
+    """Init pose q=[0,0,0,-2,0,1.8675,0,.02,.02], base (-0.45,0,1.125): values computed from the
+    URDF with plain numpy in the survey (Appendix B)."""
+    sc = P.default_scene()
+    L = P.fk(sc, [0, 0, 0, -2, 0, 1.8675, 0, 0.02, 0.02])
+    np.testing.assert_allclose(L["pos"][7], [0.1032, 0, 1.6776], atol=2e-4)     # link7
+    np.testing.assert_allclose(L["pos"][8], [0.0891, 0, 1.5715], atol=2e-4)     # hand
+    np.testing.assert_allclose(L["pos"][9], [0.0954, -0.0141, 1.5118], atol=2e-4)   # left finger
+    np.testing.assert_allclose(L["pos"][10], [0.0674, 0.0141, 1.5155], atol=2e-4)   # right finger
+    ee = (L["pos"][9] + L["pos"][10]) / 2
+    np.testing.assert_allclose(ee, [0.0814, 0, 1.5136], atol=2e-4)
+    np.testing.assert_allclose(L["az"][9], [-0.1321, 0, -0.9912], atol=2e-4)
+    np.testing.assert_allclose(L["ay"][9], [0.7009, -0.7071, -0.0934], atol=2e-4)
+    # initial 10*reach term with cubeA on the table: 4.6583 (cost_functions.py:97-99,114)
+    goal = np.array([0.2, -0.2, 1.06 + 0.05])
+    assert 10 * np.linalg.norm(ee - goal) == pytest.approx(4.6583, abs=2e-3)
+    # quaternions are unit and reproduce the axes
+    q = L["quat"][9]
+    assert abs(np.linalg.norm(q) - 1) < 1e-6
+    x, y, z, w = q
+    np.testing.assert_allclose([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)],
+                               L["az"][9], atol=1e-6)
+
+
+@pytest.mark.parametrize("mm", [0, 1])
+@pytest.mark.parametrize("task", ["reach", "pick", "place"])
+def test_g6b_panda_costs_match_reference(golden, oracle, P, task, mm):
+    left, right, cubeA = golden["g6p_left"], golden["g6p_right"], golden["g6p_cubeA"]
+    K = left.shape[0]
+    half0 = cubeA[K // 2, 3:7] if mm else cubeA[0, 3:7]
+    obs = P.make_obs(left[:, :3], left[:, 3:7], right[:, :3], cubeA[:, :3], cubeA[:, 3:7],
+                     np.tile(cubeA[0, :3], (K, 1)), np.tile(half0, (K, 1)),
+                     golden["g6p_f_table"][:, :2], golden["g6p_f_shelf_stand"][:, :2],
+                     golden["g6p_f_cubeB"][:, :2])
+    cfg = P.make_cfg(K, 20, multi_modal=bool(mm), task=task, goal=golden["g6p_goal7"])
+    c = P.cost_obs(cfg, obs)
+    np.testing.assert_allclose(c, golden[f"g6p_cost_{task}_{mm}"], rtol=3e-6, atol=2e-5)
+
+
+def test_chain_tracks_velocity_targets_and_limits(P):
+    sc = P.default_scene()
+    w = P.init_world(1)
+    u = np.array([[1.0, -0.5, 0.3, 2.0, 1.0, -1.0, 0.5, 1.5, 1.5]], np.float32)
+    for _ in range(120):
+        P.step_batch(sc, w, u)
+    qd = w[0, P.W_QD:P.W_QD + 9]
+    np.testing.assert_allclose(qd[:3], u[0, :3], atol=1e-3)          # servo converged
+    assert w[0, P.W_Q + 3] == pytest.approx(-0.0698, abs=1e-6) and qd[3] == 0   # joint-4 upper limit
+    assert w[0, P.W_Q + 7] == pytest.approx(0.04) and w[0, P.W_Q + 8] == pytest.approx(0.04)  # fingers open
+    assert abs(qd[5]) <= 2.61 + 1e-6
+
+
+def test_cube_settles_on_table_and_can_be_grasped_and_lifted(P):
+    sc = P.default_scene()
+    w = P.init_world(1)
+    for _ in range(30):
+        P.step_batch(sc, w, np.zeros((1, 9), np.float32))
+    assert w[0, P.W_CUBEA + 2] == pytest.approx(1.025 + 0.025, abs=1e-6)      # resting on the table top
+    assert np.all(w[0, P.W_CUBEA + 7:P.W_CUBEA + 13] == 0)
+    # put the open gripper around the cube: solve q by crude numeric IK on the oracle FK
+    target = w[0, P.W_CUBEA:P.W_CUBEA + 3] + np.array([0, 0, sc.grasp_z])     # hand above the cube
+    q = np.array([0, 0.3, 0, -2.2, 0, 2.5, 0.785, 0.04, 0.04], np.float32)
+    def feat(L):  # hand position, hand z pointing down, hand y along world y (pads face the cube)
+        return np.concatenate([L["pos"][8], 0.3 * L["az"][8], 0.3 * L["ay"][8]])
+
+    want = np.concatenate([target, 0.3 * np.array([0, 0, -1.0]), 0.3 * np.array([0, 1.0, 0])])
+    for it in range(600):
+        L = P.fk(sc, q)
+        e = want - feat(L)
+        if np.linalg.norm(e) < 1e-4:
+            break
+        Jm = np.zeros((9, 7))
+        for j in range(7):
+            dq = q.copy(); dq[j] += 1e-3
+            Jm[:, j] = (feat(P.fk(sc, dq)) - feat(L)) / 1e-3
+        q[:7] += (np.linalg.pinv(Jm, rcond=1e-3) @ e * 0.5).astype(np.float32)
+        q[:7] = np.clip(q[:7], np.array(sc.qlo)[:7], np.array(sc.qhi)[:7])
+    assert np.linalg.norm(e) < 1e-3, "IK did not converge"
+    w[0, P.W_Q:P.W_Q + 9] = q
+    w[0, P.W_QD:P.W_QD + 9] = 0
+    close = np.zeros((1, 9), np.float32); close[0, 7:] = -1.5
+    for _ in range(40):
+        P.step_batch(sc, w, close)
+    assert w[0, P.W_HELD] == 1.0
+    assert w[0, P.W_Q + 7] + w[0, P.W_Q + 8] == pytest.approx(0.05, abs=2.1e-3)
+    lift = close.copy(); lift[0, 3] = 0.5     # bend the elbow: hand moves, cube follows
+    z0 = w[0, P.W_CUBEA + 2]
+    for _ in range(50):
+        P.step_batch(sc, w, lift)
+    assert w[0, P.W_HELD] == 1.0 and abs(w[0, P.W_CUBEA + 2] - z0) > 0.01
+    release = np.zeros((1, 9), np.float32); release[0, 7:] = 1.5
+    for _ in range(100):
+        P.step_batch(sc, w, release)
+    assert w[0, P.W_HELD] == 0.0 and w[0, P.W_CUBEA + 2] == pytest.approx(1.05, abs=1e-5)  # fell back
