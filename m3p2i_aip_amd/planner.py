@@ -271,9 +271,14 @@ class MPPI():
         if s is None:
             raise RuntimeError("fused command() needs the HIP IsaacGymWrapper; use planner.attach(sim, objective)")
         if getattr(self, "_bound_sim", None) is not s:
-            self._engine.bind_sim_point(s._dof_state, s._root_state,
-                                        scenes.actor_index(self.env_type, "box"),
-                                        scenes.actor_index(self.env_type, "dyn-obs"))
+            if self.env_type == "point_env":
+                self._engine.bind_sim_point(s._dof_state, s._root_state,
+                                            scenes.actor_index(self.env_type, "box"),
+                                            scenes.actor_index(self.env_type, "dyn-obs"))
+            else:
+                self._engine.bind_sim_panda(s._dof_state, s._root_state,
+                                            scenes.actor_index(self.env_type, "cubeA"),
+                                            scenes.actor_index(self.env_type, "cubeB"))
             self._bound_sim = s
 
     def _exchange(self, phase):
@@ -387,7 +392,8 @@ class MPPI():
         same = bool(torch.allclose(Jf, Js, rtol=1e-5, atol=1e-4))
         self._fused = same
         self.probe_result = dict(fused=same, max_abs_diff=float((Jf - Js).abs().max()))
-        if same:  # carry the suction force staged by the last cost evaluation into the fused state
+        if same and self.env_type == "point_env":
+            # carry the suction force staged by the last cost evaluation into the fused state
             simw = self._sim._engine.buffer(L.BUF_SIM_WORLD)
             self._buf(L.BUF_PENDING_FORCE).copy_(simw[18:22])
         return out
