@@ -1,0 +1,255 @@
+"""Compatibility layer: lets the reference's `scripts/reactive_tamp.py` (and `scripts/sim.py`)
+import and run unchanged on this package.
+
+`install()` registers this package's classes under the module names the scripts import
+(`reactive_tamp.py:1-8`, `sim.py:1-6`).  Nothing of the reference is copied and Isaac Gym is
+not needed.  Launcher / RPC pieces (hydra, zerorpc) are outside the hot path (SURVEY.md
+section 8(f)); when the real packages are absent, small stand-ins cover exactly the calls the
+scripts make.
+
+Host-side helpers restated here (all O(1) per command, no data parallelism):
+  PLANNER_SIMPLE            planners/task_planner/task_planner.py:13-39
+  torch_to_bytes / bytes_to_torch   utils/data_transfer.py:4-12
+  calculate_suction / check_suction_condition / check_and_apply_suction / time_tracking
+                            utils/skill_utils.py:25-94 (the 1-env "real world" side of sim.py)
+  ExampleConfig defaults    config/config_point.yaml, config_panda.yaml, mppi/*.yaml,
+                            isaacgym/*.yaml, config/config_store.py:7-29
+"""
+from __future__ import annotations
+
+import io
+import sys
+import time
+import types
+from dataclasses import dataclass, field
+from typing import List
+
+import torch
+
+from . import cost_functions, isaacgym_wrapper, planner
+
+
+# ------------------------------------------------------------------ data_transfer.py:4-12
+def torch_to_bytes(t) -> bytes:
+    buff = io.BytesIO()
+    torch.save(t, buff)
+    buff.seek(0)
+    return buff.read()
+
+
+def bytes_to_torch(b: bytes):
+    return torch.load(io.BytesIO(b))
+
+
+# ------------------------------------------------------------------ task_planner.py:13-39
+class PLANNER_SIMPLE:
+    def __init__(self, cfg) -> None:
+        self.device = cfg.mppi.device
+        self.task = cfg.task
+        self.curr_goal = cfg.goal if torch.is_tensor(cfg.goal) else torch.tensor(list(cfg.goal), device=self.device)
+        self.dist_threshold = 0.1
+
+    def update_plan(self, sim):
+        pass
+
+    def reset_plan(self):
+        pass
+
+    def check_task_success(self, sim):
+        task_success = False
+        if self.task == "navigation":
+            task_success = torch.norm(sim.robot_pos[0, :] - self.curr_goal) < self.dist_threshold
+        elif self.task in ['push', 'pull', 'push_pull']:
+            box_pos = sim.get_actor_position_by_name("box")[0, :2]
+            task_success = torch.norm(box_pos - self.curr_goal) <= self.dist_threshold
+        return task_success
+
+
+def set_task_planner(cfg):
+    if cfg.env_type == "point_env":
+        return PLANNER_SIMPLE(cfg)
+    raise NotImplementedError("PLANNER_AIF_PANDA (active-inference task planner, task_planner.py:41-107) is "
+                              "outside the hot-path scope of this build (SURVEY.md section 8(f) rank 3)")
+
+
+# ------------------------------------------------------------------ skill_utils.py:25-94
+def calculate_suction(cfg, sim):
+    dir_vector = sim.get_actor_position_by_name("box")[:, :2] - sim.robot_pos
+    magnitude = (1 / torch.linalg.norm(dir_vector, dim=1)).reshape([sim.num_envs, 1])
+    unit_force = dir_vector * magnitude
+    forces = torch.zeros((sim.num_envs, sim.bodies_per_env, 3), dtype=torch.float32, device=sim.device)
+    mask = (magnitude > (1.5 if sim.num_envs == 1 else 1.8)).reshape(sim.num_envs)
+    block_index = sim._get_actor_index_by_name("box").item()
+    forces[mask, block_index, 0] = -cfg.kp_suction * unit_force[mask, 0]
+    forces[mask, block_index, 1] = -cfg.kp_suction * unit_force[mask, 1]
+    forces[mask, -1, 0] = cfg.kp_suction * unit_force[mask, 0]
+    forces[mask, -1, 1] = cfg.kp_suction * unit_force[mask, 1]
+    return torch.clamp(forces, min=-500, max=500)
+
+
+def check_suction_condition(cfg, sim, action):
+    if cfg.task not in ['pull', 'push_pull'] or not cfg.suction_active:
+        return False
+    dir_robot_block = (sim.robot_pos - sim.get_actor_position_by_name("box")[:, :2]).squeeze(0)
+    action_align_pull = torch.sum(action * dir_robot_block).item()
+    return bool(torch.linalg.norm(dir_robot_block) < 0.6 and action_align_pull > 0)
+
+
+def check_and_apply_suction(cfg, sim, action):
+    if check_suction_condition(cfg, sim, action):
+        sim.apply_rigid_body_force_tensors(calculate_suction(cfg, sim))
+        return True
+    return False
+
+
+def time_tracking(t, cfg):
+    actual_dt = time.time() - t
+    if cfg.isaacgym.dt / actual_dt > 1.0:
+        time.sleep(cfg.isaacgym.dt - actual_dt)
+    return time.time()
+
+
+# ------------------------------------------------------------------ config_store.py + yaml values
+@dataclass
+class ExampleConfig:
+    mppi: planner.MPPIConfig
+    isaacgym: isaacgym_wrapper.IsaacGymConfig
+    env_type: str = "point_env"
+    task: str = "push"
+    goal: List[float] = field(default_factory=lambda: [-3.75, -3.75])
+    kp_suction: int = 0
+    suction_active: bool = False
+    multi_modal: bool = False
+    pre_height_diff: float = 0.0
+    cube_on_shelf: bool = False
+    render: bool = False
+    n_steps: int = 0
+    nx: int = 4
+
+
+def make_config(config_name="config_point", overrides=()):
+    """config/config_{point,panda}.yaml + the mppi/ and isaacgym/ groups they compose, then
+    `key=value` / `group.key=value` overrides as on the reference's command line."""
+    import yaml
+    if config_name == "config_point":
+        m = planner.MPPIConfig(mppi_mode="halton-spline", sampling_method="halton", num_samples=200,
+                               horizon=15, nx=4, device="cuda:0", lambda_=0.5, u_min=[-3.0, -3.0],
+                               u_max=[3.0, 3.0], noise_sigma=[[3.0, 0.0], [0.0, 3.0]], u_per_command=15,
+                               sample_null_action=True, filter_u=True, use_priors=False)
+        g = isaacgym_wrapper.IsaacGymConfig(dt=0.05, spacing=10)
+        cfg = ExampleConfig(mppi=m, isaacgym=g, env_type="point_env", task="push", goal=[-3.75, -3.75],
+                            kp_suction=400, suction_active=True, multi_modal=False)
+    elif config_name == "config_panda":
+        sig = [[0.0] * 9 for _ in range(9)]
+        for i in range(7):
+            sig[i][i] = 10.0
+        sig[7][7] = sig[8][8] = 0.8
+        m = planner.MPPIConfig(mppi_mode="halton-spline", sampling_method="halton", num_samples=200,
+                               horizon=12, nx=18, device="cuda:0", u_min=[-2.0] * 7 + [-1.5] * 2,
+                               u_max=[2.0] * 7 + [1.5] * 2, lambda_=0.05, noise_sigma=sig, u_per_command=12,
+                               sample_null_action=True, filter_u=True, use_priors=False)
+        g = isaacgym_wrapper.IsaacGymConfig(dt=0.01, spacing=2, camera_pos=[0, 1.5, 2.8], camera_target=[0, 0, 1])
+        cfg = ExampleConfig(mppi=m, isaacgym=g, env_type="panda_env", task="reactive_pick", goal=[0.0] * 7,
+                            multi_modal=False, pre_height_diff=0.05, cube_on_shelf=False)
+    else:
+        raise ValueError(f"unknown config {config_name!r}")
+    for ov in overrides:
+        key, _, val = ov.partition("=")
+        obj = cfg
+        parts = key.split(".")
+        for p in parts[:-1]:
+            obj = getattr(obj, p)
+        if not hasattr(obj, parts[-1]):
+            raise AttributeError(f"unknown config key {key!r}")
+        setattr(obj, parts[-1], yaml.safe_load(val))
+    return cfg
+
+
+def _hydra_standin():
+    m = types.ModuleType("hydra")
+
+    def main(version_base=None, config_path=None, config_name="config_point"):
+        def deco(fn):
+            def run(*a, **k):
+                if a or k:
+                    return fn(*a, **k)
+                argv, name, ov = sys.argv[1:], config_name, []
+                i = 0
+                while i < len(argv):
+                    if argv[i] in ("-cn", "--config-name"):
+                        name = argv[i + 1]
+                        i += 2
+                    else:
+                        ov.append(argv[i])
+                        i += 1
+                return fn(make_config(name, ov))
+            return run
+        return deco
+
+    m.main = main
+    return m
+
+
+def _zerorpc_standin():
+    m = types.ModuleType("zerorpc")
+
+    class _NoRPC:
+        def __init__(self, *a, **k):
+            self.target = a[0] if a else None
+
+        def bind(self, *a, **k):
+            raise RuntimeError("zerorpc is not installed: the RPC transport of reactive_tamp.py:92-94 is "
+                               "outside this build's scope; call REACTIVE_TAMP.run_tamp() in-process")
+
+        connect = run = bind
+
+    m.Server = m.Client = _NoRPC
+    return m
+
+
+def install(force_standins: bool = False):
+    """Make `import m3p2i_aip...`, `import isaacgym`, `hydra`, `zerorpc` resolve to this build."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    ig = mod("isaacgym")
+    ig.gymtorch = mod("isaacgym.gymtorch")
+    ig.gymapi = mod("isaacgym.gymapi")
+    root = mod("m3p2i_aip")
+    mod("m3p2i_aip.planners")
+    mp = mod("m3p2i_aip.planners.motion_planner")
+    mp.m3p2i = mod("m3p2i_aip.planners.motion_planner.m3p2i", M3P2I=planner.M3P2I)
+    mp.mppi = mod("m3p2i_aip.planners.motion_planner.mppi", MPPI=planner.MPPI, MPPIConfig=planner.MPPIConfig)
+    mp.cost_functions = mod("m3p2i_aip.planners.motion_planner.cost_functions",
+                            Objective=cost_functions.Objective)
+    tp = mod("m3p2i_aip.planners.task_planner")
+    tp.task_planner = mod("m3p2i_aip.planners.task_planner.task_planner", set_task_planner=set_task_planner,
+                          PLANNER_SIMPLE=PLANNER_SIMPLE)
+    cfgm = mod("m3p2i_aip.config")
+    cfgm.config_store = mod("m3p2i_aip.config.config_store", ExampleConfig=ExampleConfig)
+    ut = mod("m3p2i_aip.utils")
+    ut.data_transfer = mod("m3p2i_aip.utils.data_transfer", torch_to_bytes=torch_to_bytes,
+                           bytes_to_torch=bytes_to_torch)
+    ut.skill_utils = mod("m3p2i_aip.utils.skill_utils", calculate_suction=calculate_suction,
+                         check_suction_condition=check_suction_condition,
+                         check_and_apply_suction=check_and_apply_suction, time_tracking=time_tracking)
+    iu = mod("m3p2i_aip.utils.isaacgym_utils")
+    sys.modules["m3p2i_aip.utils.isaacgym_utils.isaacgym_wrapper"] = isaacgym_wrapper
+    iu.isaacgym_wrapper = isaacgym_wrapper
+    ut.isaacgym_utils = iu
+    root.planners, root.config, root.utils = sys.modules["m3p2i_aip.planners"], cfgm, ut
+    sys.modules["m3p2i_aip.planners"].motion_planner = mp
+    sys.modules["m3p2i_aip.planners"].task_planner = tp
+    for name, make in (("hydra", _hydra_standin), ("zerorpc", _zerorpc_standin)):
+        have = False
+        if not force_standins:
+            try:
+                __import__(name)
+                have = True
+            except Exception:
+                have = False
+        if not have:
+            sys.modules[name] = make()

@@ -64,6 +64,9 @@ class IsaacGymWrapper:
         self.cube_on_shelf = cube_on_shelf
         self.viewer = None
         dev = torch.device(device)
+        if dev.type != "cuda" or not torch.cuda.is_available():
+            raise L.M3Error(f"IsaacGymWrapper(device={device!r}): the rollout simulator runs on a HIP "
+                            "device only (no CPU fallback)")
         self.robot_indices = torch.tensor(
             [i for i, a in enumerate(self.env_cfg) if a.type == "robot"], device=dev)
         self.robot_per_env = len(self.robot_indices)

@@ -1,0 +1,106 @@
+"""The reference's scripts import through `m3p2i_aip_amd.compat`."""
+import os
+import runpy
+import sys
+
+import pytest
+
+REF_SCRIPT = "/root/reference/scripts/reactive_tamp.py"
+
+
+def test_reference_import_names_resolve():
+    from m3p2i_aip_amd import compat
+    compat.install(force_standins=True)
+    from isaacgym import gymtorch  # noqa: F401
+    import hydra, zerorpc  # noqa: F401,E401
+    from m3p2i_aip.planners.motion_planner import m3p2i
+    from m3p2i_aip.planners.task_planner import task_planner
+    from m3p2i_aip.config.config_store import ExampleConfig
+    import m3p2i_aip.utils.isaacgym_utils.isaacgym_wrapper as wrapper
+    from m3p2i_aip.planners.motion_planner.cost_functions import Objective
+    from m3p2i_aip.utils.data_transfer import bytes_to_torch, torch_to_bytes
+    from m3p2i_aip.utils.skill_utils import check_and_apply_suction, time_tracking  # noqa: F401
+    import torch
+    assert hasattr(m3p2i, "M3P2I") and hasattr(wrapper, "IsaacGymWrapper") and Objective and ExampleConfig
+    assert torch.equal(bytes_to_torch(torch_to_bytes(torch.arange(5.0))), torch.arange(5.0))
+    cfg = compat.make_config("config_point", ["task=push_pull", "multi_modal=True", "goal=[-1, -1]",
+                                               "mppi.num_samples=64"])
+    assert cfg.multi_modal is True and cfg.goal == [-1, -1] and cfg.mppi.num_samples == 64
+    assert cfg.mppi.horizon == 15 and cfg.isaacgym.dt == 0.05 and cfg.kp_suction == 400
+    p = compat.make_config("config_panda")
+    assert p.env_type == "panda_env" and p.mppi.nx == 18 and p.isaacgym.dt == 0.01 and p.pre_height_diff == 0.05
+    cfg.mppi.device = "cpu"   # PLANNER_SIMPLE only builds the goal tensor (no GPU in this container)
+    tp = task_planner.set_task_planner(cfg)
+    assert tp.task == "push_pull" and tuple(tp.curr_goal.tolist()) == (-1.0, -1.0)
+    with pytest.raises(AttributeError):
+        compat.make_config("config_point", ["no_such_key=1"])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="reference checkout not mounted")
+def test_unchanged_reference_script_loads_on_the_shims():
+    """Executes the reference's scripts/reactive_tamp.py AS IS (module level: imports, class and
+    hydra-decorated entry point) on top of compat; constructing REACTIVE_TAMP then fails loudly
+    here only because this container has no GPU."""
+    from m3p2i_aip_amd import compat
+    from m3p2i_aip_amd._lib import M3Error
+    compat.install(force_standins=True)
+    ns = runpy.run_path(REF_SCRIPT, run_name="reference_reactive_tamp")
+    assert "REACTIVE_TAMP" in ns and callable(ns["run_reactive_tamp"])
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(M3Error):
+            ns["REACTIVE_TAMP"](compat.make_config("config_point", ["mppi.num_samples=64"]))
+
+
+@pytest.mark.gpu
+def test_reactive_tamp_wiring_through_compat_names_gpu():
+    """reactive_tamp.py:22-61 written against the reference's module names, on the GPU."""
+    import torch
+    from m3p2i_aip_amd import compat
+    compat.install(force_standins=True)
+    from m3p2i_aip.planners.motion_planner import m3p2i
+    from m3p2i_aip.planners.task_planner import task_planner
+    import m3p2i_aip.utils.isaacgym_utils.isaacgym_wrapper as wrapper
+    from m3p2i_aip.planners.motion_planner.cost_functions import Objective
+    from m3p2i_aip.utils.data_transfer import bytes_to_torch, torch_to_bytes
+    cfg = compat.make_config("config_point", ["task=push", "goal=[-1, -1]", "mppi.num_samples=256",
+                                               "mppi.horizon=16"])
+
+    class R:
+        def __init__(self):
+            self.sim = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=cfg.mppi.num_samples,
+                                               viewer=False, device=cfg.mppi.device, cube_on_shelf=cfg.cube_on_shelf)
+            self.objective = Objective(cfg)
+            self.task_planner = task_planner.set_task_planner(cfg)
+            self.motion_planner = m3p2i.M3P2I(cfg, dynamics=self.dynamics, running_cost=self.running_cost)
+
+        def dynamics(self, _, u, t=None):
+            self.sim.set_dof_velocity_target_tensor(u)
+            self.sim.step()
+            return torch.stack([self.sim.robot_pos[:, 0], self.sim.robot_vel[:, 0],
+                                self.sim.robot_pos[:, 1], self.sim.robot_vel[:, 1]], dim=1), u
+
+        def running_cost(self, _):
+            return self.objective.compute_cost(self.sim)
+
+    r = R()
+    real = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=1, device=cfg.mppi.device)
+    d0 = None
+    for i in range(40):   # sim.py:38-55 + reactive_tamp.py:43-61, in-process
+        r.sim._dof_state[:] = bytes_to_torch(torch_to_bytes(real._dof_state))
+        r.sim._root_state[:] = bytes_to_torch(torch_to_bytes(real._root_state))
+        r.sim.set_dof_state_tensor(r.sim._dof_state)
+        r.sim.set_actor_root_state_tensor(r.sim._root_state)
+        r.task_planner.update_plan(r.sim)
+        r.objective.update_objective(r.task_planner.task, r.task_planner.curr_goal)
+        r.motion_planner.get_pull_preference()
+        if r.task_planner.check_task_success(r.sim):
+            break
+        action = r.motion_planner.command(r.sim._dof_state[0])[0]
+        real.set_dof_velocity_target_tensor(action.view(1, 2))
+        real.step()
+        box = real.get_actor_position_by_name("box")[0, :2]
+        d = torch.norm(box - r.task_planner.curr_goal).item()
+        d0 = d if d0 is None else d0
+    assert r.motion_planner.probe_result["fused"] is True
+    assert d < d0 - 0.3, (d0, d)   # the closed loop pushes the box towards the goal
