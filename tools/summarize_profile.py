@@ -39,3 +39,24 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
     print(f"== PMC {sub} (per-dispatch mean) ==")
     for k, cs in acc.items():
         print("  ", k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
+
+# optional: HBM bytes per launch of the rollout kernel for bench.py's roofline.traffic
+key = os.environ.get("TRAFFIC_KEY")
+if key:
+    import json
+    vals = {}
+    for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        f = find(sub, "*counter_collection.csv")
+        if f:
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                 if "k_rollout" in r["Kernel_Name"] and r["Counter_Name"] == cname]
+            if v:
+                vals[cname] = sum(v) / len(v)
+    if len(vals) == 2:
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  Calibration: on
+        # this kernel's access pattern (4-8 B per lane loads, 4-16 B per lane stores) the raw
+        # values match the known algorithmic byte counts 1:1, so no x2 read correction is applied.
+        frag = {key: {"hbm_bytes_per_launch": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+                      "fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"]}}
+        json.dump(frag, open(os.path.join(root, "traffic_fragment.json"), "w"))
+        print("traffic", frag)
