@@ -1,0 +1,88 @@
+"""Two PROCESSES sharing the one GPU of the test box, real HIP engines, collectives over gloo
+(RCCL refuses two ranks on one device).  Exercises exactly the code bench.py runs for N > 1 --
+`planner.py` phase sequencing with `distributed.attach_collectives` on device tensors that are
+zero-copy views of library-owned buffers -- and checks sharded == unsharded."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+K, T = 512, 30
+
+
+def build(rank, world, multi_modal, task, goal):
+    sys.path.insert(0, ROOT)
+    from m3p2i_aip_amd import isaacgym_wrapper as wrapper
+    from m3p2i_aip_amd.cost_functions import Objective
+    from m3p2i_aip_amd.planner import M3P2I, MPPIConfig
+    m = MPPIConfig(num_samples=K, horizon=T, nx=4, device="cuda:0", lambda_=0.5, u_min=[-3.0, -3.0],
+                   u_max=[3.0, 3.0], noise_sigma=[[3.0, 0.0], [0.0, 3.0]], u_per_command=T,
+                   sample_null_action=True, filter_u=True, fused=True, rank=rank, world_size=world)
+    cfg = SimpleNamespace(env_type="point_env", multi_modal=multi_modal, suction_active=True, kp_suction=400,
+                          pre_height_diff=0.0, task=task, goal=list(goal), cube_on_shelf=False, mppi=m,
+                          isaacgym=wrapper.IsaacGymConfig(dt=0.05))
+    sim = wrapper.IsaacGymWrapper(cfg.isaacgym, "point_env", num_envs=64, device="cuda:0")
+    sim._dof_state[:, 2] = 1.5   # robot at (0, 1.5): inside the suction range of the box
+    sim.set_dof_state_tensor(sim._dof_state)
+    obj = Objective(cfg)
+    obj.update_objective(task, list(goal))
+    pl = M3P2I(cfg).attach(sim, obj)
+    return pl, sim
+
+
+def run(pl, sim, delta, n=4):
+    pl.set_noise(delta[pl.k_offset:pl.k_offset + pl.K_local])
+    out = []
+    for _ in range(n):
+        a = pl.command(sim._dof_state[0])
+        out.append(dict(action=a.cpu().numpy(), weights=pl.weights.cpu().numpy().copy(),
+                        top=pl.top_trajs.cpu().numpy().copy(), pref=pl.get_pull_preference()))
+    return out
+
+
+def worker(rank, world, port, multi_modal, task, goal, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from m3p2i_aip_amd.distributed import attach_collectives
+    delta = np.load(os.path.join(ROOT, "tests", "golden", "ref_golden.npz"))["g9_push_delta"]
+    delta = np.concatenate([delta, delta[::-1] * 0.7]).astype(np.float32)   # 512 distinct rows
+    pl, sim = build(rank, world, multi_modal, task, goal)
+    attach_collectives(pl)
+    out = run(pl, sim, delta)
+    if rank == 0:
+        ret.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("multi_modal,task,goal", [(False, "push", (-1.0, -1.0)),
+                                                   (True, "push_pull", (-3.75, -3.75))])
+def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal):
+    import torch.multiprocessing as mp
+    delta = golden["g9_push_delta"]
+    delta = np.concatenate([delta, delta[::-1] * 0.7]).astype(np.float32)
+    pl, sim = build(0, 1, multi_modal, task, goal)
+    ref = run(pl, sim, delta)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29700 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=worker, args=(r, 2, port, multi_modal, task, goal, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = ret.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for c, (a, b) in enumerate(zip(ref, got)):
+        np.testing.assert_allclose(a["action"], b["action"], atol=1e-5, err_msg=f"call {c}")
+        np.testing.assert_allclose(a["weights"], b["weights"], rtol=1e-3, atol=1e-8)
+        np.testing.assert_allclose(a["top"], b["top"], atol=1e-4)
+        assert a["pref"] == b["pref"]
