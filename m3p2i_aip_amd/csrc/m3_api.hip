@@ -61,55 +61,31 @@ extern "C" void m3_default_config(m3_config* c, int env_type) {
 // pointRobot.urdf, isaacgym_wrapper.py:18-37,341-344,462-469)
 static void build_point_scene(const m3_config& c, PointScene& s) {
     const float h = c.dt / (float)c.substeps;
-    s.h = h; s.substeps = c.substeps; s.iters = c.solver_iters;
+    s.h = h; s.inv_h = 1.0f / h; s.substeps = c.substeps; s.iters = c.solver_iters;
     const float g = 9.8f;
-    s.robot_r = 0.2f; s.invm_r = 1.0f / 10.0f;
+    const float invm_r = 1.0f / 10.0f;
     s.gam = 1.0f / (h * 600.0f);
-    s.md = 1.0f / (s.invm_r + s.gam);
+    s.md = 1.0f / (invm_r + s.gam);
     s.dmax = 1000.0f * h;
     const float req = 0.3825978f * 0.4f;
-    s.box_hx = 0.2f; s.box_hy = 0.2f; s.box_m = 16.0f;
-    s.box_I = 16.0f * (0.4f * 0.4f + 0.4f * 0.4f) / 12.0f;
-    s.invm_b = 1.0f / s.box_m; s.invI_b = 1.0f / s.box_I;
-    s.LlinB = ((0.75f * s.box_m) * g) * h; s.LangB = s.LlinB * req;
-    s.dyn_hx = 0.2f; s.dyn_hy = 0.2f; s.dyn_m = 16.0f;
-    s.dyn_I = 16.0f * (0.4f * 0.4f + 0.4f * 0.4f) / 12.0f;
-    s.invm_d = 1.0f / s.dyn_m; s.invI_d = 1.0f / s.dyn_I;
-    s.LlinD = ((1.0f * s.dyn_m) * g) * h; s.LangD = s.LlinD * req;
-    s.obs_x = 2.0f; s.obs_y = 2.0f; s.obs_hx = 0.15f; s.obs_hy = 0.2f;
-    s.wall = 3.95f;
-    s.mu_rb = 0.275f; s.mu_rd = 0.525f; s.mu_ro = 0.525f; s.mu_rw = 0.525f;
-    s.mu_bw = 0.75f; s.mu_dw = 1.0f; s.mu_bd = 0.75f; s.mu_bo = 0.75f; s.mu_do = 1.0f;
-    s.contact_offset = 0.01f; s.baumgarte = 0.2f; s.slop = 0.005f; s.max_bias = 2.0f;
-    s.face_tol = 0.0005f;
-    s.rad_b = std::sqrt(s.box_hx * s.box_hx + s.box_hy * s.box_hy);
-    s.rad_d = std::sqrt(s.dyn_hx * s.dyn_hx + s.dyn_hy * s.dyn_hy);
-    s.rad_o = std::sqrt(s.obs_hx * s.obs_hx + s.obs_hy * s.obs_hy);
+    s.LlinB = ((0.75f * 16.0f) * g) * h; s.LangB = s.LlinB * req;
+    s.LlinD = ((1.0f * 16.0f) * g) * h; s.LangD = s.LlinD * req;
+    // everything else of the scene is compile-time constant in PointScene (planar_dyn.hpp)
 }
 
 // "Panda chain spec v1" constants (sources: franka_panda.urdf limits, config/
 // panda_env/*.yaml, isaacgym_wrapper.py:341-344)
 static void build_panda_scene(const m3_config& c, PandaScene& s) {
-    std::memset(&s, 0, sizeof(s));
-    s.h = c.dt / (float)c.substeps; s.substeps = c.substeps; s.g = 9.8f;
-    s.base[0] = -0.45f; s.base[1] = 0.0f; s.base[2] = 1.125f;
-    s.drive_damping = 600.0f;
+    const float h = c.dt / (float)c.substeps;
+    s.h = h; s.substeps = c.substeps;
     const float inertia[9] = {1.0f, 1.0f, 0.5f, 0.5f, 0.1f, 0.1f, 0.05f, 0.1f, 0.1f};
     const float effort[9] = {87, 87, 87, 87, 12, 12, 12, 20, 20};
-    const float vlim[9] = {2.175f, 2.175f, 2.175f, 2.175f, 2.61f, 2.61f, 2.61f, 0.2f, 0.2f};
-    const float lo[9] = {-2.8973f, -1.7628f, -2.8973f, -3.0718f, -2.8973f, -0.0175f, -2.8973f, 0.0f, 0.0f};
-    const float hi[9] = {2.8973f, 1.7628f, 2.8973f, -0.0698f, 2.8973f, 3.7525f, 2.8973f, 0.04f, 0.04f};
-    for (int i = 0; i < 9; ++i) {
-        s.inertia[i] = inertia[i]; s.effort[i] = effort[i]; s.vlim[i] = vlim[i];
-        s.qlo[i] = lo[i]; s.qhi[i] = hi[i];
+    for (int i = 0; i < 9; ++i) {  // spec: per-dof servo constants in f32
+        s.a[i] = (h * 600.0f) / inertia[i];
+        s.rden[i] = 1.0f / (1.0f + s.a[i]);
+        s.dv[i] = (h * effort[i]) / inertia[i];
     }
-    const float table[6] = {0.0f, 0.0f, 1.0f, 0.6f, 0.6f, 0.025f};
-    const float shelf[6] = {0.5f, 0.0f, 1.175f, 0.1f, 0.1f, 0.15f};
-    for (int i = 0; i < 6; ++i) { s.table[i] = table[i]; s.shelf[i] = shelf[i]; }
-    s.cube_half = 0.025f; s.cube_m = 0.125f; s.cube_mu = 1.0f;
-    s.grasp_z = 0.1034f; s.grasp_dx = 0.02f; s.grasp_dz = 0.02f; s.grasp_align = 0.95f; s.grasp_tol = 0.002f;
-    s.k_contact = 5000.0f;
-    s.tip_z = 0.045f; s.tip_r = 0.012f; s.hand_z = 0.03f; s.hand_r = 0.04f;
+    // everything else of the scene is compile-time constant in PandaScene (panda_dyn.hpp)
 }
 
 static void default_panda_world(float* w, int cube_on_shelf) {

@@ -20,18 +20,27 @@
 
 namespace m3 {
 
+// Kernel argument: only what depends on dt/substeps (per-dof servo constants, computed once on
+// the host in f32: a = hD/I, rden = 1/(1+a), dv = h*effort/I).  Everything the URDF / yaml
+// files fix is compile-time constant and folds into the (fully unrolled) per-dof code.
 struct PandaScene {
     float h;  // substep
     int substeps;
-    float g;
-    float base[3];
-    float drive_damping;
-    float inertia[9], effort[9], vlim[9], qlo[9], qhi[9];
-    float table[6], shelf[6];
-    float cube_half, cube_m, cube_mu;
-    float grasp_z, grasp_dx, grasp_dz, grasp_align, grasp_tol;
-    float k_contact;
-    float tip_z, tip_r, hand_z, hand_r;
+    float a[9], rden[9], dv[9];
+    static constexpr float g = 9.8f;
+    static constexpr float drive_damping = 600.0f;                       // isaacgym_wrapper.py:344
+    static constexpr float base[3] = {-0.45f, 0.0f, 1.125f};             // panda.yaml:8
+    static constexpr float effort[9] = {87, 87, 87, 87, 12, 12, 12, 20, 20};  // urdf :34..240
+    static constexpr float vlim[9] = {2.175f, 2.175f, 2.175f, 2.175f, 2.61f, 2.61f, 2.61f, 0.2f, 0.2f};
+    static constexpr float qlo[9] = {-2.8973f, -1.7628f, -2.8973f, -3.0718f, -2.8973f, -0.0175f, -2.8973f, 0.0f, 0.0f};
+    static constexpr float qhi[9] = {2.8973f, 1.7628f, 2.8973f, -0.0698f, 2.8973f, 3.7525f, 2.8973f, 0.04f, 0.04f};
+    static constexpr float table[6] = {0.0f, 0.0f, 1.0f, 0.6f, 0.6f, 0.025f};    // 1_table.yaml
+    static constexpr float shelf[6] = {0.5f, 0.0f, 1.175f, 0.1f, 0.1f, 0.15f};   // 3_shelf_stand.yaml
+    static constexpr float cube_half = 0.025f, cube_m = 0.125f, cube_mu = 1.0f;  // 5_cubeA.yaml
+    static constexpr float grasp_z = 0.1034f, grasp_dx = 0.02f, grasp_dz = 0.02f;
+    static constexpr float grasp_align = 0.95f, grasp_tol = 0.002f;
+    static constexpr float k_contact = 5000.0f;
+    static constexpr float tip_z = 0.045f, tip_r = 0.012f, hand_z = 0.03f, hand_r = 0.04f;
 };
 
 struct PandaWorld {
@@ -240,11 +249,10 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             if (w.held != 0.0f && i >= 7) { w.qd[i] = 0.0f; continue; }
-            const float a = (h * sc.drive_damping) / sc.inertia[i];
-            float qd1 = (w.qd[i] + a * u[i]) / (1.0f + a);
+            float qd1 = (w.qd[i] + sc.a[i] * u[i]) * sc.rden[i];
             const float tau = sc.drive_damping * (u[i] - qd1);
-            if (tau > sc.effort[i]) qd1 = w.qd[i] + (h * sc.effort[i]) / sc.inertia[i];
-            if (tau < -sc.effort[i]) qd1 = w.qd[i] - (h * sc.effort[i]) / sc.inertia[i];
+            if (tau > sc.effort[i]) qd1 = w.qd[i] + sc.dv[i];
+            if (tau < -sc.effort[i]) qd1 = w.qd[i] - sc.dv[i];
             qd1 = fminf(fmaxf(qd1, -sc.vlim[i]), sc.vlim[i]);
             float q1 = w.q[i] + h * qd1;
             if (q1 < sc.qlo[i]) { q1 = sc.qlo[i]; qd1 = 0.0f; }

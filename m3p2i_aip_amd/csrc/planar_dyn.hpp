@@ -18,19 +18,33 @@
 
 namespace m3 {
 
+// Only what depends on dt / substeps / iterations travels as a kernel argument (10 scalars in
+// SGPRs).  The scene the reference fixes in its yaml/urdf files is compile-time constant: it
+// folds into the instruction stream instead of occupying ~40 more SGPRs (the first version
+// passed everything at run time and spilled 120+ SGPRs to VGPR lanes).
 struct PointScene {
     float h;  // substep = dt / substeps
+    float inv_h;  // 1 / h (spec v1.2: divisions by h, d, den, nrm are one reciprocal + multiplies)
     int substeps;
     int iters;
-    float robot_r, invm_r;
     float gam, md, dmax;  // velocity drive: 1/(h*D), 1/(invm_r+gam), fmax*h
-    float box_hx, box_hy, box_m, box_I, invm_b, invI_b, LlinB, LangB;
-    float dyn_hx, dyn_hy, dyn_m, dyn_I, invm_d, invI_d, LlinD, LangD;
-    float obs_x, obs_y, obs_hx, obs_hy;
-    float wall;
-    float mu_rb, mu_rd, mu_ro, mu_rw, mu_bw, mu_dw, mu_bd, mu_bo, mu_do;
-    float contact_offset, baumgarte, slop, max_bias, face_tol;
-    float rad_b, rad_d, rad_o;  // bounding radii for the (conservative) broad phase
+    float LlinB, LangB, LlinD, LangD;  // ground-friction impulse limits (mu m g h, * r_eq)
+    // ---- constants of the scene (config/point_env/*.yaml, pointRobot.urdf) ----
+    static constexpr float robot_r = 0.2f, invm_r = 1.0f / 10.0f;
+    static constexpr float box_hx = 0.2f, box_hy = 0.2f, box_m = 16.0f;
+    static constexpr float box_I = 16.0f * (0.4f * 0.4f + 0.4f * 0.4f) / 12.0f;
+    static constexpr float invm_b = 1.0f / box_m, invI_b = 1.0f / box_I;
+    static constexpr float dyn_hx = 0.2f, dyn_hy = 0.2f, dyn_m = 16.0f;
+    static constexpr float dyn_I = 16.0f * (0.4f * 0.4f + 0.4f * 0.4f) / 12.0f;
+    static constexpr float invm_d = 1.0f / dyn_m, invI_d = 1.0f / dyn_I;
+    static constexpr float obs_x = 2.0f, obs_y = 2.0f, obs_hx = 0.15f, obs_hy = 0.2f;
+    static constexpr float wall = 3.95f;
+    static constexpr float mu_rb = 0.275f, mu_rd = 0.525f, mu_ro = 0.525f, mu_rw = 0.525f;
+    static constexpr float mu_bw = 0.75f, mu_dw = 1.0f, mu_bd = 0.75f, mu_bo = 0.75f, mu_do = 1.0f;
+    static constexpr float contact_offset = 0.01f, baumgarte = 0.2f, slop = 0.005f, max_bias = 2.0f;
+    static constexpr float face_tol = 0.0005f;
+    // bounding radii for the (conservative) broad phase: >= sqrt(hx^2 + hy^2)
+    static constexpr float rad_b = 0.28285f, rad_d = 0.28285f, rad_o = 0.25f;
 };
 
 struct Box {
@@ -135,11 +149,11 @@ __device__ __forceinline__ void prepare(const PointScene& sc, Slot& c, float nx,
     c.mn = 1.0f / kn;
     c.mt = 1.0f / kt;
     if (sep > 0.0f) {
-        c.bias = sep / sc.h;
+        c.bias = sep * sc.inv_h;
     } else {
         float pen = -sep - sc.slop;
         if (pen < 0.0f) pen = 0.0f;
-        float push = sc.baumgarte * pen / sc.h;
+        float push = (sc.baumgarte * pen) * sc.inv_h;
         if (push > sc.max_bias) push = sc.max_bias;
         c.bias = -push;
     }
@@ -200,7 +214,8 @@ __device__ __forceinline__ void detect_disc_box(const PointScene& sc, Slot& c, f
     float nlx, nly, sep;
     if (d2 > 0.0f) {
         const float d = sqrtf(d2);
-        nlx = ex / d; nly = ey / d;
+        const float rd = 1.0f / d;
+        nlx = ex * rd; nly = ey * rd;
         sep = d - r;
     } else {
         const float ppx = hx - fabsf(lx), ppy = hy - fabsf(ly);
@@ -399,13 +414,15 @@ __device__ __forceinline__ void integrate_box(Box& X, float h) {
     const float a = 0.5f * (h * X.w);
     const float a2 = a * a;
     const float den = 1.0f + a2;
-    const float cd = (1.0f - a2) / den;
-    const float sd = (2.0f * a) / den;
+    const float rden = 1.0f / den;
+    const float cd = (1.0f - a2) * rden;
+    const float sd = (2.0f * a) * rden;
     const float c = X.c * cd - X.s * sd;
     const float s = X.s * cd + X.c * sd;
     const float nrm = sqrtf(c * c + s * s);
-    X.c = c / nrm;
-    X.s = s / nrm;
+    const float rn = 1.0f / nrm;
+    X.c = c * rn;
+    X.s = s * rn;
 }
 
 // impulse of slot c on its body b (+) / a (-), accumulated in slot order like the oracle
@@ -520,7 +537,7 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
                 M3_ACC(fx, fy, s_do1, -1) M3_ACC(fx, fy, s_do2, -1)
             }
             fx += fD.lx; fy += fD.ly;
-            w.fcDx = fx / h; w.fcDy = fy / h;
+            w.fcDx = fx * sc.inv_h; w.fcDy = fy * sc.inv_h;
         }
         if constexpr (ALL_FORCES) {
             float fx = 0.0f, fy = 0.0f;
@@ -530,11 +547,11 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
             M3_ACC(fx, fy, s_bd1, -1) M3_ACC(fx, fy, s_bd2, -1)
             M3_ACC(fx, fy, s_bo1, -1) M3_ACC(fx, fy, s_bo2, -1)
             fx += fB.lx; fy += fB.ly;
-            w.fcBx = fx / h; w.fcBy = fy / h;
+            w.fcBx = fx * sc.inv_h; w.fcBy = fy * sc.inv_h;
             fx = 0.0f; fy = 0.0f;
             M3_ACC(fx, fy, s_rb, -1) M3_ACC(fx, fy, s_rd, -1) M3_ACC(fx, fy, s_ro, -1)
             M3_ACC(fx, fy, s_rwx, -1) M3_ACC(fx, fy, s_rwy, -1)
-            w.fcRx = fx / h; w.fcRy = fy / h;
+            w.fcRx = fx * sc.inv_h; w.fcRy = fy * sc.inv_h;
         }
 
         // 4. integrate

@@ -193,11 +193,14 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
         /* 1. velocity servo per dof (implicit damper, torque + velocity + position limits) */
         for (int i = 0; i < 9; ++i) {
             if (w->held != 0.0f && i >= 7) { w->qd[i] = 0.0f; continue; } /* fingers locked on the cube */
+            /* spec: per-dof constants a = hD/I, rden = 1/(1+a), dv = h*effort/I (f32) */
             float a = (h * sc->drive_damping) / sc->inertia[i];
-            float qd1 = (w->qd[i] + a * u[i]) / (1.0f + a);
+            float rden = 1.0f / (1.0f + a);
+            float dv = (h * sc->effort[i]) / sc->inertia[i];
+            float qd1 = (w->qd[i] + a * u[i]) * rden;
             float tau = sc->drive_damping * (u[i] - qd1);
-            if (tau > sc->effort[i]) qd1 = w->qd[i] + (h * sc->effort[i]) / sc->inertia[i];
-            if (tau < -sc->effort[i]) qd1 = w->qd[i] - (h * sc->effort[i]) / sc->inertia[i];
+            if (tau > sc->effort[i]) qd1 = w->qd[i] + dv;
+            if (tau < -sc->effort[i]) qd1 = w->qd[i] - dv;
             qd1 = fminf(fmaxf(qd1, -sc->vlim[i]), sc->vlim[i]);
             float q1 = w->q[i] + h * qd1;
             if (q1 < sc->qlo[i]) { q1 = sc->qlo[i]; qd1 = 0.0f; }

@@ -109,7 +109,8 @@ static void detect_disc_box(const m3o_point_scene* sc, solver_t* s, const m3o_bo
     float nlx, nly, sep;
     if (d2 > 0.0f) {
         float d = sqrtf(d2);
-        nlx = ex / d; nly = ey / d;
+        float rd = 1.0f / d; /* spec v1.2: one reciprocal, two multiplies */
+        nlx = ex * rd; nly = ey * rd;
         sep = d - r;
     } else {
         float px = hx - fabsf(lx), py = hy - fabsf(ly);
@@ -259,6 +260,7 @@ static void detect_box_box(const m3o_point_scene* sc, solver_t* s, int ia, float
 }
 
 static void prepare_contacts(const m3o_point_scene* sc, solver_t* s, float h) {
+    const float inv_h = 1.0f / h; /* spec v1.2 */
     for (int i = 0; i < s->nc; ++i) {
         contact_t* c = &s->c[i];
         float tx = -c->ny, ty = c->nx;
@@ -273,11 +275,11 @@ static void prepare_contacts(const m3o_point_scene* sc, solver_t* s, float h) {
         c->mn = 1.0f / kn;
         c->mt = 1.0f / kt;
         if (c->sep > 0.0f) {
-            c->bias = c->sep / h;
+            c->bias = c->sep * inv_h;
         } else {
             float pen = -c->sep - sc->slop;
             if (pen < 0.0f) pen = 0.0f;
-            float push = sc->baumgarte * pen / h;
+            float push = (sc->baumgarte * pen) * inv_h;
             if (push > sc->max_bias) push = sc->max_bias;
             c->bias = -push;
         }
@@ -351,18 +353,21 @@ static void integrate_body(m3o_body* X, float h, int rotate) {
         float a = 0.5f * (h * X->w);
         float a2 = a * a;
         float den = 1.0f + a2;
-        float cd = (1.0f - a2) / den;
-        float sd = (2.0f * a) / den;
+        float rden = 1.0f / den;
+        float cd = (1.0f - a2) * rden;
+        float sd = (2.0f * a) * rden;
         float c = X->c * cd - X->s * sd;
         float s = X->s * cd + X->c * sd;
         float nrm = sqrtf(c * c + s * s);
-        X->c = c / nrm;
-        X->s = s / nrm;
+        float rn = 1.0f / nrm;
+        X->c = c * rn;
+        X->s = s * rn;
     }
 }
 
 void m3o_point_step(const m3o_point_scene* sc, m3o_point_world* w, const float u[2]) {
     const float h = sc->dt / (float)sc->substeps;
+    const float inv_h = 1.0f / h;
     solver_t s;
     s.invm[BR] = 1.0f / sc->robot_m; s.invI[BR] = 0.0f;
     s.invm[BB] = 1.0f / sc->box_m;   s.invI[BB] = 1.0f / sc->box_I;
@@ -444,9 +449,9 @@ void m3o_point_step(const m3o_point_scene* sc, m3o_point_world* w, const float u
         }
         fx[BB] += fB.lx; fy[BB] += fB.ly;
         fx[BD] += fD.lx; fy[BD] += fD.ly;
-        w->fc_R[0] = fx[BR] / h; w->fc_R[1] = fy[BR] / h;
-        w->fc_B[0] = fx[BB] / h; w->fc_B[1] = fy[BB] / h;
-        w->fc_D[0] = fx[BD] / h; w->fc_D[1] = fy[BD] / h;
+        w->fc_R[0] = fx[BR] * inv_h; w->fc_R[1] = fy[BR] * inv_h;
+        w->fc_B[0] = fx[BB] * inv_h; w->fc_B[1] = fy[BB] * inv_h;
+        w->fc_D[0] = fx[BD] * inv_h; w->fc_D[1] = fy[BD] * inv_h;
 
         /* 4. integrate */
         integrate_body(&w->R, h, 0);
