@@ -49,6 +49,7 @@ struct VI {  // (cost, global sample index) candidate of the top-k selection
 struct UpdateArgs {
     VI* cand;    // [n_cand][M3_TOPK] per-workgroup top-k candidates (k_weights -> k_wsum)
     int n_cand;
+    int lds_floats;  // costs staged in dynamic LDS by k_weights (set by launch_weights)
     int Kg, Kl, k0, T, nu;
     int multi_modal, mode_simple, env_type, filter_u, u_per_command;
     float lambda_, step_size_mean;

@@ -157,7 +157,9 @@ __device__ __forceinline__ VI block_argmin(VI x, VI* lds) {
     return r;
 }
 
-// grid = 2 workgroups: 0 -> weights/info, 1 -> top-k (independent, runs concurrently)
+// grid = 1 + n_cand workgroups: 0 -> weights/info, 1.. -> top-k stage A (run concurrently).
+// JR = costs per thread held in registers by workgroup 0.
+template <int JR>
 __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
     __shared__ float red[3 * 16];
     __shared__ VI redvi[16];
@@ -219,22 +221,39 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
         return;
     }
 
-    // stage the costs in LDS once: every later pass (min, up to ~25 beta-search passes x 3
-    // searches, final weights) then reads LDS at stride blockDim (conflict-free) instead of
-    // paying an L2 round trip per element per pass
+    // The costs are read ONCE into registers (thread t holds J[t + e*blockDim], e < JR): the
+    // min pass, the up-to-~25 beta-search passes x 3 searches and the final weight pass are
+    // then pure VALU + wave reductions instead of an L2 round trip per element per pass
+    // (K = 64000 multi-modal: 207 us with the costs re-read from L2 beyond a 60 KB LDS stage).
+    // Costs beyond JR*blockDim (K > 65536) fall back to memory.
+    float jr[JR];
+#pragma unroll
+    for (int e_ = 0; e_ < JR; ++e_) {
+        const int k = e_ * WT + tid;
+        jr[e_] = (k < Kg) ? J[k] : INF;
+    }
+    // second tier: the next a.lds_floats costs live in LDS (1024 threads x 48 registers +
+    // 15000 LDS floats cover K = 64000 without touching L2 again); third tier: memory
     extern __shared__ __attribute__((aligned(16))) float sJ[];
-    const int n_lds = (Kg < WEIGHTS_LDS_MAX) ? Kg : WEIGHTS_LDS_MAX;
-    for (int k = tid; k < n_lds; k += WT) sJ[k] = J[k];
+    const int lds0 = JR * WT;
+    const int lds1 = (Kg < lds0 + a.lds_floats) ? Kg : lds0 + a.lds_floats;
+    for (int k = lds0 + tid; k < lds1; k += WT) sJ[k - lds0] = J[k];
     __syncthreads();
-#define LDJ(k) (((k) < n_lds) ? sJ[(k)] : J[(k)])
+#define FOR_J(...)                                                                   \
+    _Pragma("unroll") for (int e_ = 0; e_ < JR; ++e_) {                              \
+        if (e_ * WT >= Kg) break; /* wave-uniform */                                 \
+        const int k = e_ * WT + tid;                                                 \
+        if (k < Kg) { const float v = jr[e_]; __VA_ARGS__ }                          \
+    }                                                                                \
+    for (int k = lds0 + tid; k < lds1; k += WT) { const float v = sJ[k - lds0]; __VA_ARGS__ } \
+    for (int k = (lds1 > lds0 ? lds1 : lds0) + tid; k < Kg; k += WT) { const float v = J[k]; __VA_ARGS__ }
 
     // ---- minima (all, first half, second half) ----
     float mn[3] = {INF, INF, INF};
-    for (int k = tid; k < Kg; k += WT) {
-        const float v = LDJ(k);
+    FOR_J({
         mn[0] = fminf(mn[0], v);
         if (k < half) mn[1] = fminf(mn[1], v); else mn[2] = fminf(mn[2], v);
-    }
+    })
     block_min<3>(mn, red);
 
     float beta[3], eta[3];
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
         const float b = a.mode_simple ? a.lambda_ : a.info->beta;
         float e[1] = {0.0f};
         const float nib = -1.0f / b;
-        for (int k = tid; k < Kg; k += WT) e[0] += m3_exp(nib * (LDJ(k) - mn[0]));
+        FOR_J({ e[0] += m3_exp(nib * (v - mn[0])); })
         block_sum<1>(e, red);
         beta[0] = b; eta[0] = e[0];
         beta[1] = beta[2] = 1.0f; eta[1] = eta[2] = 0.0f;
@@ -260,12 +279,11 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
             if (d0 && d1 && d2) break;
             float e[3] = {0.0f, 0.0f, 0.0f};
             const float n0 = -1.0f / b0, n1 = -1.0f / b1, n2 = -1.0f / b2;
-            for (int k = tid; k < Kg; k += WT) {
-                const float v = LDJ(k);
+            FOR_J({
                 if (!d0) e[0] += m3_exp(n0 * (v - mn[0]));
                 if (k < half) { if (!d1) e[1] += m3_exp(n1 * (v - mn[1])); }
                 else { if (!d2) e[2] += m3_exp(n2 * (v - mn[2])); }
-            }
+            })
             block_sum<3>(e, red);
             __syncthreads();
             if (tid < 3 && !s_done[tid]) {
@@ -290,8 +308,7 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
     const float i0 = 1.0f / eta[0], n0 = -1.0f / beta[0];
     float hs[2] = {0.0f, 0.0f};
     VI b0 = {INF, 0x7fffffff}, b1 = {INF, 0x7fffffff}, b2 = {INF, 0x7fffffff};
-    for (int k = tid; k < Kg; k += WT) {
-        const float v = LDJ(k);
+    FOR_J({
         const float wk = i0 * m3_exp(n0 * (v - mn[0]));
         a.w[k] = wk;
         if (k < half) hs[0] += wk; else hs[1] += wk;
@@ -308,7 +325,8 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
                 if (vi_less(-w2k, k, b2.v, b2.i)) { b2.v = -w2k; b2.i = k; }
             }
         }
-    }
+    })
+#undef FOR_J
     block_sum<2>(hs, red);
     b0 = block_argmin(b0, redvi);
     if (a.multi_modal && !a.mode_simple) {
@@ -347,7 +365,15 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
     // few waves for small K: the block-wide reductions (2 barriers + a serial pass over the
     // waves' partials) dominate, not the K/threads elements per thread
     const int threads = weights_threads(a.Kg);
-    hipLaunchKernelGGL(k_weights, dim3(1 + a.n_cand), dim3(threads), weights_lds_floats(a.Kg) * sizeof(float), s, a);
+    UpdateArgs b = a;
+    if (threads == 256) {
+        b.lds_floats = 0;
+        hipLaunchKernelGGL(k_weights<32>, dim3(1 + a.n_cand), dim3(256), 0, s, b);
+    } else {
+        const int rest = a.Kg - 48 * WT_MAX;
+        b.lds_floats = rest <= 0 ? 0 : (rest < WEIGHTS_LDS_MAX ? rest : WEIGHTS_LDS_MAX);
+        hipLaunchKernelGGL(k_weights<48>, dim3(1 + a.n_cand), dim3(WT_MAX), b.lds_floats * sizeof(float), s, b);
+    }
 }
 
 // one workgroup per time step t: sum_k w_k * actions[t][k][:] over the local shard, for the
