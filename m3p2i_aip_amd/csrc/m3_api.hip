@@ -178,6 +178,8 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     A(M3_BUF_INFO, sizeof(m3_info));
     if (rc == M3_OK && hipMalloc((void**)&h->world0_dev, 18 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->topk_cand, (size_t)topk_workgroups((int)Kg) * M3_TOPK * sizeof(VI)) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->part_min, (size_t)mins_workgroups((int)Kg) * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->lad, (size_t)ladder_workgroups((int)Kg) * 96 * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK) {
         m3_info init;
         std::memset(&init, 0, sizeof(init));
@@ -200,6 +202,8 @@ extern "C" void m3_destroy(m3_handle* h) {
         if (h->buf[i]) (void)hipFree(h->buf[i]);
     if (h->world0_dev) (void)hipFree(h->world0_dev);
     if (h->topk_cand) (void)hipFree(h->topk_cand);
+    if (h->part_min) (void)hipFree(h->part_min);
+    if (h->lad) (void)hipFree(h->lad);
     if (h->sim_world) (void)hipFree(h->sim_world);
     if (h->sim_u) (void)hipFree(h->sim_u);
     if (h->noise_stage) (void)hipFree(h->noise_stage);
@@ -431,7 +435,11 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.filter_u = c.filter_u; a.u_per_command = c.u_per_command;
     a.lambda_ = c.lambda_; a.step_size_mean = c.step_size_mean;
     a.cand = h->topk_cand;
+    a.part_min = h->part_min;
     a.n_cand = topk_workgroups(c.K_global);
+    a.n_mins = mins_workgroups(c.K_global);
+    a.lad = h->lad;
+    a.n_lad = ladder_workgroups(c.K_global);
     a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST_ALL];
     a.w = (float*)h->buf[M3_BUF_WEIGHTS];
     a.w1 = (float*)h->buf[M3_BUF_WEIGHTS_1];
@@ -459,6 +467,12 @@ extern "C" int m3_update(m3_handle* h) {
     fill_update_args(h, a);
     if (c.K_local == c.K_global)  // unsharded: the local costs ARE the global costs (no copy)
         a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST];
+    // (minima + beta ladder for the multi-modal search) -> weights (+ top-k stage A as extra
+    // workgroups) -> weighted sums (+ top-k stage B as an extra workgroup)
+    if (c.multi_modal && !c.mode_simple) {
+        launch_mins(a, h->stream);
+        launch_ladder(a, h->stream);
+    }
     launch_weights(a, h->stream);
     launch_wsum(a, h->stream);
     HIPCHK(h, hipGetLastError());

@@ -47,9 +47,13 @@ struct VI {  // (cost, global sample index) candidate of the top-k selection
 };
 
 struct UpdateArgs {
-    VI* cand;    // [n_cand][M3_TOPK] per-workgroup top-k candidates (k_weights -> k_wsum)
-    int n_cand;
-    int lds_floats;  // costs staged in dynamic LDS by k_weights (set by launch_weights)
+    VI* cand;         // [n_cand][M3_TOPK] per-workgroup top-k candidates (k_prep -> k_wsum)
+    float* part_min;  // [n_mins][3] per-workgroup minima (all, first half, second half)
+    int n_mins;       // workgroups of k_mins
+    int n_cand;       // top-k stage-A workgroups (extra workgroups of the k_weights launch)
+    float* lad;       // [n_lad][96][3] per-workgroup eta sums on the beta ladders (k_ladder)
+    int n_lad;        // workgroups of k_ladder
+    int lds_floats;   // costs staged in dynamic LDS by k_weights (set by launch_weights)
     int Kg, Kl, k0, T, nu;
     int multi_modal, mode_simple, env_type, filter_u, u_per_command;
     float lambda_, step_size_mean;
@@ -87,7 +91,11 @@ void launch_weights(const UpdateArgs& a, hipStream_t s);
 void launch_wsum(const UpdateArgs& a, hipStream_t s);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);
 int rollout_lanes_for(int Kl);
+int mins_workgroups(int Kg);
 int topk_workgroups(int Kg);
+int ladder_workgroups(int Kg);
+void launch_mins(const UpdateArgs& a, hipStream_t s);
+void launch_ladder(const UpdateArgs& a, hipStream_t s);
 
 // step mode
 struct SimViews {
@@ -153,6 +161,8 @@ struct m3_handle {
     long long nbytes[M3_BUF_COUNT] = {};
     float* world0_dev = nullptr;
     m3::VI* topk_cand = nullptr;
+    float* part_min = nullptr;
+    float* lad = nullptr;
     float* sim_world = nullptr;  // step mode SoA [NW][Kl]
     float* sim_u = nullptr;      // [Kl][nu]
     float* noise_stage = nullptr;

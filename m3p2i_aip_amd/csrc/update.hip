@@ -1,26 +1,43 @@
-// update.hip -- importance-weight update of MPPI / M3P2I as three small kernels (gfx950).
+// update.hip -- importance-weight update of MPPI / M3P2I (gfx950).
 //
-//   k_weights : softmin weights with wavefront (DPP shuffle) + LDS reductions
+//   k_prep    : per-workgroup minima of the trajectory costs + top-k stage A (registers + DPP)
+//               argmax / top-k                 mppi.py:248, 493; m3p2i.py:75-76
+//   k_ladder  : (multi-modal only) eta(beta) for the whole ladder of betas the reference's
+//               on-the-fly search can visit, in ONE chip-wide pass
+//               update_infinite_beta           m3p2i.py:24-44
+//   k_weights : walks the search on the ladder table (iterative passes only after a direction
+//               reversal), softmin weights, argmax, half sums
 //               _exp_util                      mppi.py:430-456
-//               update_infinite_beta           m3p2i.py:24-44   (3 searches run in lock-step)
 //               _multi_modal_exp_util          m3p2i.py:46-64
-//               argmax / top-k                 mppi.py:493, 248; m3p2i.py:75-76
 //               simple-mode weights            mppi.py:225-229
 //   k_wsum    : weighted action sums + best / top-trajectory row gathers (per time step)
 //               mppi.py:497-498, 252-254; m3p2i.py:77-83
 //   k_finalize: mean update, per-mode means, simple-mode U update, Savitzky-Golay
 //               mppi.py:502-503, 231, 245, 257-263; m3p2i.py:86-87
 //
-// The reference runs each beta-search pass as exp + sum kernels and a host sync
-// (10-25 passes x 3 searches per command); here the searches stay on the device in one
-// workgroup.  No MFMA: there is no dense contraction in this path (K x T*nu weighted sums
-// are K-long dot products against ONE weight vector -> bandwidth-bound reductions).
-#include <cstdlib>
+// The reference runs each beta-search pass as exp + sum kernels and a host sync (10-25 passes x
+// 3 searches per command()).  A pass is a full reduction over the K costs, and the passes are
+// sequential -- on one workgroup that is ~7 us per pass at K = 64000 (measured: 190-207 us per
+// command).  But the betas a search can visit are known in advance: it starts at 1 and moves by
+// x0.9 while eta > 10 or by x1.2 while eta < 3, so until it reverses direction it walks the
+// ladder {0.9^j} or {1.2^j}.  k_ladder evaluates eta on both ladders for all three searches in
+// one pass spread over the whole chip (K x 2 x 96 exps: ~3 us), and one thread per search then
+// walks the table.  Only a search that overshoots the [3,10] window and has to turn around
+// continues with iterative passes.  Values are identical to the iterative search (same betas by
+// repeated multiplication, same per-sample exponent expression); only the summation order
+// differs.  No MFMA: there is no dense contraction in this path.
 #include "m3_internal.hpp"
 
 namespace m3 {
 
-constexpr int WT_MAX = 1024;  // max threads of k_weights (16 wavefronts); 256 for small K
+constexpr int WT_MAX = 1024;       // threads of k_weights for large K (16 wavefronts); 256 for small K
+constexpr int PREP_T = 256;        // threads of k_prep
+constexpr int PREP_RPT = 16;       // costs per thread held in registers by k_prep
+constexpr int LAD_S = 64;          // shrink ladder: beta = 0.9^j, j = 0..63
+constexpr int LAD_G = 32;          // grow ladder:   beta = 1.2^j, j = 1..32
+constexpr int LAD_N = LAD_S + LAD_G;
+constexpr int LAD_EL = 256;        // costs per k_ladder workgroup
+constexpr int WEIGHTS_LDS_MAX = 14000;  // costs staged in LDS by k_weights (56 KB)
 
 // exp for the softmin weights: v_exp_f32 on x*log2(e) (2 instructions, ~2 ulp + the argument
 // rounding, i.e. <= ~5e-6 relative at |x| = 88) instead of the ~40-instruction correctly
@@ -30,11 +47,10 @@ __device__ __forceinline__ float m3_exp(float x) { return __expf(x); }
 
 // ---- wavefront (64-lane) reductions on the DPP cross-lane path ---------------------------
 // __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~100+ cycles each, six
-// dependent steps per reduction); the update kernels are nothing but chains of such
-// reductions (20+20 top-k rounds, up to ~25 beta-search passes), so they were latency-bound
-// on it.  DPP row operations are ordinary VALU instructions: butterfly inside each 16-lane
-// row with quad_perm / row_half_mirror / row_mirror, then row_bcast:15 / row_bcast:31 fold
-// the four rows into lane 63, which v_readlane broadcasts.
+// dependent steps per reduction); the update kernels are chains of such reductions, so they
+// were latency-bound on it.  DPP row operations are ordinary VALU instructions: butterfly
+// inside each 16-lane row with quad_perm / row_half_mirror / row_mirror, then row_bcast:15 /
+// row_bcast:31 fold the four rows into lane 63, which v_readlane broadcasts.
 #define M3_DPP_XOR1 0xB1        // quad_perm [1,0,3,2]
 #define M3_DPP_XOR2 0x4E        // quad_perm [2,3,0,1]
 #define M3_DPP_HALF_MIRROR 0x141
@@ -106,12 +122,6 @@ __device__ __forceinline__ void block_min(float (&v)[N], float* lds) {
     }
 }
 
-// lexicographic (value, index) argmin over the block; "greater than (pv,pi)" filter gives
-// the next-smallest element each round (no exclusion list).
-constexpr int TOPK_RPT = 8;  // costs per thread held in registers by a top-k workgroup
-constexpr int WEIGHTS_LDS_MAX = 15000;  // costs staged in LDS by k_weights (60 KB, within the
-                                        // 64 KB a launch gets without a function attribute)
-int weights_lds_floats(int Kg) { return Kg < WEIGHTS_LDS_MAX ? Kg : WEIGHTS_LDS_MAX; }
 __device__ __forceinline__ bool vi_less(float av, int ai, float bv, int bi) {
     return (av < bv) || (av == bv && ai < bi);
 }
@@ -157,83 +167,218 @@ __device__ __forceinline__ VI block_argmin(VI x, VI* lds) {
     return r;
 }
 
-// grid = 1 + n_cand workgroups: 0 -> weights/info, 1.. -> top-k stage A (run concurrently).
-// JR = costs per thread held in registers by workgroup 0.
+// ---------------------------------------------------------------------------------------
+// k_prep: each workgroup owns PREP_T*PREP_RPT consecutive costs, held in REGISTERS (re-reading
+// J from L2 every round cost ~1 us per round: 47 us at K = 2000 in the first version).
+//   * minima of the costs (all / first half / second half) of the workgroup -> part_min
+//   * top-k stage A: top-k weights == k smallest costs (weights are monotone in J; ties towards
+//     the lower sample index).  Every wave extracts the sorted top-k of its registers with DPP
+//     argmin rounds, wave 0 merges the waves' candidates.  Stage B (merge across workgroups)
+//     runs in k_wsum.
+// minima only (critical path of the multi-modal search: k_ladder needs them)
+__global__ __launch_bounds__(PREP_T) void k_mins(const UpdateArgs a) {
+    __shared__ float red[3 * 16];
+    const int Kg = a.Kg, half = Kg / 2, tid = threadIdx.x;
+    const float INF = __builtin_inff();
+    const int base = blockIdx.x * PREP_T * PREP_RPT;
+    float mn[3] = {INF, INF, INF};
+#pragma unroll
+    for (int e = 0; e < PREP_RPT; ++e) {
+        const int k = base + e * PREP_T + tid;
+        const float v = (k < Kg) ? a.Jall[k] : INF;
+        mn[0] = fminf(mn[0], v);
+        if (k < half) mn[1] = fminf(mn[1], v); else mn[2] = fminf(mn[2], v);
+    }
+    block_min<3>(mn, red);
+    if (tid < 3) a.part_min[blockIdx.x * 3 + tid] = mn[tid];
+}
+
+// top-k stage A for workgroup `blk` of blockDim threads (runs as extra workgroups of the
+// k_weights launch, beside workgroup 0)
+__device__ __forceinline__ void topk_stage_a(const UpdateArgs& a, int blk) {
+    __shared__ VI cand[16 * M3_TOPK];
+    const int Kg = a.Kg, tid = threadIdx.x, WT = blockDim.x;
+    const int lane = tid & 63, wv = tid >> 6, nw = WT >> 6;
+    const float INF = __builtin_inff();
+    const float* J = a.Jall;
+    const int base = blk * WT * PREP_RPT;
+    float rv[PREP_RPT];
+#pragma unroll
+    for (int e = 0; e < PREP_RPT; ++e) {
+        const int k = base + e * WT + tid;
+        rv[e] = (k < Kg) ? J[k] : INF;
+    }
+    unsigned used = 0u;
+    for (int r = 0; r < M3_TOPK; ++r) {
+        VI best = {INF, 0x7fffffff};
+        int be = -1;
+#pragma unroll
+        for (int e = 0; e < PREP_RPT; ++e) {
+            const int k = base + e * WT + tid;
+            if (!((used >> e) & 1u) && k < Kg && vi_less(rv[e], k, best.v, best.i)) {
+                best.v = rv[e]; best.i = k; be = e;
+            }
+        }
+        const VI win = wave_argmin(best);
+        if (be >= 0 && win.i == best.i) used |= 1u << be;
+        if (lane == 0) cand[wv * M3_TOPK + r] = win;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        float pv = -INF;
+        int pi = -1;
+        for (int r = 0; r < M3_TOPK; ++r) {
+            VI best = {INF, 0x7fffffff};
+            for (int c = lane; c < nw * M3_TOPK; c += 64) {
+                const VI x = cand[c];
+                if (vi_less(pv, pi, x.v, x.i) && vi_less(x.v, x.i, best.v, best.i)) best = x;
+            }
+            best = wave_argmin(best);
+            pv = best.v; pi = best.i;
+            if (lane == 0) a.cand[blk * M3_TOPK + r] = best;
+        }
+    }
+}
+
+// top-k stage B (the extra workgroup of the k_wsum launch): wave 0 merges the stage-A candidates (registers +
+// DPP argmin rounds), then the workgroup gathers the top-k trajectories for every t
+// (mppi.py:252-254) into the packed reduce buffer (zero rows for samples of other ranks).
+__device__ __forceinline__ void topk_stage_b(const UpdateArgs& a) {
+    __shared__ int s_top[M3_TOPK];
+    const int tid = threadIdx.x, T = a.T, nu = a.nu, Kl = a.Kl, k0 = a.k0;
+    if (tid < 64) {
+        const int lane = tid, nc = a.n_cand * M3_TOPK;
+        VI rc[6];  // first 384 candidates in registers (covers K <= 78643)
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const int c = lane + 64 * e;
+            rc[e] = (c < nc) ? a.cand[c] : VI{__builtin_inff(), 0x7fffffff};
+        }
+        float pv = -__builtin_inff();
+        int pi = -1;
+        for (int r = 0; r < M3_TOPK; ++r) {
+            VI best = {__builtin_inff(), 0x7fffffff};
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                if (vi_less(pv, pi, rc[e].v, rc[e].i) && vi_less(rc[e].v, rc[e].i, best.v, best.i)) best = rc[e];
+            for (int c = lane + 384; c < nc; c += 64) {
+                const VI x = a.cand[c];
+                if (vi_less(pv, pi, x.v, x.i) && vi_less(x.v, x.i, best.v, best.i)) best = x;
+            }
+            best = wave_argmin(best);
+            pv = best.v; pi = best.i;
+            if (lane == 0) { s_top[r] = best.i; a.top_idx[r] = best.i; }
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < M3_TOPK * T * 2; o += 256) {
+        const int c = o & 1, tt = (o >> 1) % T, r = (o >> 1) / T;
+        const int li = s_top[r] - k0;
+        float v = 0.0f;  // zero unless this rank owns the sample (summed by the all-reduce)
+        if (li >= 0 && li < Kl) v = a.states[((size_t)tt * Kl + li) * 4 + (c ? 2 : 0)];  // [0, 2]
+        a.reduce[reduce_off_top(T, nu) + o] = v;
+    }
+}
+int weights_threads(int Kg);
+int mins_workgroups(int Kg) {
+    const int per = PREP_T * PREP_RPT;
+    return (Kg + per - 1) / per;
+}
+int topk_workgroups(int Kg) {  // stage-A workgroups ride in the k_weights launch
+    const int per = weights_threads(Kg) * PREP_RPT;
+    return (Kg + per - 1) / per;
+}
+void launch_mins(const UpdateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_mins, dim3(a.n_mins), dim3(PREP_T), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_ladder: partial eta sums of one workgroup's LAD_EL costs for every beta of both ladders and
+// the three searches (all / first half / second half).  Thread = (ladder index j, element
+// parity g): it loops over its half of the workgroup's costs (LDS broadcast reads) -- no
+// reductions inside the loop, one LDS combine at the end.  lad[b][j][s].
+__device__ __forceinline__ float ladder_beta(int j) {
+    float b = 1.0f;  // same repeated multiplication as the iterative search => identical bits
+    if (j < LAD_S) { for (int i = 0; i < j; ++i) b = b * 0.9f; }
+    else { for (int i = 0; i < j - LAD_S + 1; ++i) b = b * 1.2f; }
+    return b;
+}
+__global__ __launch_bounds__(256) void k_ladder(const UpdateArgs a) {
+    __shared__ float2 sd[LAD_EL];  // (J - min_all, J - min_of_its_half); +inf past the end => exp = 0
+    __shared__ float sacc[2][LAD_N][3];
+    __shared__ float smn[3];
+    const int Kg = a.Kg, half = Kg / 2, tid = threadIdx.x, b = blockIdx.x;
+    if (tid < 3) {
+        float m = __builtin_inff();
+        for (int i = 0; i < a.n_mins; ++i) m = fminf(m, a.part_min[i * 3 + tid]);
+        smn[tid] = m;
+    }
+    __syncthreads();
+    {
+        const int k = b * LAD_EL + tid;
+        float2 d = make_float2(__builtin_inff(), __builtin_inff());
+        if (k < Kg) {
+            const float v = a.Jall[k];
+            d.x = v - smn[0];
+            d.y = v - smn[(k < half) ? 1 : 2];
+        }
+        sd[tid] = d;
+    }
+    __syncthreads();
+    if (tid < 2 * LAD_N) {
+        const int j = tid % LAD_N, g = tid / LAD_N;
+        const float nib = -1.0f / ladder_beta(j);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll 8
+        for (int i = 0; i < LAD_EL / 2; ++i) {
+            const int e = 2 * i + g;
+            const float2 d = sd[e];              // same address for every lane of a group: broadcast
+            a0 += m3_exp(nib * d.x);
+            const float xh = m3_exp(nib * d.y);
+            if (b * LAD_EL + e < half) a1 += xh; else a2 += xh;
+        }
+        sacc[g][j][0] = a0; sacc[g][j][1] = a1; sacc[g][j][2] = a2;
+    }
+    __syncthreads();
+    for (int o = tid; o < LAD_N * 3; o += 256) {
+        const int j = o / 3, s = o % 3;
+        a.lad[((size_t)b * LAD_N + j) * 3 + s] = sacc[0][j][s] + sacc[1][j][s];
+    }
+}
+int ladder_workgroups(int Kg) { return (Kg + LAD_EL - 1) / LAD_EL; }
+void launch_ladder(const UpdateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_ladder, dim3(a.n_lad), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_weights: ONE workgroup.  JR = costs per thread held in registers.
 template <int JR>
 __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
     __shared__ float red[3 * 16];
     __shared__ VI redvi[16];
-    __shared__ float s_beta[3];
-    __shared__ int s_done[3];
+    __shared__ float s_beta[3], s_eta[3];
+    __shared__ int s_done[3], s_it[3];
+    __shared__ float s_tab[LAD_N * 3];
     const int Kg = a.Kg, half = Kg / 2;
     const int tid = threadIdx.x;
     const int WT = blockDim.x;
     const float* J = a.Jall;
     const float INF = __builtin_inff();
-
-    if (blockIdx.x >= 1) {
-        // top-k weights == k smallest trajectory costs (weights are monotone in J); ties
-        // resolved towards the lower sample index.  Stage A (these workgroups, running beside
-        // workgroup 0): each workgroup owns TOPK_RPT*blockDim consecutive costs, held in
-        // REGISTERS (re-reading J from L2 every round costs ~1 us per round: measured 47 us
-        // for K = 2000); every wave extracts the sorted top-k of its registers with shuffles
-        // only, wave 0 merges the waves' candidates and writes the workgroup's k candidates.
-        // Stage B (merge across workgroups) runs in k_wsum.
-        __shared__ VI cand[16 * M3_TOPK];
-        const int lane = tid & 63, wv = tid >> 6, nw = WT >> 6;
-        const int base = (blockIdx.x - 1) * WT * TOPK_RPT;
-        float rv[TOPK_RPT];
-#pragma unroll
-        for (int e = 0; e < TOPK_RPT; ++e) {
-            const int k = base + e * WT + tid;
-            rv[e] = (k < Kg) ? J[k] : INF;
-        }
-        unsigned used = 0u;
-        for (int r = 0; r < M3_TOPK; ++r) {
-            VI best = {INF, 0x7fffffff};
-            int be = -1;
-#pragma unroll
-            for (int e = 0; e < TOPK_RPT; ++e) {
-                const int k = base + e * WT + tid;
-                if (!((used >> e) & 1u) && k < Kg && vi_less(rv[e], k, best.v, best.i)) {
-                    best.v = rv[e]; best.i = k; be = e;
-                }
-            }
-            const VI win = wave_argmin(best);
-            if (be >= 0 && win.i == best.i) used |= 1u << be;
-            if (lane == 0) cand[wv * M3_TOPK + r] = win;
-        }
-        __syncthreads();
-        if (wv == 0) {
-            float pv = -INF;
-            int pi = -1;
-            for (int r = 0; r < M3_TOPK; ++r) {
-                VI best = {INF, 0x7fffffff};
-                for (int c = lane; c < nw * M3_TOPK; c += 64) {
-                    const VI x = cand[c];
-                    if (vi_less(pv, pi, x.v, x.i) && vi_less(x.v, x.i, best.v, best.i)) best = x;
-                }
-                best = wave_argmin(best);
-                pv = best.v; pi = best.i;
-                if (lane == 0) a.cand[(blockIdx.x - 1) * M3_TOPK + r] = best;
-            }
-        }
+    const bool multi = a.multi_modal && !a.mode_simple;
+    if (blockIdx.x > 0) {  // workgroups 1..n_cand: top-k stage A, concurrent with workgroup 0
+        topk_stage_a(a, blockIdx.x - 1);
         return;
     }
 
-    // The costs are read ONCE into registers (thread t holds J[t + e*blockDim], e < JR): the
-    // min pass, the up-to-~25 beta-search passes x 3 searches and the final weight pass are
-    // then pure VALU + wave reductions instead of an L2 round trip per element per pass
-    // (K = 64000 multi-modal: 207 us with the costs re-read from L2 beyond a 60 KB LDS stage).
-    // Costs beyond JR*blockDim (K > 65536) fall back to memory.
+    // The costs are read ONCE into registers (thread t holds J[t + e*blockDim], e < JR); a
+    // second tier of a.lds_floats costs lives in LDS, anything beyond falls back to memory.
+    // Every later pass is then pure VALU + wave reductions.
     float jr[JR];
 #pragma unroll
     for (int e_ = 0; e_ < JR; ++e_) {
         const int k = e_ * WT + tid;
         jr[e_] = (k < Kg) ? J[k] : INF;
     }
-    // second tier: the next a.lds_floats costs live in LDS (1024 threads x 48 registers +
-    // 15000 LDS floats cover K = 64000 without touching L2 again); third tier: memory
     extern __shared__ __attribute__((aligned(16))) float sJ[];
     const int lds0 = JR * WT;
     const int lds1 = (Kg < lds0 + a.lds_floats) ? Kg : lds0 + a.lds_floats;
@@ -258,7 +403,7 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
 
     float beta[3], eta[3];
     int iters[3] = {1, 1, 1};
-    if (!a.multi_modal || a.mode_simple) {
+    if (!multi) {
         // single softmin: beta persists in info (panda adapts it), simple mode uses lambda
         const float b = a.mode_simple ? a.lambda_ : a.info->beta;
         float e[1] = {0.0f};
@@ -268,11 +413,55 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
         beta[0] = b; eta[0] = e[0];
         beta[1] = beta[2] = 1.0f; eta[1] = eta[2] = 0.0f;
     } else {
-        // three on-the-fly beta searches in lock-step; each restarts at beta = 1
-        // (beta_1/beta_2/beta are never written back: m3p2i.py:58-60)
-        if (tid < 3) { s_beta[tid] = 1.0f; s_done[tid] = 0; }
+        // (1) ladder table: sum k_ladder's partials over its workgroups, fixed order
+        for (int o = tid; o < LAD_N * 3; o += WT) {
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            int b = 0;
+            for (; b + 3 < a.n_lad; b += 4) {  // 4 independent loads in flight
+                s0 += a.lad[(size_t)(b + 0) * LAD_N * 3 + o];
+                s1 += a.lad[(size_t)(b + 1) * LAD_N * 3 + o];
+                s2 += a.lad[(size_t)(b + 2) * LAD_N * 3 + o];
+                s3 += a.lad[(size_t)(b + 3) * LAD_N * 3 + o];
+            }
+            for (; b < a.n_lad; ++b) s0 += a.lad[(size_t)b * LAD_N * 3 + o];
+            s_tab[o] = (s0 + s1) + (s2 + s3);
+        }
         __syncthreads();
-        eta[0] = eta[1] = eta[2] = 0.0f;
+        // (2) one thread per search walks the reference's rule on the table; each search
+        // restarts at beta = 1 (beta_1/beta_2/beta are never written back: m3p2i.py:58-60)
+        if (tid < 3) {
+            const int s = tid;
+            float b = 1.0f, et = s_tab[0 * 3 + s];
+            int it = 1, done = 0;
+            if (et > 10.0f) {
+                int j = 0;
+                for (;;) {
+                    b = b * 0.9f; ++j;
+                    if (j >= LAD_S) break;                 // off the ladder: continue iteratively
+                    et = s_tab[j * 3 + s]; ++it;
+                    if (et > 10.0f) continue;
+                    if (et < 3.0f) b = b * 1.2f;           // overshoot: reversal, continue iteratively
+                    else done = 1;
+                    break;
+                }
+            } else if (et < 3.0f) {
+                int j = 0;
+                for (;;) {
+                    b = b * 1.2f; ++j;
+                    if (j > LAD_G) break;
+                    et = s_tab[(LAD_S + j - 1) * 3 + s]; ++it;
+                    if (et < 3.0f) continue;
+                    if (et > 10.0f) b = b * 0.9f;
+                    else done = 1;
+                    break;
+                }
+            } else {
+                done = 1;
+            }
+            s_beta[s] = b; s_eta[s] = et; s_done[s] = done; s_it[s] = it;
+        }
+        __syncthreads();
+        // (3) iterative passes for searches that left their ladder (rare)
         for (int pass = 0; pass < 1000; ++pass) {
             const float b0 = s_beta[0], b1 = s_beta[1], b2 = s_beta[2];
             const int d0 = s_done[0], d1 = s_done[1], d2 = s_done[2];
@@ -288,22 +477,20 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
             __syncthreads();
             if (tid < 3 && !s_done[tid]) {
                 const float et = e[tid];
+                s_eta[tid] = et;
+                s_it[tid] = s_it[tid] + 1;
                 if (et > 10.0f) s_beta[tid] = s_beta[tid] * 0.9f;
                 else if (et < 3.0f) s_beta[tid] = s_beta[tid] * 1.2f;
                 else s_done[tid] = 1;
             }
-            if (!d0) { eta[0] = e[0]; iters[0] = pass + 1; }
-            if (!d1) { eta[1] = e[1]; iters[1] = pass + 1; }
-            if (!d2) { eta[2] = e[2]; iters[2] = pass + 1; }
             __syncthreads();
         }
-        beta[0] = s_beta[0]; beta[1] = s_beta[1]; beta[2] = s_beta[2];
-        // a search that stopped by "found" keeps the beta that satisfied the bounds; one cut
-        // off by the pass cap keeps its last evaluated beta -- recompute below is consistent
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { beta[s] = s_beta[s]; eta[s] = s_eta[s]; iters[s] = s_it[s]; }
     }
 
     // ---- normalised weights, half sums, argmax ----
-    // NOTE: when a search ended with `found`, s_beta was not changed after the last eta, so
+    // A search that ended with `found` did not change beta after the eta it accepted, so
     // exp(-(J-min)/beta) recomputed here equals the reference's returned exp_.
     const float i0 = 1.0f / eta[0], n0 = -1.0f / beta[0];
     float hs[2] = {0.0f, 0.0f};
@@ -314,7 +501,7 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
         if (k < half) hs[0] += wk; else hs[1] += wk;
         // argmax of the weights, first index on ties (torch.argmax on CPU): key = -w
         if (vi_less(-wk, k, b0.v, b0.i)) { b0.v = -wk; b0.i = k; }
-        if (a.multi_modal && !a.mode_simple) {
+        if (multi) {
             if (k < half) {
                 const float w1k = (1.0f / eta[1]) * m3_exp((-1.0f / beta[1]) * (v - mn[1]));
                 a.w1[k] = w1k;
@@ -329,7 +516,7 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
 #undef FOR_J
     block_sum<2>(hs, red);
     b0 = block_argmin(b0, redvi);
-    if (a.multi_modal && !a.mode_simple) {
+    if (multi) {
         b1 = block_argmin(b1, redvi);
         b2 = block_argmin(b2, redvi);
     }
@@ -338,8 +525,8 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
         f->eta = eta[0]; f->eta_1 = eta[1]; f->eta_2 = eta[2];
         f->iters = iters[0]; f->iters_1 = iters[1]; f->iters_2 = iters[2];
         f->best_idx = b0.i;
-        f->best_idx_1 = (a.multi_modal && !a.mode_simple) ? b1.i : -1;
-        f->best_idx_2 = (a.multi_modal && !a.mode_simple) ? b2.i : -1;
+        f->best_idx_1 = multi ? b1.i : -1;
+        f->best_idx_2 = multi ? b2.i : -1;
         f->wsum_push = hs[0]; f->wsum_pull = hs[1];
         f->pull_preference = hs[1] > hs[0];
         float nb = beta[0];
@@ -356,14 +543,9 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
 }
 
 int weights_threads(int Kg) { return Kg <= 8192 ? 256 : WT_MAX; }
-int topk_workgroups(int Kg) {
-    const int per = weights_threads(Kg) * TOPK_RPT;
-    return (Kg + per - 1) / per;
-}
 
 void launch_weights(const UpdateArgs& a, hipStream_t s) {
-    // few waves for small K: the block-wide reductions (2 barriers + a serial pass over the
-    // waves' partials) dominate, not the K/threads elements per thread
+    // few waves for small K: the block-wide reductions dominate there, not the elements/thread
     const int threads = weights_threads(a.Kg);
     UpdateArgs b = a;
     if (threads == 256) {
@@ -376,52 +558,18 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
 // one workgroup per time step t: sum_k w_k * actions[t][k][:] over the local shard, for the
 // global weights and (multi-modal) the two per-mode weight sets; plus row gathers.
 constexpr int ST = 256;
 __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     __shared__ float red[3 * 16];
-    __shared__ int s_top[M3_TOPK];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int Kl = a.Kl, k0 = a.k0, nu = a.nu, T = a.T, half = a.Kg / 2;
     const bool multi = a.multi_modal && !a.mode_simple;
     const float* act = a.actions + (size_t)t * Kl * nu;
-    // workgroup T: top-k stage B.  Wave 0 merges the stage-A candidates (registers + DPP
-    // argmin rounds), then the whole workgroup gathers the top-k trajectories for every t
-    // (mppi.py:252-254) -- in parallel with the T weighted-sum workgroups.
-    if (t == T) {
-        if (tid < 64) {
-            const int lane = tid, nc = a.n_cand * M3_TOPK;
-            VI rc[4];  // first 256 candidates in registers (covers K <= 98304)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = lane + 64 * e;
-                rc[e] = (c < nc) ? a.cand[c] : VI{__builtin_inff(), 0x7fffffff};
-            }
-            float pv = -__builtin_inff();
-            int pi = -1;
-            for (int r = 0; r < M3_TOPK; ++r) {
-                VI best = {__builtin_inff(), 0x7fffffff};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (vi_less(pv, pi, rc[e].v, rc[e].i) && vi_less(rc[e].v, rc[e].i, best.v, best.i)) best = rc[e];
-                for (int c = lane + 256; c < nc; c += 64) {
-                    const VI x = a.cand[c];
-                    if (vi_less(pv, pi, x.v, x.i) && vi_less(x.v, x.i, best.v, best.i)) best = x;
-                }
-                best = wave_argmin(best);
-                pv = best.v; pi = best.i;
-                if (lane == 0) { s_top[r] = best.i; a.top_idx[r] = best.i; }
-            }
-        }
-        __syncthreads();
-        for (int o = tid; o < M3_TOPK * T * 2; o += ST) {
-            const int c = o & 1, tt = (o >> 1) % T, r = (o >> 1) / T;
-            const int li = s_top[r] - k0;
-            float v = 0.0f;  // zero unless this rank owns the sample (summed by the all-reduce)
-            if (li >= 0 && li < Kl) v = a.states[((size_t)tt * Kl + li) * 4 + (c ? 2 : 0)];  // [0, 2]
-            a.reduce[reduce_off_top(T, nu) + o] = v;
-        }
+    if (t == T) {  // extra workgroup: top-k stage B + top-trajectory gathers, beside the sums
+        topk_stage_b(a);
         return;
     }
     for (int j0 = 0; j0 < nu; ++j0) {
@@ -443,7 +591,7 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         }
         __syncthreads();
     }
-    // best rows (zero unless the owning rank) and top-k trajectories
+    // best rows (zero unless the owning rank)
     if (tid < 3 * nu) {
         const int which = tid / nu, j = tid % nu;
         const int gi = (which == 0) ? a.info->best_idx : (which == 1 ? a.info->best_idx_1 : a.info->best_idx_2);
