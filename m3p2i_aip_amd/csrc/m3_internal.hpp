@@ -53,6 +53,9 @@ struct UpdateArgs {
     int n_cand;       // top-k stage-A workgroups (extra workgroups of the k_weights launch)
     float* lad;       // [n_lad][96][3] per-workgroup eta sums on the beta ladders (k_ladder)
     int n_lad;        // workgroups of k_ladder
+    float* wpart;     // [n_chunk][3][T][nu] partial weighted sums of k_wsum (n_chunk > 1 only)
+    int* wcount;      // [T] arrival counters of the k_wsum chunks (zero between launches)
+    int n_chunk;      // k_wsum workgroups per time step
     int lds_floats;   // costs staged in dynamic LDS by k_weights (set by launch_weights)
     int Kg, Kl, k0, T, nu;
     int multi_modal, mode_simple, env_type, filter_u, u_per_command;
@@ -94,6 +97,7 @@ int rollout_lanes_for(int Kl);
 int mins_workgroups(int Kg);
 int topk_workgroups(int Kg);
 int ladder_workgroups(int Kg);
+int wsum_chunks(int Kl);
 void launch_mins(const UpdateArgs& a, hipStream_t s);
 void launch_ladder(const UpdateArgs& a, hipStream_t s);
 
@@ -163,6 +167,8 @@ struct m3_handle {
     m3::VI* topk_cand = nullptr;
     float* part_min = nullptr;
     float* lad = nullptr;
+    float* wpart = nullptr;
+    int* wcount = nullptr;
     float* sim_world = nullptr;  // step mode SoA [NW][Kl]
     float* sim_u = nullptr;      // [Kl][nu]
     float* noise_stage = nullptr;

@@ -559,50 +559,100 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// one workgroup per time step t: sum_k w_k * actions[t][k][:] over the local shard, for the
-// global weights and (multi-modal) the two per-mode weight sets; plus row gathers.
+// weighted action sums: sum_k w_k * actions[t][k][:] over the local shard, for the global
+// weights and (multi-modal) the two per-mode weight sets; plus row gathers.  Grid = T x n_chunk
+// workgroups (+1 for top-k stage B): each reads its slice of the action rows once (all nu
+// columns in one pass) and, when n_chunk > 1, the last workgroup to arrive for a time step adds
+// the partials in chunk order -- the result does not depend on which one that is.
 constexpr int ST = 256;
+constexpr int WS_CHUNK = 2048;  // samples per k_wsum workgroup
+int wsum_chunks(int Kl) { return (Kl + WS_CHUNK - 1) / WS_CHUNK; }
+
+template <int NU>
 __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     __shared__ float red[3 * 16];
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const int Kl = a.Kl, k0 = a.k0, nu = a.nu, T = a.T, half = a.Kg / 2;
-    const bool multi = a.multi_modal && !a.mode_simple;
-    const float* act = a.actions + (size_t)t * Kl * nu;
-    if (t == T) {  // extra workgroup: top-k stage B + top-trajectory gathers, beside the sums
+    const int tid = threadIdx.x, C = a.n_chunk;
+    const int Kl = a.Kl, k0 = a.k0, T = a.T, half = a.Kg / 2;
+    if ((int)blockIdx.x == T * C) {  // extra workgroup: top-k stage B + top-trajectory gathers
         topk_stage_b(a);
         return;
     }
-    for (int j0 = 0; j0 < nu; ++j0) {
-        float acc[3] = {0.0f, 0.0f, 0.0f};
-        for (int i = tid; i < Kl; i += ST) {
-            const int k = k0 + i;
-            const float av = act[(size_t)i * nu + j0];
-            acc[0] += a.w[k] * av;
-            if (multi) {
-                if (k < half) acc[1] += a.w1[k] * av;
-                else acc[2] += a.w2[k - half] * av;
-            }
+    const int t = blockIdx.x / C, c = blockIdx.x % C;
+    const bool multi = a.multi_modal && !a.mode_simple;
+    const float* act = a.actions + (size_t)t * Kl * NU;
+    float acc[3][NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
+    const int i1 = min(Kl, (c + 1) * WS_CHUNK);
+    for (int i = c * WS_CHUNK + tid; i < i1; i += ST) {
+        const int k = k0 + i;
+        float av[NU];
+        if constexpr (NU == 2) {
+            const float2 v = reinterpret_cast<const float2*>(act)[i];
+            av[0] = v.x; av[1] = v.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) av[j] = act[(size_t)i * NU + j];
         }
-        block_sum<3>(acc, red);
-        if (tid == 0) {
-            a.reduce[reduce_off_psum(0, T, nu) + t * nu + j0] = acc[0];
-            a.reduce[reduce_off_psum(1, T, nu) + t * nu + j0] = acc[1];
-            a.reduce[reduce_off_psum(2, T, nu) + t * nu + j0] = acc[2];
+        const float w = a.w[k];
+        float wa = 0.0f, wb = 0.0f;
+        if (multi) {
+            if (k < half) wa = a.w1[k]; else wb = a.w2[k - half];
         }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            acc[0][j] += w * av[j];
+            acc[1][j] += wa * av[j];
+            acc[2][j] += wb * av[j];
+        }
+    }
+    float* out = (C == 1) ? a.reduce : a.wpart + (size_t)c * 3 * T * NU;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        float r[3] = {acc[0][j], acc[1][j], acc[2][j]};
+        block_sum<3>(r, red);
+        const float rv = tid == 0 ? r[0] : (tid == 1 ? r[1] : r[2]);
+        if (tid < 3) out[tid * T * NU + t * NU + j] = rv;  // == reduce_off_psum(tid) + t*NU + j
         __syncthreads();
     }
+    if (C > 1) {
+        // in-launch combine (agent-scope release -> ticket -> acquire; per-XCD L2s are not
+        // coherent with each other, so workgroup-scope fences would read stale partials)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(&a.wcount[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = ticket == C - 1;
+            if (is_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                a.wcount[t] = 0;  // re-armed for the next launch (zeroed at m3_create)
+            }
+            red[47] = __int_as_float(is_last);
+        }
+        __syncthreads();
+        if (__float_as_int(red[47]) && tid < 3 * NU) {
+            const int which = tid / NU, j = tid % NU;
+            float sum = 0.0f;
+            for (int cc = 0; cc < C; ++cc) sum += a.wpart[((size_t)cc * 3 + which) * T * NU + t * NU + j];
+            a.reduce[reduce_off_psum(which, T, NU) + t * NU + j] = sum;
+        }
+    }
     // best rows (zero unless the owning rank)
-    if (tid < 3 * nu) {
-        const int which = tid / nu, j = tid % nu;
+    if (c == 0 && tid < 3 * NU) {
+        const int which = tid / NU, j = tid % NU;
         const int gi = (which == 0) ? a.info->best_idx : (which == 1 ? a.info->best_idx_1 : a.info->best_idx_2);
         float v = 0.0f;
         const int li = gi - k0;
-        if (gi >= 0 && li >= 0 && li < Kl) v = act[(size_t)li * nu + j];
-        a.reduce[reduce_off_best(which, T, nu) + t * nu + j] = v;
+        if (gi >= 0 && li >= 0 && li < Kl) v = act[(size_t)li * NU + j];
+        a.reduce[reduce_off_best(which, T, NU) + t * NU + j] = v;
     }
 }
 void launch_wsum(const UpdateArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_wsum, dim3(a.T + 1), dim3(ST), 0, s, a);
+    const dim3 grid(a.T * a.n_chunk + 1);
+    if (a.nu == 2) hipLaunchKernelGGL(k_wsum<2>, grid, dim3(ST), 0, s, a);
+    else hipLaunchKernelGGL(k_wsum<9>, grid, dim3(ST), 0, s, a);
 }
 
 // Savitzky-Golay(9, 2, 'interp') as a fixed linear map: value at window position p of the
