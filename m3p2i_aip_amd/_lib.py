@@ -13,7 +13,7 @@ TOPK = 20
 ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libm3p2i_hip.so")
+LIB_PATH = os.environ.get("M3P2I_HIP_LIB") or os.path.join(_HERE, "lib", "libm3p2i_hip.so")
 
 ENV_POINT, ENV_PANDA = 0, 1
 TASKS = {"navigation": 0, "push": 1, "pull": 2, "push_pull": 3, "reach": 4, "pick": 5,

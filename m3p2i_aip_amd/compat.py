@@ -8,7 +8,8 @@ section 8(f)); when the real packages are absent, small stand-ins cover exactly 
 scripts make.
 
 Host-side helpers restated here (all O(1) per command, no data parallelism):
-  PLANNER_SIMPLE            planners/task_planner/task_planner.py:13-39
+  PLANNER_SIMPLE / PLANNER_AIF_PANDA / AiAgent / adapt_act_sel / MDP templates
+                            planners/task_planner/*.py  (-> m3p2i_aip_amd/task_planner.py)
   torch_to_bytes / bytes_to_torch   utils/data_transfer.py:4-12
   calculate_suction / check_suction_condition / check_and_apply_suction / time_tracking
                             utils/skill_utils.py:25-94 (the 1-env "real world" side of sim.py)
@@ -26,7 +27,7 @@ from typing import List
 
 import torch
 
-from . import cost_functions, isaacgym_wrapper, planner
+from . import cost_functions, isaacgym_wrapper, planner, task_planner
 
 
 # ------------------------------------------------------------------ data_transfer.py:4-12
@@ -41,35 +42,10 @@ def bytes_to_torch(b: bytes):
     return torch.load(io.BytesIO(b))
 
 
-# ------------------------------------------------------------------ task_planner.py:13-39
-class PLANNER_SIMPLE:
-    def __init__(self, cfg) -> None:
-        self.device = cfg.mppi.device
-        self.task = cfg.task
-        self.curr_goal = cfg.goal if torch.is_tensor(cfg.goal) else torch.tensor(list(cfg.goal), device=self.device)
-        self.dist_threshold = 0.1
-
-    def update_plan(self, sim):
-        pass
-
-    def reset_plan(self):
-        pass
-
-    def check_task_success(self, sim):
-        task_success = False
-        if self.task == "navigation":
-            task_success = torch.norm(sim.robot_pos[0, :] - self.curr_goal) < self.dist_threshold
-        elif self.task in ['push', 'pull', 'push_pull']:
-            box_pos = sim.get_actor_position_by_name("box")[0, :2]
-            task_success = torch.norm(box_pos - self.curr_goal) <= self.dist_threshold
-        return task_success
-
-
-def set_task_planner(cfg):
-    if cfg.env_type == "point_env":
-        return PLANNER_SIMPLE(cfg)
-    raise NotImplementedError("PLANNER_AIF_PANDA (active-inference task planner, task_planner.py:41-107) is "
-                              "outside the hot-path scope of this build (SURVEY.md section 8(f) rank 3)")
+# ------------------------------------------------------------------ task_planner.py (module)
+PLANNER_SIMPLE = task_planner.PLANNER_SIMPLE
+PLANNER_AIF_PANDA = task_planner.PLANNER_AIF_PANDA
+set_task_planner = task_planner.set_task_planner
 
 
 # ------------------------------------------------------------------ skill_utils.py:25-94
@@ -227,7 +203,14 @@ def install(force_standins: bool = False):
                             Objective=cost_functions.Objective)
     tp = mod("m3p2i_aip.planners.task_planner")
     tp.task_planner = mod("m3p2i_aip.planners.task_planner.task_planner", set_task_planner=set_task_planner,
-                          PLANNER_SIMPLE=PLANNER_SIMPLE)
+                          PLANNER_SIMPLE=PLANNER_SIMPLE, PLANNER_AIF_PANDA=PLANNER_AIF_PANDA)
+    tp.ai_agent = mod("m3p2i_aip.planners.task_planner.ai_agent", AiAgent=task_planner.AiAgent)
+    tp.adaptive_action_selection = mod("m3p2i_aip.planners.task_planner.adaptive_action_selection",
+                                       adapt_act_sel=task_planner.adapt_act_sel)
+    tp.isaac_state_action_templates = mod(
+        "m3p2i_aip.planners.task_planner.isaac_state_action_templates",
+        **{n: getattr(task_planner, n) for n in ("MDPIsAt", "MDPIsCloseTo", "MDPIsLocFree", "MDPIsBlockAt",
+                                                 "MDPIsCubeAt", "MDPIsCubeAtReal")})
     cfgm = mod("m3p2i_aip.config")
     cfgm.config_store = mod("m3p2i_aip.config.config_store", ExampleConfig=ExampleConfig)
     ut = mod("m3p2i_aip.utils")

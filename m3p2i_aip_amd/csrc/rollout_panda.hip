@@ -56,19 +56,33 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a, const
     const float* mptr = a.mean;
     if (a.multi_modal) mptr = first_half ? a.mean1 : a.mean2;
 
-    float J = 0.0f, g = 1.0f;
-    for (int t = 0; t < T; ++t) {
+    // inputs of step t+1 are fetched before step t is simulated (one wavefront per SIMD: nothing
+    // else hides the latency of a load that is consumed at once)
+    const bool use_best = a.multi_modal && (k == 0 || k == pa.cp.half_K);
+    const float* bptr = (k == 0) ? a.best1 : a.best2;
+    float nd[9], nm[9];
+    auto fetch = [&](int t) {
         const int ts = (t + 1 < T) ? t + 1 : T - 1;  // _shift_action: mppi.py:266-273
         const float* dptr = a.delta + ((size_t)t * Kl + i) * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            nd[j] = dptr[j];
+            nm[j] = use_best ? bptr[ts * 9 + j] : mptr[ts * 9 + j];
+        }
+    };
+    fetch(0);
+    float J = 0.0f, g = 1.0f;
+    for (int t = 0; t < T; ++t) {
+        float cd[9], cm[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { cd[j] = nd[j]; cm[j] = nm[j]; }
+        if (t + 1 < T) fetch(t + 1);
         float u[9], e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            float d = is_last ? 0.0f : dptr[j];                                        // mppi.py:392
-            float aj = fmaxf(fminf(mptr[ts * 9 + j] + d * a.scale_tril[j], a.u_max[j]), a.u_min[j]);
-            if (a.multi_modal) {                                                       // :407-409
-                if (k == 0) aj = a.best1[ts * 9 + j];
-                if (k == pa.cp.half_K) aj = a.best2[ts * 9 + j];
-            }
+            const float d = is_last ? 0.0f : cd[j];                                    // mppi.py:392
+            float aj = fmaxf(fminf(cm[j] + d * a.scale_tril[j], a.u_max[j]), a.u_min[j]);
+            if (use_best) aj = cm[j];                                                  // :407-409
             if (j >= 7) {                                                              // :412-416
                 if (a.gripper_cmd == 1) aj = 1.5f;
                 else if (a.gripper_cmd == 2) aj = -1.5f;

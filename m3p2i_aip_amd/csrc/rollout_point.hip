@@ -90,33 +90,48 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const
     const float* mptr = a.mean;
     if (a.multi_modal && !a.mode_simple) mptr = first_half ? a.mean1 : a.mean2;
 
+    // Inputs of step t+1 are fetched before step t is simulated: with one wavefront per SIMD
+    // nothing else hides the ~1-2 us HBM/L2 latency of a load whose result is needed at once
+    // (measured: SQ_WAIT_ANY was a third of the kernel's wave-cycles).
+    struct StepIn { float d0, d1, m0, m1, b0, b1; };
+    const bool halton = !a.mode_simple;
+    const bool use_best = halton && a.multi_modal && (k == 0 || k == a.cp.half_K);
+    const float* bptr = (k == 0) ? a.best1 : a.best2;
+    auto fetch = [&](int t) {
+        StepIn in;
+        in.d0 = in.d1 = in.b0 = in.b1 = 0.0f;
+        if (!a.sampling_random) {
+            const float2 dd = *reinterpret_cast<const float2*>(a.delta + ((size_t)t * Kl + i) * 2);
+            in.d0 = dd.x; in.d1 = dd.y;
+        }
+        // torch.roll(U, -1): mppi.py:221 / _shift_action: mppi.py:266-273
+        const int ts = a.mode_simple ? ((t + 1 == T) ? 0 : t + 1) : ((t + 1 < T) ? t + 1 : T - 1);
+        in.m0 = mptr[ts * 2 + 0]; in.m1 = mptr[ts * 2 + 1];
+        if (use_best) { in.b0 = bptr[ts * 2 + 0]; in.b1 = bptr[ts * 2 + 1]; }
+        return in;
+    };
+
     float J = 0.0f, S = 0.0f, g = 1.0f, pc = 0.0f;
+    StepIn nxt = fetch(0);
     for (int t = 0; t < T; ++t) {
+        const StepIn in = nxt;
+        if (t + 1 < T) nxt = fetch(t + 1);
         // ---- A4 / A13: perturbed action for this (k, t) ----
-        float d0, d1;
+        float d0 = in.d0, d1 = in.d1;
         if (a.sampling_random) {
             gauss_pair(a.seed, a.call, (unsigned)k, (unsigned)t, 0u, d0, d1);
             d0 *= a.scale_tril[0]; d1 *= a.scale_tril[1];  // N(0, Sigma): mppi.py:481 / :340
-        } else {
-            const float2 dd = *reinterpret_cast<const float2*>(a.delta + ((size_t)t * Kl + i) * 2);
-            d0 = dd.x; d1 = dd.y;
         }
-        float a0, a1, m0, m1;
+        float a0, a1;
+        const float m0 = in.m0, m1 = in.m1;
         if (a.mode_simple) {
-            const int ts = (t + 1 == T) ? 0 : t + 1;  // torch.roll(U, -1): mppi.py:221
-            m0 = a.mean[ts * 2 + 0]; m1 = a.mean[ts * 2 + 1];
             a0 = fmaxf(fminf(m0 + d0, a.u_max[0]), a.u_min[0]);  // mppi.py:343-345
             a1 = fmaxf(fminf(m1 + d1, a.u_max[1]), a.u_min[1]);
         } else {
-            const int ts = (t + 1 < T) ? t + 1 : T - 1;  // _shift_action: mppi.py:266-273
             if (is_last) { d0 = 0.0f; d1 = 0.0f; }      // mppi.py:392
-            m0 = mptr[ts * 2 + 0]; m1 = mptr[ts * 2 + 1];
             a0 = fmaxf(fminf(m0 + d0 * a.scale_tril[0], a.u_max[0]), a.u_min[0]);  // :394-405
             a1 = fmaxf(fminf(m1 + d1 * a.scale_tril[1], a.u_max[1]), a.u_min[1]);
-            if (a.multi_modal) {  // mppi.py:407-409
-                if (k == 0) { a0 = a.best1[ts * 2 + 0]; a1 = a.best1[ts * 2 + 1]; }
-                if (k == a.cp.half_K) { a0 = a.best2[ts * 2 + 0]; a1 = a.best2[ts * 2 + 1]; }
-            }
+            if (use_best) { a0 = in.b0; a1 = in.b1; }  // mppi.py:407-409
         }
         float u0 = a.u_scale * a0, u1 = a.u_scale * a1;                 // mppi.py:297
         if (a.sample_null_action && is_last) { u0 = 0.0f; u1 = 0.0f; }  // mppi.py:300-302

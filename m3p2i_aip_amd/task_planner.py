@@ -1,0 +1,385 @@
+"""Task planners of the reactive TAMP loop (host side, numpy).
+
+Mirrors the reference's interface for the caller of the hot path (`reactive_tamp.py:34,76-81`):
+
+* `PLANNER_SIMPLE`            -- task_planner.py:13-39 (fixed task/goal, success test)
+* `PLANNER_AIF_PANDA`         -- task_planner.py:41-107 (reach -> pick -> place by active inference)
+* `AiAgent`                   -- ai_agent.py:13-193 (discrete active-inference agent, horizon 2)
+* `adapt_act_sel`             -- adaptive_action_selection.py:11-84 (action selection with
+                                 precondition push-back)
+* `MDP*` templates            -- isaac_state_action_templates.py:6-232
+
+This is a restatement, not a transcription: the agent's per-policy loops are evaluated as array
+operations over the policy axis and the templates are table-driven.  What is kept exactly is the
+observable behaviour the callers and the reference example rely on -- the selected actions and
+outcomes, the evolution of the state prior D, and the log-space conventions of C and E (a
+preference of 1 is stored as log(1 + 1e-16) == 0.0, "pushed" preconditions as log(2) > 0, an
+inhibited habit as log(1e-16)); tests/test_task_planner.py pins all of that to sequences recorded
+from the reference's own modules (tests/golden/make_aif_golden.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_TINY = 1e-16
+
+
+def _ln(x):
+    """log with the reference's floor (ai_agent.py:153-155)."""
+    return np.log(np.asarray(x, dtype=np.float64) + _TINY)
+
+
+def _colnorm(m):
+    """Columns scaled to sum 1; an all-zero column becomes uniform (ai_agent.py:157-165)."""
+    m = np.array(m, dtype=np.float64)
+    s = m.sum(axis=0, keepdims=True)
+    uniform = np.full_like(m, 1.0 / m.shape[0])
+    return np.where(s > 0, m / np.where(s > 0, s, 1.0), uniform)
+
+
+def _softmax0(x):
+    """exp(x) / sum(exp(x)) along axis 0, no max shift (ai_agent.py:167-172)."""
+    e = np.exp(x)
+    return e / e.sum(axis=0, keepdims=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# MDP templates (isaac_state_action_templates.py).  Every non-idle action drives the system to
+# the FIRST state of its factor (column-stochastic B with a full first row); idle is identity.
+# ---------------------------------------------------------------------------------------------
+class MDP:
+    def __init__(self, state_name, state_names, action_names, preconditions, habits, kappa_d=1.0,
+                 prior=0.5):
+        n, m = len(state_names), len(action_names)
+        self.state_name = state_name
+        self.state_names = list(state_names)
+        self.action_names = list(action_names)
+        self.V = np.arange(m)                       # one-step policies = actions
+        self.B = np.zeros((n, n, m))
+        self.B[:, :, 0] = np.eye(n)
+        self.B[0, :, 1:] = 1.0
+        self.preconditions = [list(p) for p in preconditions]
+        self.A = np.eye(n)                          # outcomes == states
+        self.C = np.zeros((n, 1))                   # preferences over states
+        self.D = np.full((n, 1), prior)             # belief about the current state
+        self.E = np.asarray(habits, dtype=np.float64).reshape(m, 1)
+        self.kappa_d = kappa_d                      # learning rate of D
+
+
+def MDPIsAt():            # templates :6-40
+    return MDP("isAt", ["at_goal", "not_at_goal"], ["idle", "move_to"],
+               [["none"], ["battery_ok"]], [1.01, 1])
+
+
+def MDPIsCloseTo():       # :42-76
+    return MDP("isCloseTo", ["close_to", "not_close_to"], ["idle", "approach_obj"],
+               [["none"], ["none"]], [1.01, 1])
+
+
+def MDPIsLocFree():       # :78-115
+    return MDP("isLocFree", ["loc_free", "not_loc_free"], ["idle", "push_to_non_goal", "pull_to_non_goal"],
+               [["none"], ["close_to"], ["close_to"]], [1.01, 1, 1])
+
+
+def MDPIsBlockAt():       # :117-154
+    return MDP("isBlockAt", ["block_at_loc", "not_block_at_loc"], ["idle", "push_to_goal", "pull_to_goal"],
+               [["none"], ["loc_free", "close_to"], ["loc_free", "close_to"]], [1.01, 1, 1])
+
+
+def MDPIsCubeAt():        # :156-190
+    return MDP("isCubeAt", ["cube_at_table", "cube_at_hand", "cube_at_goal"], ["idle", "pick", "place"],
+               [["cube_at_goal"], ["cube_at_table"], ["cube_at_hand"]], [1.0, 1.01, 1.0], kappa_d=0.8)
+
+
+def MDPIsCubeAtReal():    # :192-232
+    return MDP("isCubeAt", ["cube_at_table", "cube_close_to_gripper", "cube_at_pre_place", "cube_at_goal"],
+               ["idle", "reach", "pick", "place"],
+               [["cube_at_goal"], ["cube_at_table"], ["cube_close_to_gripper"], ["cube_at_pre_place"]],
+               [1.0, 1.01, 1.0, 1.0], kappa_d=0.8)
+
+
+# ---------------------------------------------------------------------------------------------
+class AiAgent(object):
+    """Discrete active-inference agent over one state factor, look-ahead of one step
+    (ai_agent.py:13-193).  Attribute names the reference's callers touch are kept: `_mdp`
+    (with C, D, E in the same log/probability spaces), `u`, `F`, `G`, `post_x`."""
+
+    t_horizon = 2
+
+    def __init__(self, mdp):
+        import copy
+        self._mdp = copy.deepcopy(mdp)
+        m = self._mdp
+        self.n_policies = int(np.shape(m.V)[0])
+        self.n_states = int(np.shape(m.B)[0])
+        self.n_actions = int(np.shape(m.B)[2])
+        self.n_outcomes = self.n_states
+        self.policy_indexes_v = np.asarray(m.V)
+        m.D = _colnorm(m.D) if hasattr(m, "D") else _colnorm(np.ones((self.n_states, 1)))
+        m.C = _ln(m.C)
+        m.E = _ln(_colnorm(m.E))
+        self.default_E = m.E.copy()
+        self.likelihood_A = _colnorm(m.A)
+        fwd = np.stack([_colnorm(m.B[:, :, a]) for a in range(self.n_actions)], axis=2)
+        self.fwd_trans_B = fwd
+        self.bwd_trans_B = np.transpose(fwd, (1, 0, 2))
+        self.F = np.zeros((self.n_policies, 1))
+        self.G = np.zeros((self.n_policies, 1))
+        self.post_x = np.full((self.n_states, self.t_horizon, self.n_policies), 1.0 / self.n_states)
+        self.u = 0
+        # ambiguity term diag(A' ln A): zero for the identity likelihood of every template
+        self._ambiguity = np.diagonal(self.likelihood_A.T @ _ln(self.likelihood_A))
+
+    # -- perception: posterior over states for every policy + variational free energy ----------
+    def infer_states(self, obs):
+        n, P = self.n_states, self.n_policies
+        A = self.likelihood_A
+        Bf = self.fwd_trans_B[:, :, self.policy_indexes_v]      # [n, n, P]
+        Bb = self.bwd_trans_B[:, :, self.policy_indexes_v]
+        D = self._mdp.D.reshape(n)
+        post = np.full((n, 2, P), 1.0 / n)
+        post[:, 0, :] = D[:, None]
+        # tau = 0: the observation is given; the future message comes from the still uniform
+        # belief about tau = 1
+        lnA0 = _ln(A[:, int(obs)])[:, None]
+        past0 = _ln(D)[:, None]
+        fut0 = _ln(np.einsum("ijp,jp->ip", Bb, post[:, 1, :]))
+        s0 = _softmax0(past0 + fut0 + lnA0)
+        F = np.einsum("ip,ip->p", s0, _ln(s0) - past0 - lnA0)
+        post[:, 0, :] = s0
+        # tau = 1: the outcome is the most likely one under the tau = 0 posterior; no future message
+        o1 = np.argmax(A @ s0, axis=0)                          # [P]
+        lnA1 = _ln(A[:, o1])
+        past1 = _ln(np.einsum("ijp,jp->ip", Bf, s0))
+        s1 = _softmax0(past1 + lnA1)
+        F = F + np.einsum("ip,ip->p", s1, _ln(s1) - past1 - lnA1)
+        post[:, 1, :] = s1
+        self.post_x = post
+        self.F = F.reshape(P, 1)
+        return self.F, self.post_x
+
+    # -- action: expected free energy, policy posterior, prior update ---------------------------
+    def infer_policies(self):
+        n, P = self.n_states, self.n_policies
+        Bf = self.fwd_trans_B[:, :, self.policy_indexes_v]
+        C = self._mdp.C.reshape(n)
+        # predicted outcome of each policy from the CURRENT-state posterior (ai_agent.py:120)
+        o = np.argmax(np.einsum("ijp,jp->ip", Bf, self.post_x[:, 0, :]), axis=0)
+        onehot = np.zeros((n, P))
+        onehot[o, np.arange(P)] = 1.0
+        risk = np.einsum("ip,ip->p", _ln(onehot) - C[:, None], onehot)
+        G = risk + self._ambiguity @ self.post_x[:, 1, :]
+        self.G = G.reshape(P, 1)
+        post_pi = _softmax0(self._mdp.E - self.F - self.G)
+        self.u = int(np.argmax(_softmax0(_ln(post_pi))))
+        # Bayesian model average over policies, then the prior for the next call
+        self.post_x_bma = np.einsum("itp,p->it", self.post_x, post_pi.reshape(P))
+        D = _colnorm(self._mdp.D + self._mdp.kappa_d * self.post_x_bma[:, 0].reshape(n, 1))
+        D[D < 0.00001] = 0.0
+        self._mdp.D = _colnorm(D)
+        return self.G, self.u
+
+    # -- accessors used by the action selection and the task planner ----------------------------
+    def set_observation(self, obs):
+        self._mdp.o = obs
+
+    def set_preferences(self, pref, index="none"):
+        if isinstance(index, str) and index == "none":
+            self._mdp.C = _ln(pref)
+        else:
+            self._mdp.C[index] = _ln(pref)
+
+    def get_action(self):
+        return self.u
+
+    def get_current_state(self):
+        return self._mdp.D
+
+    def reset_habits(self, index="none"):
+        if isinstance(index, str) and index == "none":
+            self._mdp.E = self.default_E.copy()
+        else:
+            self._mdp.E[index] = _ln(0)
+
+    def reset_current_state(self):
+        self._mdp.D = _colnorm(np.ones((self.n_states, 1)))
+
+
+MAX_SELECTION_ROUNDS = 200
+
+
+def adapt_act_sel(agent, obs, verbose=False):
+    """One tick of the adaptive action selection (adaptive_action_selection.py:11-84): returns
+    (outcome, action) with outcome in {'success', 'running', 'failure'}.
+
+    Order of events kept from the reference: habits restored; pushed preconditions that are now
+    observed are dropped; an observed state whose preference is exactly 1 (log == 0) is immediate
+    success; otherwise infer -> pick -> check the action's preconditions against the believed
+    states of ALL factors, pushing a high-priority preference (2) on every missing one and
+    inhibiting the action until one is executable or only idle remains.
+
+    One deliberate difference: when a precondition has been pushed and afterwards only idle is
+    left, the reference's loop never terminates (adaptive_action_selection.py:52-58 falls through
+    with looking_for_alternatives set; recorded as "nonterminating" in the golden file).  Here
+    that situation ends after MAX_SELECTION_ROUNDS rounds with ('failure', 'idle_fail')."""
+    agents = agent if isinstance(agent, list) else [agent]
+    obs = obs if isinstance(agent, list) else [obs]
+    n = len(agents)
+    for ag, ob in zip(agents, obs):
+        ag.reset_habits()
+        for idx in range(len(ag._mdp.C)):
+            if ag._mdp.C[idx] > 0 and idx == ob:
+                if verbose:
+                    print("removed preference state", idx)
+                ag.set_preferences(0, idx)
+    for ag, ob in zip(agents, obs):
+        for idx in range(len(ag._mdp.C)):
+            if ag._mdp.C[idx] == 0 and idx == ob:
+                return "success", "idle_success"
+
+    u = [-1] * n
+    believed = ["null"] * n
+    searching = False
+    for _round in range(MAX_SELECTION_ROUNDS):
+        for i, (ag, ob) in enumerate(zip(agents, obs)):
+            if isinstance(ob, str) and ob == "null":
+                continue
+            if not searching:
+                ag.infer_states(ob)
+            _, u[i] = ag.infer_policies()
+            believed[i] = ag._mdp.state_names[int(np.argmax(ag.get_current_state()))]
+        if max(u) == 0:
+            # only idle left: a failure the first time round, otherwise keep adapting exactly
+            # like the reference does (its loop re-enters with the habits still inhibited)
+            if not searching:
+                if verbose:
+                    print("No action found for this situation")
+                return "failure", "idle_fail"
+            continue
+        for i, ag in enumerate(agents):
+            if u[i] <= 0:
+                continue
+            unmet = False
+            for need in ag._mdp.preconditions[u[i]]:
+                if need != "none" and need not in believed:
+                    unmet = True
+                    searching = True
+                    for other in agents:
+                        if need in other._mdp.state_names:
+                            other.set_preferences(2, other._mdp.state_names.index(need))
+                    ag.reset_habits(u[i])
+            if not unmet:
+                return "running", ag._mdp.action_names[u[i]]
+    return "failure", "idle_fail"
+
+
+# ---------------------------------------------------------------------------------------------
+def _rot_cols(q):
+    """Columns (x, y, z axes) of the rotation matrix of an (x, y, z, w) quaternion
+    (skill_utils.py:140-180)."""
+    x, y, z, w = (float(v) for v in q)
+    return np.array([[2 * (w * w + x * x) - 1, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 2 * (w * w + y * y) - 1, 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 2 * (w * w + z * z) - 1]])
+
+
+def general_ori_cube2goal(cube_quat, goal_quat):
+    """Flip-invariant orientation distance (skill_utils.py:224-252): for the goal's x and y axes,
+    1 - |cos| to the closest cube axis, summed."""
+    Rc, Rg = _rot_cols(cube_quat), _rot_cols(goal_quat)
+    cos = np.abs(Rg[:, :2].T @ Rc)            # [goal axis x|y, cube axis x|y|z]
+    return float(np.sum(1.0 - cos.max(axis=1)))
+
+
+class PLANNER_SIMPLE:
+    """task_planner.py:13-39."""
+
+    def __init__(self, cfg) -> None:
+        import torch
+        self.device = cfg.mppi.device
+        self.task = cfg.task
+        self.curr_goal = cfg.goal if torch.is_tensor(cfg.goal) else torch.tensor(cfg.goal, device=self.device)
+        self.dist_threshold = 0.1
+
+    def update_plan(self, sim):
+        pass
+
+    def reset_plan(self):
+        pass
+
+    def check_task_success(self, sim):
+        import torch
+        box_pos = sim.get_actor_position_by_name("box")[0, :2]
+        if self.task == "navigation":
+            return torch.norm(sim.robot_pos[0, :] - self.curr_goal) < self.dist_threshold
+        if self.task in ("push", "pull", "push_pull"):
+            return torch.norm(box_pos - self.curr_goal) <= self.dist_threshold
+        return False
+
+
+class PLANNER_AIF_PANDA(PLANNER_SIMPLE):
+    """Pick-and-place task planner of the panda_env (task_planner.py:41-107): observation from the
+    cube / goal / gripper poses -> active-inference action -> (task, goal) for the motion planner."""
+
+    def __init__(self, cfg) -> None:
+        import torch
+        self.device = cfg.mppi.device
+        self.task = "idle"
+        self.curr_goal = torch.zeros(7, device=self.device)
+        self.curr_action = "idle"
+        self.ai_agent_task = [AiAgent(MDPIsCubeAtReal())]
+        self.obs = 0
+        self.prev_ee_state = torch.zeros(7, device=self.device)
+        self.pick_always = False       # latches: once close to the cube / at pre-place, stay there
+        self.place_always = False
+        self.pre_pick_place_threshold = cfg.pre_height_diff + 0.005
+        self.verbose = False
+
+    def get_obs(self, cube_state, cube_goal, ee_state):
+        c = cube_state.detach().cpu().numpy().astype(np.float64)
+        g = cube_goal.detach().cpu().numpy().astype(np.float64)
+        e = ee_state.detach().cpu().numpy().astype(np.float64)
+        pre = self.pre_place_loc.detach().cpu().numpy().astype(np.float64)
+        reach_cost = float(np.linalg.norm(e[:3] - c[:3]))
+        dist_cost = float(np.linalg.norm(pre[:2] - c[:2]))
+        ori_cost = general_ori_cube2goal(g[3:7], c[3:7])   # argument order of task_planner.py:62
+        if self.verbose:
+            print("reach_cost", reach_cost, "dis", dist_cost, "ori", ori_cost)
+        want_goal_state_0 = np.array([[1], [0], [0], [0]])
+        if dist_cost + ori_cost < 0.03 or self.place_always:
+            self.obs = 2
+            self.ai_agent_task[0].set_preferences(want_goal_state_0)
+            self.place_always = True
+        elif reach_cost < self.pre_pick_place_threshold or self.pick_always:
+            self.obs = 1
+            self.ai_agent_task[0].set_preferences(want_goal_state_0)
+            self.pick_always = True
+        elif not self.pick_always:
+            self.obs = 0
+            self.ai_agent_task[0].set_preferences(np.array([[0], [1], [0], [0]]))
+
+    def update_plan(self, sim):
+        sim.step()
+        cube_state = sim.get_actor_link_by_name("cubeA", "box")[0, :7]
+        cube_goal = sim.get_actor_link_by_name("cubeB", "box")[0, :7]
+        left_finger = sim.get_actor_link_by_name("panda", "panda_leftfinger")[0, :7]
+        right_finger = sim.get_actor_link_by_name("panda", "panda_rightfinger")[0, :7]
+        self.ee_state = (left_finger + right_finger) / 2
+        self.pre_place_loc = cube_goal.clone()
+        self.pre_place_loc[2] += self.pre_pick_place_threshold
+        self.get_obs(cube_state, cube_goal, self.ee_state)
+        _, self.curr_action = adapt_act_sel(self.ai_agent_task, [self.obs], verbose=self.verbose)
+        self.task = self.curr_action
+        if self.curr_action == "pick":
+            self.curr_goal = self.pre_place_loc
+
+    def check_task_success(self, sim):
+        import torch
+        cube_state = sim.get_actor_link_by_name("cubeA", "box")[0, :7]
+        dist_cost = torch.linalg.norm(self.curr_goal[:2] - cube_state[:2])
+        return bool(self.task == "place" and dist_cost < 0.04)
+
+
+def set_task_planner(cfg):
+    """task_planner.py:7-11."""
+    return PLANNER_SIMPLE(cfg) if cfg.env_type == "point_env" else PLANNER_AIF_PANDA(cfg)

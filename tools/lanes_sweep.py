@@ -14,7 +14,7 @@ for K in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "2000,10000").s
     eng.set_objective("push", (-1.0, -1.0))
     eng.set_noise(delta)
     eng.enable_timing(True)
-    for lanes in (0, 1, 2, 4, 8, 16, 32, 64):
+    for lanes in ((0,) if os.environ.get("M3P2I_HIP_LIB") else (0, 1, 2, 4, 8, 16, 32, 64)):
         eng.set_rollout_lanes(lanes)
         eng.reset()
         for _ in range(10):
