@@ -104,3 +104,72 @@ def test_reactive_tamp_wiring_through_compat_names_gpu():
         d0 = d if d0 is None else d0
     assert r.motion_planner.probe_result["fused"] is True
     assert d < d0 - 0.3, (d0, d)   # the closed loop pushes the box towards the goal
+
+
+@pytest.mark.gpu
+def test_panda_reactive_tamp_with_aif_task_planner_gpu():
+    """reactive_tamp.py:22-88 for config_panda through the reference's module names: the
+    active-inference task planner picks reach -> (pick) from the wrapper's link poses, M3P2I gets
+    the gripper command + objective, and the 1-env world driven by the returned action brings
+    the gripper towards the cube."""
+    import torch
+    from m3p2i_aip_amd import compat
+    compat.install(force_standins=True)
+    from m3p2i_aip.planners.motion_planner import m3p2i
+    from m3p2i_aip.planners.task_planner import task_planner
+    import m3p2i_aip.utils.isaacgym_utils.isaacgym_wrapper as wrapper
+    from m3p2i_aip.planners.motion_planner.cost_functions import Objective
+    cfg = compat.make_config("config_panda", ["mppi.num_samples=512"])
+
+    class R:
+        def __init__(self):
+            self.sim = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=cfg.mppi.num_samples,
+                                               viewer=False, device=cfg.mppi.device, cube_on_shelf=cfg.cube_on_shelf)
+            self.objective = Objective(cfg)
+            self.task_planner = task_planner.set_task_planner(cfg)
+            self.motion_planner = m3p2i.M3P2I(cfg, dynamics=self.dynamics, running_cost=self.running_cost)
+
+        def dynamics(self, _, u, t=None):
+            self.sim.set_dof_velocity_target_tensor(u)
+            self.sim.step()
+            return torch.stack([self.sim.robot_pos[:, 0], self.sim.robot_vel[:, 0],
+                                self.sim.robot_pos[:, 1], self.sim.robot_vel[:, 1]], dim=1), u
+
+        def running_cost(self, _):
+            return self.objective.compute_cost(self.sim)
+
+    r = R()
+    assert isinstance(r.task_planner, task_planner.PLANNER_AIF_PANDA)
+    real = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=1, device=cfg.mppi.device,
+                                   cube_on_shelf=cfg.cube_on_shelf)
+
+    def reach_dist():
+        ee = (real.get_actor_link_by_name("panda", "panda_leftfinger")[0, :3]
+              + real.get_actor_link_by_name("panda", "panda_rightfinger")[0, :3]) / 2
+        return torch.norm(ee - real.get_actor_link_by_name("cubeA", "box")[0, :3]).item()
+
+    d0 = reach_dist()
+    tasks = []
+    for i in range(150):
+        r.sim._dof_state[:] = real._dof_state
+        r.sim._root_state[:] = real._root_state
+        r.sim.set_dof_state_tensor(r.sim._dof_state)
+        r.sim.set_actor_root_state_tensor(r.sim._root_state)
+        r.task_planner.update_plan(r.sim)                                  # tamp_interface()
+        r.motion_planner.update_gripper_command(r.task_planner.task)
+        r.objective.update_objective(r.task_planner.task, r.task_planner.curr_goal)
+        r.motion_planner.get_pull_preference()
+        tasks.append(r.task_planner.task)
+        if r.task_planner.check_task_success(r.sim):
+            break
+        action = r.motion_planner.command(r.sim._dof_state[0])[0]
+        assert action.shape == (9,) and torch.isfinite(action).all()
+        real.set_dof_velocity_target_tensor(action.view(1, 9))
+        real.step()
+        if tasks[-1] == "pick":
+            break
+    d1 = reach_dist()
+    print("panda closed loop: ticks", len(tasks), "tasks", sorted(set(tasks)), "reach dist", d0, "->", d1)
+    assert tasks[0] == "reach" and set(tasks) <= {"reach", "pick"}
+    assert d1 < 0.5 * d0, (d0, d1)
+    assert r.motion_planner.probe_result["fused"] is True

@@ -1,0 +1,123 @@
+"""Closed-loop reactive TAMP in one process (GPU): the flow of the reference's scripts/sim.py:19-58
+(1-env "real world") and scripts/reactive_tamp.py:22-88 (planner side) without the RPC hop.
+
+    python tools/closed_loop.py [-cn config_point|config_panda] [key=value ...] [--ticks N] [--json out]
+
+e.g.  python tools/closed_loop.py task=push goal=[-1,-1] mppi.num_samples=2000 mppi.horizon=30
+      python tools/closed_loop.py task=push_pull multi_modal=True mppi.num_samples=4000 mppi.horizon=30
+      python tools/closed_loop.py -cn config_panda mppi.num_samples=4000 mppi.horizon=20
+
+Reports what the reference logs per run: task timeline, ticks and simulated
+time to success, final position error, and the per-tick command() wall time (p50 / p99).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from m3p2i_aip_amd import compat  # noqa: E402
+
+
+def main(argv):
+    cn, ticks, out, overrides = "config_point", 2000, None, []
+    it = iter(argv)
+    for a in it:
+        if a in ("-cn", "--config-name"):
+            cn = next(it)
+        elif a == "--ticks":
+            ticks = int(next(it))
+        elif a == "--json":
+            out = next(it)
+        else:
+            overrides.append(a)
+    compat.install(force_standins=True)
+    from m3p2i_aip.planners.motion_planner import m3p2i
+    from m3p2i_aip.planners.task_planner import task_planner
+    import m3p2i_aip.utils.isaacgym_utils.isaacgym_wrapper as wrapper
+    from m3p2i_aip.planners.motion_planner.cost_functions import Objective
+    from m3p2i_aip.utils.skill_utils import check_and_apply_suction
+    cfg = compat.make_config(cn, overrides)
+
+    class Tamp:   # reactive_tamp.py:22-88
+        def __init__(self):
+            self.sim = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=cfg.mppi.num_samples,
+                                               viewer=False, device=cfg.mppi.device, cube_on_shelf=cfg.cube_on_shelf)
+            self.objective = Objective(cfg)
+            self.task_planner = task_planner.set_task_planner(cfg)
+            self.task_success = False
+            self.motion_planner = m3p2i.M3P2I(cfg, dynamics=self.dynamics, running_cost=self.running_cost)
+
+        def dynamics(self, _, u, t=None):
+            self.sim.set_dof_velocity_target_tensor(u)
+            self.sim.step()
+            return torch.stack([self.sim.robot_pos[:, 0], self.sim.robot_vel[:, 0],
+                                self.sim.robot_pos[:, 1], self.sim.robot_vel[:, 1]], dim=1), u
+
+        def running_cost(self, _):
+            return self.objective.compute_cost(self.sim)
+
+        def run_tamp(self, dof_state, root_state):
+            self.sim._dof_state[:] = dof_state
+            self.sim._root_state[:] = root_state
+            self.sim.set_dof_state_tensor(self.sim._dof_state)
+            self.sim.set_actor_root_state_tensor(self.sim._root_state)
+            self.task_planner.update_plan(self.sim)
+            self.motion_planner.update_gripper_command(self.task_planner.task)
+            self.objective.update_objective(self.task_planner.task, self.task_planner.curr_goal)
+            self.suction_active = self.motion_planner.get_pull_preference()
+            self.task_success = bool(self.task_planner.check_task_success(self.sim))
+            if self.task_success:
+                return torch.zeros(self.sim.dofs_per_robot, device=cfg.mppi.device)
+            return self.motion_planner.command(self.sim._dof_state[0])[0]
+
+    tamp = Tamp()
+    real = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=1, viewer=False, device=cfg.mppi.device,
+                                   cube_on_shelf=cfg.cube_on_shelf)
+    nu = real.dofs_per_robot
+    timeline, lat = [], []
+    success_tick = None
+    for i in range(ticks):
+        if cfg.env_type == "point_env":
+            real.update_dyn_obs(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        action = tamp.run_tamp(real._dof_state, real._root_state)
+        action_host = action.cpu()               # command() wall time incl. the action on the host
+        lat.append(time.perf_counter() - t0)
+        task = tamp.task_planner.task
+        if not timeline or timeline[-1][1] != task:
+            timeline.append((i, task))
+        if tamp.task_success:
+            success_tick = i
+            break
+        real.set_dof_velocity_target_tensor(action.view(1, nu))
+        if cfg.env_type == "point_env":
+            cfg.suction_active = tamp.suction_active
+            check_and_apply_suction(cfg, real, action.view(1, nu))
+        real.step()
+    res = dict(config=cn, overrides=overrides, K=cfg.mppi.num_samples, T=cfg.mppi.horizon,
+               ticks=i + 1, success=success_tick is not None,
+               sim_time_s=(i + 1) * cfg.isaacgym.dt, timeline=timeline,
+               command_ms_p50=float(np.percentile(lat[5:], 50) * 1e3), command_ms_p99=float(np.percentile(lat[5:], 99) * 1e3),
+               command_hz_mean=float(1.0 / np.mean(lat[5:])))
+    if cfg.env_type == "point_env":
+        goal = tamp.task_planner.curr_goal.float().cpu()
+        who = real.robot_pos[0].cpu() if cfg.task == "navigation" else real.get_actor_position_by_name("box")[0, :2].cpu()
+        res["final_pos_error"] = float(torch.norm(who - goal))
+    else:
+        cube = real.get_actor_link_by_name("cubeA", "box")[0, :3].cpu()
+        goal = real.get_actor_link_by_name("cubeB", "box")[0, :3].cpu()
+        res["cube_to_goal_xy"] = float(torch.norm(cube[:2] - goal[:2]))
+        res["cube_height_above_goal"] = float(cube[2] - goal[2])
+    print(json.dumps(res))
+    if out:
+        os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+        json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
