@@ -190,6 +190,15 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
 
+    # command() latency: host clock from the call to the [T, nu] plan's first action on the host
+    # (SURVEY.md section 8(d)(ii)); outside the timed region, rank-local
+    lat = []
+    for _ in range(min(args.steps, 200)):
+        t1 = time.perf_counter()
+        pl.command(state)[0].cpu()
+        lat.append(time.perf_counter() - t1)
+    lat_ms = np.asarray(lat) * 1e3
+
     # dominant kernel: average duration from HIP events recorded by the library on its stream
     eng.enable_timing(True)
     tr, tu, tf = [], [], []
@@ -225,6 +234,9 @@ def main():
                                    f"{'multi-modal' if multi_modal else 'single-mode'} halton-spline, "
                                    "initial scene, open loop (fixed world, warm-started plan)",
                        "name": args.config, "command_hz": args.steps / wall,
+                       "command_latency_ms": {"p50": float(np.percentile(lat_ms, 50)),
+                                              "p99": float(np.percentile(lat_ms, 99)),
+                                              "what": "host clock, command() + action on host, synchronous"},
                        "parallelism": f"samples sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

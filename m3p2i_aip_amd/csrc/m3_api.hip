@@ -465,6 +465,7 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.best2 = (float*)h->buf[M3_BUF_BEST_2];
     a.action_out = (float*)h->buf[M3_BUF_ACTION_OUT];
     a.top_trajs = (float*)h->buf[M3_BUF_TOP_TRAJS];
+    a.top_dst = (c.K_local == c.K_global) ? a.top_trajs : a.reduce + reduce_off_top(c.T, c.nu);
 }
 
 extern "C" int m3_update(m3_handle* h) {
@@ -476,7 +477,7 @@ extern "C" int m3_update(m3_handle* h) {
     if (c.K_local == c.K_global)  // unsharded: the local costs ARE the global costs (no copy)
         a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST];
     // (minima + beta ladder for the multi-modal search) -> weights (+ top-k stage A as extra
-    // workgroups) -> weighted sums (+ top-k stage B as an extra workgroup)
+    // workgroups) -> weighted sums (+ top-k stage B as an extra workgroup when K > 4096)
     if (c.multi_modal && !c.mode_simple) {
         launch_mins(a, h->stream);
         launch_ladder(a, h->stream);

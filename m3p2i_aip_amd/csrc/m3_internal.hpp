@@ -50,7 +50,7 @@ struct UpdateArgs {
     VI* cand;         // [n_cand][M3_TOPK] per-workgroup top-k candidates (k_prep -> k_wsum)
     float* part_min;  // [n_mins][3] per-workgroup minima (all, first half, second half)
     int n_mins;       // workgroups of k_mins
-    int n_cand;       // top-k stage-A workgroups (extra workgroups of the k_weights launch)
+    int n_cand;       // top-k stage-A workgroups
     float* lad;       // [n_lad][96][3] per-workgroup eta sums on the beta ladders (k_ladder)
     int n_lad;        // workgroups of k_ladder
     float* wpart;     // [n_chunk][3][T][nu] partial weighted sums of k_wsum (n_chunk > 1 only)
@@ -77,6 +77,8 @@ struct UpdateArgs {
     float* best2;
     float* action_out;   // [T][nu]
     float* top_trajs;    // [M3_TOPK][T][2]
+    float* top_dst;      // where top-k stage B writes the rows: top_trajs (unsharded) or the
+                         // reduce buffer's top section (sharded: summed over ranks first)
 };
 
 // REDUCE buffer: [3][T][nu] weighted sums (all, mode 1, mode 2) | [3][T][nu] best rows

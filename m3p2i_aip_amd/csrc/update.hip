@@ -185,7 +185,8 @@ __global__ __launch_bounds__(PREP_T) void k_mins(const UpdateArgs a) {
 #pragma unroll
     for (int e = 0; e < PREP_RPT; ++e) {
         const int k = base + e * PREP_T + tid;
-        const float v = (k < Kg) ? a.Jall[k] : INF;
+        const float jv = a.Jall[min(k, Kg - 1)];  // unconditional: loads stay in flight together
+        const float v = (k < Kg) ? jv : INF;
         mn[0] = fminf(mn[0], v);
         if (k < half) mn[1] = fminf(mn[1], v); else mn[2] = fminf(mn[2], v);
     }
@@ -193,11 +194,70 @@ __global__ __launch_bounds__(PREP_T) void k_mins(const UpdateArgs a) {
     if (tid < 3) a.part_min[blockIdx.x * 3 + tid] = mn[tid];
 }
 
-// top-k stage A for workgroup `blk` of blockDim threads (runs as extra workgroups of the
-// k_weights launch, beside workgroup 0)
-__device__ __forceinline__ void topk_stage_a(const UpdateArgs& a, int blk) {
+// ---- top-k: threshold filter + rank counting -------------------------------------------------
+// top-k weights == k smallest costs (weights are monotone in J; ties towards the lower sample
+// index).  Extracting the k minima by k argmin rounds cost ~1.4 us per round (29 + 15 us for the
+// two stages at K = 2000).  Instead:
+//   1. a threshold tau that is certainly >= the k-th smallest cost of the workgroup: every lane
+//      takes the minimum of its registers, each wave radix-selects the k-th smallest of its 64
+//      lane minima (32 ballot steps on order-preserving keys), tau = min over the waves -- the
+//      wave that supplied it has >= k elements <= tau;
+//   2. the few elements <= tau (typically 20..60 of 4096) are compacted into LDS;
+//   3. every survivor counts how many survivors precede it in (cost, index) order -- its rank --
+//      and the ones with rank < k write themselves to slot `rank`: sorted output, no rounds.
+// Stage A does this per workgroup of 4096 costs, stage B over the workgroups' sorted lists
+// (tau = smallest of the lists' k-th entries).  If the survivors do not fit the LDS list
+// (massive ties, e.g. all costs equal) the old argmin-round code runs instead.
+constexpr int TK_CAP = 1024;
+
+__device__ __forceinline__ unsigned wave_kth_key(unsigned key, int kth) {  // kth: 1-based
+    bool active = true;
+    unsigned res = 0u;
+    int need = kth;
+    for (int bit = 31; bit >= 0; --bit) {
+        const bool zero = !((key >> bit) & 1u);
+        const int cnt = __builtin_popcountll(__ballot(active && zero));
+        if (need <= cnt) {
+            active = active && zero;
+        } else {
+            need -= cnt;
+            active = active && !zero;
+            res |= 1u << bit;
+        }
+    }
+    return res;
+}
+
+// sorted top-k of list[0..n) by rank counting -> out[0..M3_TOPK) (padded when n < k).  Four
+// lanes share one candidate (each scans a quarter of the list, partial ranks added with two
+// quad-permute DPP steps); the scan is unrolled so several LDS reads are in flight.
+// The list holds 64-bit keys (order-preserving cost bits : sample index) so that the compare is
+// one unsigned 64-bit compare on one ds_read_b64 (a (float, int) pair compare made the compiler
+// load the index lazily behind a branch: two dependent LDS round trips per element).
+typedef unsigned long long tkey;
+__device__ __forceinline__ tkey vi_key(float v, int i) { return ((tkey)f2ord(v) << 32) | (unsigned)i; }
+__device__ __forceinline__ VI key_vi(tkey k) { return VI{ord2f((unsigned)(k >> 32)), (int)(unsigned)k}; }
+
+__device__ __forceinline__ void topk_rank_emit(const tkey* list, int n, VI* out, int nt /* threads */) {
+    const int tid = threadIdx.x, part = tid & 3, per = nt >> 2;
+    for (int c0 = 0; c0 < n; c0 += per) {
+        const int c = c0 + (tid >> 2);
+        const bool valid = c < n;
+        const tkey my = list[valid ? c : 0];
+        unsigned rank = 0u;
+#pragma unroll 4
+        for (int q = part; q < n; q += 4) rank += (list[q] < my) ? 1u : 0u;
+        rank += dpp_u<M3_DPP_XOR1, 0xF>(0u, rank);
+        rank += dpp_u<M3_DPP_XOR2, 0xF>(0u, rank);
+        if (valid && part == 0 && rank < (unsigned)M3_TOPK) out[rank] = key_vi(my);
+    }
+    for (int r = n + tid; r < M3_TOPK; r += nt) out[r] = VI{__builtin_inff(), 0x7fffffff};
+}
+
+// fallback stage A: k argmin rounds per wave over the registers, wave 0 merges the waves' lists
+__device__ __noinline__ void topk_stage_a_rounds(const UpdateArgs& a, int blk, VI* out) {
     __shared__ VI cand[16 * M3_TOPK];
-    const int Kg = a.Kg, tid = threadIdx.x, WT = blockDim.x;
+    const int Kg = a.Kg, tid = threadIdx.x, WT = PREP_T;  // called by the first PREP_T threads
     const int lane = tid & 63, wv = tid >> 6, nw = WT >> 6;
     const float INF = __builtin_inff();
     const float* J = a.Jall;
@@ -206,7 +266,8 @@ __device__ __forceinline__ void topk_stage_a(const UpdateArgs& a, int blk) {
 #pragma unroll
     for (int e = 0; e < PREP_RPT; ++e) {
         const int k = base + e * WT + tid;
-        rv[e] = (k < Kg) ? J[k] : INF;
+        const float jv = J[min(k, Kg - 1)];
+        rv[e] = (k < Kg) ? jv : INF;
     }
     unsigned used = 0u;
     for (int r = 0; r < M3_TOPK; ++r) {
@@ -235,20 +296,17 @@ __device__ __forceinline__ void topk_stage_a(const UpdateArgs& a, int blk) {
             }
             best = wave_argmin(best);
             pv = best.v; pi = best.i;
-            if (lane == 0) a.cand[blk * M3_TOPK + r] = best;
+            if (lane == 0) out[r] = best;
         }
     }
 }
 
-// top-k stage B (the extra workgroup of the k_wsum launch): wave 0 merges the stage-A candidates (registers +
-// DPP argmin rounds), then the workgroup gathers the top-k trajectories for every t
-// (mppi.py:252-254) into the packed reduce buffer (zero rows for samples of other ranks).
-__device__ __forceinline__ void topk_stage_b(const UpdateArgs& a) {
-    __shared__ int s_top[M3_TOPK];
-    const int tid = threadIdx.x, T = a.T, nu = a.nu, Kl = a.Kl, k0 = a.k0;
+// fallback stage B: wave 0 merges the stage-A lists with argmin rounds (registers + global tail)
+__device__ __noinline__ void topk_stage_b_rounds(const UpdateArgs& a, VI* out) {
+    const int tid = threadIdx.x;
     if (tid < 64) {
         const int lane = tid, nc = a.n_cand * M3_TOPK;
-        VI rc[6];  // first 384 candidates in registers (covers K <= 78643)
+        VI rc[6];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
             const int c = lane + 64 * e;
@@ -267,25 +325,153 @@ __device__ __forceinline__ void topk_stage_b(const UpdateArgs& a) {
             }
             best = wave_argmin(best);
             pv = best.v; pi = best.i;
-            if (lane == 0) { s_top[r] = best.i; a.top_idx[r] = best.i; }
+            if (lane == 0) out[r] = best;
+        }
+    }
+}
+
+// top_idx + the top-k trajectories for every t (mppi.py:252-254; zero rows for samples of other
+// ranks: summed by the all-reduce when sharded)
+__device__ __forceinline__ void topk_finish(const UpdateArgs& a, const VI* top /* LDS, sorted */, int nt) {
+    const int tid = threadIdx.x, T = a.T, Kl = a.Kl, k0 = a.k0;
+    if (tid < M3_TOPK) a.top_idx[tid] = top[tid].i;
+    // one (x, vx, y, vy) row per (r, t); the rows were written by other CUs (HBM / remote-L2
+    // latency per load), so a batch of independent loads is issued before the first is consumed
+    const float4* st4 = reinterpret_cast<const float4*>(a.states);
+    float2* dst = reinterpret_cast<float2*>(a.top_dst);
+    const int total = M3_TOPK * T;
+    constexpr int UN = 4;
+    for (int o0 = tid; o0 < total; o0 += UN * nt) {
+        float4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int o = o0 + u * nt;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o < total) {
+                const int r = o / T, tt = o - r * T;
+                const int li = top[r].i - k0;
+                if (li >= 0 && li < Kl) v[u] = st4[(size_t)tt * Kl + li];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int o = o0 + u * nt;
+            if (o < total) dst[o] = make_float2(v[u].x, v[u].z);  // states[..., [0, 2]]
+        }
+    }
+}
+
+// Nothing of the control update depends on the top-k selection (only top_idx / top_trajs,
+// mppi.py:248-254), so it rides along as EXTRA workgroups of launches that exist anyway, on CUs
+// the update does not use: stage A beside workgroup 0 of k_weights, stage B beside the sums of
+// k_wsum (no extra launch, no extra stream; with K <= 4096 stage A is the whole selection).
+__device__ __forceinline__ void topk_stage_a(const UpdateArgs& a, int blk) {
+    __shared__ tkey flt[TK_CAP];
+    __shared__ VI s_top[M3_TOPK];
+    __shared__ unsigned s_tau[PREP_T / 64];
+    __shared__ int s_cnt[PREP_T / 64];
+    const int Kg = a.Kg, tid = threadIdx.x;
+    if (tid >= PREP_T) return;  // launched with k_weights' block size: the first 4 waves work
+    const int lane = tid & 63, wv = tid >> 6;
+    const int base = blk * PREP_T * PREP_RPT;
+    float rv[PREP_RPT];
+    unsigned mk = 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < PREP_RPT; ++e) {
+        const int k = base + e * PREP_T + tid;
+        const float jv = a.Jall[min(k, Kg - 1)];  // unconditional: the 16 loads stay in flight together
+        rv[e] = (k < Kg) ? jv : __builtin_inff();
+        if (k < Kg) mk = min(mk, f2ord(rv[e]));
+    }
+    const unsigned tau_w = wave_kth_key(mk, M3_TOPK);
+    if (lane == 0) s_tau[wv] = tau_w;
+    __syncthreads();
+    unsigned tau = s_tau[0];
+#pragma unroll
+    for (int w = 1; w < PREP_T / 64; ++w) tau = min(tau, s_tau[w]);
+    // compaction without atomics: ballot masks per register row, wave totals through LDS,
+    // position = waves before + rows before + lanes before (mbcnt)
+    unsigned long long hit[PREP_RPT];
+    int tot = 0;
+#pragma unroll
+    for (int e = 0; e < PREP_RPT; ++e) {
+        const int k = base + e * PREP_T + tid;
+        hit[e] = __ballot(k < Kg && f2ord(rv[e]) <= tau);
+        tot += __builtin_popcountll(hit[e]);
+    }
+    if (lane == 0) s_cnt[wv] = tot;
+    __syncthreads();
+    int off = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < PREP_T / 64; ++w) {
+        if (w < wv) off += s_cnt[w];
+        n += s_cnt[w];
+    }
+#pragma unroll
+    for (int e = 0; e < PREP_RPT; ++e) {
+        if (hit[e] == 0ull) continue;
+        const int pos = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit[e] >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned)hit[e], 0u));
+        if (((hit[e] >> lane) & 1ull) && pos < TK_CAP) flt[pos] = vi_key(rv[e], base + e * PREP_T + tid);
+        off += __builtin_popcountll(hit[e]);
+    }
+    __syncthreads();
+    const bool single = a.n_cand == 1;  // K <= 4096: this workgroup's list is the final one
+    VI* out = single ? s_top : a.cand + blk * M3_TOPK;
+    if (n <= TK_CAP) topk_rank_emit(flt, n, out, PREP_T);
+    else topk_stage_a_rounds(a, blk, out);
+    if (single) {
+        __syncthreads();
+        topk_finish(a, s_top, PREP_T);
+    }
+}
+
+// stage B (n_cand > 1): merge the workgroups' sorted lists
+__device__ __forceinline__ void topk_stage_b(const UpdateArgs& a) {
+    __shared__ tkey flt[TK_CAP];
+    __shared__ VI s_top[M3_TOPK];
+    __shared__ VI s_arg[16];
+    __shared__ int s_n;
+    const int tid = threadIdx.x, nb = a.n_cand, nc = nb * M3_TOPK;
+    VI tau = {__builtin_inff(), 0x7fffffff};
+    for (int b = tid; b < nb; b += blockDim.x) {
+        const VI x = a.cand[b * M3_TOPK + M3_TOPK - 1];
+        if (vi_less(x.v, x.i, tau.v, tau.i)) tau = x;
+    }
+    if (tid == 0) s_n = 0;
+    tau = block_argmin(tau, s_arg);
+    const tkey tau_key = vi_key(tau.v, tau.i);
+    const unsigned long long* cand64 = reinterpret_cast<const unsigned long long*>(a.cand);
+    const int lane = tid & 63;
+    for (int c0 = 0; c0 < nc; c0 += blockDim.x) {  // uniform trip count: ballots see whole waves
+        const int c = c0 + tid;
+        const unsigned long long raw = cand64[min(c, nc - 1)];  // {v: low word, i: high word}
+        const tkey key = vi_key(__int_as_float((int)(unsigned)raw), (int)(unsigned)(raw >> 32));
+        const bool hit = c < nc && key <= tau_key;
+        const unsigned long long m = __ballot(hit);
+        if (m != 0ull) {  // one LDS atomic per wave and iteration that has survivors
+            int first = 0;
+            if (lane == 0) first = atomicAdd(&s_n, __builtin_popcountll(m));
+            first = __builtin_amdgcn_readfirstlane(first);
+            const int pos = first + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (hit && pos < TK_CAP) flt[pos] = key;
         }
     }
     __syncthreads();
-    for (int o = tid; o < M3_TOPK * T * 2; o += 256) {
-        const int c = o & 1, tt = (o >> 1) % T, r = (o >> 1) / T;
-        const int li = s_top[r] - k0;
-        float v = 0.0f;  // zero unless this rank owns the sample (summed by the all-reduce)
-        if (li >= 0 && li < Kl) v = a.states[((size_t)tt * Kl + li) * 4 + (c ? 2 : 0)];  // [0, 2]
-        a.reduce[reduce_off_top(T, nu) + o] = v;
-    }
+    const int n = s_n;
+    if (n <= TK_CAP) topk_rank_emit(flt, n, s_top, blockDim.x);
+    else topk_stage_b_rounds(a, s_top);
+    __syncthreads();
+    topk_finish(a, s_top, blockDim.x);
 }
 int weights_threads(int Kg);
 int mins_workgroups(int Kg) {
     const int per = PREP_T * PREP_RPT;
     return (Kg + per - 1) / per;
 }
-int topk_workgroups(int Kg) {  // stage-A workgroups ride in the k_weights launch
-    const int per = weights_threads(Kg) * PREP_RPT;
+int topk_workgroups(int Kg) {
+    const int per = PREP_T * PREP_RPT;
     return (Kg + per - 1) / per;
 }
 void launch_mins(const UpdateArgs& a, hipStream_t s) {
@@ -377,7 +563,8 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
 #pragma unroll
     for (int e_ = 0; e_ < JR; ++e_) {
         const int k = e_ * WT + tid;
-        jr[e_] = (k < Kg) ? J[k] : INF;
+        const float jv_ = J[min(k, Kg - 1)];
+        jr[e_] = (k < Kg) ? jv_ : INF;
     }
     extern __shared__ __attribute__((aligned(16))) float sJ[];
     const int lds0 = JR * WT;
@@ -573,7 +760,7 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     __shared__ float red[3 * 16];
     const int tid = threadIdx.x, C = a.n_chunk;
     const int Kl = a.Kl, k0 = a.k0, T = a.T, half = a.Kg / 2;
-    if ((int)blockIdx.x == T * C) {  // extra workgroup: top-k stage B + top-trajectory gathers
+    if ((int)blockIdx.x == T * C) {  // extra workgroup (n_cand > 1 only): top-k stage B
         topk_stage_b(a);
         return;
     }
@@ -650,7 +837,7 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     }
 }
 void launch_wsum(const UpdateArgs& a, hipStream_t s) {
-    const dim3 grid(a.T * a.n_chunk + 1);
+    const dim3 grid(a.T * a.n_chunk + (a.n_cand > 1 ? 1 : 0));
     if (a.nu == 2) hipLaunchKernelGGL(k_wsum<2>, grid, dim3(ST), 0, s, a);
     else hipLaunchKernelGGL(k_wsum<9>, grid, dim3(ST), 0, s, a);
 }
@@ -718,8 +905,9 @@ __global__ __launch_bounds__(256) void k_finalize(const UpdateArgs a) {
         }
         a.action_out[o] = v;
     }
-    for (int o = tid; o < M3_TOPK * T * 2; o += blockDim.x)
-        a.top_trajs[o] = a.reduce[reduce_off_top(T, nu) + o];
+    if (a.Kl != a.Kg)  // sharded: the rows were summed over ranks in the reduce buffer
+        for (int o = tid; o < M3_TOPK * T * 2; o += blockDim.x)
+            a.top_trajs[o] = a.reduce[reduce_off_top(T, nu) + o];
 }
 void launch_finalize(const UpdateArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), a.T * a.nu * sizeof(float), s, a);

@@ -92,6 +92,30 @@ def test_degenerate_cost_inputs_match_torch_semantics(oracle):
         eng.close()
 
 
+@pytest.mark.parametrize("K", [3000, 9000])
+def test_topk_with_massive_ties(oracle, K):
+    """All samples identical (zero noise) -> every cost ties: the threshold filter of the top-k
+    selection overflows its LDS list and the argmin-round fallback runs; ties resolve towards the
+    lower sample index, and the weights are uniform."""
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    T = 12
+    eng = HipEngine(make_config(K=K, T=T, nu=2, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3],
+                                sample_null_action=False))
+    eng.set_objective("navigation", (-3.0, 3.0))
+    eng.set_noise(np.zeros((K, T, 2), np.float32))
+    eng.set_world_point_raw(raw_world(oracle.init_world(1)[0]))
+    eng.command(sync_host=True)
+    J = eng.buffer(L.BUF_TRAJ_COST).cpu().numpy()
+    assert (J == J[0]).all()
+    np.testing.assert_array_equal(eng.buffer(L.BUF_TOP_IDX).cpu().numpy(), np.arange(20))
+    np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), 1.0 / K, rtol=1e-4)
+    tt = eng.buffer(L.BUF_TOP_TRAJS).cpu().numpy()
+    st = eng.states.cpu().numpy()
+    np.testing.assert_array_equal(tt, st[:20][:, :, [0, 2]])
+    eng.close()
+
+
 def test_large_k_sanity():
     """K = 131072 samples x T = 30 on one GPU: finite plan, normalised weights, sorted top-k."""
     from m3p2i_aip_amd import _lib as L

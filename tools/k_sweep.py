@@ -1,0 +1,31 @@
+"""GPU experiment: where does the rollout saturate?  Push task, T = 30, in-kernel noise
+(sampling_random: no host sampler, 36 B algorithmic traffic per state-step), K = 2k .. 1M.
+Prints one JSON line per K and writes gpurun_out/k_sweep.json."""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from m3p2i_aip_amd.engine import HipEngine, make_config
+
+T = 30
+Ks = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "2000,8000,32000,65536,131072,262144,524288,1048576").split(",")]
+out = []
+for K in Ks:
+    eng = HipEngine(make_config(K=K, T=T, nu=2, sampling_random=True, u_min=[-3, -3], u_max=[3, 3],
+                                noise_sigma_diag=[3, 3], seed=1))
+    eng.set_objective("push", (-1.0, -1.0))
+    eng.enable_timing(True)
+    for _ in range(5):
+        eng.command()
+    ts = []
+    for _ in range(20):
+        eng.command()
+        t = eng.timing()
+        ts.append((t.rollout_ms, t.update_ms, t.finalize_ms, t.total_ms))
+    m = np.mean(ts, axis=0)
+    rec = dict(K=K, T=T, rollout_ms=float(m[0]), update_ms=float(m[1]), finalize_ms=float(m[2]), total_ms=float(m[3]),
+               state_steps_per_s=K * T / (m[3] * 1e-3), rollout_alg_GBps=36.0 * K * T / (m[0] * 1e-3) / 1e9,
+               waves=(K + 63) // 64)
+    out.append(rec)
+    print(json.dumps(rec), flush=True)
+    eng.close()
+json.dump(out, open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "k_sweep.json"), "w"), indent=1)
