@@ -752,7 +752,8 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
 // columns in one pass) and, when n_chunk > 1, the last workgroup to arrive for a time step adds
 // the partials in chunk order -- the result does not depend on which one that is.
 constexpr int ST = 256;
-constexpr int WS_CHUNK = 2048;  // samples per k_wsum workgroup
+constexpr int WS_CHUNK = 8192;  // samples per k_wsum workgroup
+constexpr int WS_BATCH = 8;     // loads in flight per thread and array
 int wsum_chunks(int Kl) { return (Kl + WS_CHUNK - 1) / WS_CHUNK; }
 
 template <int NU>
@@ -770,22 +771,34 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     float acc[3][NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
+    // fixed trip count, clamped unconditional loads: all the loads of a workgroup's slice are in
+    // flight together (conditional loads each became a branch region ending in s_waitcnt vmcnt(0))
     const int i1 = min(Kl, (c + 1) * WS_CHUNK);
-    for (int i = c * WS_CHUNK + tid; i < i1; i += ST) {
-        const int k = k0 + i;
+    const int nh2 = a.Kg - half;
+    for (int i0 = c * WS_CHUNK; i0 < i1; i0 += WS_BATCH * ST)
+#pragma unroll
+    for (int it = 0; it < WS_BATCH; ++it) {
+        const int i = i0 + it * ST + tid;
+        const bool ok = i < i1;
+        const int ic = ok ? i : (i1 - 1);
+        const int k = k0 + ic;
         float av[NU];
         if constexpr (NU == 2) {
-            const float2 v = reinterpret_cast<const float2*>(act)[i];
+            const float2 v = reinterpret_cast<const float2*>(act)[ic];
             av[0] = v.x; av[1] = v.y;
         } else {
 #pragma unroll
-            for (int j = 0; j < NU; ++j) av[j] = act[(size_t)i * NU + j];
+            for (int j = 0; j < NU; ++j) av[j] = act[(size_t)ic * NU + j];
         }
-        const float w = a.w[k];
+        float w = a.w[k];
         float wa = 0.0f, wb = 0.0f;
-        if (multi) {
-            if (k < half) wa = a.w1[k]; else wb = a.w2[k - half];
+        if (multi) {  // wave-uniform
+            const float x1 = a.w1[min(k, max(half - 1, 0))];
+            const float x2 = a.w2[min(max(k - half, 0), nh2 - 1)];
+            wa = (k < half) ? x1 : 0.0f;
+            wb = (k < half) ? 0.0f : x2;
         }
+        if (!ok) { w = 0.0f; wa = 0.0f; wb = 0.0f; }
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             acc[0][j] += w * av[j];
@@ -799,30 +812,33 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         float r[3] = {acc[0][j], acc[1][j], acc[2][j]};
         block_sum<3>(r, red);
         const float rv = tid == 0 ? r[0] : (tid == 1 ? r[1] : r[2]);
-        if (tid < 3) out[tid * T * NU + t * NU + j] = rv;  // == reduce_off_psum(tid) + t*NU + j
+        if (tid < 3) {
+            float* dst = &out[tid * T * NU + t * NU + j];  // == reduce_off_psum(tid) + t*NU + j
+            if (C == 1) *dst = rv;
+            else __hip_atomic_store(dst, rv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
+        }
         __syncthreads();
     }
     if (C > 1) {
-        // in-launch combine (agent-scope release -> ticket -> acquire; per-XCD L2s are not
-        // coherent with each other, so workgroup-scope fences would read stale partials)
+        // in-launch combine.  Per-XCD L2s are not coherent with each other: the partials are
+        // written through (sc1 stores) and read back with sc1 loads, so no L2 write-back /
+        // invalidate (agent-scope fences cost ~3.5 us per workgroup here) is needed; the ticket
+        // is an agent-scope atomic issued after every partial store of the workgroup has retired.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int ticket = __hip_atomic_fetch_add(&a.wcount[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int is_last = ticket == C - 1;
-            if (is_last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                a.wcount[t] = 0;  // re-armed for the next launch (zeroed at m3_create)
-            }
+            if (is_last) a.wcount[t] = 0;  // re-armed for the next launch (zeroed at m3_create)
             red[47] = __int_as_float(is_last);
         }
         __syncthreads();
         if (__float_as_int(red[47]) && tid < 3 * NU) {
             const int which = tid / NU, j = tid % NU;
             float sum = 0.0f;
-            for (int cc = 0; cc < C; ++cc) sum += a.wpart[((size_t)cc * 3 + which) * T * NU + t * NU + j];
+            for (int cc = 0; cc < C; ++cc)
+                sum += __hip_atomic_load(&a.wpart[((size_t)cc * 3 + which) * T * NU + t * NU + j],
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.reduce[reduce_off_psum(which, T, NU) + t * NU + j] = sum;
         }
     }
