@@ -79,16 +79,56 @@ def halton_spline_delta(K: int, T: int, nu: int, knot_scale: int = 4, degree: in
     g = halton_gaussian(K, n_knots * nu).view(K, nu, n_knots).numpy()
     rows = g[k0:k1].astype(np.float32)
     if workers is None:
-        workers = min(_usable_cores(), 32) if (k1 - k0) * nu >= 8192 else 1
+        workers = min(_usable_cores(), 32) if (k1 - k0) * nu >= 100000 else 1  # ~30 us per fit;
+        # worker start-up (python + scipy import) is ~2 s, so small jobs stay in-process
     if workers > 1:
-        import multiprocessing as mp
-        chunks = np.array_split(rows, workers * 4)
-        with mp.get_context("fork").Pool(workers) as pool:
-            parts = pool.starmap(_spline_rows, [(c, T, degree) for c in chunks if len(c)])
-        out = np.concatenate(parts, axis=0)
+        out = _spline_rows_parallel(rows, T, degree, workers)
     else:
         out = _spline_rows(rows, T, degree)
     return torch.from_numpy(out)
+
+
+_PROFILER_ENV = ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE", "ROCP_TOOL_LIBRARIES",
+                 "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_ATTACH")
+
+
+def _spline_rows_parallel(rows: np.ndarray, T: int, degree: int, workers: int) -> np.ndarray:
+    """Init-time only: the K*nu independent FITPACK fits spread over plain worker processes
+    (`python -m m3p2i_aip_amd._spline_worker`, numpy + scipy only).  They are started with
+    subprocess and a profiler-free environment rather than multiprocessing.fork: forked
+    children inherit a loaded rocprofv3 tool and its signal handlers, which was seen to hang
+    the pool's teardown under `rocprofv3 --pmc`."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in _PROFILER_ENV and not k.startswith("ROCPROF")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    chunks = [c for c in np.array_split(rows, workers) if len(c)]
+    procs = []
+    for c in chunks:
+        p = subprocess.Popen([sys.executable, "-m", "m3p2i_aip_amd._spline_worker"], stdin=subprocess.PIPE,
+                             stdout=subprocess.PIPE, env=env)
+        procs.append(p)
+    # feed and drain from threads: a worker's stdout pipe would fill up while another is written
+    import threading
+    parts = [None] * len(procs)
+
+    def run(i):
+        data, _ = procs[i].communicate(pickle.dumps((chunks[i], T, degree), protocol=4))
+        if procs[i].returncode != 0:
+            raise RuntimeError(f"spline worker {i} failed with exit code {procs[i].returncode}")
+        parts[i] = pickle.loads(data)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(procs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if any(p is None for p in parts):
+        raise RuntimeError("a spline worker failed")
+    return np.concatenate(parts, axis=0)
 
 
 def _spline_rows(rows: np.ndarray, T: int, degree: int) -> np.ndarray:
