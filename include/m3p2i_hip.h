@@ -188,6 +188,12 @@ int m3_set_multi_modal(m3_handle* h, int multi_modal);
 /* warm-start state (means, best trajs, U): which = M3_BUF_MEAN.., host pointer [T][nu] */
 int m3_set_plan(m3_handle* h, int which, const float* host_values);
 int m3_reset(m3_handle* h); /* zero means/best/pending forces, beta = 1, call counter = 0 */
+/* Where m3_finalize writes the returned plan (`action`, mppi.py:257-263): a caller-owned device
+ * buffer of [T][nu] floats ([u_per_command][nu] in simple mode), or NULL for the library's
+ * M3_BUF_ACTION_OUT.  The reference returns a fresh tensor per command(); a host wrapper that
+ * hands out slots of a small ring through this call gets the same aliasing behaviour without a
+ * device-to-device copy per command. */
+int m3_set_action_out(m3_handle* h, float* dev_ptr);
 
 /* initial state of every rollout (host values; copied by value into the launch) */
 int m3_set_world_point(m3_handle* h, const m3_point_world* w);

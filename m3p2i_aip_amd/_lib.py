@@ -73,6 +73,7 @@ SYMBOLS = [
     ("m3_set_objective", C.c_int, [_H, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int]),
     ("m3_set_multi_modal", C.c_int, [_H, C.c_int]),
     ("m3_set_plan", C.c_int, [_H, C.c_int, _FP]),
+    ("m3_set_action_out", C.c_int, [_H, C.c_void_p]),
     ("m3_reset", C.c_int, [_H]),
     ("m3_set_world_point", C.c_int, [_H, C.POINTER(PointWorld)]),
     ("m3_set_world_point_raw", C.c_int, [_H, C.POINTER(C.c_float)]),

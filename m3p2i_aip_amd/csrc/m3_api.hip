@@ -291,6 +291,13 @@ extern "C" int m3_set_plan(m3_handle* h, int which, const float* v) {
     return M3_OK;
 }
 
+extern "C" int m3_set_action_out(m3_handle* h, float* dev_ptr) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (h->cfg.sim_only) return fail(h, M3_ERR_STATE, "m3_set_action_out: handle was created sim_only");
+    h->action_out = dev_ptr;
+    return M3_OK;
+}
+
 extern "C" int m3_reset(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     for (int id = M3_BUF_MEAN; id <= M3_BUF_ACTION_OUT; ++id)
@@ -463,7 +470,7 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.best = (float*)h->buf[M3_BUF_BEST];
     a.best1 = (float*)h->buf[M3_BUF_BEST_1];
     a.best2 = (float*)h->buf[M3_BUF_BEST_2];
-    a.action_out = (float*)h->buf[M3_BUF_ACTION_OUT];
+    a.action_out = h->action_out ? h->action_out : (float*)h->buf[M3_BUF_ACTION_OUT];
     a.top_trajs = (float*)h->buf[M3_BUF_TOP_TRAJS];
     a.top_dst = (c.K_local == c.K_global) ? a.top_trajs : a.reduce + reduce_off_top(c.T, c.nu);
 }
@@ -510,7 +517,7 @@ extern "C" int m3_command(m3_handle* h, float* action_host) {
     if (action_host) {
         const m3_config& c = h->cfg;
         const int rows = c.mode_simple ? c.u_per_command : c.T;
-        HIPCHK(h, hipMemcpyAsync(action_host, h->buf[M3_BUF_ACTION_OUT], (size_t)rows * c.nu * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(action_host, h->action_out ? h->action_out : (float*)h->buf[M3_BUF_ACTION_OUT], (size_t)rows * c.nu * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return M3_OK;

@@ -166,6 +166,7 @@ struct m3_handle {
     void* buf[M3_BUF_COUNT] = {};
     long long nbytes[M3_BUF_COUNT] = {};
     float* world0_dev = nullptr;
+    float* action_out = nullptr;  // caller-owned destination of the plan (m3_set_action_out)
     m3::VI* topk_cand = nullptr;
     float* part_min = nullptr;
     float* lad = nullptr;

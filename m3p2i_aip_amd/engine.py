@@ -73,6 +73,7 @@ class HipEngine:
         L.check(self.lib.m3_create(C.byref(cfg), C.byref(self._h)))
         self.device = torch.device(f"cuda:{cfg.device}")
         self._views = {}
+        self._action_out = None
         self.use_torch_stream()
 
     # ---- lifetime ----
@@ -134,6 +135,17 @@ class HipEngine:
     def reset(self):
         self._ck(self.lib.m3_reset(self._h))
 
+    def set_action_out(self, tensor):
+        """Redirect the returned plan into a caller-owned device tensor (None: library buffer)."""
+        self._action_out = tensor
+        if tensor is None:
+            self._ck(self.lib.m3_set_action_out(self._h, None))
+            return
+        rows = self.cfg.u_per_command if self.cfg.mode_simple else self.cfg.T
+        assert tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous()
+        assert tuple(tensor.shape) == (rows, self.cfg.nu)
+        self._ck(self.lib.m3_set_action_out(self._h, C.c_void_p(tensor.data_ptr())))
+
     def set_world_point(self, robot, box, dyn_obs):
         w = L.PointWorld()
         for dst, src, n in ((w.robot, robot, 4), (w.box, box, 7), (w.dyn_obs, dyn_obs, 7)):
@@ -170,7 +182,7 @@ class HipEngine:
             self._ck(self.lib.m3_command(self._h, out.ctypes.data))
             return out
         self._ck(self.lib.m3_command(self._h, None))
-        return self.buffer(L.BUF_ACTION_OUT)
+        return self._action_out if self._action_out is not None else self.buffer(L.BUF_ACTION_OUT)
 
     def rollout(self):
         self._ck(self.lib.m3_rollout(self._h))

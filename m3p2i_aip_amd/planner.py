@@ -285,10 +285,25 @@ class MPPI():
         if self.collective is not None:
             self.collective(self, phase)
 
+    ACTION_RING = 8   # command() returns slot (call % 8) of a ring: a returned plan stays valid
+                      # for the next 7 calls (the reference returns a fresh tensor each time; a
+                      # clone per command costs a ~5 us device copy on the critical path)
+
+    def _next_action_slot(self):
+        rows = self.u_per_command if self.mppi_mode == "simple" else self.T
+        if getattr(self, "_action_ring", None) is None:
+            self._action_ring = torch.zeros(self.ACTION_RING, rows, self.nu, **self.tensor_args)
+            self._action_slot = 0
+        out = self._action_ring[self._action_slot]
+        self._action_slot = (self._action_slot + 1) % self.ACTION_RING
+        self._engine.set_action_out(out)
+        return out
+
     def _command_fused(self):
         self._push_objective()
         self._bind_world()
         e = self._engine
+        out = self._next_action_slot()
         if self.world_size == 1:
             e.command()
         else:
@@ -297,9 +312,7 @@ class MPPI():
             e.update()
             self._exchange("reduce")
             e.finalize()
-        out = self._buf(L.BUF_ACTION_OUT)
-        rows = self.u_per_command if self.mppi_mode == "simple" else self.T
-        return out[:rows].clone()
+        return out
 
     def _assemble_torch(self):
         """mppi.py:381-416 / :335-347 in torch ops (STEP mode only; the fused kernel does this
@@ -355,11 +368,12 @@ class MPPI():
             J = J + gs * c
             gs = gs * self.gamma
         self._buf(L.BUF_TRAJ_COST).copy_(J)
+        out = self._next_action_slot()
         self._exchange("gather")
         e.update()
         self._exchange("reduce")
         e.finalize()
-        return self._buf(L.BUF_ACTION_OUT)[:T].clone()
+        return out
 
     def command(self, state):
         if not torch.is_tensor(state):

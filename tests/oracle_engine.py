@@ -143,8 +143,13 @@ class OracleEngine:
             n[L.BUF_BEST][...] = red[3 * T * nu:4 * T * nu].reshape(T, nu)
         a = n[L.BUF_MEAN].copy()
         n[L.BUF_ACTION_OUT][...] = O.savgol9(a) if cfg.filter_u else a
+        if getattr(self, "_action_out", None) is not None:
+            self._action_out.copy_(self.t[L.BUF_ACTION_OUT])
         n[L.BUF_TOP_TRAJS][...] = red[6 * T * nu:].reshape(L.TOPK, T, 2)
         self.calls += 1
+
+    def set_action_out(self, tensor):
+        self._action_out = tensor
 
     def command(self, sync_host=False):
         self.rollout()
