@@ -237,7 +237,10 @@ def main():
                        "command_latency_ms": {"p50": float(np.percentile(lat_ms, 50)),
                                               "p99": float(np.percentile(lat_ms, 99)),
                                               "what": "host clock, command() + action on host, synchronous"},
-                       "parallelism": f"samples sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"samples sharded x{world}, " + ("one all-gather of per-rank softmin records"
+                                                                             if pl.shard_mix else
+                                                                             "all-gather J + all-reduce packed sums")
+                                       + " (RCCL)") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kern, "kernel_ms": rollout_ms, "bytes_per_launch": alg_bytes,

@@ -50,7 +50,7 @@ extern "C" {
 
 #define M3_MAX_NU 9
 #define M3_TOPK 20
-#define M3_ABI_VERSION 1
+#define M3_ABI_VERSION 2
 
 typedef enum {
     M3_OK = 0,
@@ -107,6 +107,16 @@ typedef struct {
     int sim_only;           /* 1: handle is used only through m3_sim_* / m3_cost (the wrapper's
                                environments); planner-shape checks (K >= 20, filter rows) are
                                skipped and m3_rollout/m3_update are refused */
+    int shard_mix;          /* sharded single-mode MPPI only (K_local < K_global, !multi_modal):
+                               1 = ONE collective per command.  Every rank runs the softmin on
+                               its own shard (local minimum m_r, local eta_r, normalised local
+                               sums) and publishes a record; m3_finalize mixes the ranks' records
+                               with rho_r = exp(-(m_r - m)/beta) eta_r / sum_r(...) -- exact in
+                               real arithmetic because beta is fixed during a command (mppi.py:
+                               430-456), equal to the gather + reduce protocol up to f32
+                               rounding (~1e-6 relative).  0 = gather + reduce (bit-identical
+                               to the unsharded run; the only protocol for the multi-modal
+                               on-the-fly beta search) */
     unsigned long long seed;
 } m3_config;
 
@@ -160,7 +170,12 @@ typedef enum {
     M3_BUF_INFO = 20,       /* device copy of m3_info */
     M3_BUF_SIM_WORLD = 21,  /* f32 [28][Kl] step-mode environments (SoA; rows 18..21 = pending
                                force in M3_BUF_PENDING_FORCE order); allocated on first use */
-    M3_BUF_COUNT = 22
+    M3_BUF_RECORD = 22,     /* f32 [record_len] this rank's record (shard_mix): header {m_r, eta_r,
+                               half sums, best idx, top-k costs and indices} + a REDUCE-shaped
+                               body (normalised local sums, best rows, top trajectories) */
+    M3_BUF_RECORDS_ALL = 23,/* f32 [K_global/K_local][record_len]: all-gather M3_BUF_RECORD into
+                               this buffer between m3_update and m3_finalize (shard_mix) */
+    M3_BUF_COUNT = 24
 } m3_buffer_id;
 
 typedef struct m3_handle m3_handle;
@@ -217,14 +232,16 @@ int m3_bind_sim_panda(m3_handle* h, const float* dof_state_dev, const float* roo
  * [u_per_command][nu] in simple mode) host buffer; if non-NULL the call synchronises. */
 int m3_command(m3_handle* h, float* action_host);
 /* the three phases, for sharded use: rollout -> (all-gather TRAJ_COST into TRAJ_COST_ALL)
- * -> update -> (all-reduce REDUCE) -> finalize.  With K_local == K_global m3_update copies
- * TRAJ_COST itself. */
+ * -> update -> (all-reduce REDUCE) -> finalize.  With K_local == K_global m3_update uses
+ * TRAJ_COST itself.  With cfg.shard_mix: rollout -> update -> (all-gather RECORD into
+ * RECORDS_ALL) -> finalize: one collective. */
 int m3_rollout(m3_handle* h);
 int m3_update(m3_handle* h);
 int m3_finalize(m3_handle* h);
 
 int m3_get_buffer(m3_handle* h, int which, void** dev_ptr, long long* nbytes);
 int m3_reduce_len(const m3_handle* h);
+int m3_record_len(const m3_handle* h);
 int m3_get_info(m3_handle* h, m3_info* out);     /* synchronises the stream */
 int m3_get_timing(m3_handle* h, m3_timing* out); /* synchronises the stream */
 

@@ -131,6 +131,13 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
             return fail(nullptr, M3_ERR_SHAPE, "m3_create: bad u_per_command");
     }
     if (c->substeps < 1 || c->solver_iters < 1 || !(c->dt > 0.0f)) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad dt/substeps/solver_iters");
+    if (c->shard_mix && c->K_local != c->K_global) {
+        if (c->multi_modal && !c->mode_simple)
+            return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: shard_mix needs a beta that is fixed during a command (not multi_modal)");
+        if (c->K_global % c->K_local != 0 || c->k_offset % c->K_local != 0 || c->K_global / c->K_local > MIX_MAX_RANKS)
+            return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs equal shards (K_global = n * K_local, n <= 32)");
+        if (c->K_local < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs K_local >= 20");
+    }
     for (int j = 0; j < c->nu; ++j)
         if (!(c->noise_sigma_diag[j] > 0.0f) || !(c->u_max[j] >= c->u_min[j]))
             return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad noise_sigma / bounds");
@@ -176,6 +183,10 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     A(M3_BUF_NOISE, T * Kl * nu * f);
     A(M3_BUF_PENDING_FORCE, 4 * Kl * f);
     A(M3_BUF_INFO, sizeof(m3_info));
+    if (c->shard_mix && Kl != Kg) {
+        A(M3_BUF_RECORD, (long long)record_length((int)T, (int)nu) * f);
+        A(M3_BUF_RECORDS_ALL, (Kg / Kl) * (long long)record_length((int)T, (int)nu) * f);
+    }
     if (rc == M3_OK && hipMalloc((void**)&h->world0_dev, 18 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->topk_cand, (size_t)topk_workgroups((int)Kg) * M3_TOPK * sizeof(VI)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->part_min, (size_t)mins_workgroups((int)Kg) * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
@@ -473,7 +484,14 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.action_out = h->action_out ? h->action_out : (float*)h->buf[M3_BUF_ACTION_OUT];
     a.top_trajs = (float*)h->buf[M3_BUF_TOP_TRAJS];
     a.top_dst = (c.K_local == c.K_global) ? a.top_trajs : a.reduce + reduce_off_top(c.T, c.nu);
+    a.kbase = 0;
+    a.half_g = c.K_global / 2;
+    a.n_ranks = c.K_global / c.K_local;
+    a.rank = c.k_offset / c.K_local;
+    a.records_all = (const float*)h->buf[M3_BUF_RECORDS_ALL];
 }
+
+static bool mix_mode(const m3_handle* h) { return h->cfg.shard_mix && h->cfg.K_local != h->cfg.K_global; }
 
 extern "C" int m3_update(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
@@ -483,6 +501,24 @@ extern "C" int m3_update(m3_handle* h) {
     fill_update_args(h, a);
     if (c.K_local == c.K_global)  // unsharded: the local costs ARE the global costs (no copy)
         a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST];
+    if (mix_mode(h)) {
+        // one-collective sharding: softmin over the LOCAL shard into this rank's record
+        float* rec = (float*)h->buf[M3_BUF_RECORD];
+        a.record = rec;
+        a.reduce = rec + REC_HDR;
+        a.top_dst = a.reduce + reduce_off_top(c.T, c.nu);
+        a.n_cand = topk_workgroups(c.K_local);
+        UpdateArgs aw = a;  // what k_weights and top-k stage A see
+        aw.Kg = c.K_local;
+        aw.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST];
+        aw.w = a.w + c.k_offset;
+        aw.kbase = c.k_offset;
+        launch_weights(aw, h->stream);
+        launch_wsum(a, h->stream);
+        HIPCHK(h, hipGetLastError());
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+        return M3_OK;
+    }
     // (minima + beta ladder for the multi-modal search) -> weights (+ top-k stage A as extra
     // workgroups) -> weighted sums (+ top-k stage B as an extra workgroup when K > 4096)
     if (c.multi_modal && !c.mode_simple) {
@@ -500,6 +536,7 @@ extern "C" int m3_finalize(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     UpdateArgs a;
     fill_update_args(h, a);
+    if (mix_mode(h)) launch_mix(a, h->stream);  // records -> the REDUCE buffer an all-reduce would hold
     launch_finalize(a, h->stream);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
@@ -524,6 +561,10 @@ extern "C" int m3_command(m3_handle* h, float* action_host) {
 }
 
 static int ensure_sim(m3_handle* h);
+extern "C" int m3_record_len(const m3_handle* h) {
+    return h ? record_length(h->cfg.T, h->cfg.nu) : 0;
+}
+
 extern "C" int m3_get_buffer(m3_handle* h, int which, void** p, long long* nbytes) {
     if (!h || !p) return M3_ERR_BAD_ARG;
     if (which < 0 || which >= M3_BUF_COUNT) return fail(h, M3_ERR_BAD_ARG, "m3_get_buffer: unknown buffer id");

@@ -77,6 +77,13 @@ struct UpdateArgs {
     float* best2;
     float* action_out;   // [T][nu]
     float* top_trajs;    // [M3_TOPK][T][2]
+    // shard_mix (one-collective sharding): k_weights / top-k see the LOCAL shard (Kg = Kl,
+    // Jall = local costs, w = weights + k0); kbase maps their sample numbers to global indices
+    int kbase;           // global index of sample 0 of the costs k_weights sees (0 unless shard_mix)
+    int half_g;          // global K/2 (mode split, pull preference)
+    float* record;       // this rank's record (null unless shard_mix)
+    const float* records_all;  // [n_ranks][record_len]
+    int n_ranks, rank;
     float* top_dst;      // where top-k stage B writes the rows: top_trajs (unsharded) or the
                          // reduce buffer's top section (sharded: summed over ranks first)
 };
@@ -87,6 +94,12 @@ __host__ __device__ inline int reduce_off_psum(int which, int T, int nu) { retur
 __host__ __device__ inline int reduce_off_best(int which, int T, int nu) { return (3 + which) * T * nu; }
 __host__ __device__ inline int reduce_off_top(int T, int nu) { return 6 * T * nu; }
 __host__ __device__ inline int reduce_length(int T, int nu) { return 6 * T * nu + M3_TOPK * T * 2; }
+// shard_mix record: header | REDUCE-shaped body
+//   [0] min cost m_r  [1] eta_r  [2],[3] half sums of the local weights  [4] best index (int bits)
+//   [8..28) top-k costs  [28..48) top-k global indices (int bits)
+constexpr int REC_HDR = 48, REC_TOPJ = 8, REC_TOPI = 28;
+__host__ __device__ inline int record_length(int T, int nu) { return REC_HDR + reduce_length(T, nu); }
+constexpr int MIX_MAX_RANKS = 32;
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s);
@@ -95,6 +108,7 @@ void launch_transpose_noise(const float* src_ktn, float* dst_tkn, int K, int T, 
 void launch_weights(const UpdateArgs& a, hipStream_t s);
 void launch_wsum(const UpdateArgs& a, hipStream_t s);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);
+void launch_mix(const UpdateArgs& a, hipStream_t s);
 int rollout_lanes_for(int Kl);
 int mins_workgroups(int Kg);
 int topk_workgroups(int Kg);

@@ -276,8 +276,8 @@ __device__ __noinline__ void topk_stage_a_rounds(const UpdateArgs& a, int blk, V
 #pragma unroll
         for (int e = 0; e < PREP_RPT; ++e) {
             const int k = base + e * WT + tid;
-            if (!((used >> e) & 1u) && k < Kg && vi_less(rv[e], k, best.v, best.i)) {
-                best.v = rv[e]; best.i = k; be = e;
+            if (!((used >> e) & 1u) && k < Kg && vi_less(rv[e], a.kbase + k, best.v, best.i)) {
+                best.v = rv[e]; best.i = a.kbase + k; be = e;
             }
         }
         const VI win = wave_argmin(best);
@@ -334,7 +334,13 @@ __device__ __noinline__ void topk_stage_b_rounds(const UpdateArgs& a, VI* out) {
 // ranks: summed by the all-reduce when sharded)
 __device__ __forceinline__ void topk_finish(const UpdateArgs& a, const VI* top /* LDS, sorted */, int nt) {
     const int tid = threadIdx.x, T = a.T, Kl = a.Kl, k0 = a.k0;
-    if (tid < M3_TOPK) a.top_idx[tid] = top[tid].i;
+    if (tid < M3_TOPK) {
+        a.top_idx[tid] = top[tid].i;
+        if (a.record) {  // shard_mix: the ranks' lists are merged by k_mix
+            a.record[REC_TOPJ + tid] = top[tid].v;
+            a.record[REC_TOPI + tid] = __int_as_float(top[tid].i);
+        }
+    }
     // one (x, vx, y, vy) row per (r, t); the rows were written by other CUs (HBM / remote-L2
     // latency per load), so a batch of independent loads is issued before the first is consumed
     const float4* st4 = reinterpret_cast<const float4*>(a.states);
@@ -412,7 +418,7 @@ __device__ __forceinline__ void topk_stage_a(const UpdateArgs& a, int blk) {
         if (hit[e] == 0ull) continue;
         const int pos = off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit[e] >> 32),
                                                              __builtin_amdgcn_mbcnt_lo((unsigned)hit[e], 0u));
-        if (((hit[e] >> lane) & 1ull) && pos < TK_CAP) flt[pos] = vi_key(rv[e], base + e * PREP_T + tid);
+        if (((hit[e] >> lane) & 1ull) && pos < TK_CAP) flt[pos] = vi_key(rv[e], a.kbase + base + e * PREP_T + tid);
         off += __builtin_popcountll(hit[e]);
     }
     __syncthreads();
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
     __shared__ float s_beta[3], s_eta[3];
     __shared__ int s_done[3], s_it[3];
     __shared__ float s_tab[LAD_N * 3];
-    const int Kg = a.Kg, half = Kg / 2;
+    const int Kg = a.Kg, half = a.half_g - a.kbase;  // k < half <=> global index in the first mode
     const int tid = threadIdx.x;
     const int WT = blockDim.x;
     const float* J = a.Jall;
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
         m3_info* f = a.info;
         f->eta = eta[0]; f->eta_1 = eta[1]; f->eta_2 = eta[2];
         f->iters = iters[0]; f->iters_1 = iters[1]; f->iters_2 = iters[2];
-        f->best_idx = b0.i;
+        f->best_idx = a.kbase + b0.i;
         f->best_idx_1 = multi ? b1.i : -1;
         f->best_idx_2 = multi ? b2.i : -1;
         f->wsum_push = hs[0]; f->wsum_pull = hs[1];
@@ -721,7 +727,11 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
             if (eta[0] > 20.0f) nb = nb * 0.9f;
             else if (eta[0] < 10.0f) nb = nb * 1.2f;
         }
-        if (!a.multi_modal && !a.mode_simple) f->beta = nb;
+        if (a.record) {  // shard_mix: local softmin only; k_mix owns eta, beta and the best index
+            a.record[0] = mn[0]; a.record[1] = eta[0];
+            a.record[2] = hs[0]; a.record[3] = hs[1];
+            a.record[4] = __int_as_float(a.kbase + b0.i);
+        } else if (!a.multi_modal && !a.mode_simple) f->beta = nb;
         // multi-modal: the searched betas are locals in the reference (self.beta / beta_1 /
         // beta_2 are never written, m3p2i.py:58-60), so the persistent beta stays untouched;
         // the values found are reported for diagnostics only
@@ -856,6 +866,102 @@ void launch_wsum(const UpdateArgs& a, hipStream_t s) {
     const dim3 grid(a.T * a.n_chunk + (a.n_cand > 1 ? 1 : 0));
     if (a.nu == 2) hipLaunchKernelGGL(k_wsum<2>, grid, dim3(ST), 0, s, a);
     else hipLaunchKernelGGL(k_wsum<9>, grid, dim3(ST), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_mix (shard_mix): turns the ranks' records into the REDUCE buffer the all-reduce would have
+// produced, so that k_finalize runs unchanged.  With beta fixed during the command, the global
+// softmin is a mixture of the ranks' local softmins:
+//   w_k = exp(-(J_k - m)/beta) / eta,  m = min_r m_r,
+//   rho_r = exp(-(m_r - m)/beta) eta_r / sum_r' exp(-(m_r' - m)/beta) eta_r'
+//   sum_k w_k a_k = sum_r rho_r S_r   (S_r = the rank's normalised local weighted sum)
+// One workgroup; every rank computes the same thing from the same gathered records (fixed
+// order over ranks), so the plans stay identical across ranks.
+__global__ __launch_bounds__(256) void k_mix(const UpdateArgs a) {
+    __shared__ float s_rho[MIX_MAX_RANKS];
+    __shared__ int s_best_rank;
+    __shared__ tkey s_key[MIX_MAX_RANKS * M3_TOPK];
+    __shared__ int s_src[M3_TOPK];
+    const int tid = threadIdx.x, T = a.T, nu = a.nu, N = a.n_ranks;
+    const int L = record_length(T, nu);
+    const float* R = a.records_all;
+    if (tid == 0) {
+        float m = __builtin_inff();
+        int br = 0;
+        for (int r = 0; r < N; ++r) {
+            const float mr = R[(size_t)r * L + 0];
+            if (mr < m) { m = mr; br = r; }  // first rank on ties = lowest sample index
+        }
+        const float beta = a.mode_simple ? a.lambda_ : a.info->beta;
+        const float nib = -1.0f / beta;
+        float Z = 0.0f;
+        for (int r = 0; r < N; ++r) {
+            const float sr = m3_exp(nib * (R[(size_t)r * L + 0] - m)) * R[(size_t)r * L + 1];
+            s_rho[r] = sr;
+            Z += sr;
+        }
+        const float iz = 1.0f / Z;
+        float h0 = 0.0f, h1 = 0.0f;
+        for (int r = 0; r < N; ++r) {
+            s_rho[r] = s_rho[r] * iz;
+            h0 += s_rho[r] * R[(size_t)r * L + 2];
+            h1 += s_rho[r] * R[(size_t)r * L + 3];
+        }
+        s_best_rank = br;
+        m3_info* f = a.info;
+        f->eta = Z; f->eta_1 = 0.0f; f->eta_2 = 0.0f;
+        f->iters = 1; f->iters_1 = 1; f->iters_2 = 1;
+        f->best_idx = __float_as_int(R[(size_t)br * L + 4]);
+        f->best_idx_1 = -1; f->best_idx_2 = -1;
+        f->wsum_push = h0; f->wsum_pull = h1;
+        f->pull_preference = h1 > h0;
+        if (!a.mode_simple) {
+            float nb = beta;
+            if (a.env_type == M3_ENV_PANDA) {  // mppi.py:446-454, on the GLOBAL eta
+                if (Z > 20.0f) nb = nb * 0.9f;
+                else if (Z < 10.0f) nb = nb * 1.2f;
+            }
+            f->beta = nb;
+        }
+    }
+    // candidates of the global top-k: the ranks' sorted lists
+    const int nc = N * M3_TOPK;
+    for (int c = tid; c < nc; c += blockDim.x) {
+        const float* rec = R + (size_t)(c / M3_TOPK) * L;
+        s_key[c] = vi_key(rec[REC_TOPJ + c % M3_TOPK], __float_as_int(rec[REC_TOPI + c % M3_TOPK]));
+    }
+    __syncthreads();
+    // weighted sums and the best rows (mode sets 1, 2 are unused in single-mode MPPI)
+    const int n = T * nu, br = s_best_rank;
+    for (int o = tid; o < n; o += blockDim.x) {
+        float acc = 0.0f;
+        for (int r = 0; r < N; ++r) acc += s_rho[r] * R[(size_t)r * L + REC_HDR + reduce_off_psum(0, T, nu) + o];
+        a.reduce[reduce_off_psum(0, T, nu) + o] = acc;
+        a.reduce[reduce_off_best(0, T, nu) + o] = R[(size_t)br * L + REC_HDR + reduce_off_best(0, T, nu) + o];
+    }
+    // rank counting over the N*20 candidates (keys are unique: the index is part of the key)
+    for (int c = tid; c < nc; c += blockDim.x) {
+        const tkey my = s_key[c];
+        int rank = 0;
+#pragma unroll 4
+        for (int q = 0; q < nc; ++q) rank += (s_key[q] < my) ? 1 : 0;
+        if (rank < M3_TOPK) {
+            s_src[rank] = c;
+            a.top_idx[rank] = (int)(unsigned)my;
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < M3_TOPK * T * 2; o += blockDim.x) {
+        const int slot = o / (T * 2), c = s_src[slot];
+        a.reduce[reduce_off_top(T, nu) + o] =
+            R[(size_t)(c / M3_TOPK) * L + REC_HDR + reduce_off_top(T, nu) + (c % M3_TOPK) * T * 2 + o % (T * 2)];
+    }
+    // this rank's weights were normalised by its own eta_r: rescale to the global normalisation
+    const float rho = s_rho[a.rank];
+    for (int i = tid; i < a.Kl; i += blockDim.x) a.w[a.k0 + i] *= rho;
+}
+void launch_mix(const UpdateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_mix, dim3(1), dim3(256), 0, s, a);
 }
 
 // Savitzky-Golay(9, 2, 'interp') as a fixed linear map: value at window position p of the

@@ -20,6 +20,15 @@ only the importance-weight update couples them.  Per co
 
 Both messages are latency-bound (<= 256 KB and ~6 KB at K=64000): bucket size and ring
 bandwidth over the 7 xGMI links are irrelevant here, hop count is what matters.
+
+Single-mode MPPI (cfg.multi_modal False; beta is fixed during a command, mppi.py:430-456) needs
+only ONE collective (planner.shard_mix, the default there):
+
+    rollout -> update (softmin over the LOCAL shard: m_r, eta_r, normalised sums, best, top-20)
+      -> all_gather  record[~1.6 K floats]
+    finalize (k_mix: rho_r = exp(-(m_r - m)/beta) eta_r / Z; sums = sum_r rho_r S_r; merge of the
+              ranks' best / top-20; then the usual finalize) -- identical on every rank, equal to
+              the two-collective result up to f32 rounding.
 """
 from __future__ import annotations
 
@@ -43,6 +52,12 @@ def attach_collectives(planner, group=None):
                 dist.all_gather(list(out.chunk(pl.world_size)), loc, group=group)
         elif phase == "reduce":
             dist.all_reduce(e.buffer(L.BUF_REDUCE), op=dist.ReduceOp.SUM, group=group)
+        elif phase == "records":
+            out, loc = e.buffer(L.BUF_RECORDS_ALL), e.buffer(L.BUF_RECORD)
+            try:
+                dist.all_gather_into_tensor(out, loc, group=group)
+            except (RuntimeError, NotImplementedError):
+                dist.all_gather(list(out.unbind(0)), loc, group=group)
         else:
             raise ValueError(phase)
 

@@ -28,7 +28,7 @@ def make_config(K, T, nu=2, env_type="point_env", multi_modal=False, mode_simple
                 u_per_command=None, u_min=None, u_max=None, noise_sigma_diag=None, u_scale=1.0,
                 gamma=0.95, lambda_=1.0, kp_suction=400.0, pre_height_diff=0.05, dt=None,
                 substeps=2, solver_iters=6, seed=0, device=0, K_local=None, k_offset=0,
-                cube_on_shelf=False, sim_only=False) -> L.Config:
+                cube_on_shelf=False, sim_only=False, shard_mix=False) -> L.Config:
     lib = L.load()
     c = L.Config()
     env = L.ENV_POINT if env_type in ("point_env", 0) else L.ENV_PANDA
@@ -56,6 +56,7 @@ def make_config(K, T, nu=2, env_type="point_env", multi_modal=False, mode_simple
     c.substeps, c.solver_iters = int(substeps), int(solver_iters)
     c.cube_on_shelf = int(bool(cube_on_shelf))
     c.sim_only = int(bool(sim_only))
+    c.shard_mix = int(bool(shard_mix))
     c.seed = int(seed)
     return c
 
@@ -210,6 +211,8 @@ class HipEngine:
             L.BUF_REDUCE: ((self.lib.m3_reduce_len(self._h),), "<f4"),
             L.BUF_NOISE: ((T, Kl, nu), "<f4"), L.BUF_PENDING_FORCE: ((4, Kl), "<f4"),
             L.BUF_SIM_WORLD: ((28 if c.env_type == L.ENV_POINT else 45, Kl), "<f4"),
+            L.BUF_RECORD: ((self.lib.m3_record_len(self._h),), "<f4"),
+            L.BUF_RECORDS_ALL: ((Kg // Kl, self.lib.m3_record_len(self._h)), "<f4"),
         }[which]
 
     def buffer(self, which) -> torch.Tensor:

@@ -76,6 +76,7 @@ class MPPIConfig(object):
     fused: Optional[bool] = None      # None: probe the callbacks on the first command
     rank: int = 0                     # sample sharding: this process owns
     world_size: int = 1               #   num_samples/world_size consecutive samples
+    shard_mix: Optional[bool] = None  # None: one-collective protocol whenever it applies
 
 
 def _get(cfg, name, default=None):
@@ -159,6 +160,12 @@ class MPPI():
         self.k_offset = rank * self.K_local
         dev = torch.device(m.device)
         isaac = _get(cfg, "isaacgym", None)
+        # sharded protocol: single-mode MPPI (beta fixed during a command) mixes per-rank softmins
+        # after ONE all-gather of records; the multi-modal beta search needs all K costs on every
+        # rank (all-gather of J + all-reduce of the packed sums).  shard_mix=False forces the latter.
+        sm = _get(m, "shard_mix", None)
+        single = not (self.multi_modal and self.mppi_mode != "simple")
+        self.shard_mix = bool(world > 1 and single and (True if sm is None else sm))
         self._engine = ENGINE_CLS(make_config(
             K=self.K, K_local=self.K_local, k_offset=self.k_offset, T=self.T, nu=self.nu,
             env_type=self.env_type, multi_modal=self.multi_modal,
@@ -172,7 +179,7 @@ class MPPI():
             pre_height_diff=float(_get(cfg, "pre_height_diff", 0) or 0),
             dt=float(_get(isaac, "dt", 0.05 if self.env_type == "point_env" else 0.01)),
             substeps=int(_get(isaac, "substeps", 2)), seed=self.seed_val, device=dev.index or 0,
-            cube_on_shelf=bool(_get(cfg, "cube_on_shelf", False))))
+            cube_on_shelf=bool(_get(cfg, "cube_on_shelf", False)), shard_mix=self.shard_mix))
         self._fused = _get(m, "fused", None)
         self._sim = None
         self._objective = None
@@ -308,11 +315,20 @@ class MPPI():
             e.command()
         else:
             e.rollout()
+            self._update_exchange_finalize()
+        return out
+
+    def _update_exchange_finalize(self):
+        e = self._engine
+        if self.shard_mix:
+            e.update()                      # softmin over the local shard -> this rank's record
+            self._exchange("records")       # the one collective
+            e.finalize()                    # mix the ranks' records, then the usual finalize
+        else:
             self._exchange("gather")
             e.update()
             self._exchange("reduce")
             e.finalize()
-        return out
 
     def _assemble_torch(self):
         """mppi.py:381-416 / :335-347 in torch ops (STEP mode only; the fused kernel does this
@@ -369,10 +385,7 @@ class MPPI():
             gs = gs * self.gamma
         self._buf(L.BUF_TRAJ_COST).copy_(J)
         out = self._next_action_slot()
-        self._exchange("gather")
-        e.update()
-        self._exchange("reduce")
-        e.finalize()
+        self._update_exchange_finalize()
         return out
 
     def command(self, state):

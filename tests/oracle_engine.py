@@ -32,6 +32,11 @@ class OracleEngine:
         }
         for b in range(L.BUF_MEAN, L.BUF_ACTION_OUT + 1):
             self.np[b] = np.zeros((T, nu), f)
+        self.mix = bool(c.shard_mix) and Kl != Kg
+        self.HDR, self.RL = 48, 48 + 6 * T * nu + L.TOPK * T * 2   # record layout: m3_internal.hpp
+        if self.mix:
+            self.np[L.BUF_RECORD] = np.zeros(self.RL, f)
+            self.np[L.BUF_RECORDS_ALL] = np.zeros((Kg // Kl, self.RL), f)
         self.t = {k: _t(v) for k, v in self.np.items()}
         self.sc = O.default_scene()
         self.device = torch.device("cpu")
@@ -100,7 +105,68 @@ class OracleEngine:
         n[L.BUF_COST_HORIZON][...] = r["cost_h"].T
         n[L.BUF_TRAJ_COST][...] = r["J"]
 
+    def _update_mix(self):
+        """One-collective sharding (m3_config.shard_mix): softmin over the LOCAL shard, f32."""
+        n, T, nu, k0, k1, f = self.np, self.T, self.nu, self.k0, self.k0 + self.Kl, np.float32
+        c = self.cfg
+        J = n[L.BUF_TRAJ_COST]
+        beta = f(c.lambda_ if c.mode_simple else self.beta)
+        m_r = J.min()
+        e = np.exp((f(-1.0) / beta) * (J - m_r)).astype(f)
+        eta_r = e.sum(dtype=f)
+        w = (e * (f(1.0) / eta_r)).astype(f)
+        n[L.BUF_WEIGHTS][k0:k1] = w
+        actions = n[L.BUF_ACTIONS]                                  # [T, Kl, nu]
+        rec = n[L.BUF_RECORD]
+        rec[...] = 0
+        kk = np.arange(k0, k1)
+        best = int(np.argmin(J))
+        rec[0], rec[1] = m_r, eta_r
+        rec[2], rec[3] = w[kk < self.Kg // 2].sum(dtype=f), w[kk >= self.Kg // 2].sum(dtype=f)
+        rec[4:5] = np.array([k0 + best], np.int32).view(f)
+        order = np.lexsort((kk, J))[:L.TOPK]
+        rec[8:28] = J[order]
+        rec[28:48] = (k0 + order).astype(np.int32).view(f)
+        body = rec[self.HDR:]
+        body[:T * nu] = np.einsum("k,tkj->tj", w, actions).astype(f).reshape(-1)
+        body[3 * T * nu:4 * T * nu] = actions[:, best, :].reshape(-1)
+        body[6 * T * nu:] = n[L.BUF_STATES][:, order, :][:, :, [0, 2]].transpose(1, 0, 2).reshape(-1)
+
+    def _finalize_mix(self):
+        n, T, nu, f = self.np, self.T, self.nu, np.float32
+        c = self.cfg
+        R = n[L.BUF_RECORDS_ALL]
+        N = R.shape[0]
+        beta = f(c.lambda_ if c.mode_simple else self.beta)
+        m = R[:, 0].min()
+        s = (np.exp((f(-1.0) / beta) * (R[:, 0] - m)).astype(f) * R[:, 1]).astype(f)
+        rho = (s / s.sum(dtype=f)).astype(f)
+        br = int(np.argmin(R[:, 0]))
+        red = n[L.BUF_REDUCE]
+        red[...] = 0
+        B = R[:, self.HDR:]
+        red[:T * nu] = (rho[:, None] * B[:, :T * nu]).sum(axis=0, dtype=f)
+        red[3 * T * nu:4 * T * nu] = B[br, 3 * T * nu:4 * T * nu]
+        Jc = R[:, 8:28].reshape(-1)
+        Ic = R[:, 28:48].copy().view(np.int32).reshape(-1)
+        order = np.lexsort((Ic, Jc))[:L.TOPK]
+        n[L.BUF_TOP_IDX][...] = Ic[order]
+        top = red[6 * T * nu:].reshape(L.TOPK, T, 2)
+        for slot, cnd in enumerate(order):
+            top[slot] = B[cnd // L.TOPK, 6 * T * nu:].reshape(L.TOPK, T, 2)[cnd % L.TOPK]
+        n[L.BUF_WEIGHTS][self.k0:self.k0 + self.Kl] *= rho[self.k0 // self.Kl]
+
+        class _I:
+            pass
+        i = _I()
+        i.wsum_push = float((rho * R[:, 2]).sum(dtype=f))
+        i.wsum_pull = float((rho * R[:, 3]).sum(dtype=f))
+        i.beta = float(self.beta)
+        self._info = i
+
     def update(self):
+        if self.mix:
+            return self._update_mix()
         cfg = self._ocfg()
         n = self.np
         if self.Kl == self.Kg:
@@ -129,6 +195,8 @@ class OracleEngine:
         self._info = info
 
     def finalize(self):
+        if self.mix:
+            self._finalize_mix()
         cfg = self._ocfg()
         n, T, nu = self.np, self.T, self.nu
         red = n[L.BUF_REDUCE]

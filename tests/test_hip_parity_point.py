@@ -204,3 +204,62 @@ def test_sharded_handles_equal_unsharded(golden, oracle, task, goal, mm):
         assert shards[0].info().pull_preference == full.info().pull_preference
     for e in shards + [full]:
         e.close()
+
+
+@pytest.mark.parametrize("world,K,mode", [(2, 256, "halton"), (4, 512, "halton"), (8, 16000, "halton"),
+                                          (2, 256, "simple")])
+def test_one_collective_shard_mix_equals_unsharded(golden, oracle, world, K, mode):
+    """cfg.shard_mix: `world` shard handles on ONE GPU, the single collective done by hand
+    (stack the ranks' RECORD buffers into RECORDS_ALL).  The mixture of per-rank softmins must
+    reproduce the unsharded command() (same plan, means, best trajectory, top-k, eta, weights)
+    up to f32 rounding, and every rank must produce the same plan bit for bit."""
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd import sampling
+    T = 30
+    simple = mode == "simple"
+    delta = golden["g9_push_delta"] if K == 256 else sampling.halton_spline_delta(K, T, 2).numpy()
+    kw = dict(T=T, nu=2, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3], mode_simple=simple,
+              lambda_=0.5 if simple else 1.0)
+    Kl = K // world
+    full = _engine(K=K, **kw)
+    shards = [_engine(K=K, K_local=Kl, k_offset=r * Kl, shard_mix=True, **kw) for r in range(world)]
+    w0 = oracle.init_world(1)[0]
+    w0[0:2] = (0.0, 1.5)
+    for e, d in [(full, delta)] + [(shards[r], delta[r * Kl:(r + 1) * Kl]) for r in range(world)]:
+        e.set_objective("push", (-1, -1))
+        e.set_noise(d)
+        e.set_world_point_raw(raw_world(w0))
+    for call in range(4):
+        full.command()
+        for e in shards:
+            e.rollout()
+            e.update()
+        allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])        # all_gather
+        for e in shards:
+            e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
+            e.finalize()
+        torch.cuda.synchronize()
+        fi = full.info()
+        for r, e in enumerate(shards):
+            for b in (L.BUF_ACTION_OUT, L.BUF_MEAN, L.BUF_BEST, L.BUF_TOP_TRAJS):
+                np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(),
+                                           atol=3e-5, err_msg=f"call {call} rank {r} buffer {b}")
+                assert torch.equal(e.buffer(b), shards[0].buffer(b))
+            np.testing.assert_array_equal(e.buffer(L.BUF_TOP_IDX).cpu().numpy(),
+                                          full.buffer(L.BUF_TOP_IDX).cpu().numpy())
+            np.testing.assert_allclose(e.buffer(L.BUF_WEIGHTS)[r * Kl:(r + 1) * Kl].cpu().numpy(),
+                                       full.buffer(L.BUF_WEIGHTS)[r * Kl:(r + 1) * Kl].cpu().numpy(),
+                                       rtol=1e-3, atol=1e-8)
+            i = e.info()
+            assert i.best_idx == fi.best_idx
+            assert abs(i.eta - fi.eta) <= 1e-4 * fi.eta
+            assert abs(i.wsum_push - fi.wsum_push) < 1e-4 and abs(i.wsum_pull - fi.wsum_pull) < 1e-4
+    for e in shards + [full]:
+        e.close()
+
+
+def test_shard_mix_is_refused_for_the_multi_modal_search():
+    from m3p2i_aip_amd import _lib as L
+    with pytest.raises(L.M3Error):
+        _engine(K=256, K_local=128, k_offset=0, shard_mix=True, T=30, nu=2, multi_modal=True,
+                u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])

@@ -82,7 +82,10 @@ def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal):
         p.join(timeout=120)
         assert p.exitcode == 0
     for c, (a, b) in enumerate(zip(ref, got)):
-        np.testing.assert_allclose(a["action"], b["action"], atol=1e-5, err_msg=f"call {c}")
-        np.testing.assert_allclose(a["weights"], b["weights"], rtol=1e-3, atol=1e-8)
+        # single-mode runs the one-collective protocol (planner.shard_mix): a rank materialises only
+        # its own shard's weights, and the plan equals the unsharded one up to f32 rounding
+        nw = K if multi_modal else K // 2
+        np.testing.assert_allclose(a["action"], b["action"], atol=1e-5 if multi_modal else 3e-5, err_msg=f"call {c}")
+        np.testing.assert_allclose(a["weights"][:nw], b["weights"][:nw], rtol=1e-3, atol=1e-8)
         np.testing.assert_allclose(a["top"], b["top"], atol=1e-4)
         assert a["pref"] == b["pref"]
