@@ -177,6 +177,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # dominant kernel: average launch duration from HIP events recorded by the library on the
+    # stream it launches on, over min(steps, 50) commands of the same workload run right before
+    # the timed region (reading the events back synchronises, so they are not read inside it)
+    eng.enable_timing(True)
+    tr, tu, tf = [], [], []
+    for _ in range(min(args.steps, 50)):
+        pl.command(state)
+        t = eng.timing()
+        tr.append(t.rollout_ms)
+        tu.append(t.update_ms)
+        tf.append(t.finalize_ms)
+    eng.enable_timing(False)
     for _ in range(args.warmup):
         pl.command(state)
     sync()
@@ -199,16 +211,6 @@ def main():
         lat.append(time.perf_counter() - t1)
     lat_ms = np.asarray(lat) * 1e3
 
-    # dominant kernel: average duration from HIP events recorded by the library on its stream
-    eng.enable_timing(True)
-    tr, tu, tf = [], [], []
-    for _ in range(min(args.steps, 50)):
-        pl.command(state)
-        t = eng.timing()
-        tr.append(t.rollout_ms)
-        tu.append(t.update_ms)
-        tf.append(t.finalize_ms)
-    eng.enable_timing(False)
     rollout_ms = float(np.mean(tr))
     alg_bytes = BYTES_PER_STATE_STEP_ROLLOUT[env] * K_local * T
     achieved = alg_bytes / (rollout_ms * 1e-3) / 1e9
@@ -244,6 +246,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kern, "kernel_ms": rollout_ms, "bytes_per_launch": alg_bytes,
+                         "kernel_ms_from": "HIP events on the library's stream, mean over the commands "
+                                           "run immediately before the timed region",
                          "note": "latency-bound at this K (sequential T x substeps x solver passes chain); "
                                  "DESIGN.md section 6"},
             "kernel_ms": {"rollout": rollout_ms, "update": float(np.mean(tu)), "finalize": float(np.mean(tf))},
