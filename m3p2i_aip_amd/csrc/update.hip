@@ -37,7 +37,7 @@ constexpr int LAD_S = 64;          // shrink ladder: beta = 0.9^j, j = 0..63
 constexpr int LAD_G = 32;          // grow ladder:   beta = 1.2^j, j = 1..32
 constexpr int LAD_N = LAD_S + LAD_G;
 constexpr int LAD_EL = 256;        // costs per k_ladder workgroup
-constexpr int WEIGHTS_LDS_MAX = 14000;  // costs staged in LDS by k_weights (56 KB)
+constexpr int WEIGHTS_LDS_MAX = 32768;  // costs staged in LDS by k_weights (128 KB of the CU's 160 KB)
 
 // exp for the softmin weights: v_exp_f32 on x*log2(e) (2 instructions, ~2 ulp + the argument
 // rounding, i.e. <= ~5e-6 relative at |x| = 88) instead of the ~40-instruction correctly
@@ -254,13 +254,15 @@ __device__ __forceinline__ void topk_rank_emit(const tkey* list, int n, VI* out,
     for (int r = n + tid; r < M3_TOPK; r += nt) out[r] = VI{__builtin_inff(), 0x7fffffff};
 }
 
-// fallback stage A: k argmin rounds per wave over the registers, wave 0 merges the waves' lists
-__device__ __noinline__ void topk_stage_a_rounds(const UpdateArgs& a, int blk, VI* out) {
+// fallback stage A: k argmin rounds per wave over the registers, wave 0 merges the waves' lists.
+// (The out-of-line fallbacks take scalars, not the argument struct: a struct passed by reference
+// to a non-inlined function is copied to scratch, and a kernel that uses scratch at all pays
+// ~3 us more per launch.)
+__device__ __noinline__ void topk_stage_a_rounds(const float* J, int Kg, int kbase, int blk, VI* out) {
     __shared__ VI cand[16 * M3_TOPK];
-    const int Kg = a.Kg, tid = threadIdx.x, WT = PREP_T;  // called by the first PREP_T threads
+    const int tid = threadIdx.x, WT = PREP_T;  // called by the first PREP_T threads
     const int lane = tid & 63, wv = tid >> 6, nw = WT >> 6;
     const float INF = __builtin_inff();
-    const float* J = a.Jall;
     const int base = blk * WT * PREP_RPT;
     float rv[PREP_RPT];
 #pragma unroll
@@ -276,8 +278,8 @@ __device__ __noinline__ void topk_stage_a_rounds(const UpdateArgs& a, int blk, V
 #pragma unroll
         for (int e = 0; e < PREP_RPT; ++e) {
             const int k = base + e * WT + tid;
-            if (!((used >> e) & 1u) && k < Kg && vi_less(rv[e], a.kbase + k, best.v, best.i)) {
-                best.v = rv[e]; best.i = a.kbase + k; be = e;
+            if (!((used >> e) & 1u) && k < Kg && vi_less(rv[e], kbase + k, best.v, best.i)) {
+                best.v = rv[e]; best.i = kbase + k; be = e;
             }
         }
         const VI win = wave_argmin(best);
@@ -302,15 +304,16 @@ __device__ __noinline__ void topk_stage_a_rounds(const UpdateArgs& a, int blk, V
 }
 
 // fallback stage B: wave 0 merges the stage-A lists with argmin rounds (registers + global tail)
-__device__ __noinline__ void topk_stage_b_rounds(const UpdateArgs& a, VI* out) {
+__device__ __noinline__ void topk_stage_b_rounds(const VI* cands, int n_cand, VI* out) {
     const int tid = threadIdx.x;
     if (tid < 64) {
-        const int lane = tid, nc = a.n_cand * M3_TOPK;
+        const int lane = tid, nc = n_cand * M3_TOPK;
         VI rc[6];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
             const int c = lane + 64 * e;
-            rc[e] = (c < nc) ? a.cand[c] : VI{__builtin_inff(), 0x7fffffff};
+            rc[e] = cands[min(c, nc - 1)];
+            if (c >= nc) rc[e] = VI{__builtin_inff(), 0x7fffffff};
         }
         float pv = -__builtin_inff();
         int pi = -1;
@@ -320,7 +323,7 @@ __device__ __noinline__ void topk_stage_b_rounds(const UpdateArgs& a, VI* out) {
             for (int e = 0; e < 6; ++e)
                 if (vi_less(pv, pi, rc[e].v, rc[e].i) && vi_less(rc[e].v, rc[e].i, best.v, best.i)) best = rc[e];
             for (int c = lane + 384; c < nc; c += 64) {
-                const VI x = a.cand[c];
+                const VI x = cands[c];
                 if (vi_less(pv, pi, x.v, x.i) && vi_less(x.v, x.i, best.v, best.i)) best = x;
             }
             best = wave_argmin(best);
@@ -425,7 +428,7 @@ __device__ __forceinline__ void topk_stage_a(const UpdateArgs& a, int blk) {
     const bool single = a.n_cand == 1;  // K <= 4096: this workgroup's list is the final one
     VI* out = single ? s_top : a.cand + blk * M3_TOPK;
     if (n <= TK_CAP) topk_rank_emit(flt, n, out, PREP_T);
-    else topk_stage_a_rounds(a, blk, out);
+    else topk_stage_a_rounds(a.Jall, a.Kg, a.kbase, blk, out);
     if (single) {
         __syncthreads();
         topk_finish(a, s_top, PREP_T);
@@ -467,7 +470,7 @@ __device__ __forceinline__ void topk_stage_b(const UpdateArgs& a) {
     __syncthreads();
     const int n = s_n;
     if (n <= TK_CAP) topk_rank_emit(flt, n, s_top, blockDim.x);
-    else topk_stage_b_rounds(a, s_top);
+    else topk_stage_b_rounds(a.cand, a.n_cand, s_top);
     __syncthreads();
     topk_finish(a, s_top, blockDim.x);
 }
@@ -544,13 +547,17 @@ void launch_ladder(const UpdateArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------
 // k_weights: ONE workgroup.  JR = costs per thread held in registers.
-template <int JR>
-__global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
+// JR costs per thread in registers, NT threads: <32, 256> for K <= 8192 (512-VGPR budget),
+// <24, 1024> beyond (16 waves share the SIMDs' register files: 128 VGPRs each, so the register
+// tier is kept small enough not to spill and the LDS tier takes the next 32768 costs).
+template <int JR, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_weights(const UpdateArgs a) {
     __shared__ float red[3 * 16];
     __shared__ VI redvi[16];
     __shared__ float s_beta[3], s_eta[3];
     __shared__ int s_done[3], s_it[3];
     __shared__ float s_tab[LAD_N * 3];
+    __shared__ float s_part[3 * LAD_N * 3];  // WT_MAX / 288 = 3 segments
     const int Kg = a.Kg, half = a.half_g - a.kbase;  // k < half <=> global index in the first mode
     const int tid = threadIdx.x;
     const int WT = blockDim.x;
@@ -606,18 +613,34 @@ __global__ __launch_bounds__(WT_MAX) void k_weights(const UpdateArgs a) {
         beta[0] = b; eta[0] = e[0];
         beta[1] = beta[2] = 1.0f; eta[1] = eta[2] = 0.0f;
     } else {
-        // (1) ladder table: sum k_ladder's partials over its workgroups, fixed order
-        for (int o = tid; o < LAD_N * 3; o += WT) {
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-            int b = 0;
-            for (; b + 3 < a.n_lad; b += 4) {  // 4 independent loads in flight
-                s0 += a.lad[(size_t)(b + 0) * LAD_N * 3 + o];
-                s1 += a.lad[(size_t)(b + 1) * LAD_N * 3 + o];
-                s2 += a.lad[(size_t)(b + 2) * LAD_N * 3 + o];
-                s3 += a.lad[(size_t)(b + 3) * LAD_N * 3 + o];
+        // (1) ladder table: sum k_ladder's partials over its workgroups.  Each of the 288 table
+        // entries is owned by `nseg` threads that split the workgroups between them (8 loads in
+        // flight each); fixed association order, so every rank / launch adds in the same order.
+        {
+            const int NT = LAD_N * 3;
+            const int nseg = (WT / NT) > 0 ? (WT / NT) : 1;       // 3 with 1024 threads, 1 with 256
+            for (int o0 = 0; o0 < NT; o0 += WT) {                 // one trip unless WT < 288
+                const int idx = o0 + tid;
+                const int o = (nseg > 1) ? (tid % NT) : idx, sg = (nseg > 1) ? (tid / NT) : 0;
+                if (sg < nseg && o < NT) {
+                    const int b0 = (int)(((long long)a.n_lad * sg) / nseg), b1 = (int)(((long long)a.n_lad * (sg + 1)) / nseg);
+                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    int b = b0;
+                    for (; b + 7 < b1; b += 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc[u] += a.lad[(size_t)(b + u) * NT + o];
+                    }
+                    for (; b < b1; ++b) acc[0] += a.lad[(size_t)b * NT + o];
+                    s_part[sg * NT + o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+                }
+                if (nseg > 1) break;
             }
-            for (; b < a.n_lad; ++b) s0 += a.lad[(size_t)b * LAD_N * 3 + o];
-            s_tab[o] = (s0 + s1) + (s2 + s3);
+            __syncthreads();
+            for (int o = tid; o < NT; o += WT) {
+                float t = s_part[o];
+                for (int sg = 1; sg < nseg; ++sg) t += s_part[sg * NT + o];
+                s_tab[o] = t;
+            }
         }
         __syncthreads();
         // (2) one thread per search walks the reference's rule on the table; each search
@@ -747,11 +770,18 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
     UpdateArgs b = a;
     if (threads == 256) {
         b.lds_floats = 0;
-        hipLaunchKernelGGL(k_weights<32>, dim3(1 + a.n_cand), dim3(256), 0, s, b);
+        hipLaunchKernelGGL((k_weights<32, 256>), dim3(1 + a.n_cand), dim3(256), 0, s, b);
     } else {
-        const int rest = a.Kg - 48 * WT_MAX;
+        const int rest = a.Kg - 24 * WT_MAX;
         b.lds_floats = rest <= 0 ? 0 : (rest < WEIGHTS_LDS_MAX ? rest : WEIGHTS_LDS_MAX);
-        hipLaunchKernelGGL(k_weights<48>, dim3(1 + a.n_cand), dim3(WT_MAX), b.lds_floats * sizeof(float), s, b);
+        static bool lds_opt_in = false;  // > 64 KB of dynamic LDS needs the attribute once
+        if (!lds_opt_in) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_weights<24, WT_MAX>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      WEIGHTS_LDS_MAX * (int)sizeof(float));
+            lds_opt_in = true;
+        }
+        hipLaunchKernelGGL((k_weights<24, WT_MAX>), dim3(1 + a.n_cand), dim3(WT_MAX), b.lds_floats * sizeof(float), s, b);
     }
 }
 
