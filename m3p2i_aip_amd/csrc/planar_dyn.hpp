@@ -75,6 +75,16 @@ struct Vel {
     float dvx, dvy, dw;
 };
 
+// Clamps as single VALU operations.  The spec (and the oracle) write them as compare-and-assign;
+// for non-NaN operands v_max / v_med3 return the same value, and they take one dependent issue
+// slot (~8 cycles for a lone wavefront) instead of v_cmp -> s_nop -> v_cndmask (~28 cycles,
+// tools/ubench/valu_chain.hip): the solver's critical path is made of these.
+__device__ __forceinline__ float clamp_lo0(float x) { return fmaxf(x, 0.0f); }
+__device__ __forceinline__ float clamp_sym(float x, float lim) {  // lim >= 0
+    return __builtin_amdgcn_fmed3f(x, -lim, lim);
+}
+__device__ __forceinline__ float clamp_hi(float x, float hi) { return fminf(x, hi); }
+
 template <int ID> __device__ __forceinline__ float gvx(const Vel& v) {
     if constexpr (ID == ROBOT) return v.rvx;
     else if constexpr (ID == BOXB) return v.bvx;
@@ -152,9 +162,9 @@ __device__ __forceinline__ void prepare(const PointScene& sc, Slot& c, float nx,
         c.bias = sep * sc.inv_h;
     } else {
         float pen = -sep - sc.slop;
-        if (pen < 0.0f) pen = 0.0f;
+        pen = clamp_lo0(pen);
         float push = (sc.baumgarte * pen) * sc.inv_h;
-        if (push > sc.max_bias) push = sc.max_bias;
+        push = clamp_hi(push, sc.max_bias);
         c.bias = -push;
     }
     c.ln = 0.0f; c.lt = 0.0f;
@@ -171,7 +181,7 @@ __device__ __forceinline__ void solve(const PointScene& sc, Vel& v, Slot& c, flo
     float dl = -c.mn * (vn + c.bias);
     float l0 = c.ln;
     float l1 = l0 + dl;
-    if (l1 < 0.0f) l1 = 0.0f;
+    l1 = clamp_lo0(l1);
     c.ln = l1;
     dl = l1 - l0;
     apply<A, -1>(sc, v, dl, c.nx, c.ny, c.rna);
@@ -184,8 +194,7 @@ __device__ __forceinline__ void solve(const PointScene& sc, Vel& v, Slot& c, flo
     const float maxf = mu * c.ln;
     l0 = c.lt;
     l1 = l0 + dl;
-    if (l1 > maxf) l1 = maxf;
-    if (l1 < -maxf) l1 = -maxf;
+    l1 = clamp_sym(l1, maxf);
     c.lt = l1;
     dl = l1 - l0;
     apply<A, -1>(sc, v, dl, tx, ty, c.rta);
@@ -379,6 +388,11 @@ struct Fric {
     float lx, ly, la;
 };
 
+// (A branch-free version of this row -- selects instead of the two exec-mask regions, so that the
+// scheduler could overlap it with the drive rows and the other box's row -- was measured 9 %
+// SLOWER: the disc clamp's IEEE sqrt + divide chain then sits on every pass's critical path, also
+// for bodies at rest or inside the friction disc, and the compiler does not interleave two such
+// expanded chains anyway: tools/ubench/valu_chain.hip, "2 independent div/sqrt".)
 template <int ID>
 __device__ __forceinline__ void solve_ground_friction(const PointScene& sc, Vel& v, Fric& f,
                                                       float m, float I, float Llin, float Lang) {
@@ -400,8 +414,7 @@ __device__ __forceinline__ void solve_ground_friction(const PointScene& sc, Vel&
         v.dvy += sc.invm_d * (nly - f.ly);
     }
     f.lx = nlx; f.ly = nly;
-    if (nla > Lang) nla = Lang;
-    if (nla < -Lang) nla = -Lang;
+    nla = clamp_sym(nla, Lang);
     if constexpr (ID == BOXB) v.bw += sc.invI_b * (nla - f.la);
     else v.dw += sc.invI_d * (nla - f.la);
     f.la = nla;
@@ -471,6 +484,7 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
         const bool on_walls = s_rwx.on | s_rwy.on | s_bx1.on | s_bx2.on | s_by1.on | s_by2.on |
                               s_dx1.on | s_dx2.on | s_dy1.on | s_dy2.on;
         const bool on_boxes = s_bd1.on | s_bd2.on | s_bo1.on | s_bo2.on | s_do1.on | s_do2.on;
+        const bool rare = s_rd.on | s_ro.on | on_walls | on_boxes;
 
         // 3. velocity solve
         Vel v = {w.rvx, w.rvy, w.B.vx, w.B.vy, w.B.w, w.D.vx, w.D.vy, w.D.w};
@@ -480,25 +494,25 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
             {
                 float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
                 float l1 = ldx + dl;
-                if (l1 > sc.dmax) l1 = sc.dmax;
-                if (l1 < -sc.dmax) l1 = -sc.dmax;
+                l1 = clamp_sym(l1, sc.dmax);
                 v.rvx += sc.invm_r * (l1 - ldx);
                 ldx = l1;
                 dl = -(((v.rvy - uy) + sc.gam * ldy) * sc.md);
                 l1 = ldy + dl;
-                if (l1 > sc.dmax) l1 = sc.dmax;
-                if (l1 < -sc.dmax) l1 = -sc.dmax;
+                l1 = clamp_sym(l1, sc.dmax);
                 v.rvy += sc.invm_r * (l1 - ldy);
                 ldy = l1;
             }
             solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
             solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
             if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
+            // Every slot but robot-box is rarely active.  They sit behind ONE outer flag and two
+            // group flags: when no lane of the wave has any of them, a pass pays one skipped
+            // exec-mask branch (~40 cycles for a lone wavefront) instead of one per slot / group
+            // (same solve order as the spec).
+            if (rare) {
             if (s_rd.on) solve<ROBOT, BOXD>(sc, v, s_rd, sc.mu_rd);
             if (s_ro.on) solve<ROBOT, STATIC>(sc, v, s_ro, sc.mu_ro);
-            // the 16 rarely-active slots sit behind two group flags: when no lane of the wave
-            // touches a wall / has a box-box contact the whole group is ONE skipped branch
-            // instead of one exec-mask test per slot per pass (same solve order as the spec)
             if (on_walls) {
                 if (s_rwx.on) solve<ROBOT, STATIC>(sc, v, s_rwx, sc.mu_rw);
                 if (s_rwy.on) solve<ROBOT, STATIC>(sc, v, s_rwy, sc.mu_rw);
@@ -519,6 +533,7 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
                 if (s_do1.on) solve<BOXD, STATIC>(sc, v, s_do1, sc.mu_do);
                 if (s_do2.on) solve<BOXD, STATIC>(sc, v, s_do2, sc.mu_do);
             }
+            }  // rare
         }
         w.rvx = v.rvx; w.rvy = v.rvy;
         w.B.vx = v.bvx; w.B.vy = v.bvy; w.B.w = v.bw;
