@@ -397,13 +397,19 @@ template <int ID>
 __device__ __forceinline__ void solve_ground_friction(const PointScene& sc, Vel& v, Fric& f,
                                                       float m, float I, float Llin, float Lang) {
     // spec: a body at rest (v = 0 and w = 0) has no friction row in this pass
-    if (gvx<ID>(v) == 0.0f && gvy<ID>(v) == 0.0f && gw<ID>(v) == 0.0f) return;
+    // (one v_or3 + shift + compare on the bit patterns: +-0 are the only values whose bits below
+    // the sign are all zero -- instead of three float compares joined through scalar registers)
+    if (((__float_as_uint(gvx<ID>(v)) | __float_as_uint(gvy<ID>(v)) | __float_as_uint(gw<ID>(v))) << 1) == 0u) return;
     float nlx = f.lx + (-m * gvx<ID>(v));
     float nly = f.ly + (-m * gvy<ID>(v));
     const float mag2 = nlx * nlx + nly * nly;
-    if (mag2 > Llin * Llin) {
+    {   // disc clamp as a select: a body that moves is almost always sliding (saturated), so the
+        // sqrt + divide chain is on the path anyway and the exec-mask region around it only
+        // added its ~40-cycle turnaround; unused lanes' inf / NaN are discarded by the select
         const float scl = Llin / sqrtf(mag2);
-        nlx = nlx * scl; nly = nly * scl;
+        const bool sat = mag2 > Llin * Llin;
+        nlx = sat ? nlx * scl : nlx;
+        nly = sat ? nly * scl : nly;
     }
     float nla = f.la + (-I * gw<ID>(v));
     if constexpr (ID == BOXB) {
@@ -504,8 +510,13 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
                 ldy = l1;
             }
             solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
-            solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
+            // spec order: friction(dyn-obs) then robot-box.  The two rows share no body, so they
+            // commute exactly; solving robot-box first lets the dyn-obs row (usually at rest) join
+            // the rarely-taken group below: one skipped branch per pass instead of two.
             if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
+            const bool d_moving = ((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u;
+            if (d_moving | rare) {
+            solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
             // Every slot but robot-box is rarely active.  They sit behind ONE outer flag and two
             // group flags: when no lane of the wave has any of them, a pass pays one skipped
             // exec-mask branch (~40 cycles for a lone wavefront) instead of one per slot / group
@@ -534,6 +545,7 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
                 if (s_do2.on) solve<BOXD, STATIC>(sc, v, s_do2, sc.mu_do);
             }
             }  // rare
+            }  // d_moving | rare
         }
         w.rvx = v.rvx; w.rvy = v.rvy;
         w.B.vx = v.bvx; w.B.vy = v.bvy; w.B.w = v.bw;
