@@ -79,6 +79,19 @@ struct Vel {
 // for non-NaN operands v_max / v_med3 return the same value, and they take one dependent issue
 // slot (~8 cycles for a lone wavefront) instead of v_cmp -> s_nop -> v_cndmask (~28 cycles,
 // tools/ubench/valu_chain.hip): the solver's critical path is made of these.
+// spec v1.3: reciprocal square root = bit-trick seed + three Newton steps in binary32, in
+// exactly this order (the oracle runs the same sequence).  The correctly rounded sqrtf followed by
+// an IEEE division is a ~32-instruction dependent chain here (3 of them compare->select pairs);
+// this is 15, and it sits in the friction row of every solver pass.
+__device__ __forceinline__ float spec_rsqrt(float a) {
+    float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(a) >> 1));
+    const float hlf = 0.5f * a;
+    y = y * (1.5f - hlf * (y * y));
+    y = y * (1.5f - hlf * (y * y));
+    y = y * (1.5f - hlf * (y * y));
+    return y;
+}
+
 __device__ __forceinline__ float clamp_lo0(float x) { return fmaxf(x, 0.0f); }
 __device__ __forceinline__ float clamp_sym(float x, float lim) {  // lim >= 0
     return __builtin_amdgcn_fmed3f(x, -lim, lim);
@@ -222,8 +235,8 @@ __device__ __forceinline__ void detect_disc_box(const PointScene& sc, Slot& c, f
     const float d2 = ex * ex + ey * ey;
     float nlx, nly, sep;
     if (d2 > 0.0f) {
-        const float d = sqrtf(d2);
-        const float rd = 1.0f / d;
+        const float rd = spec_rsqrt(d2);
+        const float d = d2 * rd;
         nlx = ex * rd; nly = ey * rd;
         sep = d - r;
     } else {
@@ -406,7 +419,7 @@ __device__ __forceinline__ void solve_ground_friction(const PointScene& sc, Vel&
     {   // disc clamp as a select: a body that moves is almost always sliding (saturated), so the
         // sqrt + divide chain is on the path anyway and the exec-mask region around it only
         // added its ~40-cycle turnaround; unused lanes' inf / NaN are discarded by the select
-        const float scl = Llin / sqrtf(mag2);
+        const float scl = Llin * spec_rsqrt(mag2);
         const bool sat = mag2 > Llin * Llin;
         nlx = sat ? nlx * scl : nlx;
         nly = sat ? nly * scl : nly;
@@ -438,8 +451,7 @@ __device__ __forceinline__ void integrate_box(Box& X, float h) {
     const float sd = (2.0f * a) * rden;
     const float c = X.c * cd - X.s * sd;
     const float s = X.s * cd + X.c * sd;
-    const float nrm = sqrtf(c * c + s * s);
-    const float rn = 1.0f / nrm;
+    const float rn = spec_rsqrt(c * c + s * s);
     X.c = c * rn;
     X.s = s * rn;
 }

@@ -18,6 +18,26 @@
 #include <string.h>
 
 #include "m3_oracle.h"
+#include <stdint.h>
+#include <string.h>
+
+/* spec v1.3: reciprocal square root = bit-trick seed + three Newton steps, all in binary32 and
+ * in exactly this order (relative error < 1e-9 before the final rounding).  It replaces
+ * "sqrtf then divide" where only 1/sqrt or a normalisation is needed: on the GPU the correctly
+ * rounded sqrtf + division are ~32 dependent instructions, this is 15. */
+static inline float spec_rsqrt(float a) {
+    uint32_t i;
+    float y;
+    memcpy(&i, &a, 4);
+    i = 0x5f3759dfu - (i >> 1);
+    memcpy(&y, &i, 4);
+    const float hlf = 0.5f * a;
+    y = y * (1.5f - hlf * (y * y));
+    y = y * (1.5f - hlf * (y * y));
+    y = y * (1.5f - hlf * (y * y));
+    return y;
+}
+
 
 enum { BR = 0, BB = 1, BD = 2, BS = 3, NBODY = 4 };
 
@@ -108,8 +128,8 @@ static void detect_disc_box(const m3o_point_scene* sc, solver_t* s, const m3o_bo
     float d2 = ex * ex + ey * ey;
     float nlx, nly, sep;
     if (d2 > 0.0f) {
-        float d = sqrtf(d2);
-        float rd = 1.0f / d; /* spec v1.2: one reciprocal, two multiplies */
+        float rd = spec_rsqrt(d2); /* spec v1.3 */
+        float d = d2 * rd;
         nlx = ex * rd; nly = ey * rd;
         sep = d - r;
     } else {
@@ -333,7 +353,7 @@ static void solve_ground_friction(solver_t* s, int b, float m, float I, float Ll
     float nly = f->ly + (-m * s->vy[b]);
     float mag2 = nlx * nlx + nly * nly;
     if (mag2 > Llin * Llin) {
-        float sc = Llin / sqrtf(mag2);
+        float sc = Llin * spec_rsqrt(mag2); /* spec v1.3 */
         nlx = nlx * sc; nly = nly * sc;
     }
     s->vx[b] += s->invm[b] * (nlx - f->lx);
@@ -358,8 +378,7 @@ static void integrate_body(m3o_body* X, float h, int rotate) {
         float sd = (2.0f * a) * rden;
         float c = X->c * cd - X->s * sd;
         float s = X->s * cd + X->c * sd;
-        float nrm = sqrtf(c * c + s * s);
-        float rn = 1.0f / nrm;
+        float rn = spec_rsqrt(c * c + s * s); /* spec v1.3 */
         X->c = c * rn;
         X->s = s * rn;
     }
