@@ -12,7 +12,7 @@ for sub in ("a", "b"):
     f = glob.glob("$OUT/%s/**/*counter_collection.csv" % sub, recursive=True)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if "k_rollout_point" in r["Kernel_Name"]:
+        if "k_rollout" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("$TAG K=$K lanes=$LANES", {k: round(sum(v) / len(v)) for k, v in acc.items()})
 PY
