@@ -177,9 +177,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(args.warmup):
+        pl.command(state)
     # dominant kernel: average launch duration from HIP events recorded by the library on the
-    # stream it launches on, over min(steps, 50) commands of the same workload run right before
-    # the timed region (reading the events back synchronises, so they are not read inside it)
+    # stream it launches on, over min(steps, 50) commands of the same workload run between the
+    # warm-up and the timed region (reading the events back synchronises, so they are not read
+    # inside it)
     eng.enable_timing(True)
     tr, tu, tf = [], [], []
     for _ in range(min(args.steps, 50)):
@@ -189,8 +192,6 @@ def main():
         tu.append(t.update_ms)
         tf.append(t.finalize_ms)
     eng.enable_timing(False)
-    for _ in range(args.warmup):
-        pl.command(state)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
