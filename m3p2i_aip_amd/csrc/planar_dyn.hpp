@@ -467,7 +467,8 @@ __device__ __forceinline__ void integrate_box(Box& X, float h) {
 
 // one sim.step(): substeps x (forces, detect, solve, integrate)
 template <bool ALL_FORCES>
-__device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, float ux, float uy) {
+__device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, float ux, float uy,
+                                           bool need_dyn_force = true) {
     const float h = sc.h;
     for (int sub = 0; sub < sc.substeps; ++sub) {
         // 1. external forces
@@ -563,8 +564,11 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
         w.B.vx = v.bvx; w.B.vy = v.bvy; w.B.w = v.bw;
         w.D.vx = v.dvx; w.D.vy = v.dvy; w.D.w = v.dw;
 
-        // net contact force on the dyn-obs (get_motion_cost reads it), slot order
-        {
+        // net contact force on the dyn-obs (get_motion_cost reads it), slot order.  The cost sees
+        // only the LAST substep's value (spec), and only the navigation cost reads it at all
+        // (cost_functions.py:38,158-169), so the rollout forms it just then (the step-mode wrapper
+        // exposes all bodies' forces and keeps the general path).
+        if (ALL_FORCES || (need_dyn_force && sub == sc.substeps - 1)) {
             float fx = 0.0f, fy = 0.0f;
             M3_ACC(fx, fy, s_rd, +1)
             if (on_walls) {

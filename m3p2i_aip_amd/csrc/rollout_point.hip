@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const
         if (a.sample_null_action && is_last) { u0 = 0.0f; u1 = 0.0f; }  // mppi.py:300-302
 
         // ---- A6: one sim.step() ----
-        point_step<false>(sc, w, u0, u1);
+        point_step<false>(sc, w, u0, u1, /*need_dyn_force=*/a.cp.task == 0);
 
         // ---- A7/A8: running cost on the post-step state ----
         const float c = point_cost(a.cp, w, k);
