@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import weakref
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -42,10 +43,23 @@ class Objective(object):
 
     def update_objective(self, task, goal):
         self.task = task
-        self.goal = goal if torch.is_tensor(goal) else torch.tensor(goal, device=self.device)
+        if torch.is_tensor(goal):
+            self.goal = goal
+        else:
+            self.goal = torch.tensor(goal, device=self.device)
+            self._goal_host = ([float(x) for x in np.ravel(goal)], id(self.goal), self.goal._version)
 
     def goal_list(self):
-        return [float(x) for x in self.goal.detach().reshape(-1).cpu().tolist()]
+        """Host copy of the goal for the C-ABI (passed by value).  Reading a device tensor
+        synchronises the stream, which would serialise every command() with the previous one, so
+        the copy is cached until the tensor object or its contents (torch's version counter) change
+        -- reactive_tamp.py:79 hands the same `curr_goal` tensor over at every tick."""
+        c = getattr(self, "_goal_host", None)
+        if c is None or c[1] != id(self.goal) or c[2] != self.goal._version:
+            c = ([float(x) for x in self.goal.detach().reshape(-1).cpu().tolist()], id(self.goal),
+                 self.goal._version)
+            self._goal_host = c
+        return c[0]
 
     def compute_cost(self, sim):
         eng = getattr(sim, "_engine", None)
