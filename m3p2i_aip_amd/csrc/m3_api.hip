@@ -192,8 +192,8 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (rc == M3_OK && hipMalloc((void**)&h->part_min, (size_t)mins_workgroups((int)Kg) * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->lad, (size_t)ladder_workgroups((int)Kg) * 96 * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->wpart, (size_t)wsum_chunks((int)Kl) * 3 * T * nu * f) != hipSuccess) rc = M3_ERR_HIP;
-    if (rc == M3_OK && hipMalloc((void**)&h->wcount, (size_t)T * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
-    if (rc == M3_OK && hipMemset(h->wcount, 0, (size_t)T * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->wcount, (size_t)(T + 1) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMemset(h->wcount, 0, (size_t)(T + 1) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK) {
         m3_info init;
         std::memset(&init, 0, sizeof(init));
@@ -493,12 +493,18 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
 
 static bool mix_mode(const m3_handle* h) { return h->cfg.shard_mix && h->cfg.K_local != h->cfg.K_global; }
 
-extern "C" int m3_update(m3_handle* h) {
-    if (!h) return M3_ERR_BAD_ARG;
+// fuse: m3_command on an unsharded handle lets k_wsum's last workgroup do k_finalize's work
+static bool can_fuse_finalize(const m3_handle* h) {
+    const m3_config& c = h->cfg;
+    return c.K_local == c.K_global && (long long)c.T * c.nu <= 2048;  // plan staged in 8 KB of LDS
+}
+
+static int update_impl(m3_handle* h, bool fuse) {
     const m3_config& c = h->cfg;
     if (c.sim_only) return fail(h, M3_ERR_STATE, "m3_update: handle was created sim_only");
     UpdateArgs a;
     fill_update_args(h, a);
+    a.fuse_finalize = fuse ? 1 : 0;
     if (c.K_local == c.K_global)  // unsharded: the local costs ARE the global costs (no copy)
         a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST];
     if (mix_mode(h)) {
@@ -532,6 +538,11 @@ extern "C" int m3_update(m3_handle* h) {
     return M3_OK;
 }
 
+extern "C" int m3_update(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    return update_impl(h, false);
+}
+
 extern "C" int m3_finalize(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     UpdateArgs a;
@@ -547,10 +558,17 @@ extern "C" int m3_finalize(m3_handle* h) {
 extern "C" int m3_command(m3_handle* h, float* action_host) {
     int rc = m3_rollout(h);
     if (rc != M3_OK) return rc;
-    rc = m3_update(h);
-    if (rc != M3_OK) return rc;
-    rc = m3_finalize(h);
-    if (rc != M3_OK) return rc;
+    if (can_fuse_finalize(h)) {
+        rc = update_impl(h, true);   // weights -> sums + (last workgroup) mean update / filter
+        if (rc != M3_OK) return rc;
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+        h->calls += 1;
+    } else {
+        rc = m3_update(h);
+        if (rc != M3_OK) return rc;
+        rc = m3_finalize(h);
+        if (rc != M3_OK) return rc;
+    }
     if (action_host) {
         const m3_config& c = h->cfg;
         const int rows = c.mode_simple ? c.u_per_command : c.T;

@@ -54,7 +54,9 @@ struct UpdateArgs {
     float* lad;       // [n_lad][96][3] per-workgroup eta sums on the beta ladders (k_ladder)
     int n_lad;        // workgroups of k_ladder
     float* wpart;     // [n_chunk][3][T][nu] partial weighted sums of k_wsum (n_chunk > 1 only)
-    int* wcount;      // [T] arrival counters of the k_wsum chunks (zero between launches)
+    int* wcount;      // [T] arrival counters of the k_wsum chunks + [T] the launch-wide one of the
+                      // fused finalize (zero between launches)
+    int fuse_finalize;  // k_wsum's last workgroup also does k_finalize's work (unsharded m3_command)
     int n_chunk;      // k_wsum workgroups per time step
     int lds_floats;   // costs staged in dynamic LDS by k_weights (set by launch_weights)
     int Kg, Kl, k0, T, nu;

@@ -796,6 +796,9 @@ constexpr int WS_CHUNK = 8192;  // samples per k_wsum workgroup
 constexpr int WS_BATCH = 8;     // loads in flight per thread and array
 int wsum_chunks(int Kl) { return (Kl + WS_CHUNK - 1) / WS_CHUNK; }
 
+template <bool SC1>
+__device__ __forceinline__ void finalize_body(const UpdateArgs& a, float* sm);  // defined below
+
 template <int NU>
 __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     __shared__ float red[3 * 16];
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         const float rv = tid == 0 ? r[0] : (tid == 1 ? r[1] : r[2]);
         if (tid < 3) {
             float* dst = &out[tid * T * NU + t * NU + j];  // == reduce_off_psum(tid) + t*NU + j
-            if (C == 1) *dst = rv;
+            if (C == 1 && !a.fuse_finalize) *dst = rv;
             else __hip_atomic_store(dst, rv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
         }
         __syncthreads();
@@ -879,7 +882,9 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
             for (int cc = 0; cc < C; ++cc)
                 sum += __hip_atomic_load(&a.wpart[((size_t)cc * 3 + which) * T * NU + t * NU + j],
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.reduce[reduce_off_psum(which, T, NU) + t * NU + j] = sum;
+            float* dst = &a.reduce[reduce_off_psum(which, T, NU) + t * NU + j];
+            if (a.fuse_finalize) __hip_atomic_store(dst, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = sum;
         }
     }
     // best rows (zero unless the owning rank)
@@ -889,13 +894,33 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         float v = 0.0f;
         const int li = gi - k0;
         if (gi >= 0 && li >= 0 && li < Kl) v = act[(size_t)li * NU + j];
-        a.reduce[reduce_off_best(which, T, NU) + t * NU + j] = v;
+        float* dst = &a.reduce[reduce_off_best(which, T, NU) + t * NU + j];
+        if (a.fuse_finalize) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = v;
+    }
+    if (a.fuse_finalize) {
+        // Unsharded command(): the mean update / filter (k_finalize's work, T*nu values) is done by
+        // the LAST of the T x n_chunk workgroups to finish instead of by one more launch (a
+        // dependent launch costs ~3.5 us of turnaround + ~5 us for the one-workgroup kernel).
+        // Same hand-off as the chunk combine: write-through stores, then a relaxed agent ticket.
+        extern __shared__ float sm_fin[];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(&a.wcount[T], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = ticket == T * C - 1;
+            if (is_last) a.wcount[T] = 0;
+            red[46] = __int_as_float(is_last);
+        }
+        __syncthreads();
+        if (__float_as_int(red[46])) finalize_body<true>(a, sm_fin);
     }
 }
 void launch_wsum(const UpdateArgs& a, hipStream_t s) {
     const dim3 grid(a.T * a.n_chunk + (a.n_cand > 1 ? 1 : 0));
-    if (a.nu == 2) hipLaunchKernelGGL(k_wsum<2>, grid, dim3(ST), 0, s, a);
-    else hipLaunchKernelGGL(k_wsum<9>, grid, dim3(ST), 0, s, a);
+    const size_t lds = a.fuse_finalize ? (size_t)a.T * a.nu * sizeof(float) : 0;
+    if (a.nu == 2) hipLaunchKernelGGL(k_wsum<2>, grid, dim3(ST), lds, s, a);
+    else hipLaunchKernelGGL(k_wsum<9>, grid, dim3(ST), lds, s, a);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1005,8 +1030,15 @@ __device__ __forceinline__ float sg_coef(int p, int i) {
     return ca + cb * xp + cc * xp * xp;
 }
 
-__global__ __launch_bounds__(256) void k_finalize(const UpdateArgs a) {
-    extern __shared__ float sm[];  // [T*nu] new plan
+// SC1: the reduce buffer was written by OTHER workgroups of the same launch (fused into k_wsum):
+// read it with write-through-coherent loads; from its own launch (k_finalize) plain loads do.
+template <bool SC1>
+__device__ __forceinline__ float rd_reduce(const float* p) {
+    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool SC1>
+__device__ __forceinline__ void finalize_body(const UpdateArgs& a, float* sm /* LDS [T*nu] */) {
     const int T = a.T, nu = a.nu, n = T * nu, tid = threadIdx.x;
     const bool multi = a.multi_modal && !a.mode_simple;
     const float* ps = a.reduce + reduce_off_psum(0, T, nu);
@@ -1017,10 +1049,10 @@ __global__ __launch_bounds__(256) void k_finalize(const UpdateArgs a) {
         if (a.mode_simple) {
             const int ts = (t + 1 == T) ? 0 : t + 1;  // rolled U
             const float u = a.mean[ts * nu + j];
-            nv = u + (ps[o] - u * wtot);               // U += sum_k w_k (a_k - U): mppi.py:231
+            nv = u + (rd_reduce<SC1>(ps + o) - u * wtot);               // U += sum_k w_k (a_k - U): mppi.py:231
         } else {
             const int ts = (t + 1 < T) ? t + 1 : T - 1;  // shifted mean
-            nv = (1.0f - a.step_size_mean) * a.mean[ts * nu + j] + a.step_size_mean * ps[o];
+            nv = (1.0f - a.step_size_mean) * a.mean[ts * nu + j] + a.step_size_mean * rd_reduce<SC1>(ps + o);
         }
         sm[o] = nv;
     }
@@ -1028,12 +1060,12 @@ __global__ __launch_bounds__(256) void k_finalize(const UpdateArgs a) {
     for (int o = tid; o < n; o += blockDim.x) {
         a.mean[o] = sm[o];
         if (multi) {
-            a.mean1[o] = a.reduce[reduce_off_psum(1, T, nu) + o];  // m3p2i.py:82-83
-            a.mean2[o] = a.reduce[reduce_off_psum(2, T, nu) + o];
-            a.best1[o] = a.reduce[reduce_off_best(1, T, nu) + o];  // m3p2i.py:77-78
-            a.best2[o] = a.reduce[reduce_off_best(2, T, nu) + o];
+            a.mean1[o] = rd_reduce<SC1>(a.reduce + reduce_off_psum(1, T, nu) + o);  // m3p2i.py:82-83
+            a.mean2[o] = rd_reduce<SC1>(a.reduce + reduce_off_psum(2, T, nu) + o);
+            a.best1[o] = rd_reduce<SC1>(a.reduce + reduce_off_best(1, T, nu) + o);  // m3p2i.py:77-78
+            a.best2[o] = rd_reduce<SC1>(a.reduce + reduce_off_best(2, T, nu) + o);
         } else if (!a.mode_simple) {
-            a.best[o] = a.reduce[reduce_off_best(0, T, nu) + o];   // mppi.py:495
+            a.best[o] = rd_reduce<SC1>(a.reduce + reduce_off_best(0, T, nu) + o);   // mppi.py:495
         }
     }
     // returned plan: clone(mean) (halton) or U[:u_per_command] (simple), then the filter
@@ -1059,7 +1091,11 @@ __global__ __launch_bounds__(256) void k_finalize(const UpdateArgs a) {
     }
     if (a.Kl != a.Kg)  // sharded: the rows were summed over ranks in the reduce buffer
         for (int o = tid; o < M3_TOPK * T * 2; o += blockDim.x)
-            a.top_trajs[o] = a.reduce[reduce_off_top(T, nu) + o];
+            a.top_trajs[o] = rd_reduce<SC1>(a.reduce + reduce_off_top(T, nu) + o);
+}
+__global__ __launch_bounds__(256) void k_finalize(const UpdateArgs a) {
+    extern __shared__ float sm[];  // [T*nu] new plan
+    finalize_body<false>(a, sm);
 }
 void launch_finalize(const UpdateArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), a.T * a.nu * sizeof(float), s, a);
