@@ -80,3 +80,28 @@ def test_scene_tables():
     assert scenes.body_index("point_env", "box", "box") == scenes.actor_index("point_env", "box") == 6
     assert scenes.body_index("panda_env", "panda", "panda_leftfinger") == 15
     assert scenes.body_index("panda_env", "cubeA", "box") == 4
+
+
+def test_objective_goal_host_copy_is_cached_until_the_goal_changes():
+    """Objective.goal_list() feeds the C-ABI by value; it must not re-read the goal tensor at
+    every command (a device read is a stream sync) yet must follow every way a caller can change
+    the goal: a new tensor, a new list, or an in-place write into the same tensor."""
+    import types
+    import torch
+    from m3p2i_aip_amd.cost_functions import Objective
+    cfg = types.SimpleNamespace(mppi=types.SimpleNamespace(device="cpu", num_samples=64), multi_modal=False, env_type="point_env",
+                                kp_suction=400, suction_active=True, pre_height_diff=0.0, task="push", goal=[0, 0],
+                                cube_on_shelf=False)
+    o = Objective(cfg)
+    g = torch.tensor([1.0, 2.0])
+    o.update_objective("push", g)
+    assert o.goal_list() == [1.0, 2.0]
+    first = o._goal_host
+    o.update_objective("push", g)                 # same tensor again (every tick of reactive_tamp.py)
+    assert o.goal_list() == [1.0, 2.0] and o._goal_host is first
+    g[0] = 5.0                                    # in-place edit: torch bumps the version counter
+    assert o.goal_list() == [5.0, 2.0]
+    o.update_objective("pull", torch.tensor([7.0, 8.0]))
+    assert o.goal_list() == [7.0, 8.0]
+    o.update_objective("pull", [3.0, 4.0])        # python list
+    assert o.goal_list() == [3.0, 4.0]
