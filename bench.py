@@ -158,14 +158,11 @@ def main():
         K_local = args.samples_per_gpu
     K_global = K_local * world
 
-    from m3p2i_aip_amd import sampling
     pl, sim, obj = build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device)
-    # synthetic noise: the build's Halton-spline sampler, this rank's rows of the global set
-    # (init only, not the hot path; NOT tiled -- duplicated samples would make the reference's
-    # beta search non-terminating: eta >= number of copies of the best sample)
-    delta_local = sampling.halton_spline_delta(K_global, T, nu, k0=rank * K_local,
-                                               k1=(rank + 1) * K_local).contiguous()
-    pl.set_noise(delta_local)
+    # synthetic noise: the reference's Halton-spline sampler for this rank's rows of the global
+    # sample set, generated by the planner on its first command() (device sampler; init only, not
+    # the hot path).  NOT tiled -- duplicated samples would make the reference's beta search
+    # non-terminating: eta >= number of copies of the best sample.
     if world > 1:
         from m3p2i_aip_amd.distributed import attach_collectives
         attach_collectives(pl)
@@ -254,7 +251,8 @@ def main():
             "kernel_ms": {"rollout": rollout_ms, "update": float(np.mean(tu)), "finalize": float(np.mean(tf))},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(env, task, goal, multi_modal, K_local, T, delta_local.numpy())
+            line["cpu_baseline"] = cpu_baseline(env, task, goal, multi_modal, K_local, T,
+                                                  pl.delta.contiguous().cpu().numpy())
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -196,6 +196,13 @@ int m3_set_rollout_lanes(m3_handle* h, int lanes);
 /* delta: [K_local][T][nu] row-major (the reference's layout, rows of THIS shard).
  * on_device: 0 host pointer, 1 device pointer. */
 int m3_set_noise(m3_handle* h, const float* delta, int on_device);
+/* The reference's Halton-spline sampler on the device (mppi.py:458-483, mppi_utils.py bspline):
+ * knots [K_local][nu][n_knots] (the Gaussian Halton values of THIS shard's samples); every one of
+ * the K_local*nu series is fitted with FITPACK's smoothing spline (splrep(linspace(0,n,n), y,
+ * k=degree, s=smoothing)) and evaluated at linspace(0, n, T) with ext=3 (splev), one thread per
+ * series, into M3_BUF_NOISE.  Bit-identical to scipy 1.15.3's FITPACK (tests/test_spline_fit.py). */
+int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots, int degree, float smoothing,
+                       int on_device);
 int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd);
 /* Objective.multi_modal (cost_functions.py:9) for a sim_only handle, whose config does not
  * come from an MPPI object; refused on planner handles (fixed at m3_create) */

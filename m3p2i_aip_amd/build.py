@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libm3p2i_hip.so")
-SOURCES = ["rollout_point.hip", "rollout_panda.hip", "update.hip", "m3_api.hip"]
+SOURCES = ["rollout_point.hip", "rollout_panda.hip", "update.hip", "sampler.hip", "m3_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

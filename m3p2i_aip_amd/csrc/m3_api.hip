@@ -267,6 +267,35 @@ extern "C" int m3_set_noise(m3_handle* h, const float* delta, int on_device) {
     return M3_OK;
 }
 
+extern "C" int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots, int degree, float smoothing,
+                                  int on_device) {
+    if (!h || !knots) return fail(h, M3_ERR_BAD_ARG, "m3_set_noise_knots: null argument");
+    const m3_config& c = h->cfg;
+    if (c.sim_only) return fail(h, M3_ERR_STATE, "m3_set_noise_knots: handle was created sim_only");
+    if (degree < 1 || degree > 3) return fail(h, M3_ERR_BAD_ARG, "m3_set_noise_knots: degree must be 1..3");
+    if (n_knots <= degree || n_knots > 64)
+        return fail(h, M3_ERR_SHAPE, "m3_set_noise_knots: needs degree < n_knots <= 64 (splrep: m > k must hold)");
+    if (!(smoothing >= 0.0f)) return fail(h, M3_ERR_BAD_ARG, "m3_set_noise_knots: smoothing must be >= 0");
+    const size_t bytes = (size_t)c.K_local * c.nu * n_knots * sizeof(float);
+    const float* src = knots;
+    float* stage = nullptr;
+    if (!on_device) {
+        HIPCHK(h, hipMalloc((void**)&stage, bytes));
+        HIPCHK(h, hipMemcpyAsync(stage, knots, bytes, hipMemcpyHostToDevice, h->stream));
+        src = stage;
+    }
+    launch_spline_noise(src, (float*)h->buf[M3_BUF_NOISE], c.K_local, c.nu, n_knots, c.T, degree, (double)smoothing,
+                        h->stream);
+    hipError_t e = hipGetLastError();
+    if (stage) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipFree(stage);
+    }
+    if (e != hipSuccess) { h->err = std::string("k_spline_noise: ") + hipGetErrorString(e); return M3_ERR_HIP; }
+    h->have_noise = true;
+    return M3_OK;
+}
+
 extern "C" int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd) {
     if (!h) return M3_ERR_BAD_ARG;
     if (task < 0 || task > M3_TASK_IDLE) return fail(h, M3_ERR_BAD_ARG, "m3_set_objective: unknown task");

@@ -107,6 +107,8 @@ constexpr int MIX_MAX_RANKS = 32;
 void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s);
 void launch_transpose_noise(const float* src_ktn, float* dst_tkn, int K, int T, int nu,
                             hipStream_t s);
+void launch_spline_noise(const float* knots, float* noise, int Kl, int nu, int n_knots, int T, int degree,
+                         double smoothing, hipStream_t s);
 void launch_weights(const UpdateArgs& a, hipStream_t s);
 void launch_wsum(const UpdateArgs& a, hipStream_t s);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);

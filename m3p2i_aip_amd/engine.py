@@ -118,6 +118,16 @@ class HipEngine:
             assert d.shape == (c.K_local, c.T, c.nu), d.shape
             self._ck(self.lib.m3_set_noise(self._h, d.ctypes.data, 0))
 
+    def set_noise_knots(self, knots, degree=2, smoothing=0.5):
+        """Halton-spline sampler on the device: knots [K_local, nu, n_knots] (Gaussian Halton values
+        of this shard's samples) -> smoothing-spline noise in the library's noise buffer."""
+        c = self.cfg
+        k = np.ascontiguousarray(knots.detach().cpu().numpy() if isinstance(knots, torch.Tensor) else knots,
+                                 dtype=np.float32)
+        assert k.ndim == 3 and k.shape[:2] == (c.K_local, c.nu), k.shape
+        self._ck(self.lib.m3_set_noise_knots(self._h, k.ctypes.data, int(k.shape[2]), int(degree),
+                                             float(smoothing), 0))
+
     def set_objective(self, task, goal, gripper_cmd=0):
         t = L.TASKS[task] if isinstance(task, str) else int(task)
         g = [float(x) for x in (goal.detach().cpu().reshape(-1).tolist()

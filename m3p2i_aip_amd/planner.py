@@ -149,7 +149,7 @@ class MPPI():
         self.running_cost = running_cost
         self.terminal_state_cost = None
         self.state = None
-        self.delta = None
+        self._have_noise = False
         self.ee_states = 'None'
 
         rank, world = int(_get(m, "rank", 0) or 0), int(_get(m, "world_size", 1) or 1)
@@ -259,11 +259,24 @@ class MPPI():
     def _ensure_noise(self):
         if self.mppi_mode == "simple" or self.sampling_method == "random":
             return
-        if self.delta is None:
-            d = sampling.halton_spline_delta(self.K, self.T, self.nu, self.knot_scale, self.degree,
-                                             self.k_offset, self.k_offset + self.K_local)
-            self.delta = d.to(self.device)
-            self._engine.set_noise(self.delta)
+        if self._have_noise:
+            return
+        e = self._engine
+        if hasattr(e, "set_noise_knots"):
+            # device sampler: Halton knots on the host (K*nu*n_knots values, vectorised), the K*nu
+            # spline fits -- where the reference's ~1 s init goes -- one GPU thread each
+            e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree,
+                                                    self.k_offset, self.k_offset + self.K_local),
+                              self.degree, 0.5)
+        else:   # engines without the device sampler (the CPU test stand-in)
+            e.set_noise(sampling.halton_spline_delta(self.K, self.T, self.nu, self.knot_scale, self.degree,
+                                                     self.k_offset, self.k_offset + self.K_local))
+        self._have_noise = True
+
+    @property
+    def delta(self):
+        """[K_local, T, nu] noise (mppi.py:466-483), a strided view of the library's time-major buffer."""
+        return self._engine.buffer(L.BUF_NOISE).permute(1, 0, 2) if self._have_noise else None
 
     def _push_objective(self):
         o = self._objective
@@ -427,8 +440,8 @@ class MPPI():
 
     def set_noise(self, delta):
         """Explicit noise [K_local, T, nu] (e.g. a recorded sample set)."""
-        self.delta = torch.as_tensor(delta, dtype=torch.float32).to(self.device)
-        self._engine.set_noise(self.delta)
+        self._engine.set_noise(torch.as_tensor(delta, dtype=torch.float32).to(self.device))
+        self._have_noise = True
 
     def _shift_action(self, action_seq):
         saved = action_seq[-1].clone()

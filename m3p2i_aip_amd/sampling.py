@@ -66,6 +66,20 @@ def smoothing_spline(knots: np.ndarray, n_out: int, degree: int = 2) -> np.ndarr
     return si.splev(np.linspace(0, n, n_out), tck, ext=3)
 
 
+def halton_knots(K: int, T: int, nu: int, knot_scale: int = 4, degree: int = 2, k0: int = 0,
+                 k1: int | None = None) -> torch.Tensor:
+    """The spline knots of samples k0..k1: [k1-k0, nu, n_knots] float32 (Gaussian Halton values,
+    mppi_utils.py:81-104).  Input of the device sampler (engine.set_noise_knots)."""
+    n_knots = T // knot_scale
+    if n_knots <= degree:
+        raise ValueError(f"horizon T={T} gives n_knots={n_knots}; the degree-{degree} spline "
+                         f"needs T >= {knot_scale * (degree + 1)} (reference: splrep raises "
+                         "'m > k must hold'); use sampling_method='random' or mppi_mode='simple'")
+    k1 = K if k1 is None else k1
+    g = halton_gaussian(K, n_knots * nu).view(K, nu, n_knots)
+    return g[k0:k1].to(torch.float32).contiguous()
+
+
 def halton_spline_delta(K: int, T: int, nu: int, knot_scale: int = 4, degree: int = 2,
                         k0: int = 0, k1: int | None = None, workers: int | None = None) -> torch.Tensor:
     """delta[K, T, nu] (rows k0..k1 only if given).  n_knots = T // knot_scale must be >= 3

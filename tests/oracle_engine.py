@@ -58,6 +58,8 @@ class OracleEngine:
         self.delta = np.ascontiguousarray(delta.cpu().numpy() if torch.is_tensor(delta) else delta,
                                           dtype=np.float32)
         assert self.delta.shape == (self.Kl, self.T, self.nu)
+        self.np[L.BUF_NOISE] = np.ascontiguousarray(self.delta.transpose(1, 0, 2))
+        self.t[L.BUF_NOISE] = _t(self.np[L.BUF_NOISE])
 
     def set_objective(self, task, goal, gripper_cmd=0):
         self.task, self.goal, self.grip = task, tuple(goal), gripper_cmd
