@@ -4,7 +4,7 @@ import torch, bench
 for K, T in ((64, 12), (2000, 30)):
     pl, sim, obj = bench.build_tamp("point_env", "push", (-1.0, -1.0), False, K, 0, 1, T, "cuda:0")
     from m3p2i_aip_amd import sampling
-    pl.set_noise(sampling.halton_spline_delta(K, T, 2))
+    pl._ensure_noise()
     state = sim._dof_state[0]
     for _ in range(50): pl.command(state)
     torch.cuda.synchronize()

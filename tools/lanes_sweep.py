@@ -6,13 +6,13 @@ from m3p2i_aip_amd.engine import HipEngine, make_config
 from m3p2i_aip_amd import sampling
 
 T = 30
-base = sampling.halton_spline_delta(2000, T, 2)
+base = sampling.halton_knots(2000, T, 2)
 out = []
 for K in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "2000,10000").split(",")]:
-    delta = sampling.halton_spline_delta(K, T, 2)
+    delta = sampling.halton_knots(K, T, 2)
     eng = HipEngine(make_config(K=K, T=T, nu=2, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3]))
     eng.set_objective("push", (-1.0, -1.0))
-    eng.set_noise(delta)
+    eng.set_noise_knots(delta)
     eng.enable_timing(True)
     for lanes in ((0,) if os.environ.get("M3P2I_HIP_LIB") else (0, 1, 2, 4, 8, 16, 32, 64)):
         eng.set_rollout_lanes(lanes)
