@@ -8,6 +8,6 @@ C=m3p2i_aip_amd/csrc
 while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
-     $flags $C/rollout_point.hip $C/rollout_panda.hip $C/update.hip $C/m3_api.hip -o gpurun_variants/$tag.so || echo "FAILED $tag"
+     $flags $C/rollout_point.hip $C/rollout_panda.hip $C/update.hip $C/sampler.hip $C/m3_api.hip -o gpurun_variants/$tag.so || echo "FAILED $tag"
 done
 ls -la gpurun_variants
