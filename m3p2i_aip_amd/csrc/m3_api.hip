@@ -192,8 +192,9 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (rc == M3_OK && hipMalloc((void**)&h->part_min, (size_t)mins_workgroups((int)Kg) * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->lad, (size_t)ladder_workgroups((int)Kg) * 96 * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->wpart, (size_t)wsum_chunks((int)Kl) * 3 * T * nu * f) != hipSuccess) rc = M3_ERR_HIP;
-    if (rc == M3_OK && hipMalloc((void**)&h->wcount, (size_t)(T + 1) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
-    if (rc == M3_OK && hipMemset(h->wcount, 0, (size_t)(T + 1) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->apart, (size_t)(16 + apply_workgroups((int)Kg) * 8) * f) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->wcount, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMemset(h->wcount, 0, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK) {
         m3_info init;
         std::memset(&init, 0, sizeof(init));
@@ -219,6 +220,7 @@ extern "C" void m3_destroy(m3_handle* h) {
     if (h->part_min) (void)hipFree(h->part_min);
     if (h->lad) (void)hipFree(h->lad);
     if (h->wpart) (void)hipFree(h->wpart);
+    if (h->apart) (void)hipFree(h->apart);
     if (h->wcount) (void)hipFree(h->wcount);
     if (h->sim_world) (void)hipFree(h->sim_world);
     if (h->sim_u) (void)hipFree(h->sim_u);
@@ -492,6 +494,8 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.n_mins = mins_workgroups(c.K_global);
     a.lad = h->lad;
     a.wpart = h->wpart;
+    a.srch = (SearchOut*)h->apart;
+    a.apart = h->apart + 16;
     a.wcount = h->wcount;
     a.n_chunk = wsum_chunks(c.K_local);
     a.n_lad = ladder_workgroups(c.K_global);

@@ -41,6 +41,7 @@ struct RolloutArgs {
     float* J;                 // [Kl]
 };
 
+struct SearchOut;
 struct VI {  // (cost, global sample index) candidate of the top-k selection
     float v;
     int i;
@@ -53,6 +54,8 @@ struct UpdateArgs {
     int n_cand;       // top-k stage-A workgroups
     float* lad;       // [n_lad][96][3] per-workgroup eta sums on the beta ladders (k_ladder)
     int n_lad;        // workgroups of k_ladder
+    struct SearchOut* srch;  // beta / eta / minima found by k_search (split path, K > 8192 multi-modal)
+    float* apart;     // [apply_workgroups][8] partial half sums and argmax keys of k_apply_weights
     float* wpart;     // [n_chunk][3][T][nu] partial weighted sums of k_wsum (n_chunk > 1 only)
     int* wcount;      // [T] arrival counters of the k_wsum chunks + [T] the launch-wide one of the
                       // fused finalize (zero between launches)
@@ -118,6 +121,7 @@ int mins_workgroups(int Kg);
 int topk_workgroups(int Kg);
 int ladder_workgroups(int Kg);
 int wsum_chunks(int Kl);
+int apply_workgroups(int Kg);
 void launch_mins(const UpdateArgs& a, hipStream_t s);
 void launch_ladder(const UpdateArgs& a, hipStream_t s);
 
@@ -189,6 +193,7 @@ struct m3_handle {
     float* part_min = nullptr;
     float* lad = nullptr;
     float* wpart = nullptr;
+    float* apart = nullptr;  // + 16 floats of SearchOut at the front
     int* wcount = nullptr;
     float* sim_world = nullptr;  // step mode SoA [NW][Kl]
     float* sim_u = nullptr;      // [Kl][nu]

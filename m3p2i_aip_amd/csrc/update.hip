@@ -762,12 +762,217 @@ __global__ __launch_bounds__(NTHR) void k_weights(const UpdateArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Multi-modal search with K > 8192: in ONE workgroup the weights pass alone (3 exps, two stores and
+// three running argmaxes per cost) is ~31 us of VALU work at K = 64000, and the minima another ~11.
+// Both are embarrassingly parallel, so the path is split:
+//   k_mins (existing) -> k_ladder (existing) -> k_search: minima from k_mins' partials, ladder
+//   table, walk; iterative passes over J from memory only if a search left its ladder (rare)
+//   -> k_apply_weights: every workgroup normalises 4096 costs, keeps its half sums and argmax
+//   keys; the last one to finish (write-through partials + relaxed agent ticket) combines them in
+//   workgroup order and fills m3_info.  Same values as k_weights; half sums in a different order.
+struct SearchOut {   // device scratch, written by k_search
+    float beta[3], eta[3], mn[3];
+};
+constexpr int AP_T = 256, AP_RPT = 16;  // 4096 costs per workgroup (few workgroups: their tickets serialise on one
+                                        // address, ~0.3 us each); <= 256 workgroups (K <= 1M)
+int apply_workgroups(int Kg) { return (Kg + AP_T * AP_RPT - 1) / (AP_T * AP_RPT); }
+
+__global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
+    __shared__ float red[3 * 16];
+    __shared__ float s_beta[3], s_eta[3], s_mn[3];
+    __shared__ int s_done[3], s_it[3];
+    __shared__ float s_tab[LAD_N * 3];
+    __shared__ float s_part[3 * LAD_N * 3];
+    if (blockIdx.x > 0) {  // workgroups 1..n_cand: top-k stage A, concurrent with the search
+        topk_stage_a(a, blockIdx.x - 1);
+        return;
+    }
+    const int Kg = a.Kg, half = a.half_g - a.kbase, tid = threadIdx.x, WT = blockDim.x;
+    const float INF = __builtin_inff();
+    if (tid < 3) {
+        float m = INF;
+        for (int b = 0; b < a.n_mins; ++b) m = fminf(m, a.part_min[b * 3 + tid]);
+        s_mn[tid] = m;
+    }
+    {   // ladder table (see k_weights)
+        const int NT = LAD_N * 3;
+        const int nseg = (WT / NT) > 0 ? (WT / NT) : 1;
+        const int o = tid % NT, sg = tid / NT;
+        if (sg < nseg) {
+            const int b0 = (int)(((long long)a.n_lad * sg) / nseg), b1 = (int)(((long long)a.n_lad * (sg + 1)) / nseg);
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int b = b0;
+            for (; b + 7 < b1; b += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += a.lad[(size_t)(b + u) * NT + o];
+            }
+            for (; b < b1; ++b) acc[0] += a.lad[(size_t)b * NT + o];
+            s_part[sg * NT + o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        }
+        __syncthreads();
+        for (int q = tid; q < NT; q += WT) {
+            float t = s_part[q];
+            for (int g = 1; g < nseg; ++g) t += s_part[g * NT + q];
+            s_tab[q] = t;
+        }
+    }
+    __syncthreads();
+    if (tid < 3) {  // the reference's rule on the table (m3p2i.py:35-51), as in k_weights
+        const int s = tid;
+        float b = 1.0f, et = s_tab[0 * 3 + s];
+        int it = 1, done = 0;
+        if (et > 10.0f) {
+            int j = 0;
+            for (;;) {
+                b = b * 0.9f; ++j;
+                if (j >= LAD_S) break;
+                et = s_tab[j * 3 + s]; ++it;
+                if (et > 10.0f) continue;
+                if (et < 3.0f) b = b * 1.2f;
+                else done = 1;
+                break;
+            }
+        } else if (et < 3.0f) {
+            int j = 0;
+            for (;;) {
+                b = b * 1.2f; ++j;
+                if (j > LAD_G) break;
+                et = s_tab[(LAD_S + j - 1) * 3 + s]; ++it;
+                if (et < 3.0f) continue;
+                if (et > 10.0f) b = b * 0.9f;
+                else done = 1;
+                break;
+            }
+        } else {
+            done = 1;
+        }
+        s_beta[s] = b; s_eta[s] = et; s_done[s] = done; s_it[s] = it;
+    }
+    __syncthreads();
+    const float m0 = s_mn[0], m1 = s_mn[1], m2 = s_mn[2];
+    for (int pass = 0; pass < 1000; ++pass) {  // searches that left their ladder: passes over J in memory
+        const float b0 = s_beta[0], b1 = s_beta[1], b2 = s_beta[2];
+        const int d0 = s_done[0], d1 = s_done[1], d2 = s_done[2];
+        if (d0 && d1 && d2) break;
+        float e[3] = {0.0f, 0.0f, 0.0f};
+        const float n0 = -1.0f / b0, n1 = -1.0f / b1, n2 = -1.0f / b2;
+        for (int k = tid; k < Kg; k += WT) {
+            const float v = a.Jall[k];
+            if (!d0) e[0] += m3_exp(n0 * (v - m0));
+            if (k < half) { if (!d1) e[1] += m3_exp(n1 * (v - m1)); }
+            else { if (!d2) e[2] += m3_exp(n2 * (v - m2)); }
+        }
+        block_sum<3>(e, red);
+        __syncthreads();
+        if (tid < 3 && !s_done[tid]) {
+            const float et = e[tid];
+            s_eta[tid] = et;
+            s_it[tid] = s_it[tid] + 1;
+            if (et > 10.0f) s_beta[tid] = s_beta[tid] * 0.9f;
+            else if (et < 3.0f) s_beta[tid] = s_beta[tid] * 1.2f;
+            else s_done[tid] = 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        SearchOut* o = a.srch;
+        for (int s = 0; s < 3; ++s) { o->beta[s] = s_beta[s]; o->eta[s] = s_eta[s]; o->mn[s] = s_mn[s]; }
+        m3_info* f = a.info;
+        f->eta = s_eta[0]; f->eta_1 = s_eta[1]; f->eta_2 = s_eta[2];
+        f->iters = s_it[0]; f->iters_1 = s_it[1]; f->iters_2 = s_it[2];
+        f->beta_1 = s_beta[1]; f->beta_2 = s_beta[2];   // diagnostics; info->beta stays (m3p2i.py:58-60)
+    }
+}
+
+__global__ __launch_bounds__(AP_T) void k_apply_weights(const UpdateArgs a) {
+    __shared__ float red[3 * 16];
+    __shared__ VI redvi[16];
+    const int Kg = a.Kg, half = a.half_g - a.kbase, tid = threadIdx.x, nb = gridDim.x;
+    const SearchOut so = *a.srch;
+    const float INF = __builtin_inff();
+    const float i0 = 1.0f / so.eta[0], n0 = -1.0f / so.beta[0];
+    const float i1 = 1.0f / so.eta[1], n1 = -1.0f / so.beta[1];
+    const float i2 = 1.0f / so.eta[2], n2 = -1.0f / so.beta[2];
+    float hs[2] = {0.0f, 0.0f};
+    VI b0 = {INF, 0x7fffffff}, b1 = {INF, 0x7fffffff}, b2 = {INF, 0x7fffffff};
+    const int base = blockIdx.x * AP_T * AP_RPT;
+#pragma unroll
+    for (int e = 0; e < AP_RPT; ++e) {
+        const int k = base + e * AP_T + tid;
+        const float v = a.Jall[min(k, Kg - 1)];
+        if (k < Kg) {
+            const float wk = i0 * m3_exp(n0 * (v - so.mn[0]));
+            a.w[k] = wk;
+            if (k < half) hs[0] += wk; else hs[1] += wk;
+            if (vi_less(-wk, k, b0.v, b0.i)) { b0.v = -wk; b0.i = k; }
+            if (k < half) {
+                const float w1k = i1 * m3_exp(n1 * (v - so.mn[1]));
+                a.w1[k] = w1k;
+                if (vi_less(-w1k, k, b1.v, b1.i)) { b1.v = -w1k; b1.i = k; }
+            } else {
+                const float w2k = i2 * m3_exp(n2 * (v - so.mn[2]));
+                a.w2[k - half] = w2k;
+                if (vi_less(-w2k, k, b2.v, b2.i)) { b2.v = -w2k; b2.i = k; }
+            }
+        }
+    }
+    block_sum<2>(hs, red);
+    b0 = block_argmin(b0, redvi);
+    b1 = block_argmin(b1, redvi);
+    b2 = block_argmin(b2, redvi);
+    // partials: write-through, then a relaxed agent ticket (per-XCD L2s are not coherent)
+    __shared__ float s_p[256 * 8];
+    __shared__ int s_last;
+    float* pf = a.apart + (size_t)blockIdx.x * 8;
+    if (tid < 8) {
+        const float val = tid == 0 ? hs[0] : tid == 1 ? hs[1] : tid == 2 ? b0.v : tid == 3 ? __int_as_float(b0.i)
+                        : tid == 4 ? b1.v : tid == 5 ? __int_as_float(b1.i) : tid == 6 ? b2.v : __int_as_float(b2.i);
+        __hip_atomic_store(pf + tid, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(&a.wcount[a.T + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == nb - 1;
+        if (s_last) a.wcount[a.T + 1] = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int q = tid; q < nb * 8; q += AP_T)   // all partials in flight at once
+        s_p[q] = __hip_atomic_load(a.apart + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        float h0 = 0.0f, h1 = 0.0f;
+        VI c0 = {INF, 0x7fffffff}, c1 = c0, c2 = c0;
+        for (int b = 0; b < nb; ++b) {  // workgroup order
+            const float* x = s_p + b * 8;
+            h0 += x[0]; h1 += x[1];
+            if (vi_less(x[2], __float_as_int(x[3]), c0.v, c0.i)) { c0.v = x[2]; c0.i = __float_as_int(x[3]); }
+            if (vi_less(x[4], __float_as_int(x[5]), c1.v, c1.i)) { c1.v = x[4]; c1.i = __float_as_int(x[5]); }
+            if (vi_less(x[6], __float_as_int(x[7]), c2.v, c2.i)) { c2.v = x[6]; c2.i = __float_as_int(x[7]); }
+        }
+        m3_info* f = a.info;
+        f->best_idx = a.kbase + c0.i;
+        f->best_idx_1 = c1.i;
+        f->best_idx_2 = c2.i;
+        f->wsum_push = h0; f->wsum_pull = h1;
+        f->pull_preference = h1 > h0;
+    }
+}
+
 int weights_threads(int Kg) { return Kg <= 8192 ? 256 : WT_MAX; }
 
 void launch_weights(const UpdateArgs& a, hipStream_t s) {
     // few waves for small K: the block-wide reductions dominate there, not the elements/thread
     const int threads = weights_threads(a.Kg);
     UpdateArgs b = a;
+    if (threads != 256 && a.multi_modal && !a.mode_simple && apply_workgroups(a.Kg) <= 256) {  // split path
+        // (k_mins / k_ladder already launched)
+        hipLaunchKernelGGL(k_search, dim3(1 + a.n_cand), dim3(WT_MAX), 0, s, b);
+        hipLaunchKernelGGL(k_apply_weights, dim3(apply_workgroups(a.Kg)), dim3(AP_T), 0, s, b);
+        return;
+    }
     if (threads == 256) {
         b.lds_floats = 0;
         hipLaunchKernelGGL((k_weights<32, 256>), dim3(1 + a.n_cand), dim3(256), 0, s, b);
