@@ -70,11 +70,13 @@ __device__ __forceinline__ void spec_sincos(float x, float& s, float& c) {
     pc = pc * z - 1.388731625493765e-3f;
     pc = pc * z + 4.166664568298827e-2f;
     const float cs = (1.0f - 0.5f * z) + (z * z) * pc;
-    const int q = ((int)k) & 3;
-    if (q == 0) { s = sn; c = cs; }
-    else if (q == 1) { s = cs; c = -sn; }
-    else if (q == 2) { s = -sn; c = -cs; }
-    else { s = -cs; c = sn; }
+    // quadrant q = k mod 4: (s, c) = (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn).  One swap select and
+    // two sign-bit XORs instead of a chain of compares and selects (same values bit for bit).
+    const unsigned q = (unsigned)((int)k) & 3u;
+    const bool swap = (q & 1u) != 0u;
+    const float s0 = swap ? cs : sn, c0 = swap ? sn : cs;
+    s = __uint_as_float(__float_as_uint(s0) ^ ((q & 2u) << 30));
+    c = __uint_as_float(__float_as_uint(c0) ^ (((q + 1u) & 2u) << 30));
 }
 
 __device__ __forceinline__ void rot_xp(Frame& f) {
@@ -180,7 +182,10 @@ __device__ __forceinline__ void sphere_box_force(const PandaScene& sc, const flo
         if (d[i] != 0.0f) inside = false;
         n2 = n2 + d[i] * d[i];
     }
-    if (inside) return;
+    // out of range without the correctly rounded sqrtf (~190 cycles for a lone wavefront):
+    // n2 > (r + 1e-4)^2 implies sqrt(n2) > r, i.e. pen < 0 below
+    const float lim = r + 1.0e-4f;
+    if (inside || n2 > lim * lim) return;
     const float dist = sqrtf(n2);
     const float pen = r - dist;
     if (!(pen > 0.0f)) return;
@@ -255,8 +260,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             if (tau < -sc.effort[i]) qd1 = w.qd[i] - sc.dv[i];
             qd1 = fminf(fmaxf(qd1, -sc.vlim[i]), sc.vlim[i]);
             float q1 = w.q[i] + h * qd1;
-            if (q1 < sc.qlo[i]) { q1 = sc.qlo[i]; qd1 = 0.0f; }
-            if (q1 > sc.qhi[i]) { q1 = sc.qhi[i]; qd1 = 0.0f; }
+            const float q1c = __builtin_amdgcn_fmed3f(q1, sc.qlo[i], sc.qhi[i]);   // position limits:
+            qd1 = (q1c == q1) ? qd1 : 0.0f;                                          // clamp and stop
+            q1 = q1c;
             w.q[i] = q1; w.qd[i] = qd1;
         }
         // 2. kinematics
@@ -306,9 +312,11 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
             if (which != 0 && w.cube[2] - sc.cube_half < sup) {
                 w.cube[2] = sup + sc.cube_half;
-                if (w.cube_v[2] < 0.0f) w.cube_v[2] = 0.0f;
+                w.cube_v[2] = fmaxf(w.cube_v[2], 0.0f);
                 const float vx = w.cube_v[0], vy = w.cube_v[1];
-                const float sp = sqrtf(vx * vx + vy * vy);
+                // a cube at rest on its support skips the sqrtf: vx = vy = +-0 gives sp = 0
+                const bool sliding = ((__float_as_uint(vx) | __float_as_uint(vy)) << 1) != 0u;
+                const float sp = sliding ? sqrtf(vx * vx + vy * vy) : 0.0f;
                 if (sp > 0.0f) {
                     const float dec = (sc.cube_mu * sc.g) * h;
                     float nvx, nvy;
