@@ -95,9 +95,21 @@ __device__ __forceinline__ void rot_z(Frame& f, float s, float c) {
         f.y[i] = c * y - s * x;
     }
 }
+// p += (tx*x + ty*y) + tz*z.  The offsets are URDF literals, mostly with one or two zero components;
+// under IEEE rules the compiler must keep `0 * x + ...` (NaN / signed-zero semantics), 12 of the
+// 15 operations of a one-component offset.  The zero terms are dropped here by hand (the tests
+// fold at compile time after inlining); the value can differ from the spec's full expression only
+// in the sign of a zero, which no later operation of the chain can observe.
 __device__ __forceinline__ void trans(Frame& f, float tx, float ty, float tz) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) f.p[i] = f.p[i] + ((tx * f.x[i] + ty * f.y[i]) + tz * f.z[i]);
+    for (int i = 0; i < 3; ++i) {
+        float acc = 0.0f;
+        bool has = false;
+        if (tx != 0.0f) { acc = tx * f.x[i]; has = true; }
+        if (ty != 0.0f) { acc = has ? acc + ty * f.y[i] : ty * f.y[i]; has = true; }
+        if (tz != 0.0f) { acc = has ? acc + tz * f.z[i] : tz * f.z[i]; has = true; }
+        if (has) f.p[i] = f.p[i] + acc;
+    }
 }
 
 __device__ __forceinline__ void mat2quat(const Frame& f, float* q) {
@@ -379,7 +391,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             // clamp may have moved q7/q8 after this substep's FK)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float fo = hand.p[i] + ((0.0f * hand.x[i] + 0.0f * hand.y[i]) + 0.0584f * hand.z[i]);
+                const float fo = hand.p[i] + 0.0584f * hand.z[i];   // (0*x + 0*y) + 0.0584*z, zero terms dropped
                 obs.left[i] = fo + w.q[7] * hand.y[i];
                 obs.right[i] = fo - w.q[8] * hand.y[i];
             }
