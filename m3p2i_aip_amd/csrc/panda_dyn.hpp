@@ -259,7 +259,7 @@ struct PandaObs {
 };
 
 __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, const float* u,
-                                           PandaObs& obs) {
+                                           PandaObs& obs, bool need_forces = true) {
     const float h = sc.h;
     for (int sub = 0; sub < sc.substeps; ++sub) {
         // 1. velocity servo
@@ -360,8 +360,10 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 }
             }
         }
-        // 4. penalty contact forces
-        {
+        // 4. penalty contact forces.  They are outputs only (nothing of the dynamics reads them) and
+        // a step's value is the LAST substep's, so earlier substeps do not form them; in a rollout
+        // only the pick cost reads them (get_motion_cost, cost_functions.py:116-125,158-169).
+        if (need_forces && sub == sc.substeps - 1) {
             // (finger link origins as given by this substep's FK, i.e. before the pad clamp)
             float tipl[3], tipr[3], hc[3];
 #pragma unroll

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a, const
             e[j] = uj / a.u_scale;                                                     // :421
         }
         PandaObs obs;
-        panda_step(sc, w, u, obs);
+        panda_step(sc, w, u, obs, /*need_forces=*/pa.cp.task == 5);
         const float c = panda_cost(pa.cp, w, obs, k);
         *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
             make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
