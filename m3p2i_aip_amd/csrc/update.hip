@@ -1055,13 +1055,25 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         }
     }
     float* out = (C == 1) ? a.reduce : a.wpart + (size_t)c * 3 * T * NU;
+    // all 3*NU sums through ONE LDS exchange (one pair of barriers) instead of one per column:
+    // the nine-column Panda rows paid nine barrier rounds here (~1 us each)
+    {
+        __shared__ float sred[3 * 9 * (ST / 64)];
+        const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-        float r[3] = {acc[0][j], acc[1][j], acc[2][j]};
-        block_sum<3>(r, red);
-        const float rv = tid == 0 ? r[0] : (tid == 1 ? r[1] : r[2]);
-        if (tid < 3) {
-            float* dst = &out[tid * T * NU + t * NU + j];  // == reduce_off_psum(tid) + t*NU + j
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const float ws = wave_sum(acc[s3][j]);
+                if (lane == 0) sred[(s3 * NU + j) * (ST / 64) + wv] = ws;
+            }
+        __syncthreads();
+        if (tid < 3 * NU) {
+            float rv = 0.0f;
+#pragma unroll
+            for (int w = 0; w < ST / 64; ++w) rv += sred[tid * (ST / 64) + w];   // wave order, as block_sum
+            const int s3 = tid / NU, j = tid % NU;
+            float* dst = &out[s3 * T * NU + t * NU + j];  // == reduce_off_psum(s3) + t*NU + j
             if (C == 1 && !a.fuse_finalize) *dst = rv;
             else __hip_atomic_store(dst, rv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
         }
