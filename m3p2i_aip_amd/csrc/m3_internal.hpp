@@ -48,7 +48,7 @@ struct VI {  // (cost, global sample index) candidate of the top-k selection
 };
 
 struct UpdateArgs {
-    VI* cand;         // [n_cand][M3_TOPK] per-workgroup top-k candidates (k_prep -> k_wsum)
+    VI* cand;         // [n_cand][M3_TOPK] per-workgroup top-k candidates (stage A -> stage B)
     float* part_min;  // [n_mins][3] per-workgroup minima (all, first half, second half)
     int n_mins;       // workgroups of k_mins
     int n_cand;       // top-k stage-A workgroups

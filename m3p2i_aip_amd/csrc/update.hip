@@ -1,17 +1,21 @@
 // update.hip -- importance-weight update of MPPI / M3P2I (gfx950).
 //
-//   k_prep    : per-workgroup minima of the trajectory costs + top-k stage A (registers + DPP)
-//               argmax / top-k                 mppi.py:248, 493; m3p2i.py:75-76
+//   k_mins    : (multi-modal only) per-workgroup minima of the trajectory costs
 //   k_ladder  : (multi-modal only) eta(beta) for the whole ladder of betas the reference's
 //               on-the-fly search can visit, in ONE chip-wide pass
 //               update_infinite_beta           m3p2i.py:24-44
 //   k_weights : walks the search on the ladder table (iterative passes only after a direction
-//               reversal), softmin weights, argmax, half sums
+//               reversal), softmin weights, argmax, half sums; top-k stage A as extra workgroups
 //               _exp_util                      mppi.py:430-456
 //               _multi_modal_exp_util          m3p2i.py:46-64
 //               simple-mode weights            mppi.py:225-229
-//   k_wsum    : weighted action sums + best / top-trajectory row gathers (per time step)
+//               argmax / top-k                 mppi.py:248, 493; m3p2i.py:75-76
+//   k_search + k_apply_weights : the same for the multi-modal search with K > 8192, split so that the
+//               weights pass runs on many workgroups
+//   k_wsum    : weighted action sums + best / top-trajectory row gathers (per time step); top-k
+//               stage B as an extra workgroup; for the unsharded m3_command also k_finalize's work
 //               mppi.py:497-498, 252-254; m3p2i.py:77-83
+//   k_mix     : (sharded single-mode) per-rank softmin records -> the reduce buffer
 //   k_finalize: mean update, per-mode means, simple-mode U update, Savitzky-Golay
 //               mppi.py:502-503, 231, 245, 257-263; m3p2i.py:86-87
 //
@@ -31,8 +35,8 @@
 namespace m3 {
 
 constexpr int WT_MAX = 1024;       // threads of k_weights for large K (16 wavefronts); 256 for small K
-constexpr int PREP_T = 256;        // threads of k_prep
-constexpr int PREP_RPT = 16;       // costs per thread held in registers by k_prep
+constexpr int PREP_T = 256;        // threads of k_mins / a top-k stage-A workgroup
+constexpr int PREP_RPT = 16;       // costs per thread held in registers there
 constexpr int LAD_S = 64;          // shrink ladder: beta = 0.9^j, j = 0..63
 constexpr int LAD_G = 32;          // grow ladder:   beta = 1.2^j, j = 1..32
 constexpr int LAD_N = LAD_S + LAD_G;
@@ -168,13 +172,6 @@ __device__ __forceinline__ VI block_argmin(VI x, VI* lds) {
 }
 
 // ---------------------------------------------------------------------------------------
-// k_prep: each workgroup owns PREP_T*PREP_RPT consecutive costs, held in REGISTERS (re-reading
-// J from L2 every round cost ~1 us per round: 47 us at K = 2000 in the first version).
-//   * minima of the costs (all / first half / second half) of the workgroup -> part_min
-//   * top-k stage A: top-k weights == k smallest costs (weights are monotone in J; ties towards
-//     the lower sample index).  Every wave extracts the sorted top-k of its registers with DPP
-//     argmin rounds, wave 0 merges the waves' candidates.  Stage B (merge across workgroups)
-//     runs in k_wsum.
 // minima only (critical path of the multi-modal search: k_ladder needs them)
 __global__ __launch_bounds__(PREP_T) void k_mins(const UpdateArgs a) {
     __shared__ float red[3 * 16];
