@@ -145,7 +145,9 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const
         // ---- outputs, time-major ----
         *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
             make_float4(w.rx, w.rvx, w.ry, w.rvy);                      // reactive_tamp.py:66-69
-        const float e0 = u0 / a.u_scale, e1 = u1 / a.u_scale;           // mppi.py:421
+        // mppi.py:421 (x / 1 == x exactly: the usual u_scale = 1 skips two IEEE divisions per step)
+        float e0 = u0, e1 = u1;
+        if (a.u_scale != 1.0f) { e0 = u0 / a.u_scale; e1 = u1 / a.u_scale; }   // wave-uniform branch
         *reinterpret_cast<float2*>(a.actions + ((size_t)t * Kl + i) * 2) = make_float2(e0, e1);
         a.cost_h[(size_t)t * Kl + i] = c;                               // mppi.py:310
         J = J + g * c;                                                  // mppi_utils.py:106-113
