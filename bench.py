@@ -144,13 +144,21 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # M3_BENCH_SHARE_GPU=1 (tests only, tests/test_bench_two_ranks_gpu.py): all ranks on cuda:0 with
+    # gloo collectives, so that the N > 1 code path of this file can be exercised on a 1-GPU box
+    # (RCCL refuses two ranks on one device).  The numbers of such a run mean nothing.
+    share = os.environ.get("M3_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
 
     env, task, goal, multi_modal, K_local, T = CONFIGS[args.config]
     nu = 2 if env == "point_env" else 9
@@ -171,6 +179,7 @@ def main():
 
     def sync():
         if dist is not None:
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
