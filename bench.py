@@ -253,8 +253,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kern, "kernel_ms": rollout_ms, "bytes_per_launch": alg_bytes,
-                         "kernel_ms_from": "HIP events on the library's stream, mean over the commands "
-                                           "run immediately before the timed region",
+                         "kernel_ms_from": "HIP events recorded by the library right before / after the "
+                                           "launch on its stream (mean over the commands between warm-up and "
+                                           "the timed region); the interval includes the ~5-9 us dispatch "
+                                           "latency that rocprofv3's kernel duration (profiles/) excludes",
                          "note": "latency-bound at this K (sequential T x substeps x solver passes chain); "
                                  "DESIGN.md section 6"},
             "kernel_ms": {"rollout": rollout_ms, "update": float(np.mean(tu)), "finalize": float(np.mean(tf))},
