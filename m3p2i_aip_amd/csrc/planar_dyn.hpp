@@ -465,24 +465,58 @@ __device__ __forceinline__ void integrate_box(Box& X, float h) {
         else { fx -= ix_; fy -= iy_; }                            \
     }
 
-// one sim.step(): substeps x (forces, detect, solve, integrate)
-template <bool ALL_FORCES>
-__device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, float ux, float uy,
-                                           bool need_dyn_force = true) {
-    const float h = sc.h;
-    for (int sub = 0; sub < sc.substeps; ++sub) {
-        // 1. external forces
-        w.rvx = w.rvx + (h * w.fRx) * sc.invm_r;
-        w.rvy = w.rvy + (h * w.fRy) * sc.invm_r;
-        w.B.vx = w.B.vx + (h * w.fBx) * sc.invm_b;
-        w.B.vy = w.B.vy + (h * w.fBy) * sc.invm_b;
+// Broad-phase predicates: the same expressions as the early-outs inside the detect functions, so
+// "not near" here implies that the corresponding slots come out `on = false`.
+__device__ __forceinline__ bool near_centres(const PointScene& sc, float ax, float ay, float bx, float by,
+                                             float ra, float rb) {
+    const float dx = bx - ax, dy = by - ay;
+    const float lim = ra + rb + sc.contact_offset + 1e-3f;
+    return !(dx * dx + dy * dy > lim * lim);
+}
+__device__ __forceinline__ bool near_walls_disc(const PointScene& sc, float px, float py) {
+    return ((sc.wall - fabsf(px)) - sc.robot_r < sc.contact_offset) ||
+           ((sc.wall - fabsf(py)) - sc.robot_r < sc.contact_offset);
+}
+__device__ __forceinline__ bool near_walls_box(const PointScene& sc, const Box& X, float rad) {
+    const float lim = rad + sc.contact_offset + 1e-3f;
+    return ((sc.wall - fabsf(X.x)) <= lim) || ((sc.wall - fabsf(X.y)) <= lim);
+}
 
-        // 2. contacts (static slots)
-        Slot s_rb, s_rd, s_ro, s_rwx, s_rwy;
-        Slot s_bx1, s_bx2, s_by1, s_by2, s_dx1, s_dx2, s_dy1, s_dy2;
-        Slot s_bd1, s_bd2, s_bo1, s_bo2, s_do1, s_do2;
+// One substep: forces, detect, solve, integrate.
+// LEVEL selects which contact slots EXIST in the generated code: 2 = all 19, 1 = robot-box only,
+// 0 = none.  The full version keeps 19 slots x 11 values live across the solver loop: 344 VGPRs
+// (arch + acc, i.e. AGPR spill moves), 67 spilled SGPRs and 5.5 k instructions, and the common
+// case -- nothing but (at most) the robot-box pair in range -- paid for carrying them: compiled
+// WITHOUT the other slots the same substep needs 104 VGPRs and ran 1.75x faster.  point_step
+// therefore tests, per substep and per WAVE, whether any lane has a pair inside its broad-phase
+// range and runs the leanest instance that covers the wave; results are identical because a pair
+// outside its broad-phase range cannot produce a contact.  (Measured on C2: 47 of a wave's 60
+// substeps take level 0, 12 level 1, 1 level 2 on average -- but the worst wave takes level 2 about
+// ten times, and the kernel ends with it: 0.227 -> 0.213 ms.  Calling the level-2 instance out of line
+// (__noinline__, world through scratch) to shield the lean code's register allocation was slower,
+// 0.263 ms; so was a verdict-only narrow phase to decide on real contacts instead of ranges, 0.237.)
+template <bool ALL_FORCES, int LEVEL>
+__device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& w, float ux, float uy,
+                                              bool form_dyn_force) {
+    const float h = sc.h;
+    // 1. external forces
+    w.rvx = w.rvx + (h * w.fRx) * sc.invm_r;
+    w.rvy = w.rvy + (h * w.fRy) * sc.invm_r;
+    w.B.vx = w.B.vx + (h * w.fBx) * sc.invm_b;
+    w.B.vy = w.B.vy + (h * w.fBy) * sc.invm_b;
+
+    // 2. contacts (static slots)
+    Slot s_rb, s_rd, s_ro, s_rwx, s_rwy;
+    Slot s_bx1, s_bx2, s_by1, s_by2, s_dx1, s_dx2, s_dy1, s_dy2;
+    Slot s_bd1, s_bd2, s_bo1, s_bo2, s_do1, s_do2;
+    s_rb.on = false;
+    s_rd.on = s_ro.on = s_rwx.on = s_rwy.on = false;
+    s_bx1.on = s_bx2.on = s_by1.on = s_by2.on = s_dx1.on = s_dx2.on = s_dy1.on = s_dy2.on = false;
+    s_bd1.on = s_bd2.on = s_bo1.on = s_bo2.on = s_do1.on = s_do2.on = false;
+    if constexpr (LEVEL >= 1)
         detect_disc_box<BOXB>(sc, s_rb, w.rx, w.ry, w.B.x, w.B.y, w.B.c, w.B.s, sc.box_hx,
                               sc.box_hy, sc.rad_b);
+    if constexpr (LEVEL >= 2) {
         detect_disc_box<BOXD>(sc, s_rd, w.rx, w.ry, w.D.x, w.D.y, w.D.c, w.D.s, sc.dyn_hx,
                               sc.dyn_hy, sc.rad_d);
         detect_disc_box<STATIC>(sc, s_ro, w.rx, w.ry, sc.obs_x, sc.obs_y, 1.0f, 0.0f, sc.obs_hx,
@@ -499,77 +533,83 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
         detect_box_box<BOXD, STATIC>(sc, s_do1, s_do2, w.D.x, w.D.y, w.D.c, w.D.s, sc.dyn_hx,
                                      sc.dyn_hy, sc.rad_d, sc.obs_x, sc.obs_y, 1.0f, 0.0f,
                                      sc.obs_hx, sc.obs_hy, sc.rad_o);
+    }
+    bool on_walls = false, on_boxes = false, rare = false;
+    if constexpr (LEVEL >= 2) {
+        on_walls = s_rwx.on | s_rwy.on | s_bx1.on | s_bx2.on | s_by1.on | s_by2.on |
+                   s_dx1.on | s_dx2.on | s_dy1.on | s_dy2.on;
+        on_boxes = s_bd1.on | s_bd2.on | s_bo1.on | s_bo2.on | s_do1.on | s_do2.on;
+        rare = s_rd.on | s_ro.on | on_walls | on_boxes;
+    }
 
-        const bool on_walls = s_rwx.on | s_rwy.on | s_bx1.on | s_bx2.on | s_by1.on | s_by2.on |
-                              s_dx1.on | s_dx2.on | s_dy1.on | s_dy2.on;
-        const bool on_boxes = s_bd1.on | s_bd2.on | s_bo1.on | s_bo2.on | s_do1.on | s_do2.on;
-        const bool rare = s_rd.on | s_ro.on | on_walls | on_boxes;
-
-        // 3. velocity solve
-        Vel v = {w.rvx, w.rvy, w.B.vx, w.B.vy, w.B.w, w.D.vx, w.D.vy, w.D.w};
-        float ldx = 0.0f, ldy = 0.0f;
-        Fric fB = {0.f, 0.f, 0.f}, fD = {0.f, 0.f, 0.f};
-        for (int it = 0; it < sc.iters; ++it) {
-            {
-                float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
-                float l1 = ldx + dl;
-                l1 = clamp_sym(l1, sc.dmax);
-                v.rvx += sc.invm_r * (l1 - ldx);
-                ldx = l1;
-                dl = -(((v.rvy - uy) + sc.gam * ldy) * sc.md);
-                l1 = ldy + dl;
-                l1 = clamp_sym(l1, sc.dmax);
-                v.rvy += sc.invm_r * (l1 - ldy);
-                ldy = l1;
-            }
-            solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
-            // spec order: friction(dyn-obs) then robot-box.  The two rows share no body, so they
-            // commute exactly; solving robot-box first lets the dyn-obs row (usually at rest) join
-            // the rarely-taken group below: one skipped branch per pass instead of two.
-            if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
-            const bool d_moving = ((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u;
-            if (d_moving | rare) {
-            solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
-            // Every slot but robot-box is rarely active.  They sit behind ONE outer flag and two
-            // group flags: when no lane of the wave has any of them, a pass pays one skipped
-            // exec-mask branch (~40 cycles for a lone wavefront) instead of one per slot / group
-            // (same solve order as the spec).
-            if (rare) {
-            if (s_rd.on) solve<ROBOT, BOXD>(sc, v, s_rd, sc.mu_rd);
-            if (s_ro.on) solve<ROBOT, STATIC>(sc, v, s_ro, sc.mu_ro);
-            if (on_walls) {
-                if (s_rwx.on) solve<ROBOT, STATIC>(sc, v, s_rwx, sc.mu_rw);
-                if (s_rwy.on) solve<ROBOT, STATIC>(sc, v, s_rwy, sc.mu_rw);
-                if (s_bx1.on) solve<BOXB, STATIC>(sc, v, s_bx1, sc.mu_bw);
-                if (s_bx2.on) solve<BOXB, STATIC>(sc, v, s_bx2, sc.mu_bw);
-                if (s_by1.on) solve<BOXB, STATIC>(sc, v, s_by1, sc.mu_bw);
-                if (s_by2.on) solve<BOXB, STATIC>(sc, v, s_by2, sc.mu_bw);
-                if (s_dx1.on) solve<BOXD, STATIC>(sc, v, s_dx1, sc.mu_dw);
-                if (s_dx2.on) solve<BOXD, STATIC>(sc, v, s_dx2, sc.mu_dw);
-                if (s_dy1.on) solve<BOXD, STATIC>(sc, v, s_dy1, sc.mu_dw);
-                if (s_dy2.on) solve<BOXD, STATIC>(sc, v, s_dy2, sc.mu_dw);
-            }
-            if (on_boxes) {
-                if (s_bd1.on) solve<BOXB, BOXD>(sc, v, s_bd1, sc.mu_bd);
-                if (s_bd2.on) solve<BOXB, BOXD>(sc, v, s_bd2, sc.mu_bd);
-                if (s_bo1.on) solve<BOXB, STATIC>(sc, v, s_bo1, sc.mu_bo);
-                if (s_bo2.on) solve<BOXB, STATIC>(sc, v, s_bo2, sc.mu_bo);
-                if (s_do1.on) solve<BOXD, STATIC>(sc, v, s_do1, sc.mu_do);
-                if (s_do2.on) solve<BOXD, STATIC>(sc, v, s_do2, sc.mu_do);
-            }
-            }  // rare
-            }  // d_moving | rare
+    // 3. velocity solve
+    Vel v = {w.rvx, w.rvy, w.B.vx, w.B.vy, w.B.w, w.D.vx, w.D.vy, w.D.w};
+    float ldx = 0.0f, ldy = 0.0f;
+    Fric fB = {0.f, 0.f, 0.f}, fD = {0.f, 0.f, 0.f};
+    for (int it = 0; it < sc.iters; ++it) {
+        {
+            float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
+            float l1 = ldx + dl;
+            l1 = clamp_sym(l1, sc.dmax);
+            v.rvx += sc.invm_r * (l1 - ldx);
+            ldx = l1;
+            dl = -(((v.rvy - uy) + sc.gam * ldy) * sc.md);
+            l1 = ldy + dl;
+            l1 = clamp_sym(l1, sc.dmax);
+            v.rvy += sc.invm_r * (l1 - ldy);
+            ldy = l1;
         }
-        w.rvx = v.rvx; w.rvy = v.rvy;
-        w.B.vx = v.bvx; w.B.vy = v.bvy; w.B.w = v.bw;
-        w.D.vx = v.dvx; w.D.vy = v.dvy; w.D.w = v.dw;
+        solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
+        // spec order: friction(dyn-obs) then robot-box.  The two rows share no body, so they
+        // commute exactly; solving robot-box first lets the dyn-obs row (usually at rest) join
+        // the rarely-taken group below: one skipped branch per pass instead of two.
+        if constexpr (LEVEL >= 1) {
+            if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
+        }
+        const bool d_moving = ((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u;
+        if (d_moving | rare) {
+            solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
+            if constexpr (LEVEL >= 2) {
+                // one outer flag + two group flags: a pass in which no lane has any of these pays
+                // one skipped exec-mask branch (same solve order as the spec)
+                if (rare) {
+                    if (s_rd.on) solve<ROBOT, BOXD>(sc, v, s_rd, sc.mu_rd);
+                    if (s_ro.on) solve<ROBOT, STATIC>(sc, v, s_ro, sc.mu_ro);
+                    if (on_walls) {
+                        if (s_rwx.on) solve<ROBOT, STATIC>(sc, v, s_rwx, sc.mu_rw);
+                        if (s_rwy.on) solve<ROBOT, STATIC>(sc, v, s_rwy, sc.mu_rw);
+                        if (s_bx1.on) solve<BOXB, STATIC>(sc, v, s_bx1, sc.mu_bw);
+                        if (s_bx2.on) solve<BOXB, STATIC>(sc, v, s_bx2, sc.mu_bw);
+                        if (s_by1.on) solve<BOXB, STATIC>(sc, v, s_by1, sc.mu_bw);
+                        if (s_by2.on) solve<BOXB, STATIC>(sc, v, s_by2, sc.mu_bw);
+                        if (s_dx1.on) solve<BOXD, STATIC>(sc, v, s_dx1, sc.mu_dw);
+                        if (s_dx2.on) solve<BOXD, STATIC>(sc, v, s_dx2, sc.mu_dw);
+                        if (s_dy1.on) solve<BOXD, STATIC>(sc, v, s_dy1, sc.mu_dw);
+                        if (s_dy2.on) solve<BOXD, STATIC>(sc, v, s_dy2, sc.mu_dw);
+                    }
+                    if (on_boxes) {
+                        if (s_bd1.on) solve<BOXB, BOXD>(sc, v, s_bd1, sc.mu_bd);
+                        if (s_bd2.on) solve<BOXB, BOXD>(sc, v, s_bd2, sc.mu_bd);
+                        if (s_bo1.on) solve<BOXB, STATIC>(sc, v, s_bo1, sc.mu_bo);
+                        if (s_bo2.on) solve<BOXB, STATIC>(sc, v, s_bo2, sc.mu_bo);
+                        if (s_do1.on) solve<BOXD, STATIC>(sc, v, s_do1, sc.mu_do);
+                        if (s_do2.on) solve<BOXD, STATIC>(sc, v, s_do2, sc.mu_do);
+                    }
+                }
+            }
+        }
+    }
+    w.rvx = v.rvx; w.rvy = v.rvy;
+    w.B.vx = v.bvx; w.B.vy = v.bvy; w.B.w = v.bw;
+    w.D.vx = v.dvx; w.D.vy = v.dvy; w.D.w = v.dw;
 
-        // net contact force on the dyn-obs (get_motion_cost reads it), slot order.  The cost sees
-        // only the LAST substep's value (spec), and only the navigation cost reads it at all
-        // (cost_functions.py:38,158-169), so the rollout forms it just then (the step-mode wrapper
-        // exposes all bodies' forces and keeps the general path).
-        if (ALL_FORCES || (need_dyn_force && sub == sc.substeps - 1)) {
-            float fx = 0.0f, fy = 0.0f;
+    // net contact force on the dyn-obs (get_motion_cost reads it), slot order.  The cost sees only
+    // the LAST substep's value (spec), and only the navigation cost reads it at all
+    // (cost_functions.py:38,158-169), so the rollout forms it just then (the step-mode wrapper
+    // exposes all bodies' forces and keeps the general path).
+    if (ALL_FORCES || form_dyn_force) {
+        float fx = 0.0f, fy = 0.0f;
+        if constexpr (LEVEL >= 2) {
             M3_ACC(fx, fy, s_rd, +1)
             if (on_walls) {
                 M3_ACC(fx, fy, s_dx1, -1) M3_ACC(fx, fy, s_dx2, -1)
@@ -579,29 +619,54 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
                 M3_ACC(fx, fy, s_bd1, +1) M3_ACC(fx, fy, s_bd2, +1)
                 M3_ACC(fx, fy, s_do1, -1) M3_ACC(fx, fy, s_do2, -1)
             }
-            fx += fD.lx; fy += fD.ly;
-            w.fcDx = fx * sc.inv_h; w.fcDy = fy * sc.inv_h;
         }
-        if constexpr (ALL_FORCES) {
-            float fx = 0.0f, fy = 0.0f;
-            M3_ACC(fx, fy, s_rb, +1)
-            M3_ACC(fx, fy, s_bx1, -1) M3_ACC(fx, fy, s_bx2, -1)
-            M3_ACC(fx, fy, s_by1, -1) M3_ACC(fx, fy, s_by2, -1)
-            M3_ACC(fx, fy, s_bd1, -1) M3_ACC(fx, fy, s_bd2, -1)
-            M3_ACC(fx, fy, s_bo1, -1) M3_ACC(fx, fy, s_bo2, -1)
-            fx += fB.lx; fy += fB.ly;
-            w.fcBx = fx * sc.inv_h; w.fcBy = fy * sc.inv_h;
-            fx = 0.0f; fy = 0.0f;
-            M3_ACC(fx, fy, s_rb, -1) M3_ACC(fx, fy, s_rd, -1) M3_ACC(fx, fy, s_ro, -1)
-            M3_ACC(fx, fy, s_rwx, -1) M3_ACC(fx, fy, s_rwy, -1)
-            w.fcRx = fx * sc.inv_h; w.fcRy = fy * sc.inv_h;
-        }
+        fx += fD.lx; fy += fD.ly;
+        w.fcDx = fx * sc.inv_h; w.fcDy = fy * sc.inv_h;
+    }
+    if constexpr (ALL_FORCES) {
+        float fx = 0.0f, fy = 0.0f;
+        M3_ACC(fx, fy, s_rb, +1)
+        M3_ACC(fx, fy, s_bx1, -1) M3_ACC(fx, fy, s_bx2, -1)
+        M3_ACC(fx, fy, s_by1, -1) M3_ACC(fx, fy, s_by2, -1)
+        M3_ACC(fx, fy, s_bd1, -1) M3_ACC(fx, fy, s_bd2, -1)
+        M3_ACC(fx, fy, s_bo1, -1) M3_ACC(fx, fy, s_bo2, -1)
+        fx += fB.lx; fy += fB.ly;
+        w.fcBx = fx * sc.inv_h; w.fcBy = fy * sc.inv_h;
+        fx = 0.0f; fy = 0.0f;
+        M3_ACC(fx, fy, s_rb, -1) M3_ACC(fx, fy, s_rd, -1) M3_ACC(fx, fy, s_ro, -1)
+        M3_ACC(fx, fy, s_rwx, -1) M3_ACC(fx, fy, s_rwy, -1)
+        w.fcRx = fx * sc.inv_h; w.fcRy = fy * sc.inv_h;
+    }
 
-        // 4. integrate
-        w.rx = w.rx + h * w.rvx;
-        w.ry = w.ry + h * w.rvy;
-        integrate_box(w.B, h);
-        integrate_box(w.D, h);
+    // 4. integrate
+    w.rx = w.rx + h * w.rvx;
+    w.ry = w.ry + h * w.rvy;
+    integrate_box(w.B, h);
+    integrate_box(w.D, h);
+}
+
+// one sim.step(): substeps x (forces, detect, solve, integrate)
+template <bool ALL_FORCES>
+__device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, float ux, float uy,
+                                           bool need_dyn_force = true) {
+    for (int sub = 0; sub < sc.substeps; ++sub) {
+        const bool form = need_dyn_force && sub == sc.substeps - 1;
+        if constexpr (ALL_FORCES) {
+            point_substep<true, 2>(sc, w, ux, uy, form);   // step mode: one environment per lane, general path
+        } else {
+            const bool near_rb = near_centres(sc, w.B.x, w.B.y, w.rx, w.ry, sc.robot_r, sc.rad_b);
+            const bool near_other =
+                near_centres(sc, w.D.x, w.D.y, w.rx, w.ry, sc.robot_r, sc.rad_d) ||
+                near_centres(sc, sc.obs_x, sc.obs_y, w.rx, w.ry, sc.robot_r, sc.rad_o) ||
+                near_walls_disc(sc, w.rx, w.ry) || near_walls_box(sc, w.B, sc.rad_b) ||
+                near_walls_box(sc, w.D, sc.rad_d) ||
+                near_centres(sc, w.B.x, w.B.y, w.D.x, w.D.y, sc.rad_b, sc.rad_d) ||
+                near_centres(sc, w.B.x, w.B.y, sc.obs_x, sc.obs_y, sc.rad_b, sc.rad_o) ||
+                near_centres(sc, w.D.x, w.D.y, sc.obs_x, sc.obs_y, sc.rad_d, sc.rad_o);
+            if (__builtin_amdgcn_ballot_w64(near_other) != 0ull) point_substep<false, 2>(sc, w, ux, uy, form);
+            else if (__builtin_amdgcn_ballot_w64(near_rb) != 0ull) point_substep<false, 1>(sc, w, ux, uy, form);
+            else point_substep<false, 0>(sc, w, ux, uy, form);
+        }
     }
     w.fRx = 0.0f; w.fRy = 0.0f; w.fBx = 0.0f; w.fBy = 0.0f;
 }
