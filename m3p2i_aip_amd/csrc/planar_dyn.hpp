@@ -483,8 +483,8 @@ __device__ __forceinline__ bool near_walls_box(const PointScene& sc, const Box& 
 }
 
 // One substep: forces, detect, solve, integrate.
-// LEVEL selects which contact slots EXIST in the generated code: 2 = all 19, 1 = robot-box only,
-// 0 = none.  The full version keeps 19 slots x 11 values live across the solver loop: 344 VGPRs
+// LEVEL selects which contact slots EXIST in the generated code: 3 = all 19, 2 = the robot's five
+// (box, dyn-obs, obstacle, walls), 1 = robot-box only, 0 = none.  The full version keeps 19 slots x 11 values live across the solver loop: 344 VGPRs
 // (arch + acc, i.e. AGPR spill moves), 67 spilled SGPRs and 5.5 k instructions, and the common
 // case -- nothing but (at most) the robot-box pair in range -- paid for carrying them: compiled
 // WITHOUT the other slots the same substep needs 104 VGPRs and ran 1.75x faster.  point_step
@@ -522,6 +522,8 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
         detect_disc_box<STATIC>(sc, s_ro, w.rx, w.ry, sc.obs_x, sc.obs_y, 1.0f, 0.0f, sc.obs_hx,
                                 sc.obs_hy, sc.rad_o);
         detect_disc_walls(sc, s_rwx, s_rwy, w.rx, w.ry);
+    }
+    if constexpr (LEVEL >= 3) {
         detect_box_walls<BOXB>(sc, s_bx1, s_bx2, s_by1, s_by2, w.B, sc.box_hx, sc.box_hy, sc.rad_b);
         detect_box_walls<BOXD>(sc, s_dx1, s_dx2, s_dy1, s_dy2, w.D, sc.dyn_hx, sc.dyn_hy, sc.rad_d);
         detect_box_box<BOXB, BOXD>(sc, s_bd1, s_bd2, w.B.x, w.B.y, w.B.c, w.B.s, sc.box_hx,
@@ -535,7 +537,11 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
                                      sc.obs_hx, sc.obs_hy, sc.rad_o);
     }
     bool on_walls = false, on_boxes = false, rare = false;
-    if constexpr (LEVEL >= 2) {
+    if constexpr (LEVEL == 2) {
+        on_walls = s_rwx.on | s_rwy.on;
+        rare = s_rd.on | s_ro.on | on_walls;
+    }
+    if constexpr (LEVEL >= 3) {
         on_walls = s_rwx.on | s_rwy.on | s_bx1.on | s_bx2.on | s_by1.on | s_by2.on |
                    s_dx1.on | s_dx2.on | s_dy1.on | s_dy2.on;
         on_boxes = s_bd1.on | s_bd2.on | s_bo1.on | s_bo2.on | s_do1.on | s_do2.on;
@@ -578,16 +584,18 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
                     if (on_walls) {
                         if (s_rwx.on) solve<ROBOT, STATIC>(sc, v, s_rwx, sc.mu_rw);
                         if (s_rwy.on) solve<ROBOT, STATIC>(sc, v, s_rwy, sc.mu_rw);
-                        if (s_bx1.on) solve<BOXB, STATIC>(sc, v, s_bx1, sc.mu_bw);
-                        if (s_bx2.on) solve<BOXB, STATIC>(sc, v, s_bx2, sc.mu_bw);
-                        if (s_by1.on) solve<BOXB, STATIC>(sc, v, s_by1, sc.mu_bw);
-                        if (s_by2.on) solve<BOXB, STATIC>(sc, v, s_by2, sc.mu_bw);
-                        if (s_dx1.on) solve<BOXD, STATIC>(sc, v, s_dx1, sc.mu_dw);
-                        if (s_dx2.on) solve<BOXD, STATIC>(sc, v, s_dx2, sc.mu_dw);
-                        if (s_dy1.on) solve<BOXD, STATIC>(sc, v, s_dy1, sc.mu_dw);
-                        if (s_dy2.on) solve<BOXD, STATIC>(sc, v, s_dy2, sc.mu_dw);
+                        if constexpr (LEVEL >= 3) {
+                            if (s_bx1.on) solve<BOXB, STATIC>(sc, v, s_bx1, sc.mu_bw);
+                            if (s_bx2.on) solve<BOXB, STATIC>(sc, v, s_bx2, sc.mu_bw);
+                            if (s_by1.on) solve<BOXB, STATIC>(sc, v, s_by1, sc.mu_bw);
+                            if (s_by2.on) solve<BOXB, STATIC>(sc, v, s_by2, sc.mu_bw);
+                            if (s_dx1.on) solve<BOXD, STATIC>(sc, v, s_dx1, sc.mu_dw);
+                            if (s_dx2.on) solve<BOXD, STATIC>(sc, v, s_dx2, sc.mu_dw);
+                            if (s_dy1.on) solve<BOXD, STATIC>(sc, v, s_dy1, sc.mu_dw);
+                            if (s_dy2.on) solve<BOXD, STATIC>(sc, v, s_dy2, sc.mu_dw);
+                        }
                     }
-                    if (on_boxes) {
+                    if constexpr (LEVEL >= 3) if (on_boxes) {
                         if (s_bd1.on) solve<BOXB, BOXD>(sc, v, s_bd1, sc.mu_bd);
                         if (s_bd2.on) solve<BOXB, BOXD>(sc, v, s_bd2, sc.mu_bd);
                         if (s_bo1.on) solve<BOXB, STATIC>(sc, v, s_bo1, sc.mu_bo);
@@ -611,13 +619,15 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
         float fx = 0.0f, fy = 0.0f;
         if constexpr (LEVEL >= 2) {
             M3_ACC(fx, fy, s_rd, +1)
-            if (on_walls) {
-                M3_ACC(fx, fy, s_dx1, -1) M3_ACC(fx, fy, s_dx2, -1)
-                M3_ACC(fx, fy, s_dy1, -1) M3_ACC(fx, fy, s_dy2, -1)
-            }
-            if (on_boxes) {
-                M3_ACC(fx, fy, s_bd1, +1) M3_ACC(fx, fy, s_bd2, +1)
-                M3_ACC(fx, fy, s_do1, -1) M3_ACC(fx, fy, s_do2, -1)
+            if constexpr (LEVEL >= 3) {
+                if (on_walls) {
+                    M3_ACC(fx, fy, s_dx1, -1) M3_ACC(fx, fy, s_dx2, -1)
+                    M3_ACC(fx, fy, s_dy1, -1) M3_ACC(fx, fy, s_dy2, -1)
+                }
+                if (on_boxes) {
+                    M3_ACC(fx, fy, s_bd1, +1) M3_ACC(fx, fy, s_bd2, +1)
+                    M3_ACC(fx, fy, s_do1, -1) M3_ACC(fx, fy, s_do2, -1)
+                }
             }
         }
         fx += fD.lx; fy += fD.ly;
@@ -652,18 +662,20 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
     for (int sub = 0; sub < sc.substeps; ++sub) {
         const bool form = need_dyn_force && sub == sc.substeps - 1;
         if constexpr (ALL_FORCES) {
-            point_substep<true, 2>(sc, w, ux, uy, form);   // step mode: one environment per lane, general path
+            point_substep<true, 3>(sc, w, ux, uy, form);   // step mode: one environment per lane, general path
         } else {
             const bool near_rb = near_centres(sc, w.B.x, w.B.y, w.rx, w.ry, sc.robot_r, sc.rad_b);
-            const bool near_other =
+            const bool near_robot_other =
                 near_centres(sc, w.D.x, w.D.y, w.rx, w.ry, sc.robot_r, sc.rad_d) ||
                 near_centres(sc, sc.obs_x, sc.obs_y, w.rx, w.ry, sc.robot_r, sc.rad_o) ||
-                near_walls_disc(sc, w.rx, w.ry) || near_walls_box(sc, w.B, sc.rad_b) ||
-                near_walls_box(sc, w.D, sc.rad_d) ||
+                near_walls_disc(sc, w.rx, w.ry);
+            const bool near_box_other =
+                near_walls_box(sc, w.B, sc.rad_b) || near_walls_box(sc, w.D, sc.rad_d) ||
                 near_centres(sc, w.B.x, w.B.y, w.D.x, w.D.y, sc.rad_b, sc.rad_d) ||
                 near_centres(sc, w.B.x, w.B.y, sc.obs_x, sc.obs_y, sc.rad_b, sc.rad_o) ||
                 near_centres(sc, w.D.x, w.D.y, sc.obs_x, sc.obs_y, sc.rad_d, sc.rad_o);
-            if (__builtin_amdgcn_ballot_w64(near_other) != 0ull) point_substep<false, 2>(sc, w, ux, uy, form);
+            if (__builtin_amdgcn_ballot_w64(near_box_other) != 0ull) point_substep<false, 3>(sc, w, ux, uy, form);
+            else if (__builtin_amdgcn_ballot_w64(near_robot_other) != 0ull) point_substep<false, 2>(sc, w, ux, uy, form);
             else if (__builtin_amdgcn_ballot_w64(near_rb) != 0ull) point_substep<false, 1>(sc, w, ux, uy, form);
             else point_substep<false, 0>(sc, w, ux, uy, form);
         }
