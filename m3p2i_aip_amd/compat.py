@@ -203,7 +203,8 @@ def install(force_standins: bool = False):
                             Objective=cost_functions.Objective)
     tp = mod("m3p2i_aip.planners.task_planner")
     tp.task_planner = mod("m3p2i_aip.planners.task_planner.task_planner", set_task_planner=set_task_planner,
-                          PLANNER_SIMPLE=PLANNER_SIMPLE, PLANNER_AIF_PANDA=PLANNER_AIF_PANDA)
+                          PLANNER_SIMPLE=PLANNER_SIMPLE, PLANNER_AIF_PANDA=PLANNER_AIF_PANDA,
+                          PLANNER_PATROLLING=task_planner.PLANNER_PATROLLING)
     tp.ai_agent = mod("m3p2i_aip.planners.task_planner.ai_agent", AiAgent=task_planner.AiAgent)
     tp.adaptive_action_selection = mod("m3p2i_aip.planners.task_planner.adaptive_action_selection",
                                        adapt_act_sel=task_planner.adapt_act_sel)

@@ -380,6 +380,30 @@ class PLANNER_AIF_PANDA(PLANNER_SIMPLE):
         return bool(self.task == "place" and dist_cost < 0.04)
 
 
+class PLANNER_PATROLLING(PLANNER_SIMPLE):
+    """task_planner.py:109-124 (not used by reactive_tamp.py).  Kept as the reference has it,
+    including that update_plan() advances `goal_id` without moving `curr_goal` to the new goal."""
+
+    def __init__(self, goals, device=None) -> None:
+        import torch
+        self.task = "navigation"
+        self.goals = torch.tensor(goals, device=device if device is not None else
+                                  ("cuda:0" if torch.cuda.is_available() else "cpu"))
+        self.goal_id = 0
+        self.curr_goal = self.goals[self.goal_id]
+
+    def reset_plan(self):
+        self.goal_id = 0
+        self.curr_goal = self.goals[self.goal_id]
+
+    def update_plan(self, robot_pos, stay_still=False):
+        import torch
+        if torch.norm(robot_pos - self.curr_goal) < 0.1:
+            self.goal_id += 1
+            if self.goal_id >= self.goals.size(0):
+                self.goal_id = 0
+
+
 def set_task_planner(cfg):
     """task_planner.py:7-11."""
     return PLANNER_SIMPLE(cfg) if cfg.env_type == "point_env" else PLANNER_AIF_PANDA(cfg)

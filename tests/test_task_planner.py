@@ -126,3 +126,17 @@ def test_planner_simple_success_thresholds():
     assert bool(pl.check_task_success(sim))
     sim.get_actor_position_by_name = lambda n: torch.tensor([[-1.0, -0.85, 0.0]])
     assert not bool(pl.check_task_success(sim))
+
+
+def test_planner_patrolling_matches_reference_behaviour():
+    torch = pytest.importorskip("torch")
+    pl = tp.PLANNER_PATROLLING([[1.0, 1.0], [2.0, 2.0]], device="cpu")
+    assert pl.task == "navigation" and pl.goal_id == 0
+    pl.update_plan(torch.tensor([0.0, 0.0]), False)
+    assert pl.goal_id == 0
+    pl.update_plan(torch.tensor([1.0, 0.95]), False)
+    assert pl.goal_id == 1 and torch.equal(pl.curr_goal, torch.tensor([1.0, 1.0]))   # as in the reference
+    pl.update_plan(torch.tensor([1.0, 1.0]), False)
+    assert pl.goal_id == 0                                                              # wraps around
+    pl.reset_plan()
+    assert pl.goal_id == 0 and torch.equal(pl.curr_goal, torch.tensor([1.0, 1.0]))
