@@ -40,6 +40,7 @@ __device__ __forceinline__ void panda_world_from_sim(const float* dof, const flo
     panda_world_from_raw(raw, w);
 }
 
+template <bool FORCES>
 __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a, const PandaArgs pa,
                                                       const PandaScene sc) {
     const int i = blockIdx.x * 64 + threadIdx.x;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a, const
             e[j] = uj / a.u_scale;                                                     // :421
         }
         PandaObs obs;
-        panda_step(sc, w, u, obs, /*need_forces=*/pa.cp.task == 5);
+        panda_step<FORCES>(sc, w, u, obs);
         const float c = panda_cost(pa.cp, w, obs, k);
         *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
             make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a, const
 }
 
 void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
-    hipLaunchKernelGGL(k_rollout_panda, dim3((a.Kl + 63) / 64), dim3(64), 0, s, a, pa, sc);
+    if (pa.cp.task == 5) hipLaunchKernelGGL(k_rollout_panda<true>, dim3((a.Kl + 63) / 64), dim3(64), 0, s, a, pa, sc);
+    else hipLaunchKernelGGL(k_rollout_panda<false>, dim3((a.Kl + 63) / 64), dim3(64), 0, s, a, pa, sc);
 }
 
 // ======================= step mode ======================================================
