@@ -483,21 +483,44 @@ __device__ __forceinline__ bool near_walls_box(const PointScene& sc, const Box& 
 }
 
 // One substep: forces, detect, solve, integrate.
-// LEVEL selects which contact slots EXIST in the generated code: 3 = all 19, 2 = the robot's five
-// (box, dyn-obs, obstacle, walls), 1 = robot-box only, 0 = none.  The full version keeps 19 slots x 11 values live across the solver loop: 344 VGPRs
-// (arch + acc, i.e. AGPR spill moves), 67 spilled SGPRs and 5.5 k instructions, and the common
-// case -- nothing but (at most) the robot-box pair in range -- paid for carrying them: compiled
-// WITHOUT the other slots the same substep needs 104 VGPRs and ran 1.75x faster.  point_step
-// therefore tests, per substep and per WAVE, whether any lane has a pair inside its broad-phase
-// range and runs the leanest instance that covers the wave; results are identical because a pair
-// outside its broad-phase range cannot produce a contact.  (Measured on C2: 47 of a wave's 60
-// substeps take level 0, 12 level 1, 1 level 2 on average -- but the worst wave takes level 2 about
-// ten times, and the kernel ends with it: 0.227 -> 0.213 ms.  Calling the level-2 instance out of line
-// (__noinline__, world through scratch) to shield the lean code's register allocation was slower,
-// 0.263 ms; so was a verdict-only narrow phase to decide on real contacts instead of ranges, 0.237.)
-template <bool ALL_FORCES, int LEVEL>
+// The mask M selects which pair groups' contact slots EXIST in the generated code.  The full
+// version keeps 19 slots x 11 values live across the solver loop: 344 VGPRs (arch + acc, i.e. AGPR
+// spill moves), 67 spilled SGPRs and 5.5 k instructions, and the common case -- nothing but (at
+// most) the robot-box pair in range -- paid for carrying them: compiled WITHOUT the other slots
+// the same substep needs 104 VGPRs and ran 1.75x faster.  point_step therefore forms, per substep
+// and per WAVE, the mask of pair groups with any lane inside its broad-phase range and runs the
+// leanest instance that covers it; results are identical because a pair outside its broad-phase
+// range cannot produce a contact.  Which instances exist was chosen from the mask histogram of the
+// bench workloads in steady state (tools/mask_count.py, -DM3_ABL_COUNT build; push / hybrid /
+// north-star): no pair 36-41 %, robot-box 36-43 %, + robot-dyn-obs 16-19 %, + box-dyn-obs 1-9 %,
+// everything else < 2 % together.  (History on C2: one general instance 0.227 ms; {none, robot-box,
+// all} 0.213; + the robot's five slots 0.208; the set below 0.189.  Calling a heavy instance out of
+// line (__noinline__, world through scratch) to shield the lean code's register allocation was
+// slower, 0.263 ms; so was a verdict-only narrow phase to decide on real contacts instead of ranges,
+// 0.237; keeping the 18 rare slots of the general instance in LDS instead of registers (164 VGPRs
+// for the whole kernel) changed nothing at K <= 32000 and cost a quarter of the saturated
+// throughput: 50 KB of LDS per wave allow three waves per CU instead of four.)
+// pair groups of the 19 static slots (bit mask M of point_substep)
+enum : unsigned {
+    G_RB = 1u,    // robot - box                       1 slot
+    G_RD = 2u,    // robot - dyn-obs                   1
+    G_RO = 4u,    // robot - obstacle                  1
+    G_RW = 8u,    // robot - walls                     2
+    G_BW = 16u,   // box - walls                       4
+    G_DW = 32u,   // dyn-obs - walls                   4
+    G_BD = 64u,   // box - dyn-obs                     2
+    G_BO = 128u,  // box - obstacle                    2
+    G_DO = 256u,  // dyn-obs - obstacle                2
+    G_ALL = 511u,
+    G_NO_BOX_STATICS = G_RB | G_RD | G_RO | G_RW | G_BD  // everything but box/dyn-obs vs walls and obstacle
+};
+
+template <bool ALL_FORCES, unsigned M>
 __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& w, float ux, float uy,
                                               bool form_dyn_force) {
+    constexpr bool RB = M & G_RB, RD = M & G_RD, RO = M & G_RO, RW = M & G_RW, BW = M & G_BW,
+                   DW = M & G_DW, BD = M & G_BD, BO = M & G_BO, DO = M & G_DO;
+    constexpr bool ANY_RARE = (M & ~G_RB) != 0u, ANY_WALLS = RW || BW || DW, ANY_BOXES = BD || BO || DO;
     const float h = sc.h;
     // 1. external forces
     w.rvx = w.rvx + (h * w.fRx) * sc.invm_r;
@@ -505,7 +528,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     w.B.vx = w.B.vx + (h * w.fBx) * sc.invm_b;
     w.B.vy = w.B.vy + (h * w.fBy) * sc.invm_b;
 
-    // 2. contacts (static slots)
+    // 2. contacts (static slots; a group that is not in M stays `on = false` and compiles away)
     Slot s_rb, s_rd, s_ro, s_rwx, s_rwy;
     Slot s_bx1, s_bx2, s_by1, s_by2, s_dx1, s_dx2, s_dy1, s_dy2;
     Slot s_bd1, s_bd2, s_bo1, s_bo2, s_do1, s_do2;
@@ -513,40 +536,37 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     s_rd.on = s_ro.on = s_rwx.on = s_rwy.on = false;
     s_bx1.on = s_bx2.on = s_by1.on = s_by2.on = s_dx1.on = s_dx2.on = s_dy1.on = s_dy2.on = false;
     s_bd1.on = s_bd2.on = s_bo1.on = s_bo2.on = s_do1.on = s_do2.on = false;
-    if constexpr (LEVEL >= 1)
+    if constexpr (RB)
         detect_disc_box<BOXB>(sc, s_rb, w.rx, w.ry, w.B.x, w.B.y, w.B.c, w.B.s, sc.box_hx,
                               sc.box_hy, sc.rad_b);
-    if constexpr (LEVEL >= 2) {
+    if constexpr (RD)
         detect_disc_box<BOXD>(sc, s_rd, w.rx, w.ry, w.D.x, w.D.y, w.D.c, w.D.s, sc.dyn_hx,
                               sc.dyn_hy, sc.rad_d);
+    if constexpr (RO)
         detect_disc_box<STATIC>(sc, s_ro, w.rx, w.ry, sc.obs_x, sc.obs_y, 1.0f, 0.0f, sc.obs_hx,
                                 sc.obs_hy, sc.rad_o);
-        detect_disc_walls(sc, s_rwx, s_rwy, w.rx, w.ry);
-    }
-    if constexpr (LEVEL >= 3) {
+    if constexpr (RW) detect_disc_walls(sc, s_rwx, s_rwy, w.rx, w.ry);
+    if constexpr (BW)
         detect_box_walls<BOXB>(sc, s_bx1, s_bx2, s_by1, s_by2, w.B, sc.box_hx, sc.box_hy, sc.rad_b);
+    if constexpr (DW)
         detect_box_walls<BOXD>(sc, s_dx1, s_dx2, s_dy1, s_dy2, w.D, sc.dyn_hx, sc.dyn_hy, sc.rad_d);
+    if constexpr (BD)
         detect_box_box<BOXB, BOXD>(sc, s_bd1, s_bd2, w.B.x, w.B.y, w.B.c, w.B.s, sc.box_hx,
                                    sc.box_hy, sc.rad_b, w.D.x, w.D.y, w.D.c, w.D.s, sc.dyn_hx,
                                    sc.dyn_hy, sc.rad_d);
+    if constexpr (BO)
         detect_box_box<BOXB, STATIC>(sc, s_bo1, s_bo2, w.B.x, w.B.y, w.B.c, w.B.s, sc.box_hx,
                                      sc.box_hy, sc.rad_b, sc.obs_x, sc.obs_y, 1.0f, 0.0f,
                                      sc.obs_hx, sc.obs_hy, sc.rad_o);
+    if constexpr (DO)
         detect_box_box<BOXD, STATIC>(sc, s_do1, s_do2, w.D.x, w.D.y, w.D.c, w.D.s, sc.dyn_hx,
                                      sc.dyn_hy, sc.rad_d, sc.obs_x, sc.obs_y, 1.0f, 0.0f,
                                      sc.obs_hx, sc.obs_hy, sc.rad_o);
-    }
-    bool on_walls = false, on_boxes = false, rare = false;
-    if constexpr (LEVEL == 2) {
-        on_walls = s_rwx.on | s_rwy.on;
-        rare = s_rd.on | s_ro.on | on_walls;
-    }
-    if constexpr (LEVEL >= 3) {
-        on_walls = s_rwx.on | s_rwy.on | s_bx1.on | s_bx2.on | s_by1.on | s_by2.on |
-                   s_dx1.on | s_dx2.on | s_dy1.on | s_dy2.on;
-        on_boxes = s_bd1.on | s_bd2.on | s_bo1.on | s_bo2.on | s_do1.on | s_do2.on;
-        rare = s_rd.on | s_ro.on | on_walls | on_boxes;
-    }
+    // (flags of absent groups are compile-time false)
+    const bool on_walls = s_rwx.on | s_rwy.on | s_bx1.on | s_bx2.on | s_by1.on | s_by2.on |
+                          s_dx1.on | s_dx2.on | s_dy1.on | s_dy2.on;
+    const bool on_boxes = s_bd1.on | s_bd2.on | s_bo1.on | s_bo2.on | s_do1.on | s_do2.on;
+    const bool rare = s_rd.on | s_ro.on | on_walls | on_boxes;
 
     // 3. velocity solve
     Vel v = {w.rvx, w.rvy, w.B.vx, w.B.vy, w.B.w, w.D.vx, w.D.vy, w.D.w};
@@ -569,39 +589,49 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
         // spec order: friction(dyn-obs) then robot-box.  The two rows share no body, so they
         // commute exactly; solving robot-box first lets the dyn-obs row (usually at rest) join
         // the rarely-taken group below: one skipped branch per pass instead of two.
-        if constexpr (LEVEL >= 1) {
+        if constexpr (RB) {
             if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
         }
         const bool d_moving = ((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u;
         if (d_moving | rare) {
             solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
-            if constexpr (LEVEL >= 2) {
+            if constexpr (ANY_RARE) {
                 // one outer flag + two group flags: a pass in which no lane has any of these pays
                 // one skipped exec-mask branch (same solve order as the spec)
                 if (rare) {
-                    if (s_rd.on) solve<ROBOT, BOXD>(sc, v, s_rd, sc.mu_rd);
-                    if (s_ro.on) solve<ROBOT, STATIC>(sc, v, s_ro, sc.mu_ro);
-                    if (on_walls) {
-                        if (s_rwx.on) solve<ROBOT, STATIC>(sc, v, s_rwx, sc.mu_rw);
-                        if (s_rwy.on) solve<ROBOT, STATIC>(sc, v, s_rwy, sc.mu_rw);
-                        if constexpr (LEVEL >= 3) {
+                    if constexpr (RD) if (s_rd.on) solve<ROBOT, BOXD>(sc, v, s_rd, sc.mu_rd);
+                    if constexpr (RO) if (s_ro.on) solve<ROBOT, STATIC>(sc, v, s_ro, sc.mu_ro);
+                    if constexpr (ANY_WALLS) if (on_walls) {
+                        if constexpr (RW) {
+                            if (s_rwx.on) solve<ROBOT, STATIC>(sc, v, s_rwx, sc.mu_rw);
+                            if (s_rwy.on) solve<ROBOT, STATIC>(sc, v, s_rwy, sc.mu_rw);
+                        }
+                        if constexpr (BW) {
                             if (s_bx1.on) solve<BOXB, STATIC>(sc, v, s_bx1, sc.mu_bw);
                             if (s_bx2.on) solve<BOXB, STATIC>(sc, v, s_bx2, sc.mu_bw);
                             if (s_by1.on) solve<BOXB, STATIC>(sc, v, s_by1, sc.mu_bw);
                             if (s_by2.on) solve<BOXB, STATIC>(sc, v, s_by2, sc.mu_bw);
+                        }
+                        if constexpr (DW) {
                             if (s_dx1.on) solve<BOXD, STATIC>(sc, v, s_dx1, sc.mu_dw);
                             if (s_dx2.on) solve<BOXD, STATIC>(sc, v, s_dx2, sc.mu_dw);
                             if (s_dy1.on) solve<BOXD, STATIC>(sc, v, s_dy1, sc.mu_dw);
                             if (s_dy2.on) solve<BOXD, STATIC>(sc, v, s_dy2, sc.mu_dw);
                         }
                     }
-                    if constexpr (LEVEL >= 3) if (on_boxes) {
-                        if (s_bd1.on) solve<BOXB, BOXD>(sc, v, s_bd1, sc.mu_bd);
-                        if (s_bd2.on) solve<BOXB, BOXD>(sc, v, s_bd2, sc.mu_bd);
-                        if (s_bo1.on) solve<BOXB, STATIC>(sc, v, s_bo1, sc.mu_bo);
-                        if (s_bo2.on) solve<BOXB, STATIC>(sc, v, s_bo2, sc.mu_bo);
-                        if (s_do1.on) solve<BOXD, STATIC>(sc, v, s_do1, sc.mu_do);
-                        if (s_do2.on) solve<BOXD, STATIC>(sc, v, s_do2, sc.mu_do);
+                    if constexpr (ANY_BOXES) if (on_boxes) {
+                        if constexpr (BD) {
+                            if (s_bd1.on) solve<BOXB, BOXD>(sc, v, s_bd1, sc.mu_bd);
+                            if (s_bd2.on) solve<BOXB, BOXD>(sc, v, s_bd2, sc.mu_bd);
+                        }
+                        if constexpr (BO) {
+                            if (s_bo1.on) solve<BOXB, STATIC>(sc, v, s_bo1, sc.mu_bo);
+                            if (s_bo2.on) solve<BOXB, STATIC>(sc, v, s_bo2, sc.mu_bo);
+                        }
+                        if constexpr (DO) {
+                            if (s_do1.on) solve<BOXD, STATIC>(sc, v, s_do1, sc.mu_do);
+                            if (s_do2.on) solve<BOXD, STATIC>(sc, v, s_do2, sc.mu_do);
+                        }
                     }
                 }
             }
@@ -617,18 +647,14 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     // exposes all bodies' forces and keeps the general path).
     if (ALL_FORCES || form_dyn_force) {
         float fx = 0.0f, fy = 0.0f;
-        if constexpr (LEVEL >= 2) {
-            M3_ACC(fx, fy, s_rd, +1)
-            if constexpr (LEVEL >= 3) {
-                if (on_walls) {
-                    M3_ACC(fx, fy, s_dx1, -1) M3_ACC(fx, fy, s_dx2, -1)
-                    M3_ACC(fx, fy, s_dy1, -1) M3_ACC(fx, fy, s_dy2, -1)
-                }
-                if (on_boxes) {
-                    M3_ACC(fx, fy, s_bd1, +1) M3_ACC(fx, fy, s_bd2, +1)
-                    M3_ACC(fx, fy, s_do1, -1) M3_ACC(fx, fy, s_do2, -1)
-                }
-            }
+        if constexpr (RD) { M3_ACC(fx, fy, s_rd, +1) }
+        if constexpr (DW) if (on_walls) {
+            M3_ACC(fx, fy, s_dx1, -1) M3_ACC(fx, fy, s_dx2, -1)
+            M3_ACC(fx, fy, s_dy1, -1) M3_ACC(fx, fy, s_dy2, -1)
+        }
+        if constexpr (BD || DO) if (on_boxes) {
+            M3_ACC(fx, fy, s_bd1, +1) M3_ACC(fx, fy, s_bd2, +1)
+            M3_ACC(fx, fy, s_do1, -1) M3_ACC(fx, fy, s_do2, -1)
         }
         fx += fD.lx; fy += fD.ly;
         w.fcDx = fx * sc.inv_h; w.fcDy = fy * sc.inv_h;
@@ -655,6 +681,9 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     integrate_box(w.D, h);
 }
 
+#ifdef M3_ABL_COUNT
+__device__ unsigned int g_lvl[512];
+#endif
 // one sim.step(): substeps x (forces, detect, solve, integrate)
 template <bool ALL_FORCES>
 __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, float ux, float uy,
@@ -662,22 +691,33 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
     for (int sub = 0; sub < sc.substeps; ++sub) {
         const bool form = need_dyn_force && sub == sc.substeps - 1;
         if constexpr (ALL_FORCES) {
-            point_substep<true, 3>(sc, w, ux, uy, form);   // step mode: one environment per lane, general path
+            point_substep<true, G_ALL>(sc, w, ux, uy, form);   // step mode: one environment per lane, general path
         } else {
-            const bool near_rb = near_centres(sc, w.B.x, w.B.y, w.rx, w.ry, sc.robot_r, sc.rad_b);
-            const bool near_robot_other =
-                near_centres(sc, w.D.x, w.D.y, w.rx, w.ry, sc.robot_r, sc.rad_d) ||
-                near_centres(sc, sc.obs_x, sc.obs_y, w.rx, w.ry, sc.robot_r, sc.rad_o) ||
-                near_walls_disc(sc, w.rx, w.ry);
-            const bool near_box_other =
-                near_walls_box(sc, w.B, sc.rad_b) || near_walls_box(sc, w.D, sc.rad_d) ||
-                near_centres(sc, w.B.x, w.B.y, w.D.x, w.D.y, sc.rad_b, sc.rad_d) ||
-                near_centres(sc, w.B.x, w.B.y, sc.obs_x, sc.obs_y, sc.rad_b, sc.rad_o) ||
-                near_centres(sc, w.D.x, w.D.y, sc.obs_x, sc.obs_y, sc.rad_d, sc.rad_o);
-            if (__builtin_amdgcn_ballot_w64(near_box_other) != 0ull) point_substep<false, 3>(sc, w, ux, uy, form);
-            else if (__builtin_amdgcn_ballot_w64(near_robot_other) != 0ull) point_substep<false, 2>(sc, w, ux, uy, form);
-            else if (__builtin_amdgcn_ballot_w64(near_rb) != 0ull) point_substep<false, 1>(sc, w, ux, uy, form);
-            else point_substep<false, 0>(sc, w, ux, uy, form);
+            // wave-uniform mask of the pair groups with any lane inside its broad-phase range
+            unsigned m = 0u;
+#define M3_NEAR(bit, expr) if (__builtin_amdgcn_ballot_w64(expr) != 0ull) m |= (bit);
+            M3_NEAR(G_RB, near_centres(sc, w.B.x, w.B.y, w.rx, w.ry, sc.robot_r, sc.rad_b))
+            M3_NEAR(G_RD, near_centres(sc, w.D.x, w.D.y, w.rx, w.ry, sc.robot_r, sc.rad_d))
+            M3_NEAR(G_RO, near_centres(sc, sc.obs_x, sc.obs_y, w.rx, w.ry, sc.robot_r, sc.rad_o))
+            M3_NEAR(G_RW, near_walls_disc(sc, w.rx, w.ry))
+            M3_NEAR(G_BW, near_walls_box(sc, w.B, sc.rad_b))
+            M3_NEAR(G_DW, near_walls_box(sc, w.D, sc.rad_d))
+            M3_NEAR(G_BD, near_centres(sc, w.B.x, w.B.y, w.D.x, w.D.y, sc.rad_b, sc.rad_d))
+            M3_NEAR(G_BO, near_centres(sc, w.B.x, w.B.y, sc.obs_x, sc.obs_y, sc.rad_b, sc.rad_o))
+            M3_NEAR(G_DO, near_centres(sc, w.D.x, w.D.y, sc.obs_x, sc.obs_y, sc.rad_d, sc.rad_o))
+#undef M3_NEAR
+#ifdef M3_ABL_COUNT
+            if ((threadIdx.x & 63) == 0) atomicAdd(&g_lvl[m], 1u);
+#endif
+            // the leanest instance that covers the mask
+#define M3_COVERS(set) ((m & ~(set)) == 0u)
+            if (m == 0u) point_substep<false, 0u>(sc, w, ux, uy, form);
+            else if (M3_COVERS(G_RB)) point_substep<false, G_RB>(sc, w, ux, uy, form);
+            else if (M3_COVERS(G_RB | G_RD)) point_substep<false, G_RB | G_RD>(sc, w, ux, uy, form);
+            else if (M3_COVERS(G_RB | G_RD | G_BD)) point_substep<false, G_RB | G_RD | G_BD>(sc, w, ux, uy, form);
+            else if (M3_COVERS(G_NO_BOX_STATICS)) point_substep<false, G_NO_BOX_STATICS>(sc, w, ux, uy, form);
+            else point_substep<false, G_ALL>(sc, w, ux, uy, form);
+#undef M3_COVERS
         }
     }
     w.fRx = 0.0f; w.fRy = 0.0f; w.fBx = 0.0f; w.fBy = 0.0f;

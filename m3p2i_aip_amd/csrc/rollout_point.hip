@@ -335,3 +335,10 @@ void launch_sim_forces(const SimViews& v, float* world, const float* f, int Kl, 
 }
 
 }  // namespace m3
+
+#ifdef M3_ABL_COUNT
+extern "C" void m3_dbg_levels(unsigned int* out, int reset) {
+    if (reset) { static unsigned int z[512]; (void)hipMemcpyToSymbol(HIP_SYMBOL(m3::g_lvl), z, sizeof(z)); }
+    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(m3::g_lvl), 512 * sizeof(unsigned int));
+}
+#endif

@@ -1,0 +1,28 @@
+"""GPU experiment (needs a -DM3_ABL_COUNT build loaded through M3P2I_HIP_LIB): histogram of the
+wave-uniform pair-group masks the substep dispatcher sees, over commands 5..60 of a bench config."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+NAMES = ["RB", "RD", "RO", "RW", "BW", "DW", "BD", "BO", "DO"]
+for name in sys.argv[1:] or ["push"]:
+    env, task, goal, mm, K, T = bench.CONFIGS[name]
+    pl, sim, obj = bench.build_tamp(env, task, goal, mm, K, 0, 1, T, "cuda:0")
+    state = sim._dof_state[0]
+    lib = ctypes.CDLL(os.environ["M3P2I_HIP_LIB"])
+    buf = (ctypes.c_uint * 512)()
+    for it in range(5):
+        pl.command(state)
+    torch.cuda.synchronize()
+    lib.m3_dbg_levels(buf, 1)
+    for it in range(200):
+        pl.command(state)
+    torch.cuda.synchronize()
+    lib.m3_dbg_levels(buf, 0)
+    a = np.frombuffer(buf, dtype=np.uint32).astype(np.float64)
+    a /= a.sum()
+    print(name)
+    for m in np.argsort(-a)[:16]:
+        if a[m] > 0:
+            print("  %5.1f %%  %s" % (100 * a[m], "|".join(n for i, n in enumerate(NAMES) if m >> i & 1) or "-"))
