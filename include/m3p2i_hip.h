@@ -193,6 +193,11 @@ int m3_enable_timing(m3_handle* h, int on);
  * (DESIGN.md "Lanes per wavefront").  Results do not depend on it. */
 int m3_set_rollout_lanes(m3_handle* h, int lanes);
 
+/* assignment of samples to wavefronts in the point_env rollout: 1 (default) = sorted by the
+ * direction of each sample's noise path (computed on the device whenever the noise is set, so that
+ * a wavefront's samples meet the same obstacles), 0 = by index.  Results do not depend on it. */
+int m3_set_wave_order(m3_handle* h, int on);
+
 /* delta: [K_local][T][nu] row-major (the reference's layout, rows of THIS shard).
  * on_device: 0 host pointer, 1 device pointer. */
 int m3_set_noise(m3_handle* h, const float* delta, int on_device);

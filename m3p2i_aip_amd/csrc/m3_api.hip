@@ -225,6 +225,8 @@ extern "C" void m3_destroy(m3_handle* h) {
     if (h->sim_world) (void)hipFree(h->sim_world);
     if (h->sim_u) (void)hipFree(h->sim_u);
     if (h->noise_stage) (void)hipFree(h->noise_stage);
+    if (h->order) (void)hipFree(h->order);
+    if (h->order_scratch) (void)hipFree(h->order_scratch);
     for (auto& ev : h->ev)
         if (ev) (void)hipEventDestroy(ev);
     delete h;
@@ -252,6 +254,45 @@ extern "C" int m3_enable_timing(m3_handle* h, int on) {
     return M3_OK;
 }
 
+// (re)computes the wavefront order of the samples (sampler.hip) from the noise buffer and the
+// current world; stream-ordered, no sync.  Called by m3_rollout when the noise changed and every
+// ORDER_REFRESH commands (the objects move).
+constexpr unsigned ORDER_REFRESH = 256;
+static int refresh_wave_order(m3_handle* h) {
+    const m3_config& c = h->cfg;
+    h->order_valid = false;
+    h->order_dirty = false;
+    if (!h->wave_order || c.env_type != M3_ENV_POINT || c.nu != 2 || c.K_local < 128 || c.sampling_random ||
+        c.mode_simple || !h->have_noise)
+        return M3_OK;
+    if (!h->order) {
+        h->order_temp_bytes = wave_order_temp_bytes(c.K_local);
+        HIPCHK(h, hipMalloc((void**)&h->order, sizeof(int) * (size_t)c.K_local));
+        HIPCHK(h, hipMalloc(&h->order_scratch, 3 * sizeof(float) * (size_t)c.K_local + h->order_temp_bytes));
+    }
+    long long half_local = (long long)(c.K_global / 2) - c.k_offset;
+    if (!c.multi_modal || half_local > c.K_local) half_local = c.K_local;
+    if (half_local < 0) half_local = 0;
+    OrderScene os;
+    std::memset(&os, 0, sizeof(os));
+    if (h->bind_dof) { os.sim_root = h->bind_root; os.sim_box = h->bind_box; os.sim_dyn = h->bind_dyn; }
+    os.bx = h->world0[4]; os.by = h->world0[5]; os.dx = h->world0[11]; os.dy = h->world0[12];
+    os.ox = h->scene.obs_x; os.oy = h->scene.obs_y;
+    hipError_t e = launch_wave_order((const float*)h->buf[M3_BUF_NOISE], c.K_local, c.T, c.nu,
+                                     std::sqrt(c.noise_sigma_diag[0]), std::sqrt(c.noise_sigma_diag[1]),
+                                     (int)half_local, os, h->order_scratch, h->order_temp_bytes, h->order, h->stream);
+    if (e != hipSuccess) { h->err = std::string("wave order: ") + hipGetErrorString(e); return M3_ERR_HIP; }
+    h->order_valid = true;
+    return M3_OK;
+}
+
+extern "C" int m3_set_wave_order(m3_handle* h, int on) {
+    if (!h) return M3_ERR_BAD_ARG;
+    h->wave_order = on != 0;
+    h->order_dirty = true;
+    return M3_OK;
+}
+
 extern "C" int m3_set_noise(m3_handle* h, const float* delta, int on_device) {
     if (!h || !delta) return fail(h, M3_ERR_BAD_ARG, "m3_set_noise: null argument");
     const m3_config& c = h->cfg;
@@ -266,6 +307,7 @@ extern "C" int m3_set_noise(m3_handle* h, const float* delta, int on_device) {
     HIPCHK(h, hipGetLastError());
     if (!on_device) HIPCHK(h, hipStreamSynchronize(h->stream));  // host buffer may be released
     h->have_noise = true;
+    h->order_dirty = true;
     return M3_OK;
 }
 
@@ -295,6 +337,7 @@ extern "C" int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots,
     }
     if (e != hipSuccess) { h->err = std::string("k_spline_noise: ") + hipGetErrorString(e); return M3_ERR_HIP; }
     h->have_noise = true;
+    h->order_dirty = true;
     return M3_OK;
 }
 
@@ -456,6 +499,11 @@ extern "C" int m3_rollout(m3_handle* h) {
     }
     a.lanes = h->lanes_override > 0 ? h->lanes_override : rollout_lanes_for(c.K_local);
     a.delta = (const float*)h->buf[M3_BUF_NOISE];
+    if (h->order_dirty || (h->wave_order && h->calls % ORDER_REFRESH == 0)) {
+        const int rc = refresh_wave_order(h);
+        if (rc != M3_OK) return rc;
+    }
+    a.order = h->order_valid ? h->order : nullptr;
     a.mean = (const float*)h->buf[M3_BUF_MEAN];
     a.mean1 = (const float*)h->buf[M3_BUF_MEAN_1];
     a.mean2 = (const float*)h->buf[M3_BUF_MEAN_2];

@@ -29,6 +29,7 @@ struct RolloutArgs {
     const float* sim_root;
     int sim_box, sim_dyn;
     const float* delta;       // [T][Kl][nu]
+    const int* order;         // [Kl] lane -> local sample (null = identity)
     const float* mean;        // [T][nu] (U in simple mode)
     const float* mean1;
     const float* mean2;
@@ -112,6 +113,15 @@ void launch_transpose_noise(const float* src_ktn, float* dst_tkn, int K, int T, 
                             hipStream_t s);
 void launch_spline_noise(const float* knots, float* noise, int Kl, int nu, int n_knots, int T, int degree,
                          double smoothing, hipStream_t s);
+struct OrderScene {   // where the scene's objects are when the wavefront order is computed
+    const float* sim_root;  // != null: box / dyn-obs positions are read from the bound root_state tensor
+    int sim_box, sim_dyn;
+    float bx, by, dx, dy;   // otherwise these (host world)
+    float ox, oy;           // obstacle
+};
+size_t wave_order_temp_bytes(int Kl);
+hipError_t launch_wave_order(const float* noise, int Kl, int T, int nu, float s0, float s1, int half_local,
+                             const OrderScene& os, void* scratch, size_t temp_bytes, int* order, hipStream_t s);
 void launch_weights(const UpdateArgs& a, hipStream_t s);
 void launch_wsum(const UpdateArgs& a, hipStream_t s);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);
@@ -166,6 +176,12 @@ void launch_psim_cost(const PandaScene& sc, const PandaCostParams& cp, const flo
 
 struct m3_handle {
     m3_config cfg;
+    int* order = nullptr;          // [Kl] lane slot -> local sample (null: identity), sampler.hip
+    void* order_scratch = nullptr;
+    size_t order_temp_bytes = 0;
+    bool wave_order = true;        // m3_set_wave_order
+    bool order_valid = false;
+    bool order_dirty = true;       // recomputed by the next m3_rollout (needs the world)
     m3::PointScene scene;
     m3::PandaScene pscene;
     float pworld0[31];

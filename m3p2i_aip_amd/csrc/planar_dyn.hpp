@@ -683,6 +683,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
 
 #ifdef M3_ABL_COUNT
 __device__ unsigned int g_lvl[512];
+__device__ unsigned int g_cyc[64 * 16];
 #endif
 // one sim.step(): substeps x (forces, detect, solve, integrate)
 template <bool ALL_FORCES>
@@ -708,6 +709,7 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
 #undef M3_NEAR
 #ifdef M3_ABL_COUNT
             if ((threadIdx.x & 63) == 0) atomicAdd(&g_lvl[m], 1u);
+            const unsigned long long t0_ = wall_clock64();
 #endif
             // the leanest instance that covers the mask
 #define M3_COVERS(set) ((m & ~(set)) == 0u)
@@ -717,6 +719,16 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
             else if (M3_COVERS(G_RB | G_RD | G_BD)) point_substep<false, G_RB | G_RD | G_BD>(sc, w, ux, uy, form);
             else if (M3_COVERS(G_NO_BOX_STATICS)) point_substep<false, G_NO_BOX_STATICS>(sc, w, ux, uy, form);
             else point_substep<false, G_ALL>(sc, w, ux, uy, form);
+#ifdef M3_ABL_COUNT
+            {
+                const unsigned long long dt_ = wall_clock64() - t0_;
+                const int cls_ = m == 0u ? 0 : M3_COVERS(G_RB) ? 1 : M3_COVERS(G_RB | G_RD) ? 2 : M3_COVERS(G_RB | G_RD | G_BD) ? 3 : M3_COVERS(G_NO_BOX_STATICS) ? 4 : 5;
+                if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) {
+                    atomicAdd(&g_cyc[blockIdx.x * 16 + cls_], (unsigned int)dt_);
+                    atomicAdd(&g_cyc[blockIdx.x * 16 + 8 + cls_], 1u);
+                }
+            }
+#endif
 #undef M3_COVERS
         }
     }

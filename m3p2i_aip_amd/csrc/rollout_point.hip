@@ -75,8 +75,9 @@ __device__ __forceinline__ void load_world_from_sim(const float* dof, const floa
 // (default 64 = one lane per sample; lanes = 1 is the north_star's literal "one wavefront
 // per sample" and was measured 2-9x slower, see rollout_lanes_for below).
 __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const PointScene sc) {
-    const int i = blockIdx.x * a.lanes + threadIdx.x;
-    if ((int)threadIdx.x >= a.lanes || i >= a.Kl) return;
+    const int slot = blockIdx.x * a.lanes + threadIdx.x;
+    if ((int)threadIdx.x >= a.lanes || slot >= a.Kl) return;
+    const int i = a.order ? a.order[slot] : slot;
     const int Kl = a.Kl, T = a.T;
     const int k = a.k0 + i;  // global sample index
     PointWorld w;
@@ -340,5 +341,9 @@ void launch_sim_forces(const SimViews& v, float* world, const float* f, int Kl, 
 extern "C" void m3_dbg_levels(unsigned int* out, int reset) {
     if (reset) { static unsigned int z[512]; (void)hipMemcpyToSymbol(HIP_SYMBOL(m3::g_lvl), z, sizeof(z)); }
     else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(m3::g_lvl), 512 * sizeof(unsigned int));
+}
+extern "C" void m3_dbg_cycles(unsigned int* out, int reset) {
+    if (reset) { static unsigned int z[64 * 16]; (void)hipMemcpyToSymbol(HIP_SYMBOL(m3::g_cyc), z, sizeof(z)); }
+    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(m3::g_cyc), 64 * 16 * sizeof(unsigned int));
 }
 #endif

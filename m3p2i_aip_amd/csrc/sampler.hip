@@ -10,6 +10,8 @@
 #include "m3_internal.hpp"
 #include "spline_fit.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 namespace m3 {
 
 __global__ __launch_bounds__(64) void k_spline_noise(const float* __restrict__ knots /*[Kl][nu][n_knots]*/,
@@ -29,6 +31,69 @@ void launch_spline_noise(const float* knots, float* noise, int Kl, int nu, int n
     const int n = Kl * nu;
     hipLaunchKernelGGL(k_spline_noise, dim3((n + 63) / 64), dim3(64), 0, s, knots, noise, Kl, nu, n_knots, T,
                        degree, smoothing);
+}
+
+// ---- wavefront order of the samples (point_env rollout) ---------------------------------
+// The rollout kernel picks, per substep and per WAVE, the leanest dynamics instance that covers
+// every lane's nearby pairs (planar_dyn.hpp), so a wave costs the UNION of its 64 samples' contact
+// situations.  Consecutive Halton indices are spread over the whole action space by construction
+// -- every wave got a sample that meets the dyn-obs, one that meets the box, one at the obstacle.
+// The noise is fixed after init, so the samples are assigned to wavefronts by a sort instead:
+// key = position of the sample's path centroid relative to the mean path (sum_t cumsum_t(scale *
+// delta)) projected on the axis along which the scene's objects (box, dyn-obs, obstacle) are spread
+// (principal axis of their positions; in the reference's point_env they sit in one row).  Samples of a wave
+// then meet the same object, or none.  Lane placement cannot change a sample's numbers (all
+// arithmetic is lane-local; tests/test_full_size_properties.py).  Measured (bench.py, order off ->
+// on): push K=2000 0.191 -> 0.171 ms, hybrid K=4000 0.231 -> 0.210, north-star K=10000 0.208 -> 0.190,
+// although the rollout's loads and stores become scattered 8-16 B pieces instead of coalesced rows.
+// Keys tried and measured worse: direction (angle) of the centroid, of the mid-horizon and end
+// displacement, radius, Morton cells, sectors x radius (0 .. -5 %); the mid-horizon displacement
+// on the same axis is equivalent.
+__global__ void k_order_keys(const float* __restrict__ noise /*[T][Kl][nu]*/, int Kl, int T, int nu, float s0,
+                             float s1, int half_local, OrderScene os, float* __restrict__ keys,
+                             int* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Kl) return;
+    float bx = os.bx, by = os.by, dx = os.dx, dy = os.dy;
+    if (os.sim_root) {
+        bx = os.sim_root[(size_t)os.sim_box * 13 + 0]; by = os.sim_root[(size_t)os.sim_box * 13 + 1];
+        dx = os.sim_root[(size_t)os.sim_dyn * 13 + 0]; dy = os.sim_root[(size_t)os.sim_dyn * 13 + 1];
+    }
+    // principal axis of the three object positions
+    const float mx = (bx + dx + os.ox) * (1.0f / 3.0f), my = (by + dy + os.oy) * (1.0f / 3.0f);
+    const float cxx = (bx - mx) * (bx - mx) + (dx - mx) * (dx - mx) + (os.ox - mx) * (os.ox - mx);
+    const float cyy = (by - my) * (by - my) + (dy - my) * (dy - my) + (os.oy - my) * (os.oy - my);
+    const float cxy = (bx - mx) * (by - my) + (dx - mx) * (dy - my) + (os.ox - mx) * (os.oy - my);
+    const float th = 0.5f * atan2f(2.0f * cxy, cxx - cyy);
+    const float ex = cosf(th), ey = sinf(th);
+    float cx = 0.0f, cy = 0.0f, sx = 0.0f, sy = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        const float* d = noise + ((size_t)t * Kl + i) * nu;
+        cx += s0 * d[0]; cy += s1 * d[1];
+        sx += cx; sy += cy;
+    }
+    // the two modes of a multi-modal planner follow different means: keep them in separate waves
+    keys[i] = (sx * ex + sy * ey) + (i >= half_local ? 1e9f : 0.0f);
+    idx[i] = i;
+}
+
+size_t wave_order_temp_bytes(int Kl) {
+    size_t n = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, n, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
+                                             (int*)nullptr, Kl);
+    return n;
+}
+
+// scratch: keys_in [Kl] | keys_out [Kl] | idx_in [Kl] (floats / ints), then the radix sort's own storage
+hipError_t launch_wave_order(const float* noise, int Kl, int T, int nu, float s0, float s1, int half_local,
+                             const OrderScene& os, void* scratch, size_t temp_bytes, int* order, hipStream_t s) {
+    float* keys_in = (float*)scratch;
+    float* keys_out = keys_in + Kl;
+    int* idx_in = (int*)(keys_out + Kl);
+    void* temp = (void*)(idx_in + Kl);
+    hipLaunchKernelGGL(k_order_keys, dim3((Kl + 255) / 256), dim3(256), 0, s, noise, Kl, T, nu, s0, s1, half_local,
+                       os, keys_in, idx_in);
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, order, Kl, 0, 32, s);
 }
 
 }  // namespace m3

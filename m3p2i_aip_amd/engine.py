@@ -6,6 +6,8 @@ path happens inside the HIP kernels.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 
 import numpy as np
@@ -76,6 +78,8 @@ class HipEngine:
         self._views = {}
         self._action_out = None
         self.use_torch_stream()
+        if os.environ.get("M3P2I_WAVE_ORDER", "1") == "0":   # experiments (tools/): samples to wavefronts by index
+            self.set_wave_order(False)
 
     # ---- lifetime ----
     def close(self):
@@ -100,6 +104,10 @@ class HipEngine:
 
     def set_rollout_lanes(self, lanes=0):
         self._ck(self.lib.m3_set_rollout_lanes(self._h, int(lanes)))
+
+    def set_wave_order(self, on=True):
+        """Samples sorted into coherent wavefronts (default) or assigned by index; same results."""
+        self._ck(self.lib.m3_set_wave_order(self._h, int(bool(on))))
 
     def enable_timing(self, on=True):
         self._ck(self.lib.m3_enable_timing(self._h, int(on)))

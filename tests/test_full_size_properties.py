@@ -145,3 +145,24 @@ def test_rollout_is_deterministic_and_sample_local():
     assert torch.equal(small.states[:-1], a[1000:2999])
     big.close()
     small.close()
+
+
+@pytest.mark.parametrize("name", ["C2_push_K2000_T30", "C3_hybrid_K4000_T30"])
+def test_wave_order_does_not_change_results(name):
+    """m3_set_wave_order: the samples are sorted into spatially coherent wavefronts (default) or
+    assigned by index.  Lane placement must not change a single bit of any output."""
+    from m3p2i_aip_amd import _lib as L
+    c = CONFIGS[name]
+    outs = []
+    for on in (True, False):
+        eng = build(c, seed=11)
+        eng.set_wave_order(on)
+        for _ in range(3):
+            eng.command()
+        torch.cuda.synchronize()
+        outs.append([eng.buffer(b).clone() for b in (L.BUF_TRAJ_COST, L.BUF_STATES, L.BUF_ACTIONS, L.BUF_COST_HORIZON,
+                                                      L.BUF_WEIGHTS, L.BUF_MEAN, L.BUF_ACTION_OUT, L.BUF_TOP_IDX,
+                                                      L.BUF_TOP_TRAJS, L.BUF_PENDING_FORCE)])
+        eng.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -16,6 +16,8 @@ for name in sys.argv[1:] or ["push"]:
         pl.command(state)
     torch.cuda.synchronize()
     lib.m3_dbg_levels(buf, 1)
+    cyc = (ctypes.c_uint * 1024)()
+    lib.m3_dbg_cycles(cyc, 1)
     for it in range(200):
         pl.command(state)
     torch.cuda.synchronize()
@@ -26,3 +28,12 @@ for name in sys.argv[1:] or ["push"]:
     for m in np.argsort(-a)[:16]:
         if a[m] > 0:
             print("  %5.1f %%  %s" % (100 * a[m], "|".join(n for i, n in enumerate(NAMES) if m >> i & 1) or "-"))
+    lib.m3_dbg_cycles(cyc, 0)
+    c = np.frombuffer(cyc, dtype=np.uint32).astype(np.float64).reshape(64, 16) / 200.0
+    c = c[c[:, 8:].sum(1) > 0]
+    tot = c[:, :6].sum(1)
+    wv = int(np.argmax(tot))
+    print("  per command, instance classes [none, RB, RB|RD, +BD, no-box-statics, all]; 100 MHz ticks")
+    print("  mean wave : n", c[:, 8:14].mean(0).round(1), "us", (c[:, :6].mean(0) / 100).round(1), "sum %.1f us" % (tot.mean() / 100))
+    print("  worst wave: n", c[wv, 8:14].round(1), "us", (c[wv, :6] / 100).round(1), "sum %.1f us" % (tot[wv] / 100))
+    print("  us per substep (mean over waves):", (c[:, :6].sum(0) / np.maximum(c[:, 8:14].sum(0), 1e-9) / 100).round(2))
