@@ -227,6 +227,7 @@ extern "C" void m3_destroy(m3_handle* h) {
     if (h->noise_stage) (void)hipFree(h->noise_stage);
     if (h->order) (void)hipFree(h->order);
     if (h->order_scratch) (void)hipFree(h->order_scratch);
+    if (h->noise_sorted) (void)hipFree(h->noise_sorted);
     for (auto& ev : h->ev)
         if (ev) (void)hipEventDestroy(ev);
     delete h;
@@ -269,6 +270,7 @@ static int refresh_wave_order(m3_handle* h) {
         h->order_temp_bytes = wave_order_temp_bytes(c.K_local);
         HIPCHK(h, hipMalloc((void**)&h->order, sizeof(int) * (size_t)c.K_local));
         HIPCHK(h, hipMalloc(&h->order_scratch, 3 * sizeof(float) * (size_t)c.K_local + h->order_temp_bytes));
+        HIPCHK(h, hipMalloc((void**)&h->noise_sorted, sizeof(float) * (size_t)c.T * c.K_local * c.nu));
     }
     long long half_local = (long long)(c.K_global / 2) - c.k_offset;
     if (!c.multi_modal || half_local > c.K_local) half_local = c.K_local;
@@ -280,7 +282,8 @@ static int refresh_wave_order(m3_handle* h) {
     os.ox = h->scene.obs_x; os.oy = h->scene.obs_y;
     hipError_t e = launch_wave_order((const float*)h->buf[M3_BUF_NOISE], c.K_local, c.T, c.nu,
                                      std::sqrt(c.noise_sigma_diag[0]), std::sqrt(c.noise_sigma_diag[1]),
-                                     (int)half_local, os, h->order_scratch, h->order_temp_bytes, h->order, h->stream);
+                                     (int)half_local, os, h->order_scratch, h->order_temp_bytes, h->order, h->noise_sorted,
+                                     h->stream);
     if (e != hipSuccess) { h->err = std::string("wave order: ") + hipGetErrorString(e); return M3_ERR_HIP; }
     h->order_valid = true;
     return M3_OK;
@@ -504,6 +507,7 @@ extern "C" int m3_rollout(m3_handle* h) {
         if (rc != M3_OK) return rc;
     }
     a.order = h->order_valid ? h->order : nullptr;
+    if (a.order) a.delta = h->noise_sorted;
     a.mean = (const float*)h->buf[M3_BUF_MEAN];
     a.mean1 = (const float*)h->buf[M3_BUF_MEAN_1];
     a.mean2 = (const float*)h->buf[M3_BUF_MEAN_2];

@@ -28,7 +28,7 @@ struct RolloutArgs {
     const float* sim_dof;
     const float* sim_root;
     int sim_box, sim_dyn;
-    const float* delta;       // [T][Kl][nu]
+    const float* delta;       // [T][Kl][nu], rows in lane-slot order when `order` is set
     const int* order;         // [Kl] lane -> local sample (null = identity)
     const float* mean;        // [T][nu] (U in simple mode)
     const float* mean1;
@@ -121,7 +121,8 @@ struct OrderScene {   // where the scene's objects are when the wavefront order 
 };
 size_t wave_order_temp_bytes(int Kl);
 hipError_t launch_wave_order(const float* noise, int Kl, int T, int nu, float s0, float s1, int half_local,
-                             const OrderScene& os, void* scratch, size_t temp_bytes, int* order, hipStream_t s);
+                             const OrderScene& os, void* scratch, size_t temp_bytes, int* order, float* noise_sorted,
+                             hipStream_t s);
 void launch_weights(const UpdateArgs& a, hipStream_t s);
 void launch_wsum(const UpdateArgs& a, hipStream_t s);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);
@@ -178,6 +179,7 @@ struct m3_handle {
     m3_config cfg;
     int* order = nullptr;          // [Kl] lane slot -> local sample (null: identity), sampler.hip
     void* order_scratch = nullptr;
+    float* noise_sorted = nullptr; // [T][Kl][nu] noise rows in wavefront order
     size_t order_temp_bytes = 0;
     bool wave_order = true;        // m3_set_wave_order
     bool order_valid = false;

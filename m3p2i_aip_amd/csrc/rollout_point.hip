@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const
         StepIn in;
         in.d0 = in.d1 = in.b0 = in.b1 = 0.0f;
         if (!a.sampling_random) {
-            const float2 dd = *reinterpret_cast<const float2*>(a.delta + ((size_t)t * Kl + i) * 2);
+            const float2 dd = *reinterpret_cast<const float2*>(a.delta + ((size_t)t * Kl + slot) * 2);
             in.d0 = dd.x; in.d1 = dd.y;
         }
         // torch.roll(U, -1): mppi.py:221 / _shift_action: mppi.py:266-273

@@ -77,6 +77,20 @@ __global__ void k_order_keys(const float* __restrict__ noise /*[T][Kl][nu]*/, in
     idx[i] = i;
 }
 
+// noise rows gathered into wavefront order once, so that the rollout's noise loads stay coalesced
+// (its stores remain scattered: the outputs are indexed by sample for everything downstream)
+__global__ void k_gather_noise(const float* __restrict__ noise, const int* __restrict__ order,
+                               float* __restrict__ sorted, int Kl, int T, int nu) {
+    const size_t n = (size_t)T * Kl * nu;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(o % nu);
+        const size_t r = o / nu;
+        const int slot = (int)(r % Kl);
+        const int t = (int)(r / Kl);
+        sorted[o] = noise[((size_t)t * Kl + order[slot]) * nu + j];
+    }
+}
+
 size_t wave_order_temp_bytes(int Kl) {
     size_t n = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, n, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
@@ -86,14 +100,21 @@ size_t wave_order_temp_bytes(int Kl) {
 
 // scratch: keys_in [Kl] | keys_out [Kl] | idx_in [Kl] (floats / ints), then the radix sort's own storage
 hipError_t launch_wave_order(const float* noise, int Kl, int T, int nu, float s0, float s1, int half_local,
-                             const OrderScene& os, void* scratch, size_t temp_bytes, int* order, hipStream_t s) {
+                             const OrderScene& os, void* scratch, size_t temp_bytes, int* order, float* noise_sorted,
+                             hipStream_t s) {
     float* keys_in = (float*)scratch;
     float* keys_out = keys_in + Kl;
     int* idx_in = (int*)(keys_out + Kl);
     void* temp = (void*)(idx_in + Kl);
     hipLaunchKernelGGL(k_order_keys, dim3((Kl + 255) / 256), dim3(256), 0, s, noise, Kl, T, nu, s0, s1, half_local,
                        os, keys_in, idx_in);
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, order, Kl, 0, 32, s);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, order, Kl, 0, 32, s);
+    if (e != hipSuccess) return e;
+    const size_t n = (size_t)T * Kl * nu;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_gather_noise, dim3(blocks), dim3(256), 0, s, noise, order, noise_sorted, Kl, T, nu);
+    return hipGetLastError();
 }
 
 }  // namespace m3
