@@ -1,0 +1,45 @@
+"""Copies what tools/refresh_profiles.sh left in gpurun_out/ into profiles/<round>/ (tracked) and
+merges the PMC traffic fragments into profiles/traffic.json (read by bench.py's roofline.traffic).
+usage: python tools/collect_profiles.py [round_dir=profiles/r01]"""
+import json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "profiles/r01")
+os.makedirs(P, exist_ok=True)
+NAMES = {"push": "push_K2000_T30", "hybrid": "hybrid_K4000_T30", "panda": "panda_K4000_T20", "northstar": "northstar_K10000_T30"}
+
+
+def cp(src, dst):
+    s = os.path.join(G, src)
+    if os.path.exists(s):
+        shutil.copyfile(s, os.path.join(P, dst))
+        print("copied", dst)
+    else:
+        print("MISSING", src)
+
+
+for c, n in NAMES.items():
+    s = os.path.join(G, f"bench_{c}.json")
+    if os.path.exists(s):
+        line = open(s).read().strip().splitlines()[-1]
+        json.dump(json.loads(line), open(os.path.join(P, f"bench_{n}.json"), "w"), indent=1)
+        print("copied", f"bench_{n}.json")
+    cp(f"prof_{c}/trace/bench_kernel_stats.csv", f"bench_{n}_kernel_stats.csv")
+    cp(f"prof_{c}/summary.txt", f"bench_{n}_summary.txt")
+    cp(f"cl_{c}.json", f"closed_loop_{n}.json")
+cp("host_overhead.txt", "host_overhead.txt")
+cp("iters_sweep.txt", "iters_sweep_push_K2000.txt")
+cp("k_sweep.json", "k_sweep_push_T30.json")
+cp("lanes_sweep.json", "lanes_sweep_final.json")
+cp("pmc_final.txt", "pmc_rollout_push_K2000.txt")
+cp("pmc_panda.txt", "pmc_rollout_panda_K4000.txt")
+
+tf = os.path.join(ROOT, "profiles", "traffic.json")
+tj = json.load(open(tf)) if os.path.exists(tf) else {}
+for c in NAMES:
+    f = os.path.join(G, f"prof_{c}", "traffic_fragment.json")
+    if os.path.exists(f):
+        tj.update(json.load(open(f)))
+json.dump(tj, open(tf, "w"), indent=1)
+print("traffic keys", [k for k in tj if not k.startswith("_")])
