@@ -610,6 +610,12 @@ static int update_impl(m3_handle* h, bool fuse) {
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
         return M3_OK;
     }
+    if (update_single_applies(a)) {  // single-mode, K <= 4096: one launch (update.hip, k_update_single)
+        launch_update_single(a, h->stream);
+        HIPCHK(h, hipGetLastError());
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+        return M3_OK;
+    }
     // (minima + beta ladder for the multi-modal search) -> weights (+ top-k stage A as extra
     // workgroups) -> weighted sums (+ top-k stage B as an extra workgroup when K > 4096)
     if (c.multi_modal && !c.mode_simple) {

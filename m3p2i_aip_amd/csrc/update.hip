@@ -1138,6 +1138,162 @@ void launch_wsum(const UpdateArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Single-mode MPPI, unsharded, K <= 4096 (C2, C4): k_weights + k_wsum (+ finalize) in ONE launch.
+// The softmin over <= 4096 costs is a few microseconds of work for one workgroup but ~7 us as its
+// own launch (dispatch + first-load latency + its reductions, all exposed between the rollout and
+// the next command), so every one of the T column workgroups of the weighted sums recomputes it
+// instead: costs AND the workgroup's action rows are loaded together, min / sum-of-exps / argmax
+// through the same block reductions with the same element -> thread mapping as k_weights (identical
+// eta and weights), the sums accumulate in k_wsum's order (identical sums); workgroup 0 also stores
+// the weights and m3_info, workgroup T is the top-k stage, the last workgroup to finish does the
+// mean update / filter (same hand-off as in k_wsum) and writes the adapted beta -- after every
+// workgroup has read the old one.
+template <int NU>
+__global__ __launch_bounds__(256) void k_update_single(const UpdateArgs a) {
+    constexpr int JR = 16, WT = 256;
+    __shared__ float red[3 * 16];
+    __shared__ VI redvi[16];
+    __shared__ float sred[3 * 9 * (WT / 64)];
+    const int T = a.T, tid = threadIdx.x, Kg = a.Kg;
+    if ((int)blockIdx.x == T) {  // top-k (one stage at K <= 4096), concurrent with the column workgroups
+        topk_stage_a(a, 0);
+        return;
+    }
+    const int t = blockIdx.x;
+    const float INF = __builtin_inff();
+    const float* J = a.Jall;
+    const float* act = a.actions + (size_t)t * Kg * NU;
+    const float b = a.mode_simple ? a.lambda_ : a.info->beta;
+    float jr[JR], av[JR][NU];
+#pragma unroll
+    for (int e = 0; e < JR; ++e) {   // unconditional clamped loads: all in flight together
+        const int k = e * WT + tid;
+        const int kc = min(k, Kg - 1);
+        const float jv = J[kc];
+        jr[e] = (k < Kg) ? jv : INF;
+        if constexpr (NU == 2) {
+            const float2 v = reinterpret_cast<const float2*>(act)[kc];
+            av[e][0] = v.x; av[e][1] = v.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) av[e][j] = act[(size_t)kc * NU + j];
+        }
+    }
+    // ---- softmin (k_weights, single-softmin branch) ----
+    float mn[1] = {INF};
+#pragma unroll
+    for (int e = 0; e < JR; ++e) mn[0] = fminf(mn[0], jr[e]);
+    block_min<1>(mn, red);
+    const float nib = -1.0f / b;
+    float es[1] = {0.0f};
+#pragma unroll
+    for (int e = 0; e < JR; ++e) {
+        if (e * WT >= Kg) break;  // wave-uniform
+        if (e * WT + tid < Kg) es[0] += m3_exp(nib * (jr[e] - mn[0]));
+    }
+    __syncthreads();
+    block_sum<1>(es, red);
+    const float eta = es[0], i0 = 1.0f / eta;
+    // ---- weights, half sums, argmax, weighted sums of this workgroup's time step ----
+    const int half = a.half_g - a.kbase;
+    float hs[2] = {0.0f, 0.0f};
+    VI b0 = {INF, 0x7fffffff};
+    float acc[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < JR; ++e) {
+        if (e * WT >= Kg) break;
+        const int k = e * WT + tid;
+        if (k < Kg) {
+            const float wk = i0 * m3_exp(nib * (jr[e] - mn[0]));
+            if (t == 0) a.w[k] = wk;
+            if (k < half) hs[0] += wk; else hs[1] += wk;
+            if (vi_less(-wk, k, b0.v, b0.i)) { b0.v = -wk; b0.i = k; }
+#pragma unroll
+            for (int j = 0; j < NU; ++j) acc[j] += wk * av[e][j];
+        }
+    }
+    __syncthreads();
+    if (t == 0) block_sum<2>(hs, red);   // workgroup-uniform
+    b0 = block_argmin(b0, redvi);
+    float nb = b;
+    if (!a.mode_simple && a.env_type == M3_ENV_PANDA) {  // mppi.py:446-454
+        if (eta > 20.0f) nb = nb * 0.9f;
+        else if (eta < 10.0f) nb = nb * 1.2f;
+    }
+    if (t == 0 && tid == 0) {
+        m3_info* f = a.info;
+        f->eta = eta; f->eta_1 = 0.0f; f->eta_2 = 0.0f;
+        f->iters = 1; f->iters_1 = 1; f->iters_2 = 1;
+        f->best_idx = a.kbase + b0.i;
+        f->best_idx_1 = -1; f->best_idx_2 = -1;
+        f->wsum_push = hs[0]; f->wsum_pull = hs[1];
+        f->pull_preference = hs[1] > hs[0];
+        f->beta_1 = 1.0f; f->beta_2 = 1.0f;
+    }
+    // ---- column sums through one LDS exchange (k_wsum) ----
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const float ws = wave_sum(acc[j]);
+            if (lane == 0) sred[j * (WT / 64) + wv] = ws;
+        }
+        __syncthreads();
+        if (tid < 3 * NU) {
+            const int s3 = tid / NU, j = tid % NU;
+            float rv = 0.0f;
+            if (s3 == 0) {
+#pragma unroll
+                for (int w = 0; w < WT / 64; ++w) rv += sred[j * (WT / 64) + w];
+            }
+            __hip_atomic_store(&a.reduce[reduce_off_psum(s3, T, NU) + t * NU + j], rv, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (s3 > 0)  // no per-mode best rows in single mode
+                __hip_atomic_store(&a.reduce[reduce_off_best(s3, T, NU) + t * NU + j], 0.0f, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // best row: the thread that holds the best sample's action writes it
+#pragma unroll
+        for (int e = 0; e < JR; ++e)
+            if (e * WT + tid == b0.i) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j)
+                    __hip_atomic_store(&a.reduce[reduce_off_best(0, T, NU) + t * NU + j], av[e][j], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
+    // ---- last workgroup: mean update / filter, adapted beta ----
+    extern __shared__ float sm_fin[];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(&a.wcount[T], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int is_last = ticket == T - 1;
+        if (is_last) a.wcount[T] = 0;
+        red[46] = __int_as_float(is_last);
+    }
+    __syncthreads();
+    if (__float_as_int(red[46])) {
+        if (tid == 0 && !a.mode_simple) a.info->beta = nb;
+        finalize_body<true>(a, sm_fin);
+    }
+}
+void launch_update_single(const UpdateArgs& a, hipStream_t s) {
+    const dim3 grid(a.T + 1);
+    const size_t lds = (size_t)a.T * a.nu * sizeof(float);
+    if (a.nu == 2) hipLaunchKernelGGL(k_update_single<2>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_update_single<9>, grid, dim3(256), lds, s, a);
+}
+bool update_single_applies(const UpdateArgs& a) {
+    static const bool off = getenv("M3P2I_SPLIT_UPDATE") != nullptr;   // experiments: the two-launch path
+    if (off) return false;
+    return a.fuse_finalize && !a.multi_modal && !a.mode_simple && a.Kl == a.Kg && a.Kg <= 4096 && !a.record &&
+           topk_workgroups(a.Kg) == 1 && (a.nu == 2 || a.nu == 9);
+}
+
+// ---------------------------------------------------------------------------------------
 // k_mix (shard_mix): turns the ranks' records into the REDUCE buffer the all-reduce would have
 // produced, so that k_finalize runs unchanged.  With beta fixed during the command, the global
 // softmin is a mixture of the ranks' local softmins:
