@@ -610,8 +610,8 @@ static int update_impl(m3_handle* h, bool fuse) {
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
         return M3_OK;
     }
-    if (update_single_applies(a)) {  // single-mode, K <= 4096: one launch (update.hip, k_update_single)
-        launch_update_single(a, h->stream);
+    if (update_small_applies(a)) {  // K <= 4096: one launch (update.hip, k_update_small)
+        launch_update_small(a, h->stream);
         HIPCHK(h, hipGetLastError());
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
         return M3_OK;

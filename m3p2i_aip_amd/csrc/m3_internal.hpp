@@ -125,8 +125,8 @@ hipError_t launch_wave_order(const float* noise, int Kl, int T, int nu, float s0
                              hipStream_t s);
 void launch_weights(const UpdateArgs& a, hipStream_t s);
 void launch_wsum(const UpdateArgs& a, hipStream_t s);
-void launch_update_single(const UpdateArgs& a, hipStream_t s);
-bool update_single_applies(const UpdateArgs& a);
+void launch_update_small(const UpdateArgs& a, hipStream_t s);
+bool update_small_applies(const UpdateArgs& a);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);
 void launch_mix(const UpdateArgs& a, hipStream_t s);
 int rollout_lanes_for(int Kl);

@@ -1138,22 +1138,32 @@ void launch_wsum(const UpdateArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Single-mode MPPI, unsharded, K <= 4096 (C2, C4): k_weights + k_wsum (+ finalize) in ONE launch.
+// Unsharded command() with K <= 4096 (C2, C3, C4): the whole update in ONE launch.
 // The softmin over <= 4096 costs is a few microseconds of work for one workgroup but ~7 us as its
 // own launch (dispatch + first-load latency + its reductions, all exposed between the rollout and
-// the next command), so every one of the T column workgroups of the weighted sums recomputes it
-// instead: costs AND the workgroup's action rows are loaded together, min / sum-of-exps / argmax
-// through the same block reductions with the same element -> thread mapping as k_weights (identical
-// eta and weights), the sums accumulate in k_wsum's order (identical sums); workgroup 0 also stores
-// the weights and m3_info, workgroup T is the top-k stage, the last workgroup to finish does the
-// mean update / filter (same hand-off as in k_wsum) and writes the adapted beta -- after every
-// workgroup has read the old one.
-template <int NU>
-__global__ __launch_bounds__(256) void k_update_single(const UpdateArgs a) {
-    constexpr int JR = 16, WT = 256;
+// the next command) -- and the multi-modal search was three launches (k_mins, k_ladder, k_weights:
+// 29 us at K = 4000, most of it dispatch).  Here every one of the T column workgroups of the
+// weighted sums does the softmin itself: costs AND the workgroup's action rows are loaded together
+// into registers; min / sum-of-exps / argmax go through the same block reductions with the same
+// element -> thread mapping as k_weights (single mode: identical eta and weights); the multi-modal
+// beta searches run the reference's rule directly (m3p2i.py:24-64), all three side by side, one
+// register pass + one block reduction per iteration (~0.7 us; the ladder of k_ladder only pays
+// when the costs do not fit one workgroup's registers); the sums accumulate in k_wsum's order.
+// Workgroup 0 also stores the weights and m3_info, workgroup T is the top-k stage, the last
+// workgroup to finish does the mean update / filter (same hand-off as in k_wsum) and writes the
+// adapted beta -- after every workgroup has read the old one.
+// an optimisation barrier for a value: the compiler must take it as given
+__device__ __forceinline__ float uniform_f(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+template <int NU, bool MULTI, int JR>
+__global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
+    constexpr int WT = 256, NS = MULTI ? 3 : 1;   // JR rows of 256 costs per thread: K <= JR * 256
     __shared__ float red[3 * 16];
     __shared__ VI redvi[16];
     __shared__ float sred[3 * 9 * (WT / 64)];
+    __shared__ float s_part[2][3 * 4];
     const int T = a.T, tid = threadIdx.x, Kg = a.Kg;
     if ((int)blockIdx.x == T) {  // top-k (one stage at K <= 4096), concurrent with the column workgroups
         topk_stage_a(a, 0);
@@ -1163,14 +1173,21 @@ __global__ __launch_bounds__(256) void k_update_single(const UpdateArgs a) {
     const float INF = __builtin_inff();
     const float* J = a.Jall;
     const float* act = a.actions + (size_t)t * Kg * NU;
-    const float b = a.mode_simple ? a.lambda_ : a.info->beta;
+    const int half = a.half_g - a.kbase;
+    const float b_in = a.mode_simple ? a.lambda_ : a.info->beta;
+    // Every loop over the register rows below is fully unrolled and branch-free (invalid rows
+    // contribute through selects): one basic block, so the scheduler can overlap the rows' exp
+    // sequences -- with a wave-uniform early exit per row each row was its own block and its
+    // ~10-deep dependent chain ran alone at ~8 cycles per instruction (2.5 us per search pass).
     float jr[JR], av[JR][NU];
+    bool valid[JR];
 #pragma unroll
     for (int e = 0; e < JR; ++e) {   // unconditional clamped loads: all in flight together
         const int k = e * WT + tid;
         const int kc = min(k, Kg - 1);
         const float jv = J[kc];
-        jr[e] = (k < Kg) ? jv : INF;
+        valid[e] = k < Kg;
+        jr[e] = valid[e] ? jv : INF;
         if constexpr (NU == 2) {
             const float2 v = reinterpret_cast<const float2*>(act)[kc];
             av[e][0] = v.x; av[e][1] = v.y;
@@ -1179,90 +1196,193 @@ __global__ __launch_bounds__(256) void k_update_single(const UpdateArgs a) {
             for (int j = 0; j < NU; ++j) av[e][j] = act[(size_t)kc * NU + j];
         }
     }
-    // ---- softmin (k_weights, single-softmin branch) ----
-    float mn[1] = {INF};
-#pragma unroll
-    for (int e = 0; e < JR; ++e) mn[0] = fminf(mn[0], jr[e]);
-    block_min<1>(mn, red);
-    const float nib = -1.0f / b;
-    float es[1] = {0.0f};
+    // ---- minima ----
+    float mn[3] = {INF, INF, INF};
 #pragma unroll
     for (int e = 0; e < JR; ++e) {
-        if (e * WT >= Kg) break;  // wave-uniform
-        if (e * WT + tid < Kg) es[0] += m3_exp(nib * (jr[e] - mn[0]));
-    }
-    __syncthreads();
-    block_sum<1>(es, red);
-    const float eta = es[0], i0 = 1.0f / eta;
-    // ---- weights, half sums, argmax, weighted sums of this workgroup's time step ----
-    const int half = a.half_g - a.kbase;
-    float hs[2] = {0.0f, 0.0f};
-    VI b0 = {INF, 0x7fffffff};
-    float acc[NU];
-#pragma unroll
-    for (int j = 0; j < NU; ++j) acc[j] = 0.0f;
-#pragma unroll
-    for (int e = 0; e < JR; ++e) {
-        if (e * WT >= Kg) break;
-        const int k = e * WT + tid;
-        if (k < Kg) {
-            const float wk = i0 * m3_exp(nib * (jr[e] - mn[0]));
-            if (t == 0) a.w[k] = wk;
-            if (k < half) hs[0] += wk; else hs[1] += wk;
-            if (vi_less(-wk, k, b0.v, b0.i)) { b0.v = -wk; b0.i = k; }
-#pragma unroll
-            for (int j = 0; j < NU; ++j) acc[j] += wk * av[e][j];
+        const float v = jr[e];
+        mn[0] = fminf(mn[0], v);
+        if constexpr (MULTI) {
+            const bool first = e * WT + tid < half;
+            mn[1] = fminf(mn[1], first ? v : INF);
+            mn[2] = fminf(mn[2], first ? INF : v);
         }
     }
-    __syncthreads();
-    if (t == 0) block_sum<2>(hs, red);   // workgroup-uniform
-    b0 = block_argmin(b0, redvi);
-    float nb = b;
-    if (!a.mode_simple && a.env_type == M3_ENV_PANDA) {  // mppi.py:446-454
-        if (eta > 20.0f) nb = nb * 0.9f;
-        else if (eta < 10.0f) nb = nb * 1.2f;
+    block_min<3>(mn, red);
+    // ---- beta / eta ----
+    float beta[3] = {MULTI ? 1.0f : b_in, 1.0f, 1.0f}, eta[3] = {0.0f, 0.0f, 0.0f};
+    int iters[3] = {1, 1, 1};
+    if constexpr (!MULTI) {
+        float es[1] = {0.0f};
+        const float nib = -1.0f / b_in;
+#pragma unroll
+        for (int e = 0; e < JR; ++e) {
+            const float x = m3_exp(nib * (jr[e] - mn[0]));
+            es[0] += valid[e] ? x : 0.0f;
+        }
+        block_sum<1>(es, red);
+        eta[0] = es[0];
+    } else {
+        // every search starts at beta = 1 (beta / beta_1 / beta_2 are never written back: m3p2i.py:58-60).
+        // One pass = 2 exps per cost (the half's beta / minimum by select), three wave sums, ONE
+        // barrier (double-buffered partials); every thread then applies the rule to its own copy of
+        // (beta, eta, done) -- identical in all threads, so no second exchange.
+        int done[3] = {0, 0, 0};
+        iters[0] = iters[1] = iters[2] = 0;
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int pass = 0; pass < 1000; ++pass) {
+            if (done[0] && done[1] && done[2]) break;
+            // (quotients behind an optimisation barrier: otherwise the compiler rewrites the per-row
+            // select between two quotients as a division by a selected beta -- 16 IEEE divisions per pass)
+            const float n0 = uniform_f(-1.0f / beta[0]), n1 = uniform_f(-1.0f / beta[1]), n2 = uniform_f(-1.0f / beta[2]);
+            float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+            if (!done[0]) {   // (uniform) a finished search costs nothing more
+#pragma unroll
+                for (int e = 0; e < JR; ++e)   // rows past the end hold +inf: exp(-inf) = 0, no select needed
+                    e0 += m3_exp(n0 * (jr[e] - mn[0]));
+            }
+            if (!(done[1] && done[2])) {
+#pragma unroll
+                for (int e = 0; e < JR; ++e) {
+                    const bool first = e * WT + tid < half;
+                    const float xh = m3_exp((first ? n1 : n2) * (jr[e] - (first ? mn[1] : mn[2])));
+                    e1 += first ? xh : 0.0f;
+                    e2 += first ? 0.0f : xh;
+                }
+            }
+            e0 = wave_sum(e0); e1 = wave_sum(e1); e2 = wave_sum(e2);
+            float* buf = s_part[pass & 1];
+            if (lane == 0) { buf[0 * 4 + wv] = e0; buf[1 * 4 + wv] = e1; buf[2 * 4 + wv] = e2; }
+            __syncthreads();
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                float et = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WT / 64; ++w) et += buf[s3 * 4 + w];   // wave order, as block_sum
+                if (!done[s3]) {
+                    eta[s3] = et;
+                    iters[s3] += 1;
+                    if (et > 10.0f) beta[s3] = beta[s3] * 0.9f;
+                    else if (et < 3.0f) beta[s3] = beta[s3] * 1.2f;
+                    else done[s3] = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- weights, half sums, argmax, weighted sums of this workgroup's time step ----
+    const float i0 = uniform_f(1.0f / eta[0]), n0 = uniform_f(-1.0f / beta[0]);
+    const float i1 = uniform_f(1.0f / eta[1]), n1 = uniform_f(-1.0f / beta[1]);
+    const float i2 = uniform_f(1.0f / eta[2]), n2 = uniform_f(-1.0f / beta[2]);
+    float hs[2] = {0.0f, 0.0f};
+    VI bi[3] = {{INF, 0x7fffffff}, {INF, 0x7fffffff}, {INF, 0x7fffffff}};
+    float acc[NS][NU], wk[JR], wh[MULTI ? JR : 1];
+#pragma unroll
+    for (int s3 = 0; s3 < NS; ++s3)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) acc[s3][j] = 0.0f;
+#pragma unroll
+    for (int e = 0; e < JR; ++e) {
+        const int k = e * WT + tid;
+        const bool ok = valid[e], first = k < half;
+        const float v = jr[e];
+        const float x = i0 * m3_exp(n0 * (v - mn[0]));
+        wk[e] = ok ? x : 0.0f;
+        hs[0] += (ok && first) ? x : 0.0f;
+        hs[1] += (ok && !first) ? x : 0.0f;
+        {   // argmax of the weights, first index on ties: key = -w
+            const bool take = ok && vi_less(-x, k, bi[0].v, bi[0].i);
+            bi[0].v = take ? -x : bi[0].v; bi[0].i = take ? k : bi[0].i;
+        }
+        float wa = 0.0f, wb = 0.0f;
+        if constexpr (MULTI) {
+            const float xh = (first ? i1 : i2) * m3_exp((first ? n1 : n2) * (v - (first ? mn[1] : mn[2])));
+            wh[e] = xh;
+            wa = (ok && first) ? xh : 0.0f;
+            wb = (ok && !first) ? xh : 0.0f;
+            const bool t1 = ok && first && vi_less(-xh, k, bi[1].v, bi[1].i);
+            bi[1].v = t1 ? -xh : bi[1].v; bi[1].i = t1 ? k : bi[1].i;
+            const bool t2 = ok && !first && vi_less(-xh, k, bi[2].v, bi[2].i);
+            bi[2].v = t2 ? -xh : bi[2].v; bi[2].i = t2 ? k : bi[2].i;
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            acc[0][j] += wk[e] * av[e][j];
+            if constexpr (MULTI) { acc[1][j] += wa * av[e][j]; acc[2][j] += wb * av[e][j]; }
+        }
+    }
+    if (t == 0) {   // workgroup-uniform: this workgroup also stores the weights and the half sums
+#pragma unroll
+        for (int e = 0; e < JR; ++e) {
+            const int k = e * WT + tid;
+            if (valid[e]) {
+                a.w[k] = wk[e];
+                if constexpr (MULTI) {
+                    if (k < half) a.w1[k] = wh[e];
+                    else a.w2[k - half] = wh[e];
+                }
+            }
+        }
+        block_sum<2>(hs, red);
+    }
+    bi[0] = block_argmin(bi[0], redvi);
+    if constexpr (MULTI) {
+        bi[1] = block_argmin(bi[1], redvi);
+        bi[2] = block_argmin(bi[2], redvi);
+    }
+    float nb = beta[0];
+    if (!MULTI && !a.mode_simple && a.env_type == M3_ENV_PANDA) {  // mppi.py:446-454
+        if (eta[0] > 20.0f) nb = nb * 0.9f;
+        else if (eta[0] < 10.0f) nb = nb * 1.2f;
     }
     if (t == 0 && tid == 0) {
         m3_info* f = a.info;
-        f->eta = eta; f->eta_1 = 0.0f; f->eta_2 = 0.0f;
-        f->iters = 1; f->iters_1 = 1; f->iters_2 = 1;
-        f->best_idx = a.kbase + b0.i;
-        f->best_idx_1 = -1; f->best_idx_2 = -1;
+        f->eta = eta[0]; f->eta_1 = eta[1]; f->eta_2 = eta[2];
+        f->iters = iters[0]; f->iters_1 = iters[1]; f->iters_2 = iters[2];
+        f->best_idx = a.kbase + bi[0].i;
+        f->best_idx_1 = MULTI ? bi[1].i : -1;
+        f->best_idx_2 = MULTI ? bi[2].i : -1;
         f->wsum_push = hs[0]; f->wsum_pull = hs[1];
         f->pull_preference = hs[1] > hs[0];
-        f->beta_1 = 1.0f; f->beta_2 = 1.0f;
+        f->beta_1 = beta[1]; f->beta_2 = beta[2];
     }
     // ---- column sums through one LDS exchange (k_wsum) ----
     {
         const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-        for (int j = 0; j < NU; ++j) {
-            const float ws = wave_sum(acc[j]);
-            if (lane == 0) sred[j * (WT / 64) + wv] = ws;
-        }
+        for (int s3 = 0; s3 < NS; ++s3)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const float ws = wave_sum(acc[s3][j]);
+                if (lane == 0) sred[(s3 * NU + j) * (WT / 64) + wv] = ws;
+            }
         __syncthreads();
         if (tid < 3 * NU) {
             const int s3 = tid / NU, j = tid % NU;
             float rv = 0.0f;
-            if (s3 == 0) {
+            if (s3 < NS) {
 #pragma unroll
-                for (int w = 0; w < WT / 64; ++w) rv += sred[j * (WT / 64) + w];
+                for (int w = 0; w < WT / 64; ++w) rv += sred[tid * (WT / 64) + w];
             }
             __hip_atomic_store(&a.reduce[reduce_off_psum(s3, T, NU) + t * NU + j], rv, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            if (s3 > 0)  // no per-mode best rows in single mode
+            if (s3 >= NS)  // no per-mode best rows in single mode
                 __hip_atomic_store(&a.reduce[reduce_off_best(s3, T, NU) + t * NU + j], 0.0f, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
-        // best row: the thread that holds the best sample's action writes it
+        // best rows: the thread that holds a best sample's action writes it
 #pragma unroll
-        for (int e = 0; e < JR; ++e)
-            if (e * WT + tid == b0.i) {
+        for (int e = 0; e < JR; ++e) {
+            const int k = e * WT + tid;
 #pragma unroll
-                for (int j = 0; j < NU; ++j)
-                    __hip_atomic_store(&a.reduce[reduce_off_best(0, T, NU) + t * NU + j], av[e][j], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (int s3 = 0; s3 < NS; ++s3)
+                if (k == bi[s3].i) {
+#pragma unroll
+                    for (int j = 0; j < NU; ++j)
+                        __hip_atomic_store(&a.reduce[reduce_off_best(s3, T, NU) + t * NU + j], av[e][j],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
     }
     // ---- last workgroup: mean update / filter, adapted beta ----
     extern __shared__ float sm_fin[];
@@ -1276,20 +1396,31 @@ __global__ __launch_bounds__(256) void k_update_single(const UpdateArgs a) {
     }
     __syncthreads();
     if (__float_as_int(red[46])) {
-        if (tid == 0 && !a.mode_simple) a.info->beta = nb;
+        if (tid == 0 && !MULTI && !a.mode_simple) a.info->beta = nb;
         finalize_body<true>(a, sm_fin);
     }
 }
-void launch_update_single(const UpdateArgs& a, hipStream_t s) {
+void launch_update_small(const UpdateArgs& a, hipStream_t s) {
     const dim3 grid(a.T + 1);
     const size_t lds = (size_t)a.T * a.nu * sizeof(float);
-    if (a.nu == 2) hipLaunchKernelGGL(k_update_single<2>, grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(k_update_single<9>, grid, dim3(256), lds, s, a);
+    const bool multi = a.multi_modal && !a.mode_simple;
+    const bool rows8 = a.Kg <= 8 * 256;
+#define M3_LAUNCH_SMALL(NU_, MULTI_)                                                                         \
+    do {                                                                                                     \
+        if (rows8) hipLaunchKernelGGL((k_update_small<NU_, MULTI_, 8>), grid, dim3(256), lds, s, a);         \
+        else hipLaunchKernelGGL((k_update_small<NU_, MULTI_, 16>), grid, dim3(256), lds, s, a);              \
+    } while (0)
+    if (a.nu == 2) {
+        if (multi) M3_LAUNCH_SMALL(2, true); else M3_LAUNCH_SMALL(2, false);
+    } else {
+        if (multi) M3_LAUNCH_SMALL(9, true); else M3_LAUNCH_SMALL(9, false);
+    }
+#undef M3_LAUNCH_SMALL
 }
-bool update_single_applies(const UpdateArgs& a) {
-    static const bool off = getenv("M3P2I_SPLIT_UPDATE") != nullptr;   // experiments: the two-launch path
+bool update_small_applies(const UpdateArgs& a) {
+    static const bool off = getenv("M3P2I_SPLIT_UPDATE") != nullptr;   // experiments: the multi-launch path
     if (off) return false;
-    return a.fuse_finalize && !a.multi_modal && !a.mode_simple && a.Kl == a.Kg && a.Kg <= 4096 && !a.record &&
+    return a.fuse_finalize && !a.mode_simple && a.Kl == a.Kg && a.Kg <= 4096 && !a.record &&
            topk_workgroups(a.Kg) == 1 && (a.nu == 2 || a.nu == 9);
 }
 
