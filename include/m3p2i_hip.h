@@ -250,6 +250,10 @@ int m3_command(m3_handle* h, float* action_host);
 int m3_rollout(m3_handle* h);
 int m3_update(m3_handle* h);
 int m3_finalize(m3_handle* h);
+/* m3_update + m3_finalize for an UNSHARDED handle in as few launches as the sizes allow (what
+ * m3_command does after its rollout): for a caller that fills TRAJ_COST / ACTIONS itself (step mode,
+ * planner._command_step).  M3_ERR_STATE on a sharded handle (the collectives go in between). */
+int m3_update_finalize(m3_handle* h);
 
 int m3_get_buffer(m3_handle* h, int which, void** dev_ptr, long long* nbytes);
 int m3_reduce_len(const m3_handle* h);

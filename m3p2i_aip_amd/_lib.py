@@ -86,6 +86,7 @@ SYMBOLS = [
     ("m3_rollout", C.c_int, [_H]),
     ("m3_update", C.c_int, [_H]),
     ("m3_finalize", C.c_int, [_H]),
+    ("m3_update_finalize", C.c_int, [_H]),
     ("m3_get_buffer", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     ("m3_reduce_len", C.c_int, [_H]),
     ("m3_record_len", C.c_int, [_H]),

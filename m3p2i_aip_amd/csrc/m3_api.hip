@@ -646,14 +646,27 @@ extern "C" int m3_finalize(m3_handle* h) {
     return M3_OK;
 }
 
+extern "C" int m3_update_finalize(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (h->cfg.K_local != h->cfg.K_global)
+        return fail(h, M3_ERR_STATE, "m3_update_finalize: sharded handle (m3_update, collectives, m3_finalize)");
+    if (!can_fuse_finalize(h)) {
+        const int rc = m3_update(h);
+        return rc != M3_OK ? rc : m3_finalize(h);
+    }
+    const int rc = update_impl(h, true);
+    if (rc != M3_OK) return rc;
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    h->calls += 1;
+    return M3_OK;
+}
+
 extern "C" int m3_command(m3_handle* h, float* action_host) {
     int rc = m3_rollout(h);
     if (rc != M3_OK) return rc;
-    if (can_fuse_finalize(h)) {
-        rc = update_impl(h, true);   // weights -> sums + (last workgroup) mean update / filter
+    if (h->cfg.K_local == h->cfg.K_global) {
+        rc = m3_update_finalize(h);   // weights -> sums + (last workgroup) mean update / filter
         if (rc != M3_OK) return rc;
-        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
-        h->calls += 1;
     } else {
         rc = m3_update(h);
         if (rc != M3_OK) return rc;

@@ -212,6 +212,10 @@ class HipEngine:
     def finalize(self):
         self._ck(self.lib.m3_finalize(self._h))
 
+    def update_finalize(self):
+        """update + finalize of an unsharded handle in as few launches as possible."""
+        self._ck(self.lib.m3_update_finalize(self._h))
+
     # ---- views ----
     def _shape(self, which):
         c = self.cfg

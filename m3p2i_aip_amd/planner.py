@@ -337,6 +337,8 @@ class MPPI():
             e.update()                      # softmin over the local shard -> this rank's record
             self._exchange("records")       # the one collective
             e.finalize()                    # mix the ranks' records, then the usual finalize
+        elif self.world_size == 1 and self.collective is None:
+            e.update_finalize()             # unsharded: one or two launches
         else:
             self._exchange("gather")
             e.update()

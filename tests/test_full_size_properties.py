@@ -24,6 +24,8 @@ CONFIGS = {
     "C4_panda_K4000_T20": dict(K=4000, T=20, nu=9, env="panda_env", task="reach",
                                goal=(0.2, 0.2, 1.115, 0.0, 0.0, 0.0, 1.0), mm=False),
     "C5_hybrid_K64000_T30": dict(K=64000, T=30, nu=2, env="point_env", task="push_pull", goal=(-3.75, -3.75), mm=True),
+    "push_K6000_T30": dict(K=6000, T=30, nu=2, env="point_env", task="push", goal=(-1.0, -1.0), mm=False),
+    "hybrid_K6000_T30": dict(K=6000, T=30, nu=2, env="point_env", task="push_pull", goal=(-3.75, -3.75), mm=True),
     "northstar_push_K10000_T30": dict(K=10000, T=30, nu=2, env="point_env", task="push", goal=(-1.0, -1.0), mm=False),
 }
 
