@@ -604,8 +604,12 @@ static int update_impl(m3_handle* h, bool fuse) {
         aw.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST];
         aw.w = a.w + c.k_offset;
         aw.kbase = c.k_offset;
-        launch_weights(aw, h->stream);
-        launch_wsum(a, h->stream);
+        if (update_small_applies(aw)) {
+            launch_update_small(aw, h->stream);   // one launch: softmin + sums of the local shard
+        } else {
+            launch_weights(aw, h->stream);
+            launch_wsum(a, h->stream);
+        }
         HIPCHK(h, hipGetLastError());
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
         return M3_OK;

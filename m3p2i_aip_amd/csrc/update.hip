@@ -1345,6 +1345,11 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
         f->wsum_push = hs[0]; f->wsum_pull = hs[1];
         f->pull_preference = hs[1] > hs[0];
         f->beta_1 = beta[1]; f->beta_2 = beta[2];
+        if (a.record) {  // shard_mix: local softmin only; k_mix owns eta, beta and the best index
+            a.record[0] = mn[0]; a.record[1] = eta[0];
+            a.record[2] = hs[0]; a.record[3] = hs[1];
+            a.record[4] = __int_as_float(a.kbase + bi[0].i);
+        }
     }
     // ---- column sums through one LDS exchange (k_wsum) ----
     {
@@ -1384,6 +1389,7 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
                 }
         }
     }
+    if (!a.fuse_finalize) return;   // sharded (shard_mix): the record goes to the collective, k_mix + k_finalize follow
     // ---- last workgroup: mean update / filter, adapted beta ----
     extern __shared__ float sm_fin[];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1420,8 +1426,9 @@ void launch_update_small(const UpdateArgs& a, hipStream_t s) {
 bool update_small_applies(const UpdateArgs& a) {
     static const bool off = getenv("M3P2I_SPLIT_UPDATE") != nullptr;   // experiments: the multi-launch path
     if (off) return false;
-    return a.fuse_finalize && !a.mode_simple && a.Kl == a.Kg && a.Kg <= 4096 && !a.record &&
-           topk_workgroups(a.Kg) == 1 && (a.nu == 2 || a.nu == 9);
+    // unsharded (finalize fused in), or a shard_mix rank's local softmin (its costs ARE a.Jall)
+    if (!(a.fuse_finalize || a.record) || (a.record && (a.multi_modal || a.fuse_finalize))) return false;
+    return !a.mode_simple && a.Kl == a.Kg && a.Kg <= 4096 && topk_workgroups(a.Kg) == 1 && (a.nu == 2 || a.nu == 9);
 }
 
 // ---------------------------------------------------------------------------------------
