@@ -642,8 +642,8 @@ extern "C" int m3_finalize(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     UpdateArgs a;
     fill_update_args(h, a);
-    if (mix_mode(h)) launch_mix(a, h->stream);  // records -> the REDUCE buffer an all-reduce would hold
-    launch_finalize(a, h->stream);
+    if (mix_mode(h)) launch_mix(a, h->stream);  // records -> the REDUCE buffer an all-reduce would hold, + finalize
+    else launch_finalize(a, h->stream);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     h->calls += 1;

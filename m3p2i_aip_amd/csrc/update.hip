@@ -1522,9 +1522,16 @@ __global__ __launch_bounds__(256) void k_mix(const UpdateArgs a) {
     // this rank's weights were normalised by its own eta_r: rescale to the global normalisation
     const float rho = s_rho[a.rank];
     for (int i = tid; i < a.Kl; i += blockDim.x) a.w[a.k0 + i] *= rho;
+    // ... and the usual finalize on the buffer just formed, in the same launch (one dependent
+    // launch less on the critical path after the collective): stores out to L2, then
+    // finalize_body reads them back with L2-coherent loads
+    extern __shared__ float sm_mix[];
+    __threadfence();
+    __syncthreads();
+    finalize_body<true>(a, sm_mix);
 }
 void launch_mix(const UpdateArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_mix, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_mix, dim3(1), dim3(256), (size_t)a.T * a.nu * sizeof(float), s, a);
 }
 
 // Savitzky-Golay(9, 2, 'interp') as a fixed linear map: value at window position p of the
