@@ -572,6 +572,15 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     Vel v = {w.rvx, w.rvy, w.B.vx, w.B.vy, w.B.w, w.D.vx, w.D.vy, w.D.w};
     float ldx = 0.0f, ldy = 0.0f;
     Fric fB = {0.f, 0.f, 0.f}, fD = {0.f, 0.f, 0.f};
+    // A body that no slot of this instance touches and that is at rest now stays at rest for the
+    // whole substep (its friction row is a no-op at rest), so its per-pass rest test -- an exec-mask
+    // region of ~36 cycles, twelve of them per substep -- is decided once per wave instead.
+    constexpr bool B_FREE = (M & (G_RB | G_BW | G_BD | G_BO)) == 0u, D_FREE = (M & (G_RD | G_DW | G_BD | G_DO)) == 0u;
+    bool skipB = false, skipD = false;
+    if constexpr (B_FREE && !ALL_FORCES)
+        skipB = __builtin_amdgcn_ballot_w64(((__float_as_uint(v.bvx) | __float_as_uint(v.bvy) | __float_as_uint(v.bw)) << 1) != 0u) == 0ull;
+    if constexpr (D_FREE && !ALL_FORCES)
+        skipD = __builtin_amdgcn_ballot_w64(((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u) == 0ull;
     for (int it = 0; it < sc.iters; ++it) {
         {
             float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
@@ -585,7 +594,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
             v.rvy += sc.invm_r * (l1 - ldy);
             ldy = l1;
         }
-        solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
+        if (!skipB) solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
         // spec order: friction(dyn-obs) then robot-box.  The two rows share no body, so they
         // commute exactly; solving robot-box first lets the dyn-obs row (usually at rest) join
         // the rarely-taken group below: one skipped branch per pass instead of two.
@@ -593,7 +602,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
             if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
         }
         const bool d_moving = ((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u;
-        if (d_moving | rare) {
+        if (!skipD) if (d_moving | rare) {
             solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
             if constexpr (ANY_RARE) {
                 // one outer flag + two group flags: a pass in which no lane has any of these pays
@@ -677,8 +686,8 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     // 4. integrate
     w.rx = w.rx + h * w.rvx;
     w.ry = w.ry + h * w.rvy;
-    integrate_box(w.B, h);
-    integrate_box(w.D, h);
+    if (!skipB) integrate_box(w.B, h);   // (a wave whose boxes all rest: x + h * 0 == x)
+    if (!skipD) integrate_box(w.D, h);
 }
 
 #ifdef M3_ABL_COUNT
