@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a, const
     PandaWorld w;
     if (a.sim_dof) panda_world_from_sim(a.sim_dof, a.sim_root, pa.cubeA_actor, pa.cubeB_actor, w);
     else panda_world_from_raw(pa.world0, w);
-    panda_infer_held(sc, w);
+    float hp[3], trav = 0.0f;   // hand origin at the last evaluated kinematics, joint travel since (panda_step)
+    panda_infer_held(sc, w, hp);
 
     const bool is_last = (k == a.Kg - 1);
     const bool first_half = k < pa.cp.half_K;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a, const
             e[j] = uj / a.u_scale;                                                     // :421
         }
         PandaObs obs;
-        panda_step<FORCES>(sc, w, u, obs);
+        panda_step<FORCES, true>(sc, w, u, obs, hp, &trav);
         const float c = panda_cost(pa.cp, w, obs, k);
         *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
             make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
