@@ -17,12 +17,14 @@ def raw31(P, w58):
     return np.concatenate([w[P.W_Q:P.W_Q + 18], w[P.W_CUBEA:P.W_CUBEA + 10], w[P.W_CUBEB:P.W_CUBEB + 3]])
 
 
-def grasp_world(P, sc):
-    """A world in which the gripper holds cubeA (built with the oracle: IK + closing)."""
+def grasp_world(P, sc, close_gripper=True, lift=0.0):
+    """A world in which the gripper holds cubeA (built with the oracle: IK + closing); with
+    close_gripper=False the open gripper is left around the cube (`lift` metres above the grasp
+    pose), so that rollouts grasp -- or just miss -- it on their own."""
     w = P.init_world(1)
     for _ in range(30):
         P.step_batch(sc, w, np.zeros((1, 9), np.float32))
-    target = w[0, P.W_CUBEA:P.W_CUBEA + 3] + np.array([0, 0, sc.grasp_z])
+    target = w[0, P.W_CUBEA:P.W_CUBEA + 3] + np.array([0, 0, sc.grasp_z + lift])
     q = np.array([0, 0.3, 0, -2.2, 0, 2.5, 0.785, 0.04, 0.04], np.float32)
 
     def feat(L):
@@ -42,6 +44,8 @@ def grasp_world(P, sc):
         q[:7] = np.clip(q[:7], np.array(sc.qlo)[:7], np.array(sc.qhi)[:7])
     w[0, P.W_Q:P.W_Q + 9] = q
     w[0, P.W_QD:P.W_QD + 9] = 0
+    if not close_gripper:
+        return w[0].copy()
     close = np.zeros((1, 9), np.float32); close[0, 7:] = -1.5
     for _ in range(40):
         P.step_batch(sc, w, close)
@@ -51,7 +55,12 @@ def grasp_world(P, sc):
 
 @pytest.mark.parametrize("task,mm,grip,held", [("reach", False, 1, False), ("reach", True, 1, False),
                                                ("pick", False, 2, True), ("pick", False, 2, False),
-                                               ("place", False, 1, True)])
+                                               ("place", False, 1, True),
+                                               # open gripper around the cube / 3, 8, 15 cm above it:
+                                               # rollouts grasp during the horizon, or pass the bound of
+                                               # the lazy kinematics (panda_step LAZY_FK) closely
+                                               ("pick", False, 2, "open0"), ("pick", False, 2, "open3"),
+                                               ("pick", False, 2, "open8"), ("reach", False, 2, "open15")])
 def test_panda_command_matches_oracle(oracle, task, mm, grip, held):
     import oracle.panda as P
     from m3p2i_aip_amd import _lib as L
@@ -61,7 +70,11 @@ def test_panda_command_matches_oracle(oracle, task, mm, grip, held):
     rng = np.random.default_rng(5)
     delta = rng.standard_normal((K, T, 9)).astype(np.float32)
     goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
-    w0 = grasp_world(P, sc) if held else P.init_world(1)[0]
+    if isinstance(held, str):
+        w0 = grasp_world(P, sc, close_gripper=False, lift=0.01 * int(held[4:]))
+        held = False
+    else:
+        w0 = grasp_world(P, sc) if held else P.init_world(1)[0]
     cfg = P.make_cfg(K, T, multi_modal=mm, task=task, goal=goal, gripper_cmd=grip)
     opl = P.OraclePandaPlanner(cfg, delta, sc)
     eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", multi_modal=mm, u_min=UMIN, u_max=UMAX,
