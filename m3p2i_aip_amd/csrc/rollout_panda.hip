@@ -40,11 +40,29 @@ __device__ __forceinline__ void panda_world_from_sim(const float* dof, const flo
     panda_world_from_raw(raw, w);
 }
 
+__device__ __forceinline__ float in_vgpr(float v) {   // keep a uniform value in a vector register
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <bool FORCES>
-__global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a, const PandaArgs pa,
-                                                      const PandaScene sc) {
+__global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, const PandaArgs pa,
+                                                      const PandaScene sc_) {
     const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.Kl) return;
+    if (i >= a_.Kl) return;
+    // The per-joint constants (bounds, noise scale, servo coefficients: 54 floats) are uniform, but
+    // there are not enough scalar registers to keep them across the step loop, and the compiler
+    // re-read them from the kernel arguments every step (~12 scalar loads per step, each followed by
+    // a wait with nothing else resident on the SIMD to cover it).  Vector registers are plentiful at
+    // one wave per SIMD, so they are parked there once.
+    RolloutArgs a = a_;
+    PandaScene sc = sc_;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        a.u_min[j] = in_vgpr(a_.u_min[j]); a.u_max[j] = in_vgpr(a_.u_max[j]);
+        a.scale_tril[j] = in_vgpr(a_.scale_tril[j]);
+        sc.a[j] = in_vgpr(sc_.a[j]); sc.rden[j] = in_vgpr(sc_.rden[j]); sc.dv[j] = in_vgpr(sc_.dv[j]);
+    }
     const int Kl = a.Kl, T = a.T;
     const int k = a.k0 + i;
     PandaWorld w;
