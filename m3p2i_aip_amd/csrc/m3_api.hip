@@ -263,8 +263,10 @@ static int refresh_wave_order(m3_handle* h) {
     const m3_config& c = h->cfg;
     h->order_valid = false;
     h->order_dirty = false;
+    // (a caller that uploads fresh noise for almost every command would pay the sort -- ~25 us --
+    // more often than it pays back: by index then)
     if (!h->wave_order || c.env_type != M3_ENV_POINT || c.nu != 2 || c.K_local < 128 || c.sampling_random ||
-        c.mode_simple || !h->have_noise)
+        c.mode_simple || !h->have_noise || h->noise_churn >= 2)
         return M3_OK;
     if (!h->order) {
         h->order_temp_bytes = wave_order_temp_bytes(c.K_local);
@@ -289,6 +291,13 @@ static int refresh_wave_order(m3_handle* h) {
     return M3_OK;
 }
 
+static void note_noise_upload(m3_handle* h) {
+    h->noise_churn = (h->have_noise && h->calls - h->last_noise_call < 16u) ? h->noise_churn + 1 : 0;
+    h->last_noise_call = h->calls;
+    h->have_noise = true;
+    h->order_dirty = true;
+}
+
 extern "C" int m3_set_wave_order(m3_handle* h, int on) {
     if (!h) return M3_ERR_BAD_ARG;
     h->wave_order = on != 0;
@@ -309,8 +318,7 @@ extern "C" int m3_set_noise(m3_handle* h, const float* delta, int on_device) {
     launch_transpose_noise(src, (float*)h->buf[M3_BUF_NOISE], c.K_local, c.T, c.nu, h->stream);
     HIPCHK(h, hipGetLastError());
     if (!on_device) HIPCHK(h, hipStreamSynchronize(h->stream));  // host buffer may be released
-    h->have_noise = true;
-    h->order_dirty = true;
+    note_noise_upload(h);
     return M3_OK;
 }
 
@@ -339,8 +347,7 @@ extern "C" int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots,
         (void)hipFree(stage);
     }
     if (e != hipSuccess) { h->err = std::string("k_spline_noise: ") + hipGetErrorString(e); return M3_ERR_HIP; }
-    h->have_noise = true;
-    h->order_dirty = true;
+    note_noise_upload(h);
     return M3_OK;
 }
 

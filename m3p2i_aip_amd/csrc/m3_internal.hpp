@@ -186,6 +186,8 @@ struct m3_handle {
     bool wave_order = true;        // m3_set_wave_order
     bool order_valid = false;
     bool order_dirty = true;       // recomputed by the next m3_rollout (needs the world)
+    unsigned last_noise_call = 0;  // h->calls at the last m3_set_noise*
+    int noise_churn = 0;           // consecutive noise uploads fewer than 16 commands apart
     m3::PointScene scene;
     m3::PandaScene pscene;
     float pworld0[31];
