@@ -1230,6 +1230,97 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
         int done[3] = {0, 0, 0};
         iters[0] = iters[1] = iters[2] = 0;
         const int lane = tid & 63, wv = tid >> 6;
+        // (a) The betas a search can visit before it reverses are the ladders {0.9^j}, {1.2^j}: the T
+        // column workgroups would all walk them one pass at a time, each computing the same sums.
+        // Instead workgroup t evaluates ladder point(s) t, t + T, ... for all three searches, the
+        // workgroups exchange the table through memory (write-through stores, one arrive counter,
+        // L2-coherent loads: the T + 1 workgroups of this launch are co-resident, 256 CUs), and every
+        // workgroup walks the table -- eta(beta) is formed by the same code in the same order as in a
+        // pass, so the walk makes the same decisions.  A search that leaves the ladder or reverses
+        // continues with the passes below.  (C3: ~16 passes of 1.4 us -> one + ~2 us of exchange.)
+        if (T <= 256) {   // (co-residency of the T + 1 workgroups is what the wait relies on)
+            constexpr int LS = 16, LG = 24, NPT = LS + LG;   // 0.9^0 .. 0.9^15, 1.2^1 .. 1.2^24
+            __shared__ float s_tab[NPT * 3];
+            __shared__ float s_walk[3][4];
+            int nbuf = 0;
+            for (int p = t; p < NPT; p += T, ++nbuf) {
+                float bp = 1.0f;
+                if (p < LS) { for (int i = 0; i < p; ++i) bp = bp * 0.9f; }
+                else { for (int i = 0; i < p - LS + 1; ++i) bp = bp * 1.2f; }
+                const float np_ = uniform_f(-1.0f / bp);
+                float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+#pragma unroll
+                for (int e = 0; e < JR; ++e) e0 += m3_exp(np_ * (jr[e] - mn[0]));
+#pragma unroll
+                for (int e = 0; e < JR; ++e) {
+                    const bool first = e * WT + tid < half;
+                    const float xh = m3_exp(np_ * (jr[e] - (first ? mn[1] : mn[2])));
+                    e1 += first ? xh : 0.0f;
+                    e2 += first ? 0.0f : xh;
+                }
+                e0 = wave_sum(e0); e1 = wave_sum(e1); e2 = wave_sum(e2);
+                float* buf = s_part[nbuf & 1];
+                if (lane == 0) { buf[0 * 4 + wv] = e0; buf[1 * 4 + wv] = e1; buf[2 * 4 + wv] = e2; }
+                __syncthreads();
+                if (tid < 3) {
+                    float et = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < WT / 64; ++w) et += buf[tid * 4 + w];   // wave order, as in a pass
+                    __hip_atomic_store(&a.lad[p * 3 + tid], et, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // arrive + wait (the counter is re-armed by the last workgroup of the launch, below)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(&a.wcount[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(&a.wcount[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            __syncthreads();
+            for (int o = tid; o < NPT * 3; o += WT)
+                s_tab[o] = __hip_atomic_load(&a.lad[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid < 3) {   // the reference's rule on the table (m3p2i.py:24-64)
+                const int sx = tid;
+                float b = 1.0f, et = s_tab[0 * 3 + sx];
+                int it = 1, dn = 0;
+                if (et > 10.0f) {
+                    int j = 0;
+                    for (;;) {
+                        b = b * 0.9f; ++j;
+                        if (j >= LS) break;                    // off the ladder: passes below
+                        et = s_tab[j * 3 + sx]; ++it;
+                        if (et > 10.0f) continue;
+                        if (et < 3.0f) b = b * 1.2f;           // overshoot: reversal, passes below
+                        else dn = 1;
+                        break;
+                    }
+                } else if (et < 3.0f) {
+                    int j = 0;
+                    for (;;) {
+                        b = b * 1.2f; ++j;
+                        if (j > LG) break;
+                        et = s_tab[(LS + j - 1) * 3 + sx]; ++it;
+                        if (et < 3.0f) continue;
+                        if (et > 10.0f) b = b * 0.9f;
+                        else dn = 1;
+                        break;
+                    }
+                } else {
+                    dn = 1;
+                }
+                s_walk[sx][0] = b; s_walk[sx][1] = et; s_walk[sx][2] = __int_as_float(dn); s_walk[sx][3] = __int_as_float(it);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                beta[s3] = s_walk[s3][0]; eta[s3] = s_walk[s3][1];
+                done[s3] = __float_as_int(s_walk[s3][2]); iters[s3] = __float_as_int(s_walk[s3][3]);
+            }
+            __syncthreads();
+        }
+        // (b) passes for what the ladder did not settle
         for (int pass = 0; pass < 1000; ++pass) {
             if (done[0] && done[1] && done[2]) break;
             // (quotients behind an optimisation barrier: otherwise the compiler rewrites the per-row
@@ -1403,6 +1494,7 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
     __syncthreads();
     if (__float_as_int(red[46])) {
         if (tid == 0 && !MULTI && !a.mode_simple) a.info->beta = nb;
+        if (tid == 0 && MULTI) a.wcount[0] = 0;   // the ladder exchange's arrive counter, for the next launch
         finalize_body<true>(a, sm_fin);
     }
 }
