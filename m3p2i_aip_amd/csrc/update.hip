@@ -1165,8 +1165,25 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
     __shared__ float sred[3 * 9 * (WT / 64)];
     __shared__ float s_part[2][3 * 4];
     const int T = a.T, tid = threadIdx.x, Kg = a.Kg;
-    if ((int)blockIdx.x == T) {  // top-k (one stage at K <= 4096), concurrent with the column workgroups
-        topk_stage_a(a, 0);
+    if ((int)blockIdx.x >= T) {  // top-k workgroups, concurrent with the column workgroups
+        // one per 4096 costs; with more than one, the last of them to finish merges the lists (stage
+        // B): candidates out through agent-scope fences (off the command's critical path), a ticket
+        __shared__ int s_lastb;
+        topk_stage_a(a, blockIdx.x - T);
+        if (a.n_cand > 1) {
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                const int ticket = __hip_atomic_fetch_add(&a.wcount[T + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_lastb = ticket == a.n_cand - 1;
+                if (s_lastb) a.wcount[T + 1] = 0;
+            }
+            __syncthreads();
+            if (s_lastb) {
+                __threadfence();
+                topk_stage_b(a);
+            }
+        }
         return;
     }
     const int t = blockIdx.x;
@@ -1499,17 +1516,20 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
     }
 }
 void launch_update_small(const UpdateArgs& a, hipStream_t s) {
-    const dim3 grid(a.T + 1);
+    const dim3 grid(a.T + a.n_cand);
     const size_t lds = (size_t)a.T * a.nu * sizeof(float);
     const bool multi = a.multi_modal && !a.mode_simple;
-    const bool rows8 = a.Kg <= 8 * 256;
+    const int rows = (a.Kg + 255) / 256;
 #define M3_LAUNCH_SMALL(NU_, MULTI_)                                                                         \
     do {                                                                                                     \
-        if (rows8) hipLaunchKernelGGL((k_update_small<NU_, MULTI_, 8>), grid, dim3(256), lds, s, a);         \
+        if (rows <= 8) hipLaunchKernelGGL((k_update_small<NU_, MULTI_, 8>), grid, dim3(256), lds, s, a);     \
         else hipLaunchKernelGGL((k_update_small<NU_, MULTI_, 16>), grid, dim3(256), lds, s, a);              \
     } while (0)
     if (a.nu == 2) {
-        if (multi) M3_LAUNCH_SMALL(2, true); else M3_LAUNCH_SMALL(2, false);
+        if (multi) M3_LAUNCH_SMALL(2, true);
+        else if (rows <= 16) M3_LAUNCH_SMALL(2, false);
+        else if (rows <= 32) hipLaunchKernelGGL((k_update_small<2, false, 32>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_update_small<2, false, 64>), grid, dim3(256), lds, s, a);
     } else {
         if (multi) M3_LAUNCH_SMALL(9, true); else M3_LAUNCH_SMALL(9, false);
     }
@@ -1520,7 +1540,9 @@ bool update_small_applies(const UpdateArgs& a) {
     if (off) return false;
     // unsharded (finalize fused in), or a shard_mix rank's local softmin (its costs ARE a.Jall)
     if (!(a.fuse_finalize || a.record) || (a.record && (a.multi_modal || a.fuse_finalize))) return false;
-    return !a.mode_simple && a.Kl == a.Kg && a.Kg <= 4096 && topk_workgroups(a.Kg) == 1 && (a.nu == 2 || a.nu == 9);
+    // (single mode with two controls keeps up to 64 register rows: K <= 16384, the north-star size)
+    const int kmax = (a.nu == 2 && !a.multi_modal) ? 16384 : 4096;
+    return !a.mode_simple && a.Kl == a.Kg && a.Kg <= kmax && a.n_cand == topk_workgroups(a.Kg) && (a.nu == 2 || a.nu == 9);
 }
 
 // ---------------------------------------------------------------------------------------
