@@ -34,7 +34,7 @@ for name in ("push", "hybrid", "panda"):
             assert torch.isfinite(a).all(), (name, i)
             # the returned plan is the Savitzky-Golay filter of the (bounded) mean: it may overshoot the
             # bounds a little, like the reference's (mppi.py:257-263 does not clamp again)
-            assert (a >= 1.5 * lo).all() and (a <= 1.5 * hi).all(), (name, i)
+            assert (a >= 1.8 * lo).all() and (a <= 1.8 * hi).all(), (name, i)   # |filter row|_1 <= 1.68
             mean = eng.buffer(__import__("m3p2i_aip_amd")._lib.BUF_MEAN)
             assert (mean >= lo - 1e-4).all() and (mean <= hi + 1e-4).all(), (name, i)
             if mm:
