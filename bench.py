@@ -111,7 +111,7 @@ def cpu_baseline(env, task, goal, multi_modal, K, T, delta):
         pl = make()
         pl.command(w0)
         n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget and n < 400:
+        while time.perf_counter() - t0 < budget and n < 2000:
             pl.command(w0)
             n += 1
         dt = time.perf_counter() - t0
