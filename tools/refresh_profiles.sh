@@ -10,6 +10,7 @@ done
 TRAFFIC_KEY=push:K2000:T30 tools/profile_gpu.sh push --config push > $O/prof_push.log 2>&1
 TRAFFIC_KEY=hybrid:K4000:T30 tools/profile_gpu.sh hybrid --config hybrid > $O/prof_hybrid.log 2>&1
 TRAFFIC_KEY=panda:K4000:T20 tools/profile_gpu.sh panda --config panda > $O/prof_panda.log 2>&1
+TRAFFIC_KEY=northstar:K10000:T30 tools/profile_gpu.sh northstar --config northstar > $O/prof_northstar.log 2>&1
 cd $ROOT
 python tools/k_sweep.py > $O/k_sweep.log 2>&1
 python tools/lanes_sweep.py 2000 > $O/lanes_sweep.log 2>&1
