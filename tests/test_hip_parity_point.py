@@ -263,3 +263,62 @@ def test_shard_mix_is_refused_for_the_multi_modal_search():
     with pytest.raises(L.M3Error):
         _engine(K=256, K_local=128, k_offset=0, shard_mix=True, T=30, nu=2, multi_modal=True,
                 u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_rollout_bit_exact_on_random_worlds(oracle, seed):
+    """Fuzz: robot, box and dyn-obs anywhere in the arena -- overlapping each other, the obstacle or a
+    wall, rotated, moving and spinning -- with a random task; strong random controls.  Exercises the
+    heavy substep instances (all 19 slots, walls, box-box) that planned rollouts rarely reach.
+    States / actions / costs must equal the oracle's bit-for-bit, with the coherent wavefront order
+    (default) as well as by index."""
+    from m3p2i_aip_amd import _lib as L
+    rng = np.random.default_rng(1000 + seed)
+    K, T = 256, 30
+    task, goal, mm = [("push", (-1, -1), False), ("pull", (0, 0), False), ("push_pull", (-3.75, -3.75), True),
+                      ("navigation", (-3, 3), False)][seed % 4]
+    delta = (rng.standard_normal((K, T, 2)) * 1.5).astype(np.float32)
+    w = oracle.init_world(1)[0]
+
+    def place(lo=-3.8, hi=3.8):
+        spot = rng.integers(0, 4)
+        if spot == 0:   # anywhere
+            return rng.uniform(lo, hi, 2)
+        if spot == 1:   # against a wall / in a corner
+            p = rng.uniform(lo, hi, 2)
+            p[rng.integers(0, 2)] = rng.choice([-1, 1]) * rng.uniform(3.4, 3.85)
+            if rng.random() < 0.5:
+                p[:] = rng.choice([-1, 1], 2) * rng.uniform(3.3, 3.8, 2)
+            return p
+        if spot == 2:   # at the obstacle (2, 2)
+            return np.array([2.0, 2.0]) + rng.uniform(-0.6, 0.6, 2)
+        return np.array([0.0, 1.0]) + rng.uniform(-0.8, 0.8, 2)   # in the middle, near each other
+
+    w[0:2] = place()
+    w[4:6] = rng.normal(0, 1.0, 2)                      # robot velocity
+    for base in (oracle.W_B, oracle.W_D):
+        yaw = rng.uniform(-np.pi, np.pi)
+        w[base:base + 2] = place()
+        w[base + 2:base + 4] = (np.cos(yaw), np.sin(yaw))
+        if rng.random() < 0.5:
+            w[base + 4:base + 6] = rng.normal(0, 0.5, 2)
+            w[base + 6] = rng.normal(0, 1.0)
+    w = w.astype(np.float32)
+    ocfg = oracle.make_cfg(K, T, 2, task=task, goal=goal, multi_modal=mm)
+    opl = oracle.OraclePointPlanner(ocfg, delta)
+    opl.command(w)
+    for order in (True, False):
+        eng = _engine(K=K, T=T, nu=2, multi_modal=mm, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+        eng.set_wave_order(order)
+        eng.set_objective(task, goal)
+        eng.set_noise(delta)
+        eng.set_world_point_raw(raw_world(w))
+        eng.command(sync_host=True)
+        st = eng.states.cpu().numpy()
+        assert np.isfinite(st).all()
+        np.testing.assert_array_equal(eng.actions.cpu().numpy(), opl.last["actions"])
+        bad = np.argwhere(st != opl.last["states"])
+        assert bad.size == 0, f"seed {seed}: first mismatch at (k,t,c)={bad[0]} of {len(bad)}"
+        np.testing.assert_array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+        np.testing.assert_array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
+        eng.close()
