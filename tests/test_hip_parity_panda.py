@@ -101,3 +101,51 @@ def test_panda_command_matches_oracle(oracle, task, mm, grip, held):
     if held and task == "pick":
         assert np.ptp(ch) > 0.05       # the held cube really moves with the hand in the rollouts
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed):
+    """Fuzz: random joint configuration inside the limits, random joint velocities, cubeA anywhere on
+    the table / shelf / in the air (falls), random gripper command and task; strong random controls.
+    The rollout must equal the oracle's bit-for-bit (the lazy kinematics of panda_step decide per wave
+    whether a substep's kinematics can be skipped -- random worlds put cubes at every distance)."""
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    rng = np.random.default_rng(500 + seed)
+    sc = P.default_scene()
+    K, T = 128, 20
+    task, grip = [("reach", 1), ("pick", 2), ("place", 1), ("reach", 2)][seed % 4]
+    w0 = P.init_world(1)[0]
+    qlo, qhi = np.array(sc.qlo), np.array(sc.qhi)
+    w0[P.W_Q:P.W_Q + 9] = qlo + rng.uniform(0.05, 0.95, 9) * (qhi - qlo)
+    w0[P.W_QD:P.W_QD + 9] = rng.normal(0, 0.3, 9) * (rng.random() < 0.5)
+    spot = seed % 3
+    if spot == 0:    # on the table, anywhere
+        w0[P.W_CUBEA:P.W_CUBEA + 2] = rng.uniform(-0.5, 0.5, 2)
+    elif spot == 1:  # near the hand: FK of the random configuration, a few cm away
+        Lk = P.fk(sc, w0[P.W_Q:P.W_Q + 9].astype(np.float32))
+        w0[P.W_CUBEA:P.W_CUBEA + 3] = Lk["pos"][8] + rng.uniform(-0.12, 0.12, 3)
+    else:            # in the air above the shelf: falls onto it
+        w0[P.W_CUBEA:P.W_CUBEA + 3] = (0.5 + rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), 1.6)
+    w0 = w0.astype(np.float32)
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    delta = rng.standard_normal((K, T, 9)).astype(np.float32)
+    cfg = P.make_cfg(K, T, multi_modal=False, task=task, goal=goal, gripper_cmd=grip)
+    opl = P.OraclePandaPlanner(cfg, delta, sc)
+    eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", u_min=UMIN, u_max=UMAX,
+                                noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01))
+    eng.set_objective(task, goal, gripper_cmd=grip)
+    eng.set_noise(delta)
+    eng.set_world_panda_raw(raw31(P, w0))
+    eng.command(sync_host=True)
+    opl.command(w0)
+    st = eng.states.cpu().numpy()
+    assert np.isfinite(st).all()
+    np.testing.assert_array_equal(eng.actions.cpu().numpy(), opl.last["actions"])
+    np.testing.assert_array_equal(st, opl.last["states"])
+    ch = eng.cost_horizon.cpu().numpy()
+    bad = np.argwhere(ch != opl.last["cost_h"])
+    assert bad.size == 0, f"seed {seed}: {len(bad)} cost mismatches, first {bad[0]}"
+    np.testing.assert_array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
+    eng.close()
