@@ -1,5 +1,9 @@
 // update.hip -- importance-weight update of MPPI / M3P2I (gfx950).
 //
+//   k_update_small : the WHOLE update (weights, beta search, sums, top-k, mean update / filter) in one
+//               launch for the sizes of the reference's configs: K <= 4096 per GPU (C2, C3, C4, a
+//               shard_mix rank), K <= 16384 for single-mode point_env (the north-star size).  The
+//               kernels below are the general path: larger K and the sharded phases.
 //   k_mins    : (multi-modal only) per-workgroup minima of the trajectory costs
 //   k_ladder  : (multi-modal only) eta(beta) for the whole ladder of betas the reference's
 //               on-the-fly search can visit, in ONE chip-wide pass
