@@ -40,6 +40,7 @@ CONFIGS = {
     "hybrid": ("point_env", "push_pull", (-3.75, -3.75), True, 4000, 30),  # BASELINE configs[2]
     "panda": ("panda_env", "reach", (0.0,) * 7, False, 4000, 20),          # BASELINE configs[3]
     "northstar": ("point_env", "push", (-1.0, -1.0), False, 10000, 30),    # north_star target point
+    "c5": ("point_env", "push_pull", (-3.75, -3.75), True, 8000, 30),      # BASELINE configs[4] = 8 x this (--gpus 8)
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # rollout kernel, per state-step: delta read (4*nu) + state 16 + action 4*nu + cost 4 written

@@ -1541,7 +1541,8 @@ void launch_update_small(const UpdateArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((k_update_small<NU_, MULTI_, 16>), grid, dim3(256), lds, s, a);              \
     } while (0)
     if (a.nu == 2) {
-        if (multi) M3_LAUNCH_SMALL(2, true);
+        if (multi && rows > 16) hipLaunchKernelGGL((k_update_small<2, true, 32>), grid, dim3(256), lds, s, a);
+        else if (multi) M3_LAUNCH_SMALL(2, true);
         else if (rows <= 16) M3_LAUNCH_SMALL(2, false);
         else if (rows <= 32) hipLaunchKernelGGL((k_update_small<2, false, 32>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((k_update_small<2, false, 64>), grid, dim3(256), lds, s, a);
@@ -1555,8 +1556,9 @@ bool update_small_applies(const UpdateArgs& a) {
     if (off) return false;
     // unsharded (finalize fused in), or a shard_mix rank's local softmin (its costs ARE a.Jall)
     if (!(a.fuse_finalize || a.record) || (a.record && (a.multi_modal || a.fuse_finalize))) return false;
-    // (single mode with two controls keeps up to 64 register rows: K <= 16384, the north-star size)
-    const int kmax = (a.nu == 2 && !a.multi_modal) ? 16384 : 4096;
+    // (with two controls: up to 64 register rows in single mode, K <= 16384, the north-star size; 32 in
+    // multi-modal mode, K <= 8192, a C5 shard's size)
+    const int kmax = (a.nu != 2) ? 4096 : a.multi_modal ? 8192 : 16384;
     return !a.mode_simple && a.Kl == a.Kg && a.Kg <= kmax && a.n_cand == topk_workgroups(a.Kg) && (a.nu == 2 || a.nu == 9);
 }
 
