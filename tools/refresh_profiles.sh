@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 O=$ROOT/gpurun_out
 cd $ROOT
-for c in push hybrid panda northstar; do
+for c in push hybrid panda northstar c5; do
   python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err
 done
 TRAFFIC_KEY=push:K2000:T30 tools/profile_gpu.sh push --config push > $O/prof_push.log 2>&1
