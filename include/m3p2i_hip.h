@@ -197,6 +197,14 @@ int m3_set_rollout_lanes(m3_handle* h, int lanes);
  * direction of each sample's noise path (computed on the device whenever the noise is set, so that
  * a wavefront's samples meet the same obstacles), 0 = by index.  Results do not depend on it. */
 int m3_set_wave_order(m3_handle* h, int on);
+/* Relabels the samples instead: the noise rows are permuted ONCE (by the next m3_rollout, which knows
+ * the world) into that order, within each mode's half and with the rows of the special samples (0,
+ * K/2, K-1) left in place, so that afterwards sample k simply has another row of the SAME noise set
+ * and index order is wavefront order (coalesced stores, no per-command scatter).  For a caller whose
+ * row labels carry no meaning -- the reference's own Halton sampler: planner._ensure_noise calls it.
+ * The sample SET, and with it the plan, is unchanged up to the order of f32 summation; per-sample
+ * outputs (weights[k], states[k], top_idx) refer to the new labels. */
+int m3_relabel_samples(m3_handle* h);
 
 /* delta: [K_local][T][nu] row-major (the reference's layout, rows of THIS shard).
  * on_device: 0 host pointer, 1 device pointer. */

@@ -70,6 +70,7 @@ SYMBOLS = [
     ("m3_enable_timing", C.c_int, [_H, C.c_int]),
     ("m3_set_rollout_lanes", C.c_int, [_H, C.c_int]),
     ("m3_set_wave_order", C.c_int, [_H, C.c_int]),
+    ("m3_relabel_samples", C.c_int, [_H]),
     ("m3_set_noise", C.c_int, [_H, _FP, C.c_int]),
     ("m3_set_noise_knots", C.c_int, [_H, _FP, C.c_int, C.c_int, C.c_float, C.c_int]),
     ("m3_set_objective", C.c_int, [_H, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int]),

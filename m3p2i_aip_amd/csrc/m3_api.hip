@@ -263,6 +263,9 @@ static int refresh_wave_order(m3_handle* h) {
     const m3_config& c = h->cfg;
     h->order_valid = false;
     h->order_dirty = false;
+    const bool relabel = h->relabel_pending;
+    h->relabel_pending = false;
+    if (h->relabelled && !relabel) return M3_OK;   // rows already in wavefront order: by index
     // (a caller that uploads fresh noise for almost every command would pay the sort -- ~25 us --
     // more often than it pays back: by index then)
     if (!h->wave_order || c.env_type != M3_ENV_POINT || c.nu != 2 || c.K_local < 128 || c.sampling_random ||
@@ -282,16 +285,42 @@ static int refresh_wave_order(m3_handle* h) {
     if (h->bind_dof) { os.sim_root = h->bind_root; os.sim_box = h->bind_box; os.sim_dyn = h->bind_dyn; }
     os.bx = h->world0[4]; os.by = h->world0[5]; os.dx = h->world0[11]; os.dy = h->world0[12];
     os.ox = h->scene.obs_x; os.oy = h->scene.obs_y;
+    // relabelling keeps the samples with a role of their own at their index
+    const int specials[3] = {0 - c.k_offset, c.K_global / 2 - c.k_offset, c.K_global - 1 - c.k_offset};
     hipError_t e = launch_wave_order((const float*)h->buf[M3_BUF_NOISE], c.K_local, c.T, c.nu,
                                      std::sqrt(c.noise_sigma_diag[0]), std::sqrt(c.noise_sigma_diag[1]),
                                      (int)half_local, os, h->order_scratch, h->order_temp_bytes, h->order, h->noise_sorted,
-                                     h->stream);
+                                     relabel ? specials : nullptr, h->stream);
     if (e != hipSuccess) { h->err = std::string("wave order: ") + hipGetErrorString(e); return M3_ERR_HIP; }
+    if (relabel) {
+        // sample i := old sample order[i]: the noise rows (gathered above) and the per-sample state
+        // that outlives a command (pending suction forces) move; everything else is rewritten by
+        // the next rollout.  From here on the index order IS the wavefront order: coalesced stores.
+        HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_NOISE], h->noise_sorted, sizeof(float) * (size_t)c.T * c.K_local * c.nu,
+                                 hipMemcpyDeviceToDevice, h->stream));
+        float* tmp = (float*)h->order_scratch;   // 3 * Kl floats free again after the sort; pend needs 4 * Kl
+        (void)tmp;
+        launch_gather_rows((const float*)h->buf[M3_BUF_PENDING_FORCE], h->order, h->noise_sorted, c.K_local, 4, h->stream);
+        HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_PENDING_FORCE], h->noise_sorted, sizeof(float) * 4 * (size_t)c.K_local,
+                                 hipMemcpyDeviceToDevice, h->stream));
+        h->relabelled = true;
+        return M3_OK;
+    }
     h->order_valid = true;
     return M3_OK;
 }
 
+extern "C" int m3_relabel_samples(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->have_noise) return fail(h, M3_ERR_STATE, "m3_relabel_samples: no noise set");
+    h->relabel_pending = true;
+    h->order_dirty = true;
+    return M3_OK;
+}
+
 static void note_noise_upload(m3_handle* h) {
+    h->relabelled = false;
+    h->relabel_pending = false;
     h->noise_churn = (h->have_noise && h->calls - h->last_noise_call < 16u) ? h->noise_churn + 1 : 0;
     h->last_noise_call = h->calls;
     h->have_noise = true;

@@ -122,7 +122,8 @@ struct OrderScene {   // where the scene's objects are when the wavefront order 
 size_t wave_order_temp_bytes(int Kl);
 hipError_t launch_wave_order(const float* noise, int Kl, int T, int nu, float s0, float s1, int half_local,
                              const OrderScene& os, void* scratch, size_t temp_bytes, int* order, float* noise_sorted,
-                             hipStream_t s);
+                             const int* specials /* null, or 3 local indices (-1: none) */, hipStream_t s);
+void launch_gather_rows(const float* src, const int* order, float* dst, int Kl, int rows, hipStream_t s);
 void launch_weights(const UpdateArgs& a, hipStream_t s);
 void launch_wsum(const UpdateArgs& a, hipStream_t s);
 void launch_update_small(const UpdateArgs& a, hipStream_t s);
@@ -188,6 +189,8 @@ struct m3_handle {
     bool order_dirty = true;       // recomputed by the next m3_rollout (needs the world)
     unsigned last_noise_call = 0;  // h->calls at the last m3_set_noise*
     int noise_churn = 0;           // consecutive noise uploads fewer than 16 commands apart
+    bool relabel_pending = false;  // m3_relabel_samples: done by the next m3_rollout
+    bool relabelled = false;       // the noise rows ARE in wavefront order (identity order from then on)
     m3::PointScene scene;
     m3::PandaScene pscene;
     float pworld0[31];

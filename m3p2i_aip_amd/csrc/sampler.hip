@@ -91,6 +91,35 @@ __global__ void k_gather_noise(const float* __restrict__ noise, const int* __res
     }
 }
 
+// relabelling: samples with a role of their own (k = 0 and K/2 carry the best trajectories, K - 1 is
+// the null / zero-noise sample) keep their index: each is swapped back to its own slot
+__global__ __launch_bounds__(256) void k_fix_specials(int* __restrict__ order, int Kl, int s0, int s1, int s2) {
+    __shared__ int s_pos;
+    const int sp[3] = {s0, s1, s2};
+    for (int q = 0; q < 3; ++q) {
+        const int sidx = sp[q];
+        if (sidx < 0 || sidx >= Kl) continue;   // (uniform)
+        if (threadIdx.x == 0) s_pos = -1;
+        __syncthreads();
+        for (int p = threadIdx.x; p < Kl; p += blockDim.x)
+            if (order[p] == sidx) s_pos = p;
+        __syncthreads();
+        if (threadIdx.x == 0 && s_pos >= 0) {
+            const int other = order[sidx];
+            order[sidx] = sidx;
+            order[s_pos] = other;
+        }
+        __syncthreads();
+    }
+}
+// pending suction forces [4][Kl] follow their samples
+__global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ order, float* __restrict__ dst,
+                              int Kl, int rows) {
+    const int n = rows * Kl;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x)
+        dst[o] = src[(o / Kl) * Kl + order[o % Kl]];
+}
+
 size_t wave_order_temp_bytes(int Kl) {
     size_t n = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, n, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
@@ -101,7 +130,7 @@ size_t wave_order_temp_bytes(int Kl) {
 // scratch: keys_in [Kl] | keys_out [Kl] | idx_in [Kl] (floats / ints), then the radix sort's own storage
 hipError_t launch_wave_order(const float* noise, int Kl, int T, int nu, float s0, float s1, int half_local,
                              const OrderScene& os, void* scratch, size_t temp_bytes, int* order, float* noise_sorted,
-                             hipStream_t s) {
+                             const int* specials, hipStream_t s) {
     float* keys_in = (float*)scratch;
     float* keys_out = keys_in + Kl;
     int* idx_in = (int*)(keys_out + Kl);
@@ -110,11 +139,18 @@ hipError_t launch_wave_order(const float* noise, int Kl, int T, int nu, float s0
                        os, keys_in, idx_in);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, order, Kl, 0, 32, s);
     if (e != hipSuccess) return e;
+    if (specials) hipLaunchKernelGGL(k_fix_specials, dim3(1), dim3(256), 0, s, order, Kl, specials[0], specials[1], specials[2]);
     const size_t n = (size_t)T * Kl * nu;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_gather_noise, dim3(blocks), dim3(256), 0, s, noise, order, noise_sorted, Kl, T, nu);
     return hipGetLastError();
+}
+
+void launch_gather_rows(const float* src, const int* order, float* dst, int Kl, int rows, hipStream_t s) {
+    int blocks = (rows * Kl + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, s, src, order, dst, Kl, rows);
 }
 
 }  // namespace m3

@@ -109,6 +109,11 @@ class HipEngine:
         """Samples sorted into coherent wavefronts (default) or assigned by index; same results."""
         self._ck(self.lib.m3_set_wave_order(self._h, int(bool(on))))
 
+    def relabel_samples(self):
+        """Permute the noise rows once into wavefront order (labels of a generated sample set carry
+        no meaning): same sample set, coalesced stores.  See include/m3p2i_hip.h."""
+        self._ck(self.lib.m3_relabel_samples(self._h))
+
     def enable_timing(self, on=True):
         self._ck(self.lib.m3_enable_timing(self._h, int(on)))
 

@@ -77,6 +77,7 @@ class MPPIConfig(object):
     rank: int = 0                     # sample sharding: this process owns
     world_size: int = 1               #   num_samples/world_size consecutive samples
     shard_mix: Optional[bool] = None  # None: one-collective protocol whenever it applies
+    relabel_samples: bool = True      # generated noise rows into wavefront-coherent order (same sample set)
 
 
 def _get(cfg, name, default=None):
@@ -166,6 +167,7 @@ class MPPI():
         sm = _get(m, "shard_mix", None)
         single = not (self.multi_modal and self.mppi_mode != "simple")
         self.shard_mix = bool(world > 1 and single and (True if sm is None else sm))
+        self.relabel_samples = bool(_get(m, "relabel_samples", True))
         self._engine = ENGINE_CLS(make_config(
             K=self.K, K_local=self.K_local, k_offset=self.k_offset, T=self.T, nu=self.nu,
             env_type=self.env_type, multi_modal=self.multi_modal,
@@ -268,6 +270,8 @@ class MPPI():
             e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree,
                                                     self.k_offset, self.k_offset + self.K_local),
                               self.degree, 0.5)
+            if self.relabel_samples and hasattr(e, "relabel_samples"):
+                e.relabel_samples()   # the sampler's row labels are arbitrary: wavefront-coherent ones
         else:   # engines without the device sampler (the CPU test stand-in)
             e.set_noise(sampling.halton_spline_delta(self.K, self.T, self.nu, self.knot_scale, self.degree,
                                                      self.k_offset, self.k_offset + self.K_local))

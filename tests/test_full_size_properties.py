@@ -168,3 +168,46 @@ def test_wave_order_does_not_change_results(name):
         eng.close()
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["C2_push_K2000_T30", "C3_hybrid_K4000_T30"])
+def test_relabelled_samples_are_the_same_sample_set(name):
+    """m3_relabel_samples permutes the noise rows once into wavefront order (within each mode's half,
+    the rows of samples 0, K/2 and K-1 in place).  The sample SET must be unchanged: the trajectory
+    costs of the relabelled run are a permutation of the others (bit for bit), the special samples
+    keep theirs, the noise buffer holds the same rows, and the plan agrees to summation order."""
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd import sampling
+    c = CONFIGS[name]
+    K, T, half = c["K"], c["T"], c["K"] // 2
+    knots = sampling.halton_knots(K, T, 2)
+    runs = []
+    for relabel in (False, True):
+        eng = build(c)
+        eng.set_wave_order(False)      # by index in both runs: only the labels differ
+        eng.set_noise_knots(knots, 2, 0.5)
+        eng.set_wave_order(True)
+        if relabel:
+            eng.relabel_samples()
+        else:
+            eng.set_wave_order(False)
+        eng.command()
+        torch.cuda.synchronize()
+        runs.append(dict(J=eng.buffer(L.BUF_TRAJ_COST).clone(), noise=eng.buffer(L.BUF_NOISE).clone(),
+                         plan=eng.buffer(L.BUF_ACTION_OUT).clone(), w=eng.buffer(L.BUF_WEIGHTS).clone(),
+                         topJ=eng.buffer(L.BUF_TRAJ_COST)[eng.buffer(L.BUF_TOP_IDX).long()].clone()))
+        eng.close()
+    a, b = runs
+    assert not torch.equal(a["J"], b["J"])                                   # labels did move
+    for lo, hi in (((0, half), (half, K)) if c["mm"] else ((0, K),)):          # ... inside each mode's half only
+        assert torch.equal(torch.sort(a["J"][lo:hi]).values, torch.sort(b["J"][lo:hi]).values)
+    for k in (0, half, K - 1):
+        assert a["J"][k] == b["J"][k]
+        assert torch.equal(a["noise"][:, k], b["noise"][:, k])
+    rows_a = {bytes(r.cpu().numpy().tobytes()) for r in a["noise"].permute(1, 0, 2)}
+    rows_b = {bytes(r.cpu().numpy().tobytes()) for r in b["noise"].permute(1, 0, 2)}
+    assert rows_a == rows_b
+    assert torch.equal(a["topJ"], b["topJ"])                                 # the same 20 best trajectories
+    np.testing.assert_allclose(a["plan"].cpu().numpy(), b["plan"].cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(torch.sort(a["w"]).values.cpu().numpy(), torch.sort(b["w"]).values.cpu().numpy(),
+                               rtol=1e-4, atol=1e-9)
