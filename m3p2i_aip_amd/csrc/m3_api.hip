@@ -538,7 +538,9 @@ extern "C" int m3_rollout(m3_handle* h) {
     }
     a.lanes = h->lanes_override > 0 ? h->lanes_override : rollout_lanes_for(c.K_local);
     a.delta = (const float*)h->buf[M3_BUF_NOISE];
-    if (h->order_dirty || (h->wave_order && h->calls % ORDER_REFRESH == 0)) {
+    if (h->relabelled && h->wave_order && h->calls % ORDER_REFRESH == 0 && h->calls != h->last_noise_call)
+        h->relabel_pending = true;   // the objects move: relabel again now and then (labels carry no meaning)
+    if (h->order_dirty || h->relabel_pending || (h->wave_order && h->calls % ORDER_REFRESH == 0)) {
         const int rc = refresh_wave_order(h);
         if (rc != M3_OK) return rc;
     }

@@ -44,8 +44,12 @@ void launch_spline_noise(const float* knots, float* noise, int Kl, int nu, int n
 // (principal axis of their positions; in the reference's point_env they sit in one row).  Samples of a wave
 // then meet the same object, or none.  Lane placement cannot change a sample's numbers (all
 // arithmetic is lane-local; tests/test_full_size_properties.py).  Measured (bench.py, order off ->
-// on): push K=2000 0.191 -> 0.171 ms, hybrid K=4000 0.231 -> 0.210, north-star K=10000 0.208 -> 0.190,
-// although the rollout's loads and stores become scattered 8-16 B pieces instead of coalesced rows.
+// on): push K=2000 0.191 -> 0.171 ms, hybrid K=4000 0.231 -> 0.210, north-star K=10000 0.208 -> 0.190.
+// Two ways to apply the order: as an indirection (lane slot -> sample; noise rows gathered once so
+// the loads stay coalesced, but the stores into the sample-indexed outputs become scattered 8-16 B
+// pieces: HBM write traffic 2.8x), or -- for generated noise, whose row labels carry no meaning -- by
+// RELABELLING the samples once (m3_relabel_samples: rows permuted in place, samples with a role of
+// their own fixed): index order is then wavefront order, everything coalesced, another -5 %.
 // Keys tried and measured worse: direction (angle) of the centroid, of the mid-horizon and end
 // displacement, radius, Morton cells, sectors x radius (0 .. -5 %); the mid-horizon displacement
 // on the same axis is equivalent.
