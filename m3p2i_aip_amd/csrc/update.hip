@@ -886,12 +886,36 @@ __global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
     }
 }
 
+// MULTI = false: single-mode MPPI with K > 16384 (beyond every reference config, but the rollout's
+// saturation region): beta is given, so no search -- k_sumexp_single leaves every workgroup's local
+// softmin (m_b, S_b = sum exp(-(J - m_b)/beta)) in part_min, and every workgroup here forms the global
+// one from those <= 256 pairs itself: m = min m_b, eta = sum_b exp(-(m_b - m)/beta) S_b (workgroup order).
+template <bool MULTI>
 __global__ __launch_bounds__(AP_T) void k_apply_weights(const UpdateArgs a) {
     __shared__ float red[3 * 16];
     __shared__ VI redvi[16];
     const int Kg = a.Kg, half = a.half_g - a.kbase, tid = threadIdx.x, nb = gridDim.x;
-    const SearchOut so = *a.srch;
     const float INF = __builtin_inff();
+    SearchOut so;
+    if constexpr (MULTI) {
+        so = *a.srch;
+    } else {
+        __shared__ float s_mb[256], s_sb[256], s_so[2];
+        const float bs = a.mode_simple ? a.lambda_ : a.info->beta;
+        for (int b = tid; b < nb; b += AP_T) { s_mb[b] = a.part_min[b * 3 + 0]; s_sb[b] = a.part_min[b * 3 + 1]; }
+        __syncthreads();
+        if (tid == 0) {
+            float m = INF;
+            for (int b = 0; b < nb; ++b) m = fminf(m, s_mb[b]);
+            const float nib = -1.0f / bs;
+            float et = 0.0f;
+            for (int b = 0; b < nb; ++b) et += m3_exp(nib * (s_mb[b] - m)) * s_sb[b];
+            s_so[0] = m; s_so[1] = et;
+        }
+        __syncthreads();
+        so.beta[0] = bs; so.eta[0] = s_so[1]; so.mn[0] = s_so[0];
+        so.beta[1] = so.beta[2] = 1.0f; so.eta[1] = so.eta[2] = 1.0f; so.mn[1] = so.mn[2] = 0.0f;
+    }
     const float i0 = 1.0f / so.eta[0], n0 = -1.0f / so.beta[0];
     const float i1 = 1.0f / so.eta[1], n1 = -1.0f / so.beta[1];
     const float i2 = 1.0f / so.eta[2], n2 = -1.0f / so.beta[2];
@@ -907,21 +931,25 @@ __global__ __launch_bounds__(AP_T) void k_apply_weights(const UpdateArgs a) {
             a.w[k] = wk;
             if (k < half) hs[0] += wk; else hs[1] += wk;
             if (vi_less(-wk, k, b0.v, b0.i)) { b0.v = -wk; b0.i = k; }
-            if (k < half) {
-                const float w1k = i1 * m3_exp(n1 * (v - so.mn[1]));
-                a.w1[k] = w1k;
-                if (vi_less(-w1k, k, b1.v, b1.i)) { b1.v = -w1k; b1.i = k; }
-            } else {
-                const float w2k = i2 * m3_exp(n2 * (v - so.mn[2]));
-                a.w2[k - half] = w2k;
-                if (vi_less(-w2k, k, b2.v, b2.i)) { b2.v = -w2k; b2.i = k; }
+            if constexpr (MULTI) {
+                if (k < half) {
+                    const float w1k = i1 * m3_exp(n1 * (v - so.mn[1]));
+                    a.w1[k] = w1k;
+                    if (vi_less(-w1k, k, b1.v, b1.i)) { b1.v = -w1k; b1.i = k; }
+                } else {
+                    const float w2k = i2 * m3_exp(n2 * (v - so.mn[2]));
+                    a.w2[k - half] = w2k;
+                    if (vi_less(-w2k, k, b2.v, b2.i)) { b2.v = -w2k; b2.i = k; }
+                }
             }
         }
     }
     block_sum<2>(hs, red);
     b0 = block_argmin(b0, redvi);
-    b1 = block_argmin(b1, redvi);
-    b2 = block_argmin(b2, redvi);
+    if constexpr (MULTI) {
+        b1 = block_argmin(b1, redvi);
+        b2 = block_argmin(b2, redvi);
+    }
     // partials: write-through, then a relaxed agent ticket (per-XCD L2s are not coherent)
     __shared__ float s_p[256 * 8];
     __shared__ int s_last;
@@ -955,11 +983,51 @@ __global__ __launch_bounds__(AP_T) void k_apply_weights(const UpdateArgs a) {
         }
         m3_info* f = a.info;
         f->best_idx = a.kbase + c0.i;
-        f->best_idx_1 = c1.i;
-        f->best_idx_2 = c2.i;
+        f->best_idx_1 = MULTI ? c1.i : -1;
+        f->best_idx_2 = MULTI ? c2.i : -1;
         f->wsum_push = h0; f->wsum_pull = h1;
         f->pull_preference = h1 > h0;
+        if constexpr (!MULTI) {   // what k_weights' single-softmin branch reports
+            f->eta = so.eta[0]; f->eta_1 = 0.0f; f->eta_2 = 0.0f;
+            f->iters = 1; f->iters_1 = 1; f->iters_2 = 1;
+            f->beta_1 = 1.0f; f->beta_2 = 1.0f;
+            float nb_ = so.beta[0];
+            if (!a.mode_simple && a.env_type == M3_ENV_PANDA) {  // mppi.py:446-454
+                if (so.eta[0] > 20.0f) nb_ = nb_ * 0.9f;
+                else if (so.eta[0] < 10.0f) nb_ = nb_ * 1.2f;
+            }
+            if (!a.mode_simple) f->beta = nb_;
+        }
     }
+}
+
+// local softmin of 4096 costs per workgroup (single mode, K > 16384); the top-k stage-A workgroups ride along
+__global__ __launch_bounds__(AP_T) void k_sumexp_single(const UpdateArgs a) {
+    __shared__ float red[3 * 16];
+    const int Kg = a.Kg, tid = threadIdx.x, nb = (Kg + AP_T * AP_RPT - 1) / (AP_T * AP_RPT);
+    if ((int)blockIdx.x >= nb) {
+        topk_stage_a(a, blockIdx.x - nb);
+        return;
+    }
+    const float INF = __builtin_inff();
+    const float bs = a.mode_simple ? a.lambda_ : a.info->beta;
+    const int base = blockIdx.x * AP_T * AP_RPT;
+    float v[AP_RPT];
+    float mn[1] = {INF};
+#pragma unroll
+    for (int e = 0; e < AP_RPT; ++e) {
+        const int k = base + e * AP_T + tid;
+        const float jv = a.Jall[min(k, Kg - 1)];
+        v[e] = (k < Kg) ? jv : INF;
+        mn[0] = fminf(mn[0], v[e]);
+    }
+    block_min<1>(mn, red);
+    const float nib = -1.0f / bs;
+    float es[1] = {0.0f};
+#pragma unroll
+    for (int e = 0; e < AP_RPT; ++e) es[0] += m3_exp(nib * (v[e] - mn[0]));   // past-the-end rows: exp(-inf) = 0
+    block_sum<1>(es, red);
+    if (tid == 0) { a.part_min[blockIdx.x * 3 + 0] = mn[0]; a.part_min[blockIdx.x * 3 + 1] = es[0]; }
 }
 
 int weights_threads(int Kg) { return Kg <= 8192 ? 256 : WT_MAX; }
@@ -971,7 +1039,14 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
     if (threads != 256 && a.multi_modal && !a.mode_simple && apply_workgroups(a.Kg) <= 256) {  // split path
         // (k_mins / k_ladder already launched)
         hipLaunchKernelGGL(k_search, dim3(1 + a.n_cand), dim3(WT_MAX), 0, s, b);
-        hipLaunchKernelGGL(k_apply_weights, dim3(apply_workgroups(a.Kg)), dim3(AP_T), 0, s, b);
+        hipLaunchKernelGGL(k_apply_weights<true>, dim3(apply_workgroups(a.Kg)), dim3(AP_T), 0, s, b);
+        return;
+    }
+    if (!(a.multi_modal && !a.mode_simple) && !a.record && a.Kg > 16384 && apply_workgroups(a.Kg) <= 256 &&
+        mins_workgroups(a.Kg) == apply_workgroups(a.Kg)) {
+        // single softmin over many costs: local softmins on many workgroups, then the weights pass
+        hipLaunchKernelGGL(k_sumexp_single, dim3(apply_workgroups(a.Kg) + a.n_cand), dim3(AP_T), 0, s, b);
+        hipLaunchKernelGGL(k_apply_weights<false>, dim3(apply_workgroups(a.Kg)), dim3(AP_T), 0, s, b);
         return;
     }
     if (threads == 256) {
@@ -998,9 +1073,15 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
 // columns in one pass) and, when n_chunk > 1, the last workgroup to arrive for a time step adds
 // the partials in chunk order -- the result does not depend on which one that is.
 constexpr int ST = 256;
-constexpr int WS_CHUNK = 8192;  // samples per k_wsum workgroup
 constexpr int WS_BATCH = 8;     // loads in flight per thread and array
-int wsum_chunks(int Kl) { return (Kl + WS_CHUNK - 1) / WS_CHUNK; }
+// samples per chunk: 8192, more when that would give more than 32 chunks per time step -- their
+// arrival tickets share one address per time step and serialise (~0.3 us each)
+__host__ __device__ inline int wsum_chunk_len(int Kl) {
+    const int unit = 2048;   // WS_BATCH * ST
+    const int per32 = (((Kl + 31) / 32) + unit - 1) / unit * unit;
+    return per32 > 8192 ? per32 : 8192;
+}
+int wsum_chunks(int Kl) { const int L = wsum_chunk_len(Kl); return (Kl + L - 1) / L; }
 
 template <bool SC1>
 __device__ __forceinline__ void finalize_body(const UpdateArgs& a, float* sm);  // defined below
@@ -1022,9 +1103,10 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     for (int j = 0; j < NU; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
     // fixed trip count, clamped unconditional loads: all the loads of a workgroup's slice are in
     // flight together (conditional loads each became a branch region ending in s_waitcnt vmcnt(0))
-    const int i1 = min(Kl, (c + 1) * WS_CHUNK);
+    const int clen = wsum_chunk_len(Kl);
+    const int i1 = min(Kl, (c + 1) * clen);
     const int nh2 = a.Kg - half;
-    for (int i0 = c * WS_CHUNK; i0 < i1; i0 += WS_BATCH * ST)
+    for (int i0 = c * clen; i0 < i1; i0 += WS_BATCH * ST)
 #pragma unroll
     for (int it = 0; it < WS_BATCH; ++it) {
         const int i = i0 + it * ST + tid;
@@ -1080,6 +1162,18 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         }
         __syncthreads();
     }
+    // best rows (zero unless the owning rank); before the arrival ticket below, which covers them
+    if (c == 0 && tid < 3 * NU) {
+        const int which = tid / NU, j = tid % NU;
+        const int gi = (which == 0) ? a.info->best_idx : (which == 1 ? a.info->best_idx_1 : a.info->best_idx_2);
+        float v = 0.0f;
+        const int li = gi - k0;
+        if (gi >= 0 && li >= 0 && li < Kl) v = act[(size_t)li * NU + j];
+        float* dst = &a.reduce[reduce_off_best(which, T, NU) + t * NU + j];
+        if (a.fuse_finalize) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = v;
+    }
+    bool t_last = true;   // this workgroup completes its time step (always, with one chunk)
     if (C > 1) {
         // in-launch combine.  Per-XCD L2s are not coherent with each other: the partials are
         // written through (sc1 stores) and read back with sc1 loads, so no L2 write-back /
@@ -1094,7 +1188,8 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
             red[47] = __int_as_float(is_last);
         }
         __syncthreads();
-        if (__float_as_int(red[47]) && tid < 3 * NU) {
+        t_last = __float_as_int(red[47]) != 0;
+        if (t_last && tid < 3 * NU) {
             const int which = tid / NU, j = tid % NU;
             float sum = 0.0f;
             for (int cc = 0; cc < C; ++cc)
@@ -1105,28 +1200,19 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
             else *dst = sum;
         }
     }
-    // best rows (zero unless the owning rank)
-    if (c == 0 && tid < 3 * NU) {
-        const int which = tid / NU, j = tid % NU;
-        const int gi = (which == 0) ? a.info->best_idx : (which == 1 ? a.info->best_idx_1 : a.info->best_idx_2);
-        float v = 0.0f;
-        const int li = gi - k0;
-        if (gi >= 0 && li >= 0 && li < Kl) v = act[(size_t)li * NU + j];
-        float* dst = &a.reduce[reduce_off_best(which, T, NU) + t * NU + j];
-        if (a.fuse_finalize) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *dst = v;
-    }
-    if (a.fuse_finalize) {
+    if (a.fuse_finalize && t_last) {
         // Unsharded command(): the mean update / filter (k_finalize's work, T*nu values) is done by
-        // the LAST of the T x n_chunk workgroups to finish instead of by one more launch (a
-        // dependent launch costs ~3.5 us of turnaround + ~5 us for the one-workgroup kernel).
-        // Same hand-off as the chunk combine: write-through stores, then a relaxed agent ticket.
+        // the LAST workgroup to finish instead of by one more launch (a dependent launch costs ~3.5 us
+        // of turnaround + ~5 us for the one-workgroup kernel).  Same hand-off as the chunk combine:
+        // write-through stores, then a relaxed agent ticket -- taken only by the workgroup that
+        // completed its time step (T arrivals on this address, not T x n_chunk: 3840 of them at
+        // K = 1 M serialised to ~0.4 ms).
         extern __shared__ float sm_fin[];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             const int ticket = __hip_atomic_fetch_add(&a.wcount[T], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int is_last = ticket == T * C - 1;
+            const int is_last = ticket == T - 1;
             if (is_last) a.wcount[T] = 0;
             red[46] = __int_as_float(is_last);
         }

@@ -26,6 +26,7 @@ CONFIGS = {
     "C5_hybrid_K64000_T30": dict(K=64000, T=30, nu=2, env="point_env", task="push_pull", goal=(-3.75, -3.75), mm=True),
     "push_K6000_T30": dict(K=6000, T=30, nu=2, env="point_env", task="push", goal=(-1.0, -1.0), mm=False),
     "hybrid_K6000_T30": dict(K=6000, T=30, nu=2, env="point_env", task="push_pull", goal=(-3.75, -3.75), mm=True),
+    "push_K40000_T30": dict(K=40000, T=30, nu=2, env="point_env", task="push", goal=(-1.0, -1.0), mm=False),
     "northstar_push_K10000_T30": dict(K=10000, T=30, nu=2, env="point_env", task="push", goal=(-1.0, -1.0), mm=False),
 }
 
