@@ -31,6 +31,8 @@
  *                                 refresh of _dof_state/_root_state/_rigid_body_state/
  *                                 _net_contact_force :98-118
  *   m3_cost                     Objective.compute_cost (step mode) cost_functions.py:19-36
+ *   m3_sim_suction_forces /     calculate_suction, check_and_apply_suction utils/skill_utils.py:36-94
+ *   m3_sim_check_and_apply_suction   (the real-world side of scripts/sim.py:41-49)
  *   m3_get_buffer               attribute access MPPI.states/actions/weights/top_trajs/...
  *   m3_get_info                 M3P2I.get_pull_preference m3p2i.py:16-22 (+ diagnostics)
  *
@@ -222,6 +224,9 @@ int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, in
 int m3_set_multi_modal(m3_handle* h, int multi_modal);
 /* warm-start state (means, best trajs, U): which = M3_BUF_MEAN.., host pointer [T][nu] */
 int m3_set_plan(m3_handle* h, int which, const float* host_values);
+/* the persistent softmin temperature (MPPI.beta, mppi.py:184; adapted by the panda_env's single-mode
+ * update, mppi.py:446-454): together with m3_set_plan this restores a saved warm start */
+int m3_set_beta(m3_handle* h, float beta);
 int m3_reset(m3_handle* h); /* zero means/best/pending forces, beta = 1, call counter = 0 */
 /* Where m3_finalize writes the returned plan (`action`, mppi.py:257-263): a caller-owned device
  * buffer of [T][nu] floats ([u_per_command][nu] in simple mode), or NULL for the library's
@@ -248,8 +253,9 @@ int m3_set_world_panda_raw(m3_handle* h, const float* w31);
 int m3_bind_sim_panda(m3_handle* h, const float* dof_state_dev, const float* root_state_dev,
                       int n_actors, int cubeA_actor, int cubeB_actor);
 
-/* one MPPI iteration = rollout + update + finalize.  action_host: optional [T][nu] (or
- * [u_per_command][nu] in simple mode) host buffer; if non-NULL the call synchronises. */
+/* one MPPI iteration = rollout + update + finalize of an UNSHARDED handle.  action_host: optional
+ * [T][nu] (or [u_per_command][nu] in simple mode) host buffer; if non-NULL the call synchronises.
+ * M3_ERR_STATE on a sharded handle (K_local != K_global): the collectives go between the phases. */
 int m3_command(m3_handle* h, float* action_host);
 /* the three phases, for sharded use: rollout -> (all-gather TRAJ_COST into TRAJ_COST_ALL)
  * -> update -> (all-reduce REDUCE) -> finalize.  With K_local == K_global m3_update uses
@@ -282,6 +288,17 @@ int m3_sim_set_velocity_target(m3_handle* h, const float* u_dev /* [Kl][nu] */);
 int m3_sim_apply_body_forces(m3_handle* h, const float* f_dev /* [Kl][nB][3] */);
 int m3_sim_step(m3_handle* h);       /* one step(): dt with substeps, then push views */
 int m3_cost(m3_handle* h, float* cost_dev /* [Kl] */); /* Objective.compute_cost */
+/* the 1-env "real world" of scripts/sim.py:41-49 (point_env), evaluated on the device:
+ * calculate_suction (utils/skill_utils.py:59-94): forces_dev f32 [Kl][nB][3] is overwritten with the
+ * suction pair (box row, last body's row); threshold 1.5 for a 1-env handle, 1.8 otherwise. */
+int m3_sim_suction_forces(m3_handle* h, float kp_suction, float* forces_dev);
+/* check_suction_condition + check_and_apply_suction (utils/skill_utils.py:36-56): per environment, the
+ * robot is within 0.6 of the box and action . (robot - box) > 0; where that holds and apply != 0 the
+ * suction pair becomes the pending body force of the next m3_sim_step.  action_dev f32 [Kl][2];
+ * applied_dev i32 [Kl] (optional) receives the condition.  No host synchronisation. */
+int m3_sim_check_and_apply_suction(m3_handle* h, const float* action_dev, float kp_suction, int apply,
+                                   int* applied_dev);
+
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("m3_set_multi_modal", C.c_int, [_H, C.c_int]),
     ("m3_set_plan", C.c_int, [_H, C.c_int, _FP]),
     ("m3_set_action_out", C.c_int, [_H, C.c_void_p]),
+    ("m3_set_beta", C.c_int, [_H, C.c_float]),
     ("m3_reset", C.c_int, [_H]),
     ("m3_set_world_point", C.c_int, [_H, C.POINTER(PointWorld)]),
     ("m3_set_world_point_raw", C.c_int, [_H, C.POINTER(C.c_float)]),
@@ -100,6 +101,8 @@ SYMBOLS = [
     ("m3_sim_apply_body_forces", C.c_int, [_H, _FP]),
     ("m3_sim_step", C.c_int, [_H]),
     ("m3_cost", C.c_int, [_H, _FP]),
+    ("m3_sim_suction_forces", C.c_int, [_H, C.c_float, _FP]),
+    ("m3_sim_check_and_apply_suction", C.c_int, [_H, _FP, C.c_float, C.c_int, C.c_void_p]),
 ]
 
 _lib = None

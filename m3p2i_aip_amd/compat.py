@@ -8,11 +8,12 @@ section 8(f)); when the real packages are absent, small stand-ins cover exactly 
 scripts make.
 
 Host-side helpers restated here (all O(1) per command, no data parallelism):
-  PLANNER_SIMPLE / PLANNER_AIF_PANDA / AiAgent / adapt_act_sel / MDP templates
+  PLANNER_SIMPLE / PLANNER_AIF_PANDA / AiAgent / adapt_act_sel / MDPIsCubeAtReal
                             planners/task_planner/*.py  (-> m3p2i_aip_amd/task_planner.py)
   torch_to_bytes / bytes_to_torch   utils/data_transfer.py:4-12
-  calculate_suction / check_suction_condition / check_and_apply_suction / time_tracking
-                            utils/skill_utils.py:25-94 (the 1-env "real world" side of sim.py)
+  calculate_suction / check_suction_condition / check_and_apply_suction
+                            utils/skill_utils.py:36-94 -> HIP kernel k_sim_suction (device, no host sync)
+  time_tracking             utils/skill_utils.py:25-33
   ExampleConfig defaults    config/config_point.yaml, config_panda.yaml, mppi/*.yaml,
                             isaacgym/*.yaml, config/config_store.py:7-29
 """
@@ -49,33 +50,30 @@ set_task_planner = task_planner.set_task_planner
 
 
 # ------------------------------------------------------------------ skill_utils.py:25-94
+# The suction skill of the 1-env "real world" (scripts/sim.py:41-49).  The geometry lives in the HIP
+# library (m3_sim_suction_forces / m3_sim_check_and_apply_suction, csrc/rollout_point.hip:
+# k_sim_suction); what stays on the host is the part that only reads the config.
+def _suction_enabled(cfg):
+    return cfg.task in ("pull", "push_pull") and bool(cfg.suction_active)
+
+
 def calculate_suction(cfg, sim):
-    dir_vector = sim.get_actor_position_by_name("box")[:, :2] - sim.robot_pos
-    magnitude = (1 / torch.linalg.norm(dir_vector, dim=1)).reshape([sim.num_envs, 1])
-    unit_force = dir_vector * magnitude
-    forces = torch.zeros((sim.num_envs, sim.bodies_per_env, 3), dtype=torch.float32, device=sim.device)
-    mask = (magnitude > (1.5 if sim.num_envs == 1 else 1.8)).reshape(sim.num_envs)
-    block_index = sim._get_actor_index_by_name("box").item()
-    forces[mask, block_index, 0] = -cfg.kp_suction * unit_force[mask, 0]
-    forces[mask, block_index, 1] = -cfg.kp_suction * unit_force[mask, 1]
-    forces[mask, -1, 0] = cfg.kp_suction * unit_force[mask, 0]
-    forces[mask, -1, 1] = cfg.kp_suction * unit_force[mask, 1]
-    return torch.clamp(forces, min=-500, max=500)
+    """[num_envs, bodies_per_env, 3] suction forces on the box and the robot's last link."""
+    return sim._engine.sim_suction_forces(cfg.kp_suction)
 
 
 def check_suction_condition(cfg, sim, action):
-    if cfg.task not in ['pull', 'push_pull'] or not cfg.suction_active:
+    """bool for env 0 (one host sync, as the reference's .item())."""
+    if not _suction_enabled(cfg):
         return False
-    dir_robot_block = (sim.robot_pos - sim.get_actor_position_by_name("box")[:, :2]).squeeze(0)
-    action_align_pull = torch.sum(action * dir_robot_block).item()
-    return bool(torch.linalg.norm(dir_robot_block) < 0.6 and action_align_pull > 0)
+    return bool(sim._engine.sim_check_and_apply_suction(action, cfg.kp_suction, apply=False, want_flags=True)[0].item())
 
 
 def check_and_apply_suction(cfg, sim, action):
-    if check_suction_condition(cfg, sim, action):
-        sim.apply_rigid_body_force_tensors(calculate_suction(cfg, sim))
-        return True
-    return False
+    """Stages the suction pair for the next sim.step() wherever the condition holds; enqueued on the
+    stream, nothing is read back (the reference's "suction!!!" / "no suction..." prints are dropped)."""
+    if _suction_enabled(cfg):
+        sim._engine.sim_check_and_apply_suction(action, cfg.kp_suction, apply=True)
 
 
 def time_tracking(t, cfg):
@@ -203,15 +201,13 @@ def install(force_standins: bool = False):
                             Objective=cost_functions.Objective)
     tp = mod("m3p2i_aip.planners.task_planner")
     tp.task_planner = mod("m3p2i_aip.planners.task_planner.task_planner", set_task_planner=set_task_planner,
-                          PLANNER_SIMPLE=PLANNER_SIMPLE, PLANNER_AIF_PANDA=PLANNER_AIF_PANDA,
-                          PLANNER_PATROLLING=task_planner.PLANNER_PATROLLING)
+                          PLANNER_SIMPLE=PLANNER_SIMPLE, PLANNER_AIF_PANDA=PLANNER_AIF_PANDA)
     tp.ai_agent = mod("m3p2i_aip.planners.task_planner.ai_agent", AiAgent=task_planner.AiAgent)
     tp.adaptive_action_selection = mod("m3p2i_aip.planners.task_planner.adaptive_action_selection",
                                        adapt_act_sel=task_planner.adapt_act_sel)
     tp.isaac_state_action_templates = mod(
         "m3p2i_aip.planners.task_planner.isaac_state_action_templates",
-        **{n: getattr(task_planner, n) for n in ("MDPIsAt", "MDPIsCloseTo", "MDPIsLocFree", "MDPIsBlockAt",
-                                                 "MDPIsCubeAt", "MDPIsCubeAtReal")})
+        MDPIsCubeAtReal=task_planner.MDPIsCubeAtReal)
     cfgm = mod("m3p2i_aip.config")
     cfgm.config_store = mod("m3p2i_aip.config.config_store", ExampleConfig=ExampleConfig)
     ut = mod("m3p2i_aip.utils")

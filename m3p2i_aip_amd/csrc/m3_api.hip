@@ -2,6 +2,7 @@
 // point replaces in the reference).  Host code only: argument checking, buffer ownership,
 // launch sequencing on the handle's HIP stream.
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -415,6 +416,15 @@ extern "C" int m3_set_plan(m3_handle* h, int which, const float* v) {
     return M3_OK;
 }
 
+extern "C" int m3_set_beta(m3_handle* h, float beta) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!(beta > 0.0f)) return fail(h, M3_ERR_BAD_ARG, "m3_set_beta: beta must be > 0");
+    HIPCHK(h, hipMemcpyAsync((char*)h->buf[M3_BUF_INFO] + offsetof(m3_info, beta), &beta, sizeof(float),
+                             hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // `beta` is a stack value
+    return M3_OK;
+}
+
 extern "C" int m3_set_action_out(m3_handle* h, float* dev_ptr) {
     if (!h) return M3_ERR_BAD_ARG;
     if (h->cfg.sim_only) return fail(h, M3_ERR_STATE, "m3_set_action_out: handle was created sim_only");
@@ -704,17 +714,16 @@ extern "C" int m3_update_finalize(m3_handle* h) {
 }
 
 extern "C" int m3_command(m3_handle* h, float* action_host) {
+    if (!h) return M3_ERR_BAD_ARG;
+    // a sharded handle needs the collective(s) between the phases: running update + finalize on the
+    // local costs alone would return a plan built from zero / stale remote slices without an error
+    if (h->cfg.K_local != h->cfg.K_global)
+        return fail(h, M3_ERR_STATE, "m3_command: sharded handle (K_local != K_global): call m3_rollout, m3_update, "
+                                     "m3_finalize with the collective(s) in between (include/m3p2i_hip.h)");
     int rc = m3_rollout(h);
     if (rc != M3_OK) return rc;
-    if (h->cfg.K_local == h->cfg.K_global) {
-        rc = m3_update_finalize(h);   // weights -> sums + (last workgroup) mean update / filter
-        if (rc != M3_OK) return rc;
-    } else {
-        rc = m3_update(h);
-        if (rc != M3_OK) return rc;
-        rc = m3_finalize(h);
-        if (rc != M3_OK) return rc;
-    }
+    rc = m3_update_finalize(h);   // weights -> sums + (last workgroup) mean update / filter
+    if (rc != M3_OK) return rc;
     if (action_host) {
         const m3_config& c = h->cfg;
         const int rows = c.mode_simple ? c.u_per_command : c.T;
@@ -859,6 +868,28 @@ extern "C" int m3_sim_step(m3_handle* h) {
     }
     HIPCHK(h, hipGetLastError());
     return M3_OK;
+}
+
+static int suction_impl(m3_handle* h, float kp, const float* action, int apply, float* forces, int* flags) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (h->cfg.env_type != M3_ENV_POINT) return fail(h, M3_ERR_UNSUPPORTED, "suction is a point_env skill (skill_utils.py:36-94)");
+    if (!h->views_bound || !h->sim_world) return fail(h, M3_ERR_STATE, "suction: views not bound");
+    const float thresh = (h->cfg.K_local == 1) ? 1.5f : 1.8f;   // skill_utils.py:75-82 (sim.num_envs == 1: real world)
+    launch_sim_suction(h->views, h->sim_world, h->cfg.K_local, kp, thresh, 0.6f /* skill_utils.py:56 */, action, apply,
+                       forces, flags, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
+extern "C" int m3_sim_suction_forces(m3_handle* h, float kp_suction, float* forces_dev) {
+    if (!forces_dev) return fail(h, M3_ERR_BAD_ARG, "m3_sim_suction_forces: null argument");
+    return suction_impl(h, kp_suction, nullptr, 0, forces_dev, nullptr);
+}
+
+extern "C" int m3_sim_check_and_apply_suction(m3_handle* h, const float* action_dev, float kp_suction, int apply,
+                                              int* applied_dev) {
+    if (!action_dev) return fail(h, M3_ERR_BAD_ARG, "m3_sim_check_and_apply_suction: null argument");
+    return suction_impl(h, kp_suction, action_dev, apply, nullptr, applied_dev);
 }
 
 extern "C" int m3_cost(m3_handle* h, float* cost) {

@@ -335,6 +335,49 @@ void launch_sim_forces(const SimViews& v, float* world, const float* f, int Kl, 
     hipLaunchKernelGGL(k_sim_forces, dim3((Kl + 255) / 256), dim3(256), 0, s, v, world, f, Kl);
 }
 
+// The 1-env "real world" side of scripts/sim.py:41-49: suction between the robot and the box
+// (behaves like utils/skill_utils.py:36-94), evaluated on the wrapper's environments without a
+// host round trip.
+//   forces != null : calculate_suction -- the [Kl][nB][3] body-force tensor (zero except the box
+//                    row and the LAST body's row, +-kp * unit(box - robot) clamped to +-500, only
+//                    where 1/|box - robot| exceeds `thresh`)
+//   action != null : check_suction_condition -- robot within `reach` of the box and the commanded
+//                    velocity pointing away from it -- and, if `apply`, the force of above staged
+//                    as the pending external force of the next step (apply_rigid_body_force_tensors)
+__global__ void k_sim_suction(const SimViews v, float* wd, int Kl, float kp, float thresh, float reach,
+                              const float* action, int apply, float* forces, int* flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Kl) return;
+    float* p = wd + i;
+    const float ex = p[4 * Kl] - p[0 * Kl], ey = p[5 * Kl] - p[1 * Kl];   // robot -> box
+    const float len = sqrtf(ex * ex + ey * ey);
+    const float inv = 1.0f / len;
+    float fx = 0.0f, fy = 0.0f;                                          // force on the robot
+    if (inv > thresh) {
+        fx = clamp500(kp * (ex * inv));
+        fy = clamp500(kp * (ey * inv));
+    }
+    if (forces) {
+        float* f = forces + (size_t)i * v.n_bodies * 3;
+        for (int q = 0; q < v.n_bodies * 3; ++q) f[q] = 0.0f;
+        f[v.box_body * 3 + 0] = -fx; f[v.box_body * 3 + 1] = -fy;
+        f[(v.n_bodies - 1) * 3 + 0] = fx; f[(v.n_bodies - 1) * 3 + 1] = fy;
+    }
+    if (action) {
+        const float along = action[2 * i] * (-ex) + action[2 * i + 1] * (-ey);   // action . (robot - box)
+        const bool pulling = len < reach && along > 0.0f;
+        if (flags) flags[i] = pulling ? 1 : 0;
+        if (pulling && apply) {
+            p[18 * Kl] = fx; p[19 * Kl] = fy; p[20 * Kl] = -fx; p[21 * Kl] = -fy;
+        }
+    }
+}
+void launch_sim_suction(const SimViews& v, float* world, int Kl, float kp, float thresh, float reach,
+                        const float* action, int apply, float* forces, int* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_sim_suction, dim3((Kl + 255) / 256), dim3(256), 0, s, v, world, Kl, kp, thresh, reach,
+                       action, apply, forces, flags);
+}
+
 }  // namespace m3
 
 #ifdef M3_ABL_COUNT

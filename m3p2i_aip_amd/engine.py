@@ -156,6 +156,9 @@ class HipEngine:
         assert v.shape == (self.cfg.T, self.cfg.nu)
         self._ck(self.lib.m3_set_plan(self._h, which, v.ctypes.data))
 
+    def set_beta(self, beta):
+        self._ck(self.lib.m3_set_beta(self._h, float(beta)))
+
     def reset(self):
         self._ck(self.lib.m3_reset(self._h))
 
@@ -302,6 +305,24 @@ class HipEngine:
 
     def sim_step(self):
         self._ck(self.lib.m3_sim_step(self._h))
+
+    def sim_suction_forces(self, kp_suction):
+        """calculate_suction on the device: [K_local, n_bodies, 3] body forces (skill_utils.py:59-94)."""
+        nb = self._simviews[2].shape[1]
+        f = torch.empty(self.cfg.K_local, nb, 3, device=self.device, dtype=torch.float32)
+        self._ck(self.lib.m3_sim_suction_forces(self._h, float(kp_suction), f.data_ptr()))
+        return f
+
+    def sim_check_and_apply_suction(self, action, kp_suction, apply=True, want_flags=False):
+        """check_suction_condition (+ apply_rigid_body_force_tensors(calculate_suction) where it holds)
+        on the device, no host sync (skill_utils.py:36-56).  Returns the per-env condition (int32
+        device tensor) if want_flags."""
+        a = action.to(device=self.device, dtype=torch.float32).reshape(self.cfg.K_local, 2).contiguous()
+        flags = torch.empty(self.cfg.K_local, device=self.device, dtype=torch.int32) if want_flags else None
+        self._ck(self.lib.m3_sim_check_and_apply_suction(
+            self._h, a.data_ptr(), float(kp_suction), int(bool(apply)),
+            C.c_void_p(flags.data_ptr()) if want_flags else None))
+        return flags
 
     def cost(self, out=None):
         if out is None:

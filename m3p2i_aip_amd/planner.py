@@ -103,6 +103,13 @@ class MPPI():
             raise NotImplementedError("update_cov=True (flagged '!! weird' in mppi.py:199) is not supported")
         if _get(m, "noise_abs_cost", False):
             raise NotImplementedError("noise_abs_cost=True is not supported")
+        if _get(m, "U_init", None) is not None or float(_get(m, "u_init", 0.0) or 0.0) != 0.0:
+            raise NotImplementedError("U_init / u_init != 0 are not supported (no reference config sets them); "
+                                      "install a warm start with planner.mean_action = ... instead")
+        if float(_get(m, "u_scale", 1) or 1) != 1.0:
+            # the reference updates its distribution from the u_scale-d stack and divides afterwards
+            # (mppi.py:313,331,420); the kernels keep the unscaled actions throughout
+            raise NotImplementedError("u_scale != 1 is not supported (every reference config uses 1)")
 
         self.K = int(m.num_samples)
         self.half_K = int(self.K / 2)
@@ -337,6 +344,10 @@ class MPPI():
 
     def _update_exchange_finalize(self):
         e = self._engine
+        if self.world_size > 1 and self.collective is None:
+            raise RuntimeError("planner built with world_size > 1 but no collectives installed: call "
+                               "m3p2i_aip_amd.distributed.attach_collectives(planner) first (without the "
+                               "exchange the update would run on zero / stale remote slices)")
         if self.shard_mix:
             e.update()                      # softmin over the local shard -> this rank's record
             self._exchange("records")       # the one collective
@@ -430,9 +441,17 @@ class MPPI():
         if not can_fuse:
             self._fused = False
             return self._command_step()
+        # both legs must start from the same warm start (means, best trajectories, pending suction
+        # forces, adapted beta): snapshot it, run the fused leg, put it back, run the step leg
+        keep = [L.BUF_MEAN, L.BUF_MEAN_1, L.BUF_MEAN_2, L.BUF_BEST, L.BUF_BEST_1, L.BUF_BEST_2,
+                L.BUF_PENDING_FORCE]
+        saved = [self._buf(b).clone() for b in keep]
+        beta0 = self._engine.info().beta
         self._command_fused()
         Jf = self._buf(L.BUF_TRAJ_COST).clone()
-        self._engine.reset()
+        for b, v in zip(keep, saved):
+            self._buf(b).copy_(v)
+        self._engine.set_beta(beta0)
         out = self._command_step()
         Js = self._buf(L.BUF_TRAJ_COST)
         same = bool(torch.allclose(Jf, Js, rtol=1e-5, atol=1e-4))

@@ -7,7 +7,10 @@ Mirrors the reference's interface for the caller of the hot path (`reactive_tamp
 * `AiAgent`                   -- ai_agent.py:13-193 (discrete active-inference agent, horizon 2)
 * `adapt_act_sel`             -- adaptive_action_selection.py:11-84 (action selection with
                                  precondition push-back)
-* `MDP*` templates            -- isaac_state_action_templates.py:6-232
+* `MDP`, `MDPIsCubeAtReal`    -- isaac_state_action_templates.py:192-232 (the one template the
+                                 planner path uses; the others -- dead code in the reference,
+                                 SURVEY.md section 2 -- live on only as test data,
+                                 tests/aif_templates.py)
 
 This is a restatement, not a transcription: the agent's per-policy loops are evaluated as array
 operations over the policy axis and the templates are table-driven.  What is kept exactly is the
@@ -64,31 +67,6 @@ class MDP:
         self.D = np.full((n, 1), prior)             # belief about the current state
         self.E = np.asarray(habits, dtype=np.float64).reshape(m, 1)
         self.kappa_d = kappa_d                      # learning rate of D
-
-
-def MDPIsAt():            # templates :6-40
-    return MDP("isAt", ["at_goal", "not_at_goal"], ["idle", "move_to"],
-               [["none"], ["battery_ok"]], [1.01, 1])
-
-
-def MDPIsCloseTo():       # :42-76
-    return MDP("isCloseTo", ["close_to", "not_close_to"], ["idle", "approach_obj"],
-               [["none"], ["none"]], [1.01, 1])
-
-
-def MDPIsLocFree():       # :78-115
-    return MDP("isLocFree", ["loc_free", "not_loc_free"], ["idle", "push_to_non_goal", "pull_to_non_goal"],
-               [["none"], ["close_to"], ["close_to"]], [1.01, 1, 1])
-
-
-def MDPIsBlockAt():       # :117-154
-    return MDP("isBlockAt", ["block_at_loc", "not_block_at_loc"], ["idle", "push_to_goal", "pull_to_goal"],
-               [["none"], ["loc_free", "close_to"], ["loc_free", "close_to"]], [1.01, 1, 1])
-
-
-def MDPIsCubeAt():        # :156-190
-    return MDP("isCubeAt", ["cube_at_table", "cube_at_hand", "cube_at_goal"], ["idle", "pick", "place"],
-               [["cube_at_goal"], ["cube_at_table"], ["cube_at_hand"]], [1.0, 1.01, 1.0], kappa_d=0.8)
 
 
 def MDPIsCubeAtReal():    # :192-232
@@ -318,90 +296,70 @@ class PLANNER_SIMPLE:
 
 
 class PLANNER_AIF_PANDA(PLANNER_SIMPLE):
-    """Pick-and-place task planner of the panda_env (task_planner.py:41-107): observation from the
-    cube / goal / gripper poses -> active-inference action -> (task, goal) for the motion planner."""
+    """Pick-and-place task planner of the panda_env (behaves like task_planner.py:41-107).
+
+    Each tick maps the scene to one of three observations of the `isCubeAt` factor and lets the
+    active-inference agent pick the skill; what the motion planner receives is `(task, curr_goal)`.
+
+    The progress of the manipulation is kept as ONE monotone stage (0 cube on the table, 1 cube
+    within reach of the gripper, 2 cube above its goal): a stage, once reached, is never left --
+    the reference expresses the same with two sticky flags, exposed here as the read-only
+    `pick_always` / `place_always`."""
+
+    STAGE_PREFERENCE = ((0, 1, 0, 0),   # stage 0: want "cube_close_to_gripper"  -> reach
+                        (1, 0, 0, 0),   # stage 1: want "cube_at_table" (template order) -> pick
+                        (1, 0, 0, 0))   # stage 2: same preference, observation 2        -> place
+    PLACE_TOLERANCE = 0.03              # xy offset to the pre-place pose + orientation distance
+    SUCCESS_RADIUS = 0.04               # xy distance cube <-> goal while placing
 
     def __init__(self, cfg) -> None:
         import torch
         self.device = cfg.mppi.device
-        self.task = "idle"
+        self.task = self.curr_action = "idle"
         self.curr_goal = torch.zeros(7, device=self.device)
-        self.curr_action = "idle"
         self.ai_agent_task = [AiAgent(MDPIsCubeAtReal())]
-        self.obs = 0
-        self.prev_ee_state = torch.zeros(7, device=self.device)
-        self.pick_always = False       # latches: once close to the cube / at pre-place, stay there
-        self.place_always = False
+        self.stage = 0
         self.pre_pick_place_threshold = cfg.pre_height_diff + 0.005
         self.verbose = False
 
-    def get_obs(self, cube_state, cube_goal, ee_state):
-        c = cube_state.detach().cpu().numpy().astype(np.float64)
-        g = cube_goal.detach().cpu().numpy().astype(np.float64)
-        e = ee_state.detach().cpu().numpy().astype(np.float64)
-        pre = self.pre_place_loc.detach().cpu().numpy().astype(np.float64)
-        reach_cost = float(np.linalg.norm(e[:3] - c[:3]))
-        dist_cost = float(np.linalg.norm(pre[:2] - c[:2]))
-        ori_cost = general_ori_cube2goal(g[3:7], c[3:7])   # argument order of task_planner.py:62
+    obs = property(lambda self: self.stage)
+    pick_always = property(lambda self: self.stage >= 1)
+    place_always = property(lambda self: self.stage == 2)
+
+    @staticmethod
+    def _pose(sim, actor, link):
+        return sim.get_actor_link_by_name(actor, link)[0, :7]
+
+    def _scene_stage(self, cube, goal, ee, pre_place):
+        """Stage the scene alone would justify (no memory)."""
+        cube, goal, ee, pre_place = (v.detach().cpu().numpy().astype(np.float64) for v in (cube, goal, ee, pre_place))
+        misplacement = np.linalg.norm(pre_place[:2] - cube[:2]) + general_ori_cube2goal(goal[3:7], cube[3:7])
+        gripper_gap = np.linalg.norm(ee[:3] - cube[:3])
         if self.verbose:
-            print("reach_cost", reach_cost, "dis", dist_cost, "ori", ori_cost)
-        want_goal_state_0 = np.array([[1], [0], [0], [0]])
-        if dist_cost + ori_cost < 0.03 or self.place_always:
-            self.obs = 2
-            self.ai_agent_task[0].set_preferences(want_goal_state_0)
-            self.place_always = True
-        elif reach_cost < self.pre_pick_place_threshold or self.pick_always:
-            self.obs = 1
-            self.ai_agent_task[0].set_preferences(want_goal_state_0)
-            self.pick_always = True
-        elif not self.pick_always:
-            self.obs = 0
-            self.ai_agent_task[0].set_preferences(np.array([[0], [1], [0], [0]]))
+            print("gripper_gap", gripper_gap, "misplacement", misplacement)
+        if misplacement < self.PLACE_TOLERANCE:
+            return 2
+        return 1 if gripper_gap < self.pre_pick_place_threshold else 0
 
     def update_plan(self, sim):
-        sim.step()
-        cube_state = sim.get_actor_link_by_name("cubeA", "box")[0, :7]
-        cube_goal = sim.get_actor_link_by_name("cubeB", "box")[0, :7]
-        left_finger = sim.get_actor_link_by_name("panda", "panda_leftfinger")[0, :7]
-        right_finger = sim.get_actor_link_by_name("panda", "panda_rightfinger")[0, :7]
-        self.ee_state = (left_finger + right_finger) / 2
-        self.pre_place_loc = cube_goal.clone()
+        sim.step()   # the reference refreshes the link states with one step of the rollout envs
+        cube, goal = self._pose(sim, "cubeA", "box"), self._pose(sim, "cubeB", "box")
+        self.ee_state = 0.5 * (self._pose(sim, "panda", "panda_leftfinger") + self._pose(sim, "panda", "panda_rightfinger"))
+        self.pre_place_loc = goal.clone()
         self.pre_place_loc[2] += self.pre_pick_place_threshold
-        self.get_obs(cube_state, cube_goal, self.ee_state)
-        _, self.curr_action = adapt_act_sel(self.ai_agent_task, [self.obs], verbose=self.verbose)
+        self.stage = max(self.stage, self._scene_stage(cube, goal, self.ee_state, self.pre_place_loc))
+        agent = self.ai_agent_task[0]
+        agent.set_preferences(np.array(self.STAGE_PREFERENCE[self.stage], dtype=float).reshape(-1, 1))
+        _, self.curr_action = adapt_act_sel(self.ai_agent_task, [self.stage], verbose=self.verbose)
         self.task = self.curr_action
-        if self.curr_action == "pick":
+        if self.task == "pick":
             self.curr_goal = self.pre_place_loc
 
     def check_task_success(self, sim):
-        import torch
-        cube_state = sim.get_actor_link_by_name("cubeA", "box")[0, :7]
-        dist_cost = torch.linalg.norm(self.curr_goal[:2] - cube_state[:2])
-        return bool(self.task == "place" and dist_cost < 0.04)
-
-
-class PLANNER_PATROLLING(PLANNER_SIMPLE):
-    """task_planner.py:109-124 (not used by reactive_tamp.py).  Kept as the reference has it,
-    including that update_plan() advances `goal_id` without moving `curr_goal` to the new goal."""
-
-    def __init__(self, goals, device=None) -> None:
-        import torch
-        self.task = "navigation"
-        self.goals = torch.tensor(goals, device=device if device is not None else
-                                  ("cuda:0" if torch.cuda.is_available() else "cpu"))
-        self.goal_id = 0
-        self.curr_goal = self.goals[self.goal_id]
-
-    def reset_plan(self):
-        self.goal_id = 0
-        self.curr_goal = self.goals[self.goal_id]
-
-    def update_plan(self, robot_pos, stay_still=False):
-        import torch
-        if torch.norm(robot_pos - self.curr_goal) < 0.1:
-            self.goal_id += 1
-            if self.goal_id >= self.goals.size(0):
-                self.goal_id = 0
+        if self.task != "place":
+            return False
+        offset = self.curr_goal[:2] - self._pose(sim, "cubeA", "box")[:2]
+        return bool((offset * offset).sum() < self.SUCCESS_RADIUS ** 2)
 
 
 def set_task_planner(cfg):

