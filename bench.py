@@ -1,25 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- the MPPI/M3P2I command() hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config push|hybrid|northstar|panda]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config push|hybrid|northstar|panda|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full MPPI iteration (M3P2I.command(): rollout of every sample over the
-horizon through the contact dynamics + per-step task cost, softmin weights, mean update,
-top-k, filter) on synthetic input: the reference's initial scene.
+horizon through the contact dynamics + per-step task cost, softmin weights / multi-modal beta
+search, mean update, top-k, filter) on synthetic input: the reference's initial scene.
 
-Workload at N=1 (BASELINE.json configs[1], the config the metric is quoted on):
-task=push goal=[-1,-1], K=2000 samples, T=30 horizon, single-mode, halton-spline noise.
-For N>1 every rank keeps the per-GPU sample count (weak scaling, K_global = K*N); the ranks
-exchange the K_global trajectory costs (all-gather) and one packed buffer of weighted sums
-(all-reduce) per step over RCCL.
+Workload
+  N = 1   BASELINE.json configs[1], the config the metric is quoted on: task=push goal=[-1,-1],
+          K=2000 samples, T=30 horizon, single-mode, halton-spline noise.  After the headline loop
+          the same process also times the other BASELINE configs that fit one GPU and the north-star
+          operating point (`other_configs`: hybrid C3, panda C4, northstar K=10000, c5shard = one
+          rank's share of C5 run unsharded) and the headline config in CLOSED loop (`closed_loop`:
+          a 1-env world stepped between commands, reference flow of scripts/sim.py).
+  N > 1   BASELINE.json configs[4] (C5): task=push_pull multi_modal, 8000 samples per GPU (K = 8000 N:
+          64000 at N = 8), T=30, samples sharded over the ranks, collectives over RCCL.  Weak scaling:
+          the per-GPU sample count is fixed as N grows.  `scaling_reference` is the SAME per-GPU
+          workload on one GPU (unsharded handle on rank 0, same process), so that the line carries
+          its own 1-GPU point; `collective_ms` is the time per command spent in the collectives.
+          (--config overrides the workload for any N.)
 
 Prints ONE JSON line (rank 0).  `value` = K_global*T*steps / wall time (state-steps/s) with
 inputs resident in HBM.  `roofline` is for the dominant kernel (the fused rollout kernel):
 algorithmic bytes per launch (36 B per state-step for the point env, 92 B for the panda env,
 DESIGN.md section 6) / its average duration measured with HIP events on the launch stream.
-`cpu_baseline` times the CPU oracle (a C port of the same algorithm, oracle/) on this box's
-host cores on a bounded sample of the same workload.
+`cpu_baseline` times the CPU oracle (kind "port": a C/OpenMP port of the same algorithm, oracle/)
+on this box's host cores on a bounded sample of the same workload, and the same workload in the
+reference's loop shape (`reference_shaped`: per-t Python loop of per-op torch-CPU tensors around a
+batched simulator step, oracle/refshaped.py -- SURVEY.md section 8(d), BASELINE.md section 3 "B2").
 """
 import argparse
 import json
@@ -77,7 +87,7 @@ def build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device):
     obj.update_objective(task, list(goal))
     pl = M3P2I(cfg).attach(sim, obj)
     pl.update_gripper_command(task)
-    return pl, sim, obj
+    return pl, sim, obj, cfg
 
 
 def usable_cores():
@@ -93,7 +103,8 @@ def usable_cores():
 
 
 def cpu_baseline(env, task, goal, multi_modal, K, T, delta):
-    """Oracle (kind='port') on the host cores: bounded sample of the same workload."""
+    """Oracle (kind='port') on the host cores + the reference-shaped torch-CPU loop: bounded samples
+    of the same workload.  The ONLY place of this file that touches oracle/."""
     import oracle as O
     O.load()
     if env == "point_env":
@@ -107,7 +118,7 @@ def cpu_baseline(env, task, goal, multi_modal, K, T, delta):
         make = lambda: P.OraclePandaPlanner(cfg, delta)
     out = {}
     ncpu = usable_cores()
-    for label, threads, budget in (("all", ncpu, 8.0), ("one", 1, 8.0)):
+    for label, threads, budget in (("all", ncpu, 7.0), ("one", 1, 7.0)):
         O.load().m3o_set_threads(threads)
         pl = make()
         pl.command(w0)
@@ -118,12 +129,162 @@ def cpu_baseline(env, task, goal, multi_modal, K, T, delta):
         dt = time.perf_counter() - t0
         out[label] = dict(threads=threads, calls=n, ms=dt / n * 1e3, value=K * T * n / dt)
     best = max(out.values(), key=lambda r: r["value"])
-    return {"value": best["value"], "unit": "state-steps/s", "cores": best["threads"],
-            "kind": "port", "ms_per_command": best["ms"],
-            "single_thread_value": out["one"]["value"], "host_cores_usable": ncpu,
-            "host_cores_total": os.cpu_count(),
-            "sample": f"{best['calls']} command() calls of the same K={K},T={T} {task} workload "
-                      f"(oracle/: C port of planner + dynamics spec, OpenMP over samples)"}
+    res = {"value": best["value"], "unit": "state-steps/s", "cores": best["threads"],
+           "kind": "port", "ms_per_command": best["ms"],
+           "single_thread_value": out["one"]["value"], "host_cores_usable": ncpu,
+           "host_cores_total": os.cpu_count(),
+           "sample": f"{best['calls']} command() calls of the same K={K},T={T} {task} workload "
+                     f"(oracle/: C port of planner + dynamics spec, OpenMP over samples)"}
+    if env == "point_env":
+        try:
+            from oracle import refshaped
+            O.load().m3o_set_threads(ncpu)
+            torch.set_num_threads(ncpu)
+            res["reference_shaped"] = refshaped.time_commands(task, goal, multi_modal, K, T, delta, budget_s=7.0,
+                                                              threads=ncpu)
+        except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+            res["reference_shaped"] = {"error": repr(e)}
+    return res
+
+
+def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=None, latency=True, time_collectives=False):
+    """Builds the planner for CONFIGS[name] and measures it: `warmup` untimed commands, an event loop
+    for the kernel durations, then EXACTLY `steps` commands between barrier + synchronize pairs."""
+    env, task, goal, multi_modal, K_cfg, T = CONFIGS[name]
+    K_local = K_local or K_cfg
+    K_global = K_local * world
+    pl, sim, obj, cfg = build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device)
+    # synthetic noise: the reference's Halton-spline sampler for this rank's rows of the global
+    # sample set, generated by the planner on its first command() (device sampler; init only, not
+    # the hot path).  NOT tiled -- duplicated samples would make the reference's beta search
+    # non-terminating: eta >= number of copies of the best sample.
+    if world > 1:
+        from m3p2i_aip_amd.distributed import attach_collectives
+        attach_collectives(pl)
+    eng = pl._engine
+    state = sim._dof_state[0]
+
+    def sync():
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        pl.command(state)
+    # dominant kernel: average launch duration from HIP events recorded by the library on the
+    # stream it launches on, over min(steps, 50) commands of the same workload run between the
+    # warm-up and the timed region (reading the events back synchronises, so they are not read
+    # inside it)
+    eng.enable_timing(True)
+    pl.collective_times = [] if (time_collectives and world > 1) else None
+    tr, tu, tf = [], [], []
+    for _ in range(min(steps, 50)):
+        pl.command(state)
+        t = eng.timing()
+        tr.append(t.rollout_ms)
+        tu.append(t.update_ms)
+        tf.append(t.finalize_ms)
+    eng.enable_timing(False)
+    coll_ms = None
+    if pl.collective_times is not None:
+        torch.cuda.synchronize()
+        per_phase = {}
+        for phase, e0, e1 in pl.collective_times:
+            per_phase.setdefault(phase, []).append(e0.elapsed_time(e1))
+        n_cmd = min(steps, 50)
+        coll_ms = {ph: float(np.sum(v)) / n_cmd for ph, v in per_phase.items()}
+        coll_ms["total"] = float(sum(coll_ms.values()))
+        coll_ms["per_command"] = len(pl.collective_times) / n_cmd
+    pl.collective_times = None
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pl.command(state)
+    sync()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tw = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    lat_ms = None
+    if latency:
+        # command() latency: host clock from the call to the [T, nu] plan's first action on the host
+        # (SURVEY.md section 8(d)(ii)); outside the timed region, rank-local
+        lat = []
+        for _ in range(min(steps, 200)):
+            t1 = time.perf_counter()
+            pl.command(state)[0].cpu()
+            lat.append(time.perf_counter() - t1)
+        lat_ms = np.asarray(lat) * 1e3
+    rollout_ms = float(np.mean(tr))
+    alg_bytes = BYTES_PER_STATE_STEP_ROLLOUT[env] * K_local * T
+    achieved = alg_bytes / (rollout_ms * 1e-3) / 1e9
+    return dict(pl=pl, sim=sim, cfg=cfg, env=env, task=task, goal=goal, multi_modal=multi_modal, K_local=K_local,
+                K_global=K_global, T=T, wall=wall, steps=steps, value=K_global * T * steps / wall,
+                ms_per_step=wall / steps * 1e3, rollout_ms=rollout_ms, update_ms=float(np.mean(tu)),
+                finalize_ms=float(np.mean(tf)), alg_bytes=alg_bytes, achieved=achieved, lat_ms=lat_ms,
+                collective_ms=coll_ms)
+
+
+def brief(r):
+    """Entry of `other_configs`."""
+    out = {"workload": f"{r['env']} task={r['task']} K={r['K_global']} T={r['T']} "
+                       f"{'multi-modal' if r['multi_modal'] else 'single-mode'}",
+           "steps": r["steps"], "ms_per_step": r["ms_per_step"], "command_hz": 1e3 / r["ms_per_step"],
+           "value": r["value"], "unit": "state-steps/s",
+           "kernel_ms": {"rollout": r["rollout_ms"], "update": r["update_ms"], "finalize": r["finalize_ms"]},
+           "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": r["achieved"] / HBM_PEAK_GBS, "bytes_per_launch": r["alg_bytes"]}}
+    if r["lat_ms"] is not None:
+        out["command_latency_ms"] = {"p50": float(np.percentile(r["lat_ms"], 50)), "p99": float(np.percentile(r["lat_ms"], 99))}
+    return out
+
+
+def closed_loop(r, ticks, device):
+    """The headline planner in CLOSED loop: a 1-env "real world" (the same integrator at K = 1) is stepped
+    with the first action of every plan and its state is what the next command() starts from -- the flow
+    of scripts/sim.py:36-52 + reactive_tamp.py:43-60 in one process.  Nothing is read back on the host
+    inside the loop (the action stays on the device), so the commands pipeline as in the open-loop run."""
+    from m3p2i_aip_amd import isaacgym_wrapper as wrapper
+    from m3p2i_aip_amd.compat import check_and_apply_suction
+    pl, sim, cfg = r["pl"], r["sim"], r["cfg"]
+    real = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=1, device=device)
+    nu = real.dofs_per_robot
+    point = cfg.env_type == "point_env"
+    pull = cfg.task in ("pull", "push_pull")
+
+    def tick(i):
+        if point:
+            real.update_dyn_obs(i)
+        sim._dof_state[:] = real._dof_state          # reactive_tamp.py:45-48 (device-to-device, broadcast)
+        sim._root_state[:] = real._root_state
+        a = pl.command(sim._dof_state[0])[0]
+        real.set_dof_velocity_target_tensor(a.view(1, nu))
+        if pull:
+            cfg.suction_active = pl.get_pull_preference()   # one host sync per tick, as the reference's .item()
+            check_and_apply_suction(cfg, real, a.view(1, nu))
+        real.step()
+
+    for i in range(10):
+        tick(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(10, 10 + ticks):
+        tick(i)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    out = {"ticks": ticks, "ms_per_step": wall / ticks * 1e3, "command_hz": ticks / wall,
+           "value": r["K_global"] * r["T"] * ticks / wall, "unit": "state-steps/s",
+           "what": "command() + 1-env world step per tick, world state fed back (dyn-obs moving), action kept on "
+                   "the device; host clock over the whole loop"}
+    if point:
+        goal = torch.tensor(list(r["goal"])[:2], device=device)
+        who = real.robot_pos[0] if cfg.task == "navigation" else real.get_actor_position_by_name("box")[0, :2]
+        out["final_pos_error_m"] = float(torch.norm(who - goal))
+        out["sim_time_s"] = (10 + ticks) * cfg.isaacgym.dt
+    real.stop_sim()
+    return out
 
 
 def main():
@@ -131,9 +292,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="push", choices=list(CONFIGS))
+    ap.add_argument("--config", default=None, choices=list(CONFIGS),
+                    help="default: push (BASELINE configs[1]) on 1 GPU, c5 (configs[4]) on N > 1")
     ap.add_argument("--samples-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline line only (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,110 +324,90 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(device))
 
-    env, task, goal, multi_modal, K_local, T = CONFIGS[args.config]
-    nu = 2 if env == "point_env" else 9
-    if args.samples_per_gpu:
-        K_local = args.samples_per_gpu
-    K_global = K_local * world
-
-    pl, sim, obj = build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device)
-    # synthetic noise: the reference's Halton-spline sampler for this rank's rows of the global
-    # sample set, generated by the planner on its first command() (device sampler; init only, not
-    # the hot path).  NOT tiled -- duplicated samples would make the reference's beta search
-    # non-terminating: eta >= number of copies of the best sample.
-    if world > 1:
-        from m3p2i_aip_amd.distributed import attach_collectives
-        attach_collectives(pl)
-    eng = pl._engine
-    state = sim._dof_state[0]
-
-    def sync():
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        pl.command(state)
-    # dominant kernel: average launch duration from HIP events recorded by the library on the
-    # stream it launches on, over min(steps, 50) commands of the same workload run between the
-    # warm-up and the timed region (reading the events back synchronises, so they are not read
-    # inside it)
-    eng.enable_timing(True)
-    tr, tu, tf = [], [], []
-    for _ in range(min(args.steps, 50)):
-        pl.command(state)
-        t = eng.timing()
-        tr.append(t.rollout_ms)
-        tu.append(t.update_ms)
-        tf.append(t.finalize_ms)
-    eng.enable_timing(False)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pl.command(state)
-    sync()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        tw = torch.tensor([wall], device=device, dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-
-    # command() latency: host clock from the call to the [T, nu] plan's first action on the host
-    # (SURVEY.md section 8(d)(ii)); outside the timed region, rank-local
-    lat = []
-    for _ in range(min(args.steps, 200)):
-        t1 = time.perf_counter()
-        pl.command(state)[0].cpu()
-        lat.append(time.perf_counter() - t1)
-    lat_ms = np.asarray(lat) * 1e3
-
-    rollout_ms = float(np.mean(tr))
-    alg_bytes = BYTES_PER_STATE_STEP_ROLLOUT[env] * K_local * T
-    achieved = alg_bytes / (rollout_ms * 1e-3) / 1e9
+    name = args.config or ("c5" if world > 1 else "push")
+    r = run_config(name, args, world, rank, device, dist, args.steps, args.warmup, K_local=args.samples_per_gpu,
+                   time_collectives=True)
+    env, task, goal, multi_modal, K_local, K_global, T = (r[k] for k in ("env", "task", "goal", "multi_modal", "K_local",
+                                                                          "K_global", "T"))
+    pl = r["pl"]
+    extras = not args.no_extras
 
     if rank == 0:
         traffic = None
         try:  # HBM bytes per launch from the PMC passes of tools/profile_gpu.sh, same workload only
             tj = json.load(open(TRAFFIC_FILE))
-            key = f"{args.config}:K{K_local}:T{T}"
+            key = f"{name}:K{K_local}:T{T}"
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
         except Exception:
             pass
-        value = K_global * T * args.steps / wall
         kern = "k_rollout_point" if env == "point_env" else "k_rollout_panda"
+        if world == 1:
+            par = "single GPU"
+        else:
+            par = (f"samples sharded x{world}, " + ("ONE collective per command: all-gather of per-rank records"
+                                                    if pl.shard_mix else "all-gather J + all-reduce packed sums")
+                   + (" (gloo, shared GPU: test mode)" if share else " (RCCL)"))
         line = {
             "metric": "mppi_state_steps_per_sec (K x T per command())",
-            "value": value, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": r["value"], "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+            "higher_is_better": True,
+            # the per-GPU sample count is fixed as N grows (K_global = K_local * N)
+            "scaling": "weak", "vs_baseline": None,   # BASELINE.md holds no published number for this metric
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{env} task={task} goal={list(goal)[:3]} K={K_global} ({K_local}/GPU) T={T} "
                                    f"{'multi-modal' if multi_modal else 'single-mode'} halton-spline, "
                                    "initial scene, open loop (fixed world, warm-started plan)",
-                       "name": args.config, "command_hz": args.steps / wall,
-                       "command_latency_ms": {"p50": float(np.percentile(lat_ms, 50)),
-                                              "p99": float(np.percentile(lat_ms, 99)),
+                       "name": name, "command_hz": args.steps / r["wall"],
+                       "command_latency_ms": {"p50": float(np.percentile(r["lat_ms"], 50)),
+                                              "p99": float(np.percentile(r["lat_ms"], 99)),
                                               "what": "host clock, command() + action on host, synchronous"},
-                       "parallelism": (f"samples sharded x{world}, " + ("one all-gather of per-rank softmin records"
-                                                                             if pl.shard_mix else
-                                                                             "all-gather J + all-reduce packed sums")
-                                       + " (RCCL)") if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kern, "kernel_ms": rollout_ms, "bytes_per_launch": alg_bytes,
+                       "parallelism": par},
+            "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": r["achieved"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": kern, "kernel_ms": r["rollout_ms"], "bytes_per_launch": r["alg_bytes"],
                          "kernel_ms_from": "HIP events recorded by the library right before / after the "
                                            "launch on its stream (mean over the commands between warm-up and "
                                            "the timed region); the interval includes the ~5-9 us dispatch "
                                            "latency that rocprofv3's kernel duration (profiles/) excludes",
                          "note": "latency-bound at this K (sequential T x substeps x solver passes chain); "
                                  "DESIGN.md section 6"},
-            "kernel_ms": {"rollout": rollout_ms, "update": float(np.mean(tu)), "finalize": float(np.mean(tf))},
+            "kernel_ms": {"rollout": r["rollout_ms"], "update": r["update_ms"], "finalize": r["finalize_ms"]},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(env, task, goal, multi_modal, K_local, T,
-                                                  pl.delta.contiguous().cpu().numpy())
+        if r["collective_ms"] is not None:
+            line["collective_ms"] = r["collective_ms"]
+    delta_np = pl.delta.contiguous().cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+
+    if world > 1 and extras and not share:
+        # the same per-GPU workload on ONE GPU, unsharded (rank 0, after the distributed run; the other
+        # ranks wait at the barrier below)
+        if rank == 0:
+            r1 = run_config(name, args, 1, 0, device, None, min(args.steps, 200), args.warmup, K_local=K_local, latency=False)
+            line["scaling_reference"] = {"n_gpus": 1, "value": r1["value"], "ms_per_step": r1["ms_per_step"],
+                                         "kernel_ms": {"rollout": r1["rollout_ms"], "update": r1["update_ms"],
+                                                       "finalize": r1["finalize_ms"]},
+                                         "what": f"same per-GPU workload ({K_local} samples, unsharded handle) on rank 0's GPU"}
+        torch.cuda.synchronize()
+        dist.barrier()
+    if world == 1 and rank == 0 and extras:
+        line["closed_loop"] = closed_loop(r, min(args.steps, 200), device)
+        others = {}
+        for oname, key in (("northstar", "northstar"), ("hybrid", "hybrid"), ("panda", "panda"), ("c5", "c5shard")):
+            if oname == name:
+                continue
+            try:
+                ro = run_config(oname, args, 1, 0, device, None, max(200, min(args.steps, 400)), args.warmup)
+                others[key] = brief(ro)
+                if oname == "hybrid":
+                    others[key]["closed_loop"] = closed_loop(ro, 200, device)
+                ro["pl"]._engine.close()
+            except Exception as e:
+                others[key] = {"error": repr(e)}
+        line["other_configs"] = others
+    if rank == 0:
+        if delta_np is not None:
+            line["cpu_baseline"] = cpu_baseline(env, task, goal, multi_modal, K_local, T, delta_np)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

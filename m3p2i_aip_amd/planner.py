@@ -313,8 +313,18 @@ class MPPI():
             self._bound_sim = s
 
     def _exchange(self, phase):
-        if self.collective is not None:
+        if self.collective is None:
+            return
+        times = getattr(self, "collective_times", None)
+        if times is None:
             self.collective(self, phase)
+            return
+        # bench.py's `collective_ms`: events on the stream the collective is enqueued on
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.collective(self, phase)
+        e1.record()
+        times.append((phase, e0, e1))
 
     ACTION_RING = 8   # command() returns slot (call % 8) of a ring: a returned plan stays valid
                       # for the next 7 calls (the reference returns a fresh tensor each time; a

@@ -1,0 +1,103 @@
+"""BASELINE.json configs[4] (C5) at its real size on ONE GPU: task=push_pull, multi_modal, K=64000
+samples, T=30, sharded 8 x 8000 -- eight shard handles (rank r owns global samples [8000 r, 8000 (r+1)))
+driven in lock step with the collectives done by hand, against the unsharded K=64000 handle.
+
+This executes exactly the per-rank kernels of the 8-GPU run (global-index logic of the rollout --
+modes split at K/2, specials at k = 0, K/2, K-1 -- the large-K search k_mins / k_ladder / k_search /
+k_apply_weights on all 64000 costs, owner-only rows and k_offset != 0 in k_wsum, top-k with global
+indices); what a real node adds is only the transport (RCCL over xGMI, tools/collective_overhead.py).
+
+Protocols (m3p2i_aip_amd/distributed.py):
+  gather+reduce   all_gather J -> update -> all_reduce(sum) packed sums -> finalize
+  one collective  update (local record) -> all_gather records -> finalize   (cfg.shard_mix)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+K, T, N = 64000, 30, 8
+KL = K // N
+PLAN_BUFS = ("BUF_ACTION_OUT", "BUF_MEAN", "BUF_MEAN_1", "BUF_MEAN_2", "BUF_BEST_1", "BUF_BEST_2", "BUF_TOP_TRAJS")
+
+
+def _noise(seed=11):
+    """smooth synthetic noise, distinct rows (the Halton spline's role; values are inputs of the test)"""
+    g = torch.Generator().manual_seed(seed)
+    knots = torch.randn(K, 2, T // 4, generator=g)
+    d = torch.nn.functional.interpolate(knots, size=T, mode="linear", align_corners=True)
+    return d.permute(0, 2, 1).contiguous().numpy()
+
+
+def _engines(shard_mix):
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    kw = dict(T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+    full = HipEngine(make_config(K=K, **kw))
+    shards = [HipEngine(make_config(K=K, K_local=KL, k_offset=r * KL, shard_mix=shard_mix, **kw)) for r in range(N)]
+    return full, shards
+
+
+def _world(step):
+    """robot near the box so that both modes (push / pull with suction) have something to do; moved a
+    little from call to call so that the warm-started plans see a changing scene"""
+    w = np.array([0.0, 1.5, 0, 0, 0, 2, 1, 0, 0, 0, 0, -2, 2, 1, 0, 0, 0, 0], np.float32)
+    w[0] += 0.02 * step
+    w[1] -= 0.01 * step
+    return w
+
+
+def _compare(L, full, shards, call, atol, bitwise_ranks=True):
+    torch.cuda.synchronize()
+    fi = full.info()
+    for r, e in enumerate(shards):
+        i = e.info()
+        assert (i.iters, i.iters_1, i.iters_2) == (fi.iters, fi.iters_1, fi.iters_2), f"call {call} rank {r}"
+        assert (i.best_idx_1, i.best_idx_2) == (fi.best_idx_1, fi.best_idx_2)
+        assert i.pull_preference == fi.pull_preference
+        for name in PLAN_BUFS:
+            b = getattr(L, name)
+            np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), atol=atol,
+                                       err_msg=f"call {call} rank {r} {name}")
+            if bitwise_ranks:
+                assert torch.equal(e.buffer(b), shards[0].buffer(b)), f"ranks disagree on {name}"
+        np.testing.assert_array_equal(e.buffer(L.BUF_TOP_IDX).cpu().numpy(), full.buffer(L.BUF_TOP_IDX).cpu().numpy())
+    # the sharded rollouts are the unsharded one, slice by slice
+    st = torch.cat([e.states for e in shards])
+    assert torch.equal(st, full.states)
+    J = torch.cat([e.buffer(L.BUF_TRAJ_COST) for e in shards])
+    assert torch.equal(J, full.buffer(L.BUF_TRAJ_COST))
+    return fi
+
+
+def test_c5_gather_reduce_protocol_8x8000_equals_unsharded():
+    from m3p2i_aip_amd import _lib as L
+    delta = _noise()
+    full, shards = _engines(shard_mix=False)
+    for e, d in [(full, delta)] + [(shards[r], delta[r * KL:(r + 1) * KL]) for r in range(N)]:
+        e.set_objective("push_pull", (-3.75, -3.75))
+        e.set_noise(d)
+    seen_iters = set()
+    for call in range(4):
+        for e in [full] + shards:
+            e.set_world_point_raw(_world(call))
+        full.command()
+        for e in shards:
+            e.rollout()
+        J = torch.cat([e.buffer(L.BUF_TRAJ_COST) for e in shards])                  # all_gather
+        for e in shards:
+            e.buffer(L.BUF_TRAJ_COST_ALL).copy_(J)
+            e.update()
+        red = torch.stack([e.buffer(L.BUF_REDUCE) for e in shards]).sum(0)           # all_reduce(sum)
+        for e in shards:
+            e.buffer(L.BUF_REDUCE).copy_(red)
+            e.finalize()
+        fi = _compare(L, full, shards, call, atol=3e-5)
+        # every rank computed the weights of all K costs with the same kernels as the unsharded handle
+        for e in shards:
+            assert torch.equal(e.buffer(L.BUF_WEIGHTS), full.buffer(L.BUF_WEIGHTS))
+        assert 3.0 <= fi.eta <= 10.0 and 3.0 <= fi.eta_1 <= 10.0 and 3.0 <= fi.eta_2 <= 10.0
+        seen_iters.add((fi.iters, fi.iters_1, fi.iters_2))
+    assert all(min(t) > 1 for t in seen_iters)   # the searches really searched
+    for e in shards + [full]:
+        e.close()
