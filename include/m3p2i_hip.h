@@ -109,16 +109,23 @@ typedef struct {
     int sim_only;           /* 1: handle is used only through m3_sim_* / m3_cost (the wrapper's
                                environments); planner-shape checks (K >= 20, filter rows) are
                                skipped and m3_rollout/m3_update are refused */
-    int shard_mix;          /* sharded single-mode MPPI only (K_local < K_global, !multi_modal):
-                               1 = ONE collective per command.  Every rank runs the softmin on
-                               its own shard (local minimum m_r, local eta_r, normalised local
-                               sums) and publishes a record; m3_finalize mixes the ranks' records
-                               with rho_r = exp(-(m_r - m)/beta) eta_r / sum_r(...) -- exact in
-                               real arithmetic because beta is fixed during a command (mppi.py:
-                               430-456), equal to the gather + reduce protocol up to f32
-                               rounding (~1e-6 relative).  0 = gather + reduce (bit-identical
-                               to the unsharded run; the only protocol for the multi-modal
-                               on-the-fly beta search) */
+    int shard_mix;          /* sharded handles (K_local < K_global): 1 = ONE collective per command, an
+                               all-gather of per-rank records (M3_BUF_RECORD -> M3_BUF_RECORDS_ALL) between
+                               m3_update and m3_finalize.
+                               * single-mode MPPI (beta fixed during a command, mppi.py:430-456): m3_update
+                                 runs the softmin on the rank's own shard (local minimum m_r, local eta_r,
+                                 normalised local sums) into the record; m3_finalize mixes the ranks' records
+                                 with rho_r = exp(-(m_r - m)/beta) eta_r / sum_r(...) -- exact in real
+                                 arithmetic, equal to the gather + reduce protocol up to f32 rounding.
+                               * multi-modal M3P2I (on-the-fly beta search over ALL samples, m3p2i.py:24-64):
+                                 the record is {the shard's trajectory costs | its top-k}; after the gather
+                                 every rank holds all K_global costs and runs the unsharded update on them,
+                                 RE-GENERATING the other ranks' actions from the replicated noise table and
+                                 plan (a function of the global sample index, mppi.py:381-416) instead of
+                                 receiving them: bit-identical to the unsharded handle.  Needs the noise rows
+                                 of all K_global samples on every rank (m3_set_noise_global /
+                                 m3_set_noise_knots_global; 15 MB at K = 64000).
+                               0 = gather + reduce, two collectives (all-gather TRAJ_COST, all-reduce REDUCE) */
     unsigned long long seed;
 } m3_config;
 
@@ -172,9 +179,11 @@ typedef enum {
     M3_BUF_INFO = 20,       /* device copy of m3_info */
     M3_BUF_SIM_WORLD = 21,  /* f32 [28][Kl] step-mode environments (SoA; rows 18..21 = pending
                                force in M3_BUF_PENDING_FORCE order); allocated on first use */
-    M3_BUF_RECORD = 22,     /* f32 [record_len] this rank's record (shard_mix): header {m_r, eta_r,
-                               half sums, best idx, top-k costs and indices} + a REDUCE-shaped
-                               body (normalised local sums, best rows, top trajectories) */
+    M3_BUF_RECORD = 22,     /* f32 [record_len] this rank's record (shard_mix).  Single-mode: header {m_r,
+                               eta_r, half sums, best idx, top-k costs and indices} + a REDUCE-shaped
+                               body (normalised local sums, best rows, top trajectories).  Multi-modal:
+                               [Kl] trajectory costs (M3_BUF_TRAJ_COST aliases them) | top-k costs |
+                               top-k global indices | top-k trajectories [M3_TOPK][T][2] */
     M3_BUF_RECORDS_ALL = 23,/* f32 [K_global/K_local][record_len]: all-gather M3_BUF_RECORD into
                                this buffer between m3_update and m3_finalize (shard_mix) */
     M3_BUF_COUNT = 24
@@ -218,6 +227,11 @@ int m3_set_noise(m3_handle* h, const float* delta, int on_device);
  * series, into M3_BUF_NOISE.  Bit-identical to scipy 1.15.3's FITPACK (tests/test_spline_fit.py). */
 int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots, int degree, float smoothing,
                        int on_device);
+/* the same two for a one-collective multi-modal shard (cfg.shard_mix with multi_modal): rows / knots of
+ * ALL K_global samples, [K_global][T][nu] / [K_global][nu][n_knots] -- every rank holds the whole table */
+int m3_set_noise_global(m3_handle* h, const float* delta_all, int on_device);
+int m3_set_noise_knots_global(m3_handle* h, const float* knots_all, int n_knots, int degree, float smoothing,
+                              int on_device);
 int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd);
 /* Objective.multi_modal (cost_functions.py:9) for a sim_only handle, whose config does not
  * come from an MPPI object; refused on planner handles (fixed at m3_create) */
@@ -260,7 +274,7 @@ int m3_command(m3_handle* h, float* action_host);
 /* the three phases, for sharded use: rollout -> (all-gather TRAJ_COST into TRAJ_COST_ALL)
  * -> update -> (all-reduce REDUCE) -> finalize.  With K_local == K_global m3_update uses
  * TRAJ_COST itself.  With cfg.shard_mix: rollout -> update -> (all-gather RECORD into
- * RECORDS_ALL) -> finalize: one collective. */
+ * RECORDS_ALL) -> finalize: one collective (single-mode and multi-modal alike). */
 int m3_rollout(m3_handle* h);
 int m3_update(m3_handle* h);
 int m3_finalize(m3_handle* h);

@@ -133,8 +133,9 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     }
     if (c->substeps < 1 || c->solver_iters < 1 || !(c->dt > 0.0f)) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad dt/substeps/solver_iters");
     if (c->shard_mix && c->K_local != c->K_global) {
-        if (c->multi_modal && !c->mode_simple)
-            return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: shard_mix needs a beta that is fixed during a command (not multi_modal)");
+        if (c->multi_modal && !c->mode_simple && c->sampling_random)
+            return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: one-collective multi-modal sharding re-generates the other ranks' "
+                                                     "actions from the noise TABLE: not with sampling_random");
         if (c->K_global % c->K_local != 0 || c->k_offset % c->K_local != 0 || c->K_global / c->K_local > MIX_MAX_RANKS)
             return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs equal shards (K_global = n * K_local, n <= 32)");
         if (c->K_local < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs K_local >= 20");
@@ -148,6 +149,7 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     m3_handle* h = new (std::nothrow) m3_handle();
     if (!h) return fail(nullptr, M3_ERR_HIP, "m3_create: out of host memory");
     h->cfg = *c;
+    h->regen = c->shard_mix && c->K_local != c->K_global && c->multi_modal && !c->mode_simple;
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) {
         g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
@@ -172,7 +174,7 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     A(M3_BUF_STATES, T * Kl * 4 * f);
     A(M3_BUF_ACTIONS, T * Kl * nu * f);
     A(M3_BUF_COST_HORIZON, T * Kl * f);
-    A(M3_BUF_TRAJ_COST, Kl * f);
+    if (!h->regen) A(M3_BUF_TRAJ_COST, Kl * f);   // (regen: the costs are the head of the record)
     A(M3_BUF_TRAJ_COST_ALL, Kg * f);
     A(M3_BUF_WEIGHTS, Kg * f);
     A(M3_BUF_WEIGHTS_1, (Kg / 2) * f);
@@ -181,10 +183,21 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     A(M3_BUF_TOP_IDX, M3_TOPK * sizeof(int));
     A(M3_BUF_TOP_TRAJS, M3_TOPK * T * 2 * f);
     A(M3_BUF_REDUCE, (long long)reduce_length((int)T, (int)nu) * f);
-    A(M3_BUF_NOISE, T * Kl * nu * f);
+    if (!h->regen) A(M3_BUF_NOISE, T * Kl * nu * f);
     A(M3_BUF_PENDING_FORCE, 4 * Kl * f);
     A(M3_BUF_INFO, sizeof(m3_info));
-    if (c->shard_mix && Kl != Kg) {
+    if (h->regen) {
+        const long long rl = regen_record_length((int)Kl, (int)T);
+        A(M3_BUF_RECORD, rl * f);
+        A(M3_BUF_RECORDS_ALL, (Kg / Kl) * rl * f);
+        if (rc == M3_OK && hipMalloc((void**)&h->noise_all, (size_t)(T * Kg * nu * f)) != hipSuccess) rc = M3_ERR_HIP;
+        if (rc == M3_OK && hipMemsetAsync(h->noise_all, 0, (size_t)(T * Kg * nu * f), h->stream) != hipSuccess) rc = M3_ERR_HIP;
+        if (rc == M3_OK && hipMalloc((void**)&h->local_top_idx, M3_TOPK * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
+        if (rc == M3_OK) {   // non-owning aliases (m3_destroy skips them)
+            h->buf[M3_BUF_TRAJ_COST] = h->buf[M3_BUF_RECORD]; h->nbytes[M3_BUF_TRAJ_COST] = Kl * f;
+            h->buf[M3_BUF_NOISE] = h->noise_all + (size_t)(c->k_offset / Kl) * T * Kl * nu; h->nbytes[M3_BUF_NOISE] = T * Kl * nu * f;
+        }
+    } else if (c->shard_mix && Kl != Kg) {
         A(M3_BUF_RECORD, (long long)record_length((int)T, (int)nu) * f);
         A(M3_BUF_RECORDS_ALL, (Kg / Kl) * (long long)record_length((int)T, (int)nu) * f);
     }
@@ -192,7 +205,7 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (rc == M3_OK && hipMalloc((void**)&h->topk_cand, (size_t)topk_workgroups((int)Kg) * M3_TOPK * sizeof(VI)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->part_min, (size_t)mins_workgroups((int)Kg) * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->lad, (size_t)ladder_workgroups((int)Kg) * 96 * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
-    if (rc == M3_OK && hipMalloc((void**)&h->wpart, (size_t)wsum_chunks((int)Kl) * 3 * T * nu * f) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->wpart, (size_t)wsum_chunks((int)(h->regen ? Kg : Kl)) * 3 * T * nu * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->apart, (size_t)(16 + apply_workgroups((int)Kg) * 8) * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->wcount, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMemset(h->wcount, 0, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
@@ -214,8 +227,11 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
 
 extern "C" void m3_destroy(m3_handle* h) {
     if (!h) return;
+    if (h->regen) h->buf[M3_BUF_TRAJ_COST] = h->buf[M3_BUF_NOISE] = nullptr;   // aliases
     for (int i = 0; i < M3_BUF_COUNT; ++i)
         if (h->buf[i]) (void)hipFree(h->buf[i]);
+    if (h->noise_all) (void)hipFree(h->noise_all);
+    if (h->local_top_idx) (void)hipFree(h->local_top_idx);
     if (h->world0_dev) (void)hipFree(h->world0_dev);
     if (h->topk_cand) (void)hipFree(h->topk_cand);
     if (h->part_min) (void)hipFree(h->part_min);
@@ -260,6 +276,41 @@ extern "C" int m3_enable_timing(m3_handle* h, int on) {
 // current world; stream-ordered, no sync.  Called by m3_rollout when the noise changed and every
 // ORDER_REFRESH commands (the objects move).
 constexpr unsigned ORDER_REFRESH = 256;
+// one shard's block of noise rows [T][Kl][nu] (k_offset = global index of its first sample): sort into
+// wavefront order; `relabel`: write the rows back in that order (and, for this rank's own block, let the
+// pending suction forces follow their samples)
+static int order_block(m3_handle* h, float* block, int k_offset, bool relabel, bool own) {
+    const m3_config& c = h->cfg;
+    long long half_local = (long long)(c.K_global / 2) - k_offset;
+    if (!c.multi_modal || half_local > c.K_local) half_local = c.K_local;
+    if (half_local < 0) half_local = 0;
+    OrderScene os;
+    std::memset(&os, 0, sizeof(os));
+    if (h->bind_dof) { os.sim_root = h->bind_root; os.sim_box = h->bind_box; os.sim_dyn = h->bind_dyn; }
+    os.bx = h->world0[4]; os.by = h->world0[5]; os.dx = h->world0[11]; os.dy = h->world0[12];
+    os.ox = h->scene.obs_x; os.oy = h->scene.obs_y;
+    // relabelling keeps the samples with a role of their own at their index
+    const int specials[3] = {0 - k_offset, c.K_global / 2 - k_offset, c.K_global - 1 - k_offset};
+    hipError_t e = launch_wave_order(block, c.K_local, c.T, c.nu,
+                                     std::sqrt(c.noise_sigma_diag[0]), std::sqrt(c.noise_sigma_diag[1]),
+                                     (int)half_local, os, h->order_scratch, h->order_temp_bytes, h->order, h->noise_sorted,
+                                     relabel ? specials : nullptr, h->stream);
+    if (e != hipSuccess) { h->err = std::string("wave order: ") + hipGetErrorString(e); return M3_ERR_HIP; }
+    if (relabel) {
+        // sample i := old sample order[i]: the noise rows (gathered above) and the per-sample state
+        // that outlives a command (pending suction forces) move; everything else is rewritten by
+        // the next rollout.  From here on the index order IS the wavefront order: coalesced stores.
+        HIPCHK(h, hipMemcpyAsync(block, h->noise_sorted, sizeof(float) * (size_t)c.T * c.K_local * c.nu,
+                                 hipMemcpyDeviceToDevice, h->stream));
+        if (own) {
+            launch_gather_rows((const float*)h->buf[M3_BUF_PENDING_FORCE], h->order, h->noise_sorted, c.K_local, 4, h->stream);
+            HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_PENDING_FORCE], h->noise_sorted, sizeof(float) * 4 * (size_t)c.K_local,
+                                     hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    return M3_OK;
+}
+
 static int refresh_wave_order(m3_handle* h) {
     const m3_config& c = h->cfg;
     h->order_valid = false;
@@ -278,32 +329,24 @@ static int refresh_wave_order(m3_handle* h) {
         HIPCHK(h, hipMalloc(&h->order_scratch, 3 * sizeof(float) * (size_t)c.K_local + h->order_temp_bytes));
         HIPCHK(h, hipMalloc((void**)&h->noise_sorted, sizeof(float) * (size_t)c.T * c.K_local * c.nu));
     }
-    long long half_local = (long long)(c.K_global / 2) - c.k_offset;
-    if (!c.multi_modal || half_local > c.K_local) half_local = c.K_local;
-    if (half_local < 0) half_local = 0;
-    OrderScene os;
-    std::memset(&os, 0, sizeof(os));
-    if (h->bind_dof) { os.sim_root = h->bind_root; os.sim_box = h->bind_box; os.sim_dyn = h->bind_dyn; }
-    os.bx = h->world0[4]; os.by = h->world0[5]; os.dx = h->world0[11]; os.dy = h->world0[12];
-    os.ox = h->scene.obs_x; os.oy = h->scene.obs_y;
-    // relabelling keeps the samples with a role of their own at their index
-    const int specials[3] = {0 - c.k_offset, c.K_global / 2 - c.k_offset, c.K_global - 1 - c.k_offset};
-    hipError_t e = launch_wave_order((const float*)h->buf[M3_BUF_NOISE], c.K_local, c.T, c.nu,
-                                     std::sqrt(c.noise_sigma_diag[0]), std::sqrt(c.noise_sigma_diag[1]),
-                                     (int)half_local, os, h->order_scratch, h->order_temp_bytes, h->order, h->noise_sorted,
-                                     relabel ? specials : nullptr, h->stream);
-    if (e != hipSuccess) { h->err = std::string("wave order: ") + hipGetErrorString(e); return M3_ERR_HIP; }
+    if (relabel && h->regen) {
+        // every rank holds every shard's noise block (the other ranks' actions are re-generated from
+        // them): relabel each block exactly as its owner does -- the same deterministic procedure on the
+        // same inputs (noise table, world) -- this rank's own block LAST, so that h->order ends up as its
+        // permutation
+        const int n = c.K_global / c.K_local, me = c.k_offset / c.K_local;
+        const size_t bl = (size_t)c.T * c.K_local * c.nu;
+        for (int q = 0; q < n; ++q) {
+            const int r = (q < me) ? q : (q + 1 < n ? q + 1 : me);   // 0..me-1, me+1..n-1, me
+            const int rc = order_block(h, h->noise_all + (size_t)r * bl, r * c.K_local, true, r == me);
+            if (rc != M3_OK) return rc;
+        }
+        h->relabelled = true;
+        return M3_OK;
+    }
+    const int rc = order_block(h, (float*)h->buf[M3_BUF_NOISE], c.k_offset, relabel, true);
+    if (rc != M3_OK) return rc;
     if (relabel) {
-        // sample i := old sample order[i]: the noise rows (gathered above) and the per-sample state
-        // that outlives a command (pending suction forces) move; everything else is rewritten by
-        // the next rollout.  From here on the index order IS the wavefront order: coalesced stores.
-        HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_NOISE], h->noise_sorted, sizeof(float) * (size_t)c.T * c.K_local * c.nu,
-                                 hipMemcpyDeviceToDevice, h->stream));
-        float* tmp = (float*)h->order_scratch;   // 3 * Kl floats free again after the sort; pend needs 4 * Kl
-        (void)tmp;
-        launch_gather_rows((const float*)h->buf[M3_BUF_PENDING_FORCE], h->order, h->noise_sorted, c.K_local, 4, h->stream);
-        HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_PENDING_FORCE], h->noise_sorted, sizeof(float) * 4 * (size_t)c.K_local,
-                                 hipMemcpyDeviceToDevice, h->stream));
         h->relabelled = true;
         return M3_OK;
     }
@@ -335,25 +378,52 @@ extern "C" int m3_set_wave_order(m3_handle* h, int on) {
     return M3_OK;
 }
 
-extern "C" int m3_set_noise(m3_handle* h, const float* delta, int on_device) {
+// rows [n_rows][T][nu] (reference layout) -> n_rows / K_local consecutive time-major blocks at dst
+static int upload_noise(m3_handle* h, const float* delta, long long n_rows, float* dst, int on_device, const char* who) {
     if (!h || !delta) return fail(h, M3_ERR_BAD_ARG, "m3_set_noise: null argument");
     const m3_config& c = h->cfg;
-    const size_t bytes = (size_t)c.K_local * c.T * c.nu * sizeof(float);
+    (void)who;
+    const size_t bytes = (size_t)n_rows * c.T * c.nu * sizeof(float);
     const float* src = delta;
+    float* stage = nullptr;
     if (!on_device) {
-        if (!h->noise_stage) HIPCHK(h, hipMalloc((void**)&h->noise_stage, bytes));
-        HIPCHK(h, hipMemcpyAsync(h->noise_stage, delta, bytes, hipMemcpyHostToDevice, h->stream));
-        src = h->noise_stage;
+        if (n_rows == c.K_local) {
+            if (!h->noise_stage) HIPCHK(h, hipMalloc((void**)&h->noise_stage, bytes));
+            stage = h->noise_stage;
+        } else {
+            HIPCHK(h, hipMalloc((void**)&stage, bytes));
+        }
+        HIPCHK(h, hipMemcpyAsync(stage, delta, bytes, hipMemcpyHostToDevice, h->stream));
+        src = stage;
     }
-    launch_transpose_noise(src, (float*)h->buf[M3_BUF_NOISE], c.K_local, c.T, c.nu, h->stream);
-    HIPCHK(h, hipGetLastError());
-    if (!on_device) HIPCHK(h, hipStreamSynchronize(h->stream));  // host buffer may be released
+    const size_t bl = (size_t)c.T * c.K_local * c.nu;
+    for (long long r = 0; r < n_rows / c.K_local; ++r)
+        launch_transpose_noise(src + r * bl, dst + r * bl, c.K_local, c.T, c.nu, h->stream);
+    hipError_t e = hipGetLastError();
+    if (!on_device) (void)hipStreamSynchronize(h->stream);  // host buffer may be released
+    if (stage && stage != h->noise_stage) (void)hipFree(stage);
+    if (e != hipSuccess) { h->err = std::string("k_transpose_noise: ") + hipGetErrorString(e); return M3_ERR_HIP; }
     note_noise_upload(h);
     return M3_OK;
 }
 
-extern "C" int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots, int degree, float smoothing,
-                                  int on_device) {
+extern "C" int m3_set_noise(m3_handle* h, const float* delta, int on_device) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (h->cfg.sim_only) return fail(h, M3_ERR_STATE, "m3_set_noise: handle was created sim_only");
+    if (h->regen) return fail(h, M3_ERR_STATE, "m3_set_noise: a one-collective multi-modal shard needs the noise rows of ALL "
+                                               "K_global samples (m3_set_noise_global)");
+    return upload_noise(h, delta, h->cfg.K_local, (float*)h->buf[M3_BUF_NOISE], on_device, "m3_set_noise");
+}
+
+extern "C" int m3_set_noise_global(m3_handle* h, const float* delta_all, int on_device) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->regen) return fail(h, M3_ERR_STATE, "m3_set_noise_global: only for one-collective multi-modal shards "
+                                                "(cfg.shard_mix with multi_modal, K_local < K_global)");
+    return upload_noise(h, delta_all, h->cfg.K_global, h->noise_all, on_device, "m3_set_noise_global");
+}
+
+static int upload_knots(m3_handle* h, const float* knots, long long n_rows, float* dst, int n_knots, int degree,
+                        float smoothing, int on_device) {
     if (!h || !knots) return fail(h, M3_ERR_BAD_ARG, "m3_set_noise_knots: null argument");
     const m3_config& c = h->cfg;
     if (c.sim_only) return fail(h, M3_ERR_STATE, "m3_set_noise_knots: handle was created sim_only");
@@ -361,7 +431,7 @@ extern "C" int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots,
     if (n_knots <= degree || n_knots > 64)
         return fail(h, M3_ERR_SHAPE, "m3_set_noise_knots: needs degree < n_knots <= 64 (splrep: m > k must hold)");
     if (!(smoothing >= 0.0f)) return fail(h, M3_ERR_BAD_ARG, "m3_set_noise_knots: smoothing must be >= 0");
-    const size_t bytes = (size_t)c.K_local * c.nu * n_knots * sizeof(float);
+    const size_t bytes = (size_t)n_rows * c.nu * n_knots * sizeof(float);
     const float* src = knots;
     float* stage = nullptr;
     if (!on_device) {
@@ -369,8 +439,9 @@ extern "C" int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots,
         HIPCHK(h, hipMemcpyAsync(stage, knots, bytes, hipMemcpyHostToDevice, h->stream));
         src = stage;
     }
-    launch_spline_noise(src, (float*)h->buf[M3_BUF_NOISE], c.K_local, c.nu, n_knots, c.T, degree, (double)smoothing,
-                        h->stream);
+    const size_t bl = (size_t)c.T * c.K_local * c.nu, kl = (size_t)c.K_local * c.nu * n_knots;
+    for (long long r = 0; r < n_rows / c.K_local; ++r)
+        launch_spline_noise(src + r * kl, dst + r * bl, c.K_local, c.nu, n_knots, c.T, degree, (double)smoothing, h->stream);
     hipError_t e = hipGetLastError();
     if (stage) {
         (void)hipStreamSynchronize(h->stream);
@@ -379,6 +450,21 @@ extern "C" int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots,
     if (e != hipSuccess) { h->err = std::string("k_spline_noise: ") + hipGetErrorString(e); return M3_ERR_HIP; }
     note_noise_upload(h);
     return M3_OK;
+}
+
+extern "C" int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots, int degree, float smoothing,
+                                  int on_device) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (h->regen) return fail(h, M3_ERR_STATE, "m3_set_noise_knots: a one-collective multi-modal shard needs the knots of ALL "
+                                               "K_global samples (m3_set_noise_knots_global)");
+    return upload_knots(h, knots, h->cfg.K_local, (float*)h->buf[M3_BUF_NOISE], n_knots, degree, smoothing, on_device);
+}
+
+extern "C" int m3_set_noise_knots_global(m3_handle* h, const float* knots_all, int n_knots, int degree, float smoothing,
+                                         int on_device) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->regen) return fail(h, M3_ERR_STATE, "m3_set_noise_knots_global: only for one-collective multi-modal shards");
+    return upload_knots(h, knots_all, h->cfg.K_global, h->noise_all, n_knots, degree, smoothing, on_device);
 }
 
 extern "C" int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd) {
@@ -622,9 +708,21 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.n_ranks = c.K_global / c.K_local;
     a.rank = c.k_offset / c.K_local;
     a.records_all = (const float*)h->buf[M3_BUF_RECORDS_ALL];
+    a.rec_topj = a.rec_topi = nullptr;
+    a.regen = 0;
+    a.Kls = c.K_local;
+    a.rec_len = h->regen ? regen_record_length(c.K_local, c.T) : record_length(c.T, c.nu);
+    a.noise_all = h->noise_all;
+    for (int j = 0; j < c.nu; ++j) {
+        a.u_min[j] = c.u_min[j]; a.u_max[j] = c.u_max[j];
+        a.scale_tril[j] = std::sqrt(c.noise_sigma_diag[j]);   // as m3_rollout
+    }
+    a.u_scale = c.u_scale;
+    a.sample_null_action = c.sample_null_action;
+    a.gripper_cmd = h->gripper_cmd;
 }
 
-static bool mix_mode(const m3_handle* h) { return h->cfg.shard_mix && h->cfg.K_local != h->cfg.K_global; }
+static bool mix_mode(const m3_handle* h) { return h->cfg.shard_mix && h->cfg.K_local != h->cfg.K_global && !h->regen; }
 
 // fuse: m3_command on an unsharded handle lets k_wsum's last workgroup do k_finalize's work
 static bool can_fuse_finalize(const m3_handle* h) {
@@ -640,10 +738,29 @@ static int update_impl(m3_handle* h, bool fuse) {
     a.fuse_finalize = fuse ? 1 : 0;
     if (c.K_local == c.K_global)  // unsharded: the local costs ARE the global costs (no copy)
         a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST];
+    if (h->regen) {
+        // one-collective multi-modal sharding, phase before the all-gather: the rollout left the shard's
+        // costs at the head of the record; add the shard's own top-k (costs, global indices, trajectories)
+        float* rec = (float*)h->buf[M3_BUF_RECORD];
+        a.Kg = c.K_local;                       // the selection runs over the LOCAL costs ...
+        a.Jall = rec;
+        a.kbase = c.k_offset;                   // ... and reports global indices
+        a.n_cand = topk_workgroups(c.K_local);
+        a.top_idx = h->local_top_idx;
+        a.rec_topj = rec + regen_off_topj(c.K_local);
+        a.rec_topi = rec + regen_off_topi(c.K_local);
+        a.top_dst = rec + regen_off_trajs(c.K_local);
+        launch_local_topk(a, h->stream);
+        HIPCHK(h, hipGetLastError());
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+        return M3_OK;
+    }
     if (mix_mode(h)) {
         // one-collective sharding: softmin over the LOCAL shard into this rank's record
         float* rec = (float*)h->buf[M3_BUF_RECORD];
         a.record = rec;
+        a.rec_topj = rec + REC_TOPJ;
+        a.rec_topi = rec + REC_TOPI;
         a.reduce = rec + REC_HDR;
         a.top_dst = a.reduce + reduce_off_top(c.T, c.nu);
         a.n_cand = topk_workgroups(c.K_local);
@@ -686,8 +803,41 @@ extern "C" int m3_update(m3_handle* h) {
     return update_impl(h, false);
 }
 
+// one-collective multi-modal sharding, phase after the all-gather: the whole update on all K_global
+// samples -- the unsharded kernels, with the weighted sums re-generating the actions (k_wsum<REGEN>)
+static int regen_finalize(m3_handle* h) {
+    const m3_config& c = h->cfg;
+    UpdateArgs a;
+    fill_update_args(h, a);
+    const int rl = regen_record_length(c.K_local, c.T), n = c.K_global / c.K_local;
+    // the shards' costs, record by record -> one contiguous [K_global] array
+    HIPCHK(h, hipMemcpy2DAsync(h->buf[M3_BUF_TRAJ_COST_ALL], (size_t)c.K_local * sizeof(float), h->buf[M3_BUF_RECORDS_ALL],
+                               (size_t)rl * sizeof(float), (size_t)c.K_local * sizeof(float), (size_t)n,
+                               hipMemcpyDeviceToDevice, h->stream));
+    a.regen = 1;
+    a.Kl = c.K_global; a.k0 = 0;           // the launches cover every sample
+    a.n_chunk = wsum_chunks(c.K_global);
+    a.top_dst = a.top_trajs;               // rows come from the gathered records (topk_finish)
+    const bool fuse = (long long)c.T * c.nu <= 2048;
+    a.fuse_finalize = fuse ? 1 : 0;
+    launch_mins(a, h->stream);
+    launch_ladder(a, h->stream);
+    launch_weights(a, h->stream);
+    launch_wsum(a, h->stream);
+    if (!fuse) launch_finalize(a, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
 extern "C" int m3_finalize(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
+    if (h->regen) {
+        const int rc = regen_finalize(h);
+        if (rc != M3_OK) return rc;
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+        h->calls += 1;
+        return M3_OK;
+    }
     UpdateArgs a;
     fill_update_args(h, a);
     if (mix_mode(h)) launch_mix(a, h->stream);  // records -> the REDUCE buffer an all-reduce would hold, + finalize
@@ -735,7 +885,8 @@ extern "C" int m3_command(m3_handle* h, float* action_host) {
 
 static int ensure_sim(m3_handle* h);
 extern "C" int m3_record_len(const m3_handle* h) {
-    return h ? record_length(h->cfg.T, h->cfg.nu) : 0;
+    if (!h) return 0;
+    return h->regen ? regen_record_length(h->cfg.K_local, h->cfg.T) : record_length(h->cfg.T, h->cfg.nu);
 }
 
 extern "C" int m3_get_buffer(m3_handle* h, int which, void** p, long long* nbytes) {

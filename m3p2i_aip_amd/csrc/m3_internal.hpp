@@ -92,6 +92,19 @@ struct UpdateArgs {
     int n_ranks, rank;
     float* top_dst;      // where top-k stage B writes the rows: top_trajs (unsharded) or the
                          // reduce buffer's top section (sharded: summed over ranks first)
+    float* rec_topj;     // where topk_finish leaves the sorted top-k costs / indices for the other
+    float* rec_topi;     //   ranks (inside this rank's record; null: nowhere)
+    // ---- "regen" one-collective sharding (multi-modal): after ONE all-gather of records
+    // {J of the shard | its top-k} every rank runs the whole update on all K samples; the actions of
+    // the other ranks' samples are RE-GENERATED from the replicated noise table and plan instead of
+    // being communicated (a_k[t] is a function of the global sample index: mppi.py:381-416)
+    int regen;           // 1: the launch covers all K_global samples (Kl == Kg, k0 == 0 in this struct)
+    int Kls;             // samples per shard (= per rank)
+    int rec_len;         // floats per gathered record
+    const float* noise_all;  // [n_ranks][T][Kls][nu]: every shard's noise block
+    float u_min[M3_MAX_NU], u_max[M3_MAX_NU], scale_tril[M3_MAX_NU];
+    float u_scale;
+    int sample_null_action, gripper_cmd;
 };
 
 // REDUCE buffer: [3][T][nu] weighted sums (all, mode 1, mode 2) | [3][T][nu] best rows
@@ -106,6 +119,12 @@ __host__ __device__ inline int reduce_length(int T, int nu) { return 6 * T * nu 
 constexpr int REC_HDR = 48, REC_TOPJ = 8, REC_TOPI = 28;
 __host__ __device__ inline int record_length(int T, int nu) { return REC_HDR + reduce_length(T, nu); }
 constexpr int MIX_MAX_RANKS = 32;
+// regen record: [Kls] trajectory costs of the shard | [TOPK] its smallest costs | [TOPK] their global
+// indices (int bits) | [TOPK][T][2] their (x, y) trajectories; length padded to a multiple of 4 floats
+__host__ __device__ inline int regen_off_topj(int Kls) { return Kls; }
+__host__ __device__ inline int regen_off_topi(int Kls) { return Kls + M3_TOPK; }
+__host__ __device__ inline int regen_off_trajs(int Kls) { return Kls + 2 * M3_TOPK; }
+__host__ __device__ inline int regen_record_length(int Kls, int T) { return (Kls + 2 * M3_TOPK + M3_TOPK * T * 2 + 3) / 4 * 4; }
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s);
@@ -130,6 +149,7 @@ void launch_update_small(const UpdateArgs& a, hipStream_t s);
 bool update_small_applies(const UpdateArgs& a);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);
 void launch_mix(const UpdateArgs& a, hipStream_t s);
+void launch_local_topk(const UpdateArgs& a, hipStream_t s);
 int rollout_lanes_for(int Kl);
 int mins_workgroups(int Kg);
 int topk_workgroups(int Kg);
@@ -209,6 +229,9 @@ struct m3_handle {
     const float* bind_root = nullptr;
     int bind_nact = 0, bind_box = 0, bind_dyn = 0;
     bool have_noise = false;
+    bool regen = false;            // one-collective multi-modal sharding (UpdateArgs::regen)
+    float* noise_all = nullptr;    // regen: [n_ranks][T][Kl][nu]; buf[M3_BUF_NOISE] aliases this rank's block
+    int* local_top_idx = nullptr;  // regen: top_idx of the local pre-gather selection (scratch)
     unsigned calls = 0;
     int lanes_override = 0;  // 0 = automatic (rollout_lanes_for)
     // device buffers

@@ -340,16 +340,39 @@ __device__ __forceinline__ void topk_finish(const UpdateArgs& a, const VI* top /
     const int tid = threadIdx.x, T = a.T, Kl = a.Kl, k0 = a.k0;
     if (tid < M3_TOPK) {
         a.top_idx[tid] = top[tid].i;
-        if (a.record) {  // shard_mix: the ranks' lists are merged by k_mix
-            a.record[REC_TOPJ + tid] = top[tid].v;
-            a.record[REC_TOPI + tid] = __int_as_float(top[tid].i);
+        if (a.rec_topj) {  // sharded: the ranks' lists are merged after the collective
+            a.rec_topj[tid] = top[tid].v;
+            a.rec_topi[tid] = __int_as_float(top[tid].i);
         }
+    }
+    float2* dst = reinterpret_cast<float2*>(a.top_dst);
+    const int total = M3_TOPK * T;
+    if (a.regen) {
+        // the global top-k is a subset of the union of the shards' own top-k lists, whose trajectories
+        // came with the gathered records: find each winner in its owner's list, copy the row
+        __shared__ int s_src[M3_TOPK];
+        if (tid < M3_TOPK) {
+            const int gi = top[tid].i;
+            int off = -1;
+            if (gi >= 0 && gi < a.Kg) {
+                const float* rec = a.records_all + (size_t)(gi / a.Kls) * a.rec_len;
+                for (int q = 0; q < M3_TOPK; ++q)
+                    if (__float_as_int(rec[regen_off_topi(a.Kls) + q]) == gi) off = (gi / a.Kls) * a.rec_len + regen_off_trajs(a.Kls) + q * T * 2;
+            }
+            s_src[tid] = off;
+        }
+        __syncthreads();
+        for (int o = tid; o < total; o += nt) {
+            const int r = o / T, tt = o - r * T;
+            float2 v = make_float2(0.f, 0.f);
+            if (s_src[r] >= 0) { v.x = a.records_all[s_src[r] + tt * 2]; v.y = a.records_all[s_src[r] + tt * 2 + 1]; }
+            dst[o] = v;
+        }
+        return;
     }
     // one (x, vx, y, vy) row per (r, t); the rows were written by other CUs (HBM / remote-L2
     // latency per load), so a batch of independent loads is issued before the first is consumed
     const float4* st4 = reinterpret_cast<const float4*>(a.states);
-    float2* dst = reinterpret_cast<float2*>(a.top_dst);
-    const int total = M3_TOPK * T;
     constexpr int UN = 4;
     for (int o0 = tid; o0 < total; o0 += UN * nt) {
         float4 v[UN];
@@ -1086,7 +1109,35 @@ int wsum_chunks(int Kl) { const int L = wsum_chunk_len(Kl); return (Kl + L - 1) 
 template <bool SC1>
 __device__ __forceinline__ void finalize_body(const UpdateArgs& a, float* sm);  // defined below
 
+// The action the rollout formed for GLOBAL sample k at time step t (mppi.py:381-416 + :297-302, as in
+// rollout_point.hip / rollout_panda.hip: same f32 operations, same order => the same bits), from the
+// sample's noise row and the replicated plan -- what the "regen" sharding recomputes instead of
+// communicating.  Halton-spline mode only (explicit noise table).
 template <int NU>
+__device__ __forceinline__ void regen_action(const UpdateArgs& a, int k, int t, const float* drow, float (&e)[NU]) {
+    const int T = a.T;
+    const int ts = (t + 1 < T) ? t + 1 : T - 1;
+    const bool multi = a.multi_modal != 0;
+    const bool is_last = k == a.Kg - 1;
+    const bool use_best = multi && (k == 0 || k == a.half_g);
+    const float* mptr = multi ? (k < a.half_g ? a.mean1 : a.mean2) : a.mean;
+    const float* bptr = (k == 0) ? a.best1 : a.best2;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const float d = is_last ? 0.0f : drow[j];
+        float aj = fmaxf(fminf(mptr[ts * NU + j] + d * a.scale_tril[j], a.u_max[j]), a.u_min[j]);
+        if (use_best) aj = bptr[ts * NU + j];
+        if (NU == 9 && j >= 7) {
+            if (a.gripper_cmd == 1) aj = 1.5f;
+            else if (a.gripper_cmd == 2) aj = -1.5f;
+        }
+        float uj = a.u_scale * aj;
+        if (a.sample_null_action && is_last) uj = 0.0f;
+        e[j] = (a.u_scale != 1.0f) ? uj / a.u_scale : uj;
+    }
+}
+
+template <int NU, bool REGEN>
 __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     __shared__ float red[3 * 16];
     const int tid = threadIdx.x, C = a.n_chunk;
@@ -1114,7 +1165,20 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         const int ic = ok ? i : (i1 - 1);
         const int k = k0 + ic;
         float av[NU];
-        if constexpr (NU == 2) {
+        if constexpr (REGEN) {
+            // (Kl == Kg, k0 == 0 here) the sample's noise row lives in its shard's block
+            const int r = k / a.Kls, kk = k - r * a.Kls;
+            const float* drow = a.noise_all + (((size_t)r * T + t) * a.Kls + kk) * NU;
+            float dv[NU];
+            if constexpr (NU == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(drow);
+                dv[0] = v.x; dv[1] = v.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) dv[j] = drow[j];
+            }
+            regen_action<NU>(a, k, t, dv, av);
+        } else if constexpr (NU == 2) {
             const float2 v = reinterpret_cast<const float2*>(act)[ic];
             av[0] = v.x; av[1] = v.y;
         } else {
@@ -1168,7 +1232,20 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         const int gi = (which == 0) ? a.info->best_idx : (which == 1 ? a.info->best_idx_1 : a.info->best_idx_2);
         float v = 0.0f;
         const int li = gi - k0;
-        if (gi >= 0 && li >= 0 && li < Kl) v = act[(size_t)li * NU + j];
+        if (gi >= 0 && li >= 0 && li < Kl) {
+            if constexpr (REGEN) {
+                const int r = gi / a.Kls, kk = gi - r * a.Kls;
+                const float* drow = a.noise_all + (((size_t)r * T + t) * a.Kls + kk) * NU;
+                float dv[NU], ev[NU];
+#pragma unroll
+                for (int q = 0; q < NU; ++q) dv[q] = drow[q];
+                regen_action<NU>(a, gi, t, dv, ev);
+#pragma unroll
+                for (int q = 0; q < NU; ++q) if (q == j) v = ev[q];
+            } else {
+                v = act[(size_t)li * NU + j];
+            }
+        }
         float* dst = &a.reduce[reduce_off_best(which, T, NU) + t * NU + j];
         if (a.fuse_finalize) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *dst = v;
@@ -1223,8 +1300,38 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
 void launch_wsum(const UpdateArgs& a, hipStream_t s) {
     const dim3 grid(a.T * a.n_chunk + (a.n_cand > 1 ? 1 : 0));
     const size_t lds = a.fuse_finalize ? (size_t)a.T * a.nu * sizeof(float) : 0;
-    if (a.nu == 2) hipLaunchKernelGGL(k_wsum<2>, grid, dim3(ST), lds, s, a);
-    else hipLaunchKernelGGL(k_wsum<9>, grid, dim3(ST), lds, s, a);
+    if (a.regen) {
+        if (a.nu == 2) hipLaunchKernelGGL((k_wsum<2, true>), grid, dim3(ST), lds, s, a);
+        else hipLaunchKernelGGL((k_wsum<9, true>), grid, dim3(ST), lds, s, a);
+        return;
+    }
+    if (a.nu == 2) hipLaunchKernelGGL((k_wsum<2, false>), grid, dim3(ST), lds, s, a);
+    else hipLaunchKernelGGL((k_wsum<9, false>), grid, dim3(ST), lds, s, a);
+}
+
+// the shard's own top-k before the collective ("regen" sharding): stage A per 4096 costs, the last
+// workgroup to finish merges (as the top-k workgroups of k_update_small)
+__global__ __launch_bounds__(PREP_T) void k_local_topk(const UpdateArgs a) {
+    __shared__ int s_lastb;
+    const int tid = threadIdx.x;
+    topk_stage_a(a, blockIdx.x);
+    if (a.n_cand > 1) {
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(&a.wcount[a.T + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_lastb = ticket == a.n_cand - 1;
+            if (s_lastb) a.wcount[a.T + 1] = 0;
+        }
+        __syncthreads();
+        if (s_lastb) {
+            __threadfence();
+            topk_stage_b(a);
+        }
+    }
+}
+void launch_local_topk(const UpdateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_local_topk, dim3(a.n_cand), dim3(PREP_T), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------

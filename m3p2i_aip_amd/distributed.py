@@ -2,33 +2,34 @@
 (backend "nccl" = RCCL over xGMI).
 
 The rollouts of different samples are independent for the whole horizon (mppi.py:296-315);
-only the importance-weight update couples them.  Per command():
+only the importance-weight update couples them.  Default protocol
+(planner.shard_mix): ONE collective per command(), an all-gather of small per-rank records.
 
-    rollout (local K/N samples)
-      -> all_gather  J[K]                 K floats: every rank then runs the SAME min /
-                                          beta search / normalisation on all K costs, so the
-                                          weights are bit-identical on every rank and equal
-                                          to the single-GPU ones (the reference's on-the-fly
-                                          beta search needs eta(beta) over the whole set at
-                                          every pass -- one reduce of weight sums would only
-                                          be exact for a fixed beta)
-    update  (weights for all K, weighted sums over the local shard)
-      -> all_reduce(sum) packed buffer    3 x [T,nu] weighted sums, 3 x [T,nu] best rows
-                                          (zero except on the owning rank), 20 x [T,2] top
-                                          trajectories (same) : 6*T*nu + 40*T floats
-    finalize (identical on every rank)
-
-Both messages are latency-bound (<= 256 KB and ~6 KB at K=64000): bucket size and ring
-bandwidth over the 7 xGMI links are irrelevant here, hop count is what matters.
-
-Single-mode MPPI (cfg.multi_modal False; beta is fixed during a command, mppi.py:430-456) needs
-only ONE collective (planner.shard_mix, the default there):
-
+  single-mode MPPI (beta is fixed during a command, mppi.py:430-456)
     rollout -> update (softmin over the LOCAL shard: m_r, eta_r, normalised sums, best, top-20)
       -> all_gather  record[~1.6 K floats]
     finalize (k_mix: rho_r = exp(-(m_r - m)/beta) eta_r / Z; sums = sum_r rho_r S_r; merge of the
-              ranks' best / top-20; then the usual finalize) -- identical on every rank, equal to
-              the two-collective result up to f32 rounding.
+              ranks' best / top-20; then the usual finalize) -- identical on every rank, equal to the
+              unsharded result up to f32 rounding.
+
+  multi-modal M3P2I (the on-the-fly beta search needs eta(beta) over ALL samples at every pass,
+  m3p2i.py:24-64 -- a reduce of weight sums would only be exact for a fixed beta)
+    rollout -> update (the shard's own top-20 into its record)
+      -> all_gather  record = {J of the shard [K/N] | top-20 costs, indices, trajectories}
+    finalize (every rank now holds all K costs: the UNSHARDED update kernels on them -- same beta
+              search, same weights, bit for bit -- and the weighted action sums over all K samples with
+              the other ranks' actions RE-GENERATED from the replicated noise table and plan (a_k[t] is
+              a function of the global sample index, mppi.py:381-416) instead of communicated.)
+    Every rank holds the noise rows of all K samples (15 MB at K = 64000, init only).  Results are
+    bit-identical to the single-GPU run of the same K (tests/test_c5_sharded_gpu.py).
+
+Fallback protocol (shard_mix=False; also the multi-modal path with sampling_method='random', whose
+in-kernel noise has no table): two collectives,
+    rollout -> all_gather J[K] -> update (weights for all K, weighted sums over the local shard)
+      -> all_reduce(sum) packed buffer (6*T*nu + 40*T floats) -> finalize.
+
+All messages are latency-bound (<= 300 KB at K = 64000): bucket size and ring bandwidth over the 7
+xGMI links are irrelevant here; the number of dependent collectives per command is what counts.
 """
 from __future__ import annotations
 
@@ -38,7 +39,7 @@ from . import _lib as L
 
 
 def attach_collectives(planner, group=None):
-    """Install the two collectives on a planner built with cfg.mppi.rank/world_size."""
+    """Install the collective(s) on a planner built with cfg.mppi.rank/world_size."""
     if planner.world_size != dist.get_world_size(group):
         raise ValueError("planner.world_size does not match the process group")
 

@@ -117,29 +117,39 @@ class HipEngine:
     def enable_timing(self, on=True):
         self._ck(self.lib.m3_enable_timing(self._h, int(on)))
 
-    def set_noise(self, delta):
-        """delta: [K_local, T, nu] (reference layout), torch (cpu/cuda) or numpy."""
+    @property
+    def needs_global_noise(self):
+        """One-collective multi-modal shard: the noise rows of ALL K_global samples live on every rank."""
         c = self.cfg
+        return bool(c.shard_mix and c.K_local != c.K_global and c.multi_modal and not c.mode_simple)
+
+    def set_noise(self, delta):
+        """delta: [K_local, T, nu] (reference layout), torch (cpu/cuda) or numpy -- [K_global, T, nu] for a
+        handle with `needs_global_noise`."""
+        c = self.cfg
+        rows, fn = (c.K_global, self.lib.m3_set_noise_global) if self.needs_global_noise else (c.K_local, self.lib.m3_set_noise)
         if isinstance(delta, torch.Tensor) and delta.is_cuda:
             d = delta.to(torch.float32).contiguous()
-            assert tuple(d.shape) == (c.K_local, c.T, c.nu), d.shape
-            self._ck(self.lib.m3_set_noise(self._h, d.data_ptr(), 1))
+            assert tuple(d.shape) == (rows, c.T, c.nu), d.shape
+            self._ck(fn(self._h, d.data_ptr(), 1))
             torch.cuda.current_stream(self.device).synchronize()
         else:
             d = np.ascontiguousarray(delta.cpu().numpy() if isinstance(delta, torch.Tensor)
                                      else delta, dtype=np.float32)
-            assert d.shape == (c.K_local, c.T, c.nu), d.shape
-            self._ck(self.lib.m3_set_noise(self._h, d.ctypes.data, 0))
+            assert d.shape == (rows, c.T, c.nu), d.shape
+            self._ck(fn(self._h, d.ctypes.data, 0))
 
     def set_noise_knots(self, knots, degree=2, smoothing=0.5):
         """Halton-spline sampler on the device: knots [K_local, nu, n_knots] (Gaussian Halton values
-        of this shard's samples) -> smoothing-spline noise in the library's noise buffer."""
+        of this shard's samples; [K_global, ...] with `needs_global_noise`) -> smoothing-spline noise in
+        the library's noise buffer."""
         c = self.cfg
+        rows, fn = (c.K_global, self.lib.m3_set_noise_knots_global) if self.needs_global_noise \
+            else (c.K_local, self.lib.m3_set_noise_knots)
         k = np.ascontiguousarray(knots.detach().cpu().numpy() if isinstance(knots, torch.Tensor) else knots,
                                  dtype=np.float32)
-        assert k.ndim == 3 and k.shape[:2] == (c.K_local, c.nu), k.shape
-        self._ck(self.lib.m3_set_noise_knots(self._h, k.ctypes.data, int(k.shape[2]), int(degree),
-                                             float(smoothing), 0))
+        assert k.ndim == 3 and k.shape[:2] == (rows, c.nu), k.shape
+        self._ck(fn(self._h, k.ctypes.data, int(k.shape[2]), int(degree), float(smoothing), 0))
 
     def set_objective(self, task, goal, gripper_cmd=0):
         t = L.TASKS[task] if isinstance(task, str) else int(task)

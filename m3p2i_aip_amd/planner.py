@@ -168,12 +168,17 @@ class MPPI():
         self.k_offset = rank * self.K_local
         dev = torch.device(m.device)
         isaac = _get(cfg, "isaacgym", None)
-        # sharded protocol: single-mode MPPI (beta fixed during a command) mixes per-rank softmins
-        # after ONE all-gather of records; the multi-modal beta search needs all K costs on every
-        # rank (all-gather of J + all-reduce of the packed sums).  shard_mix=False forces the latter.
+        # sharded protocol, ONE collective per command (an all-gather of per-rank records) whenever it
+        # applies: single-mode MPPI (beta fixed during a command) mixes per-rank softmins; the multi-modal
+        # beta search gets every rank's costs in the records and re-generates the other ranks' actions
+        # from the replicated noise table (needs an explicit table: not sampling_method='random').
+        # shard_mix=False forces all-gather of J + all-reduce of the packed sums.
         sm = _get(m, "shard_mix", None)
         single = not (self.multi_modal and self.mppi_mode != "simple")
-        self.shard_mix = bool(world > 1 and single and (True if sm is None else sm))
+        can_mix = single or self.sampling_method != "random"
+        if sm and not can_mix:
+            raise ValueError("shard_mix=True with multi_modal needs sampling_method='halton' (a noise table)")
+        self.shard_mix = bool(world > 1 and can_mix and (True if sm is None else sm))
         self.relabel_samples = bool(_get(m, "relabel_samples", True))
         self._engine = ENGINE_CLS(make_config(
             K=self.K, K_local=self.K_local, k_offset=self.k_offset, T=self.T, nu=self.nu,
@@ -271,17 +276,17 @@ class MPPI():
         if self._have_noise:
             return
         e = self._engine
+        # (a one-collective multi-modal shard holds the rows of ALL samples: engine.needs_global_noise)
+        k0, k1 = (0, self.K) if getattr(e, "needs_global_noise", False) else (self.k_offset, self.k_offset + self.K_local)
         if hasattr(e, "set_noise_knots"):
             # device sampler: Halton knots on the host (K*nu*n_knots values, vectorised), the K*nu
             # spline fits -- where the reference's ~1 s init goes -- one GPU thread each
-            e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree,
-                                                    self.k_offset, self.k_offset + self.K_local),
+            e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree, k0, k1),
                               self.degree, 0.5)
             if self.relabel_samples and hasattr(e, "relabel_samples"):
                 e.relabel_samples()   # the sampler's row labels are arbitrary: wavefront-coherent ones
         else:   # engines without the device sampler (the CPU test stand-in)
-            e.set_noise(sampling.halton_spline_delta(self.K, self.T, self.nu, self.knot_scale, self.degree,
-                                                     self.k_offset, self.k_offset + self.K_local))
+            e.set_noise(sampling.halton_spline_delta(self.K, self.T, self.nu, self.knot_scale, self.degree, k0, k1))
         self._have_noise = True
 
     @property
@@ -345,7 +350,7 @@ class MPPI():
         self._bind_world()
         e = self._engine
         out = self._next_action_slot()
-        if self.world_size == 1:
+        if self.world_size == 1 and self.collective is None:
             e.command()
         else:
             e.rollout()
@@ -474,7 +479,8 @@ class MPPI():
         return out
 
     def set_noise(self, delta):
-        """Explicit noise [K_local, T, nu] (e.g. a recorded sample set)."""
+        """Explicit noise [K_local, T, nu] (e.g. a recorded sample set); [K, T, nu] -- all samples -- for a
+        sharded multi-modal planner with shard_mix (engine.needs_global_noise)."""
         self._engine.set_noise(torch.as_tensor(delta, dtype=torch.float32).to(self.device))
         self._have_noise = True
 

@@ -32,8 +32,14 @@ class OracleEngine:
         }
         for b in range(L.BUF_MEAN, L.BUF_ACTION_OUT + 1):
             self.np[b] = np.zeros((T, nu), f)
-        self.mix = bool(c.shard_mix) and Kl != Kg
+        self.regen = bool(c.shard_mix) and Kl != Kg and bool(c.multi_modal) and not c.mode_simple
+        self.mix = bool(c.shard_mix) and Kl != Kg and not self.regen
         self.HDR, self.RL = 48, 48 + 6 * T * nu + L.TOPK * T * 2   # record layout: m3_internal.hpp
+        if self.regen:   # {costs of the shard | top-k costs | top-k global indices | top-k trajectories}, padded to 4
+            self.RL = (Kl + 2 * L.TOPK + L.TOPK * T * 2 + 3) // 4 * 4
+            self.np[L.BUF_RECORD] = np.zeros(self.RL, f)
+            self.np[L.BUF_RECORDS_ALL] = np.zeros((Kg // Kl, self.RL), f)
+            self.np[L.BUF_TRAJ_COST] = self.np[L.BUF_RECORD][:Kl]     # alias, as in the library
         if self.mix:
             self.np[L.BUF_RECORD] = np.zeros(self.RL, f)
             self.np[L.BUF_RECORDS_ALL] = np.zeros((Kg // Kl, self.RL), f)
@@ -54,9 +60,17 @@ class OracleEngine:
     def buffer(self, which):
         return self.t[which]
 
+    @property
+    def needs_global_noise(self):
+        return self.regen
+
     def set_noise(self, delta):
-        self.delta = np.ascontiguousarray(delta.cpu().numpy() if torch.is_tensor(delta) else delta,
-                                          dtype=np.float32)
+        d = np.ascontiguousarray(delta.cpu().numpy() if torch.is_tensor(delta) else delta, dtype=np.float32)
+        if self.regen:   # every rank holds the rows of all samples
+            assert d.shape == (self.Kg, self.T, self.nu)
+            self.delta_all = d
+            d = np.ascontiguousarray(d[self.k0:self.k0 + self.Kl])
+        self.delta = d
         assert self.delta.shape == (self.Kl, self.T, self.nu)
         self.np[L.BUF_NOISE] = np.ascontiguousarray(self.delta.transpose(1, 0, 2))
         self.t[L.BUF_NOISE] = _t(self.np[L.BUF_NOISE])
@@ -169,7 +183,52 @@ class OracleEngine:
         i.beta = float(self.beta)
         self._info = i
 
+    def _update_regen(self):
+        """Before the all-gather: the shard's costs are the head of the record already (alias); add its
+        own top-k (costs, global indices, trajectories)."""
+        n, T, Kl, k0 = self.np, self.T, self.Kl, self.k0
+        rec = n[L.BUF_RECORD]
+        J = rec[:Kl]
+        order = np.lexsort((np.arange(Kl), J))[:L.TOPK]
+        rec[Kl:Kl + L.TOPK] = J[order]
+        rec[Kl + L.TOPK:Kl + 2 * L.TOPK] = (k0 + order).astype(np.int32).view(np.float32)
+        rec[Kl + 2 * L.TOPK:Kl + 2 * L.TOPK + L.TOPK * T * 2] = \
+            n[L.BUF_STATES][:, order, :][:, :, [0, 2]].transpose(1, 0, 2).reshape(-1)
+
+    def _finalize_regen(self):
+        """After the all-gather: all K costs are here; the other shards' actions are re-generated from the
+        replicated noise table + plan; then the unsharded update."""
+        cfg = self._ocfg()
+        n, T, nu, Kl, Kg = self.np, self.T, self.nu, self.Kl, self.Kg
+        R = n[L.BUF_RECORDS_ALL]
+        J = np.ascontiguousarray(R[:, :Kl].reshape(-1))
+        n[L.BUF_TRAJ_COST_ALL][...] = J
+        w, w1, w2, info = O.update_weights(cfg, J, self.beta)
+        n[L.BUF_WEIGHTS][...], n[L.BUF_WEIGHTS_1][...], n[L.BUF_WEIGHTS_2][...] = w, w1, w2
+        sh = np.minimum(np.arange(1, T + 1), T - 1)
+        act = O.assemble_actions(cfg, self.delta_all, n[L.BUF_MEAN][sh], n[L.BUF_MEAN_1][sh], n[L.BUF_MEAN_2][sh],
+                                 n[L.BUF_BEST_1][sh], n[L.BUF_BEST_2][sh], 0, Kg)
+        if cfg.sample_null_action:
+            act[Kg - 1] = 0.0                     # what the rollout stores for the null sample
+        ps = O.partial_sums(cfg, w, w1, w2, act, 0, Kg)
+        red = n[L.BUF_REDUCE]
+        red[...] = 0
+        red[:3 * T * nu] = ps.reshape(-1)
+        for i, g in enumerate([info.best_idx, info.best_idx_1, Kg // 2 + info.best_idx_2]):
+            red[(3 + i) * T * nu:(4 + i) * T * nu] = act[g].reshape(-1)
+        order = np.lexsort((np.arange(Kg), J))[:L.TOPK]
+        n[L.BUF_TOP_IDX][...] = order
+        top = red[6 * T * nu:].reshape(L.TOPK, T, 2)
+        for slot, g in enumerate(order):
+            rec = R[g // Kl]
+            ids = rec[Kl + L.TOPK:Kl + 2 * L.TOPK].copy().view(np.int32)
+            q = int(np.nonzero(ids == g)[0][0])
+            top[slot] = rec[Kl + 2 * L.TOPK:Kl + 2 * L.TOPK + L.TOPK * T * 2].reshape(L.TOPK, T, 2)[q]
+        self._info = info
+
     def update(self):
+        if self.regen:
+            return self._update_regen()
         if self.mix:
             return self._update_mix()
         cfg = self._ocfg()
@@ -200,6 +259,8 @@ class OracleEngine:
         self._info = info
 
     def finalize(self):
+        if self.regen:
+            self._finalize_regen()
         if self.mix:
             self._finalize_mix()
         cfg = self._ocfg()

@@ -13,19 +13,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("config,protocol", [("push", "one all-gather"), ("hybrid", "all-gather J + all-reduce")])
-def test_bench_with_two_ranks(config, protocol):
+@pytest.mark.parametrize("config,mode", [("push", "single-mode"), (None, "multi-modal")])
+def test_bench_with_two_ranks(config, mode):
+    """config None: the default of an N > 1 run, BASELINE configs[4] (c5: push_pull, multi-modal)."""
     env = dict(os.environ, M3_BENCH_SHARE_GPU="1")
     port = 29800 + os.getpid() % 150
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
-           "--warmup", "3", "--config", config, "--samples-per-gpu", "512"]
+           "--warmup", "3", "--samples-per-gpu", "512"] + (["--config", config] if config else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]           # exactly one JSON line, from rank 0
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 3 and d["scaling"] == "weak"
-    assert "K=1024 (512/GPU)" in d["config"]["workload"] and protocol in d["config"]["parallelism"]
+    assert "K=1024 (512/GPU)" in d["config"]["workload"] and mode in d["config"]["workload"]
+    assert d["config"]["name"] == (config or "c5") and "ONE collective per command" in d["config"]["parallelism"]
+    assert d["collective_ms"]["per_command"] == 1.0 and d["collective_ms"]["total"] > 0
     assert d["value"] > 0 and abs(d["value"] - 1024 * 30 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"

@@ -258,10 +258,11 @@ def test_one_collective_shard_mix_equals_unsharded(golden, oracle, world, K, mod
         e.close()
 
 
-def test_shard_mix_is_refused_for_the_multi_modal_search():
+def test_shard_mix_multi_modal_is_refused_without_a_noise_table():
+    """(the one-collective multi-modal protocol itself: tests/test_c5_sharded_gpu.py)"""
     from m3p2i_aip_amd import _lib as L
     with pytest.raises(L.M3Error):
-        _engine(K=256, K_local=128, k_offset=0, shard_mix=True, T=30, nu=2, multi_modal=True,
+        _engine(K=256, K_local=128, k_offset=0, shard_mix=True, T=30, nu=2, multi_modal=True, sampling_random=True,
                 u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
 
 

@@ -22,8 +22,10 @@ CASES = {
     "push": dict(task="push", goal=(-1.0, -1.0), multi_modal=False, shard_mix=None),
     # single-mode forced onto the exact two-collective protocol
     "push_exact": dict(task="push", goal=(-1.0, -1.0), multi_modal=False, shard_mix=False),
-    # multi-modal beta search: always all-gather J + all-reduce
+    # multi-modal beta search, one collective: all-gather of {costs | top-k}, remote actions re-generated
     "hybrid": dict(task="push_pull", goal=(-3.75, -3.75), multi_modal=True, shard_mix=None),
+    # multi-modal on the two-collective protocol (all-gather J + all-reduce)
+    "hybrid_exact": dict(task="push_pull", goal=(-3.75, -3.75), multi_modal=True, shard_mix=False),
 }
 
 
@@ -50,7 +52,7 @@ def make_planner(case, rank, world, delta):
     obj = Objective(cfg)
     obj.update_objective(kw["task"], list(kw["goal"]))
     pl = P.M3P2I(cfg).attach(sim, obj)
-    pl.set_noise(delta[pl.k_offset:pl.k_offset + pl.K_local])
+    pl.set_noise(delta if pl._engine.needs_global_noise else delta[pl.k_offset:pl.k_offset + pl.K_local])
     return pl, sim
 
 
@@ -75,8 +77,16 @@ def worker(rank, world, port, case, ret):
     delta = np.load(os.path.join(ROOT, "tests", "golden", "ref_golden.npz"))["g9_push_delta"]
     pl, sim = make_planner(case, rank, world, delta)
     attach_collectives(pl)
-    assert pl.shard_mix == (case == "push")
+    assert pl.shard_mix == (case in ("push", "hybrid"))
+    pl.collective_calls = 0
+    inner = pl.collective
+
+    def counting(p, phase):
+        p.collective_calls += 1
+        inner(p, phase)
+    pl.collective = counting
     outs = run_calls(pl, sim)
+    assert pl.collective_calls == len(outs) * (1 if pl.shard_mix else 2)   # collectives per command()
     if rank == 0:
         ret.put(outs)
     # every rank must hold the same plan
