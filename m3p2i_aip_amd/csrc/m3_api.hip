@@ -710,6 +710,7 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.records_all = (const float*)h->buf[M3_BUF_RECORDS_ALL];
     a.rec_topj = a.rec_topi = nullptr;
     a.regen = 0;
+    a.Jout = nullptr;
     a.Kls = c.K_local;
     a.rec_len = h->regen ? regen_record_length(c.K_local, c.T) : record_length(c.T, c.nu);
     a.noise_all = h->noise_all;
@@ -745,7 +746,7 @@ static int update_impl(m3_handle* h, bool fuse) {
         a.Kg = c.K_local;                       // the selection runs over the LOCAL costs ...
         a.Jall = rec;
         a.kbase = c.k_offset;                   // ... and reports global indices
-        a.n_cand = topk_workgroups(c.K_local);
+        a.n_cand = c.K_local <= 8192 ? 1 : topk_workgroups(c.K_local);
         a.top_idx = h->local_top_idx;
         a.rec_topj = rec + regen_off_topj(c.K_local);
         a.rec_topi = rec + regen_off_topi(c.K_local);
@@ -809,12 +810,8 @@ static int regen_finalize(m3_handle* h) {
     const m3_config& c = h->cfg;
     UpdateArgs a;
     fill_update_args(h, a);
-    const int rl = regen_record_length(c.K_local, c.T), n = c.K_global / c.K_local;
-    // the shards' costs, record by record -> one contiguous [K_global] array
-    HIPCHK(h, hipMemcpy2DAsync(h->buf[M3_BUF_TRAJ_COST_ALL], (size_t)c.K_local * sizeof(float), h->buf[M3_BUF_RECORDS_ALL],
-                               (size_t)rl * sizeof(float), (size_t)c.K_local * sizeof(float), (size_t)n,
-                               hipMemcpyDeviceToDevice, h->stream));
     a.regen = 1;
+    a.Jout = (float*)h->buf[M3_BUF_TRAJ_COST_ALL];   // k_mins compacts the records' costs into it
     a.Kl = c.K_global; a.k0 = 0;           // the launches cover every sample
     a.n_chunk = wsum_chunks(c.K_global);
     a.top_dst = a.top_trajs;               // rows come from the gathered records (topk_finish)

@@ -102,6 +102,8 @@ struct UpdateArgs {
     int Kls;             // samples per shard (= per rank)
     int rec_len;         // floats per gathered record
     const float* noise_all;  // [n_ranks][T][Kls][nu]: every shard's noise block
+    float* Jout;             // regen: k_mins (the first reader of the gathered records) leaves the costs
+                             // here as one [K_global] array (== Jall of the later launches)
     float u_min[M3_MAX_NU], u_max[M3_MAX_NU], scale_tril[M3_MAX_NU];
     float u_scale;
     int sample_null_action, gripper_cmd;

@@ -186,7 +186,15 @@ __global__ __launch_bounds__(PREP_T) void k_mins(const UpdateArgs a) {
 #pragma unroll
     for (int e = 0; e < PREP_RPT; ++e) {
         const int k = base + e * PREP_T + tid;
-        const float jv = a.Jall[min(k, Kg - 1)];  // unconditional: loads stay in flight together
+        const int kc = min(k, Kg - 1);
+        float jv;
+        if (a.regen) {   // (uniform) first reader of the gathered records: shard by shard -> one [K_global] array
+            const int r = kc / a.Kls;
+            jv = a.records_all[(size_t)r * a.rec_len + (kc - r * a.Kls)];
+            if (k < Kg) a.Jout[k] = jv;
+        } else {
+            jv = a.Jall[kc];  // unconditional: loads stay in flight together
+        }
         const float v = (k < Kg) ? jv : INF;
         mn[0] = fminf(mn[0], v);
         if (k < half) mn[1] = fminf(mn[1], v); else mn[2] = fminf(mn[2], v);
@@ -259,7 +267,9 @@ __device__ __forceinline__ void topk_rank_emit(const tkey* list, int n, VI* out,
 // (The out-of-line fallbacks take scalars, not the argument struct: a struct passed by reference
 // to a non-inlined function is copied to scratch, and a kernel that uses scratch at all pays
 // ~3 us more per launch.)
+template <int RPT>
 __device__ __noinline__ void topk_stage_a_rounds(const float* J, int Kg, int kbase, int blk, VI* out) {
+    constexpr int PREP_RPT = RPT;   // (shadows the namespace constant: rows per thread of THIS instance)
     __shared__ VI cand[16 * M3_TOPK];
     const int tid = threadIdx.x, WT = PREP_T;  // called by the first PREP_T threads
     const int lane = tid & 63, wv = tid >> 6, nw = WT >> 6;
@@ -398,7 +408,9 @@ __device__ __forceinline__ void topk_finish(const UpdateArgs& a, const VI* top /
 // mppi.py:248-254), so it rides along as EXTRA workgroups of launches that exist anyway, on CUs
 // the update does not use: stage A beside workgroup 0 of k_weights, stage B beside the sums of
 // k_wsum (no extra launch, no extra stream; with K <= 4096 stage A is the whole selection).
+template <int RPT = 16>
 __device__ __forceinline__ void topk_stage_a(const UpdateArgs& a, int blk) {
+    constexpr int PREP_RPT = RPT;   // rows of PREP_T costs per thread: 16 (4096 costs per workgroup) or 32
     __shared__ tkey flt[TK_CAP];
     __shared__ VI s_top[M3_TOPK];
     __shared__ unsigned s_tau[PREP_T / 64];
@@ -452,7 +464,7 @@ __device__ __forceinline__ void topk_stage_a(const UpdateArgs& a, int blk) {
     const bool single = a.n_cand == 1;  // K <= 4096: this workgroup's list is the final one
     VI* out = single ? s_top : a.cand + blk * M3_TOPK;
     if (n <= TK_CAP) topk_rank_emit(flt, n, out, PREP_T);
-    else topk_stage_a_rounds(a.Jall, a.Kg, a.kbase, blk, out);
+    else topk_stage_a_rounds<RPT>(a.Jall, a.Kg, a.kbase, blk, out);
     if (single) {
         __syncthreads();
         topk_finish(a, s_top, PREP_T);
@@ -1311,10 +1323,11 @@ void launch_wsum(const UpdateArgs& a, hipStream_t s) {
 
 // the shard's own top-k before the collective ("regen" sharding): stage A per 4096 costs, the last
 // workgroup to finish merges (as the top-k workgroups of k_update_small)
+template <int RPT>
 __global__ __launch_bounds__(PREP_T) void k_local_topk(const UpdateArgs a) {
     __shared__ int s_lastb;
     const int tid = threadIdx.x;
-    topk_stage_a(a, blockIdx.x);
+    topk_stage_a<RPT>(a, blockIdx.x);
     if (a.n_cand > 1) {
         __threadfence();
         __syncthreads();
@@ -1331,7 +1344,9 @@ __global__ __launch_bounds__(PREP_T) void k_local_topk(const UpdateArgs a) {
     }
 }
 void launch_local_topk(const UpdateArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_local_topk, dim3(a.n_cand), dim3(PREP_T), 0, s, a);
+    // up to 8192 costs: ONE workgroup with 32 rows per thread (no second stage, no ticket)
+    if (a.n_cand == 1 && a.Kg > PREP_T * 16) hipLaunchKernelGGL(k_local_topk<32>, dim3(1), dim3(PREP_T), 0, s, a);
+    else hipLaunchKernelGGL(k_local_topk<16>, dim3(a.n_cand), dim3(PREP_T), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------

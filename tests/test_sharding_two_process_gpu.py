@@ -36,7 +36,8 @@ def build(rank, world, multi_modal, task, goal):
 
 
 def run(pl, sim, delta, n=4):
-    pl.set_noise(delta[pl.k_offset:pl.k_offset + pl.K_local])
+    # (a multi-modal shard on the one-collective protocol holds the noise rows of all samples)
+    pl.set_noise(delta if pl._engine.needs_global_noise else delta[pl.k_offset:pl.k_offset + pl.K_local])
     out = []
     for _ in range(n):
         a = pl.command(sim._dof_state[0])
@@ -85,7 +86,7 @@ def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal):
         # single-mode runs the one-collective protocol (planner.shard_mix): a rank materialises only
         # its own shard's weights, and the plan equals the unsharded one up to f32 rounding
         nw = K if multi_modal else K // 2
-        np.testing.assert_allclose(a["action"], b["action"], atol=1e-5 if multi_modal else 3e-5, err_msg=f"call {c}")
+        np.testing.assert_allclose(a["action"], b["action"], atol=3e-5, err_msg=f"call {c}")
         np.testing.assert_allclose(a["weights"][:nw], b["weights"][:nw], rtol=1e-3, atol=1e-8)
         np.testing.assert_allclose(a["top"], b["top"], atol=1e-4)
         assert a["pref"] == b["pref"]

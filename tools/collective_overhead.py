@@ -10,6 +10,13 @@ Per config three loops over the same planner (K per GPU as in bench.py):
   split        the sharded phase sequence with the exchanges stubbed out (what sharding costs in launches)
   collectives  the same with world_size-1 RCCL collectives on the buffers (all_gather / all_reduce)
 and HIP-event time of each collective on the stream.
+
+  --emulate-rank-of N   additionally: rank 0's share of an N-rank run of the config (K_global = N x K),
+                        on this one GPU -- its real kernel sequence (rollout of K samples, records, the update
+                        on all N x K costs) with the collectives as world_size-1 RCCL calls into rank 0's slot;
+                        the other ranks' records / costs are filled once with shifted copies.  Both protocols:
+                        one collective (cfg.shard_mix) and all-gather + all-reduce.  What is missing vs a real
+                        node: the xGMI wire time of the collective, nothing else.
 """
 import argparse
 import json
@@ -37,8 +44,78 @@ def loop(pl, state, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def emulate_rank(name, N, steps):
+    """rank 0 of N on one GPU (see module docstring)."""
+    from m3p2i_aip_amd import _lib as L
+    env, task, goal, mm, K, T = bench.CONFIGS[name]
+    res = {}
+    for label, mix in (("one_collective", True), ("gather_reduce", False)):
+        from m3p2i_aip_amd import isaacgym_wrapper as wrapper
+        from m3p2i_aip_amd.cost_functions import Objective
+        from m3p2i_aip_amd.planner import M3P2I, MPPIConfig
+        from types import SimpleNamespace
+        m = MPPIConfig(num_samples=K * N, horizon=T, nx=4, device="cuda:0", lambda_=0.5, u_min=[-3.0, -3.0],
+                       u_max=[3.0, 3.0], noise_sigma=[[3.0, 0.0], [0.0, 3.0]], u_per_command=T, sample_null_action=True,
+                       filter_u=True, fused=True, rank=0, world_size=N, shard_mix=mix)
+        cfg = SimpleNamespace(env_type=env, multi_modal=mm, suction_active=True, kp_suction=400, pre_height_diff=0.0,
+                              task=task, goal=list(goal), cube_on_shelf=False, mppi=m, isaacgym=wrapper.IsaacGymConfig(dt=0.05))
+        sim = wrapper.IsaacGymWrapper(cfg.isaacgym, env, num_envs=64, device="cuda:0")
+        obj = Objective(cfg)
+        obj.update_objective(task, list(goal))
+        pl = M3P2I(cfg).attach(sim, obj)
+        e = pl._engine
+
+        def exchange(p, phase, e=e, K=K):
+            if phase == "records":
+                dist.all_gather_into_tensor(e.buffer(L.BUF_RECORDS_ALL)[0], e.buffer(L.BUF_RECORD))
+            elif phase == "gather":
+                dist.all_gather_into_tensor(e.buffer(L.BUF_TRAJ_COST_ALL)[:K], e.buffer(L.BUF_TRAJ_COST))
+            else:
+                dist.all_reduce(e.buffer(L.BUF_REDUCE))
+        pl.collective = exchange
+        state = sim._dof_state[0]
+        pl.command(state)
+        torch.cuda.synchronize()
+        # the other ranks' contributions: shifted copies of rank 0's (filled once; only slot 0 is live)
+        if pl.shard_mix:
+            R = e.buffer(L.BUF_RECORDS_ALL)
+            for r in range(1, N):
+                R[r].copy_(R[0])
+                R[r, :K] += 0.37 * r
+                R[r, K:K + 20] += 0.37 * r
+                R[r, K + 20:K + 40].view(torch.int32).add_(r * K)
+        else:
+            J = e.buffer(L.BUF_TRAJ_COST_ALL)
+            for r in range(1, N):
+                J[r * K:(r + 1) * K] = J[:K] + 0.37 * r
+        ms = loop(pl, state, steps)
+        e.enable_timing(True)
+        pl.collective_times = []
+        tr, tu, tf = [], [], []
+        for _ in range(100):
+            pl.command(state)
+            t = e.timing()
+            tr.append(t.rollout_ms); tu.append(t.update_ms); tf.append(t.finalize_ms)
+        e.enable_timing(False)
+        torch.cuda.synchronize()
+        per = {}
+        for ph, e0, e1 in pl.collective_times:
+            per.setdefault(ph, []).append(e0.elapsed_time(e1))
+        pl.collective_times = None
+        info = e.info()
+        res[label] = {"ms_per_command": ms, "rollout_ms": float(np.mean(tr)),
+                      "between_rollout_and_collective_ms": float(np.mean(tu)),
+                      "collective_to_end_ms": float(np.mean(tf)),
+                      "collective_stream_ms": {ph: float(np.mean(v)) for ph, v in per.items()},
+                      "collectives_per_command": len(per), "eta": [info.eta, info.eta_1, info.eta_2],
+                      "iters": [info.iters, info.iters_1, info.iters_2]}
+        e.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--emulate-rank-of", type=int, default=0)
     ap.add_argument("--config", default="c5")
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--json", default=None)
@@ -84,6 +161,8 @@ def main():
     t3 = time.perf_counter()
     torch.cuda.synchronize()
     out["host_call_us"] = {"all_gather_into_tensor": (t1 - t0) / 200 * 1e6, "all_reduce": (t3 - t2) / 200 * 1e6}
+    if a.emulate_rank_of > 1:
+        out[f"rank0_of_{a.emulate_rank_of}"] = emulate_rank(a.config, a.emulate_rank_of, a.steps)
     print(json.dumps(out))
     if a.json:
         os.makedirs(os.path.dirname(a.json) or ".", exist_ok=True)
