@@ -456,8 +456,61 @@ def g9():
     g9_trace("navr", cfg, 4, w0, noise_stream=True)
 
 
+# ---------------------------------------------------------------- G9 (panda): full command() traces
+def g9_panda_trace(tag, K, T, task, multi_modal, world0, goal7, ncalls=5):
+    """The reference's M3P2I + Objective driven through their plugin API on the panda_env (C4-shaped, reduced
+    K), the oracle's chain dynamics behind the wrapper API: pins, in ONE reference trace, what G2 / G5 / G6b
+    pin piecewise -- the gripper override (mppi.py:412-416), the persistent adapted beta (mppi.py:446-454),
+    the reach / pick dispatch (cost_functions.py:19-36, 91-136) and update_gripper_command (m3p2i.py:10-14).
+    Closed loop: the first action of every plan steps the 1-env world (scripts/sim.py:41-52)."""
+    import oracle.panda as P
+    cfg = panda_cfg(K, T, multi_modal=multi_modal)
+    sim = refshim.OraclePandaSim(K, world0)
+    obj = ref.cost_functions.Objective(cfg)
+    obj.update_objective(task, torch.from_numpy(np.array(goal7, np.float32)))
+
+    def dynamics(_, u, t=None):          # reactive_tamp.py:63-70
+        sim.set_dof_velocity_target_tensor(u)
+        sim.step()
+        return torch.stack([sim.robot_pos[:, 0], sim.robot_vel[:, 0], sim.robot_pos[:, 1], sim.robot_vel[:, 1]], dim=1), u
+
+    pl = make_planner(cfg, dynamics=dynamics, running_cost=lambda _: obj.compute_cost(sim))
+    pl.update_gripper_command(task)      # reactive_tamp.py:78
+    pl.delta = halton_delta(K, T, 9)
+    out[f"g9_{tag}_delta"] = pl.delta.numpy().copy()
+    sc = P.default_scene()
+    real = np.array(world0, np.float32).reshape(1, -1).copy()
+    rec = {k: [] for k in ("world", "action", "weights", "top_trajs", "mean", "beta", "pref")}
+    for call in range(ncalls):
+        rec["world"].append(real[0].copy())
+        sim.reset(real[0])
+        a = pl.command(sim._dof_state[0])
+        rec["action"].append(a.numpy().copy())
+        rec["weights"].append(pl.weights.numpy().copy())
+        rec["top_trajs"].append(pl.top_trajs.numpy().copy())
+        rec["mean"].append(pl.mean_action.numpy().copy())
+        rec["beta"].append(float(pl.beta))
+        rec["pref"].append(int(pl.get_pull_preference()))
+        P.step_batch(sc, real, a[0:1].numpy())
+    for k, v in rec.items():
+        out[f"g9_{tag}_{k}"] = np.array(v, np.int32 if k == "pref" else np.float32) if k in ("beta", "pref") else np.stack(v)
+    out[f"g9_{tag}_states_last"] = pl.states.numpy().copy()
+    out[f"g9_{tag}_actions_last"] = pl.actions.numpy().copy()
+
+
+def g9_panda():
+    import oracle.panda as P
+    from tests.panda_worlds import grasp_world
+    sc = P.default_scene()
+    goal7 = [0.2, 0.2, 1.115, 0.0, 0.0, 0.0, 1.0]   # pre-place pose above cubeB (task_planner.py:96-97)
+    w_init = P.init_world(1)[0]
+    g9_panda_trace("panda_reach", 256, 20, "reach", False, w_init, goal7)
+    g9_panda_trace("panda_reachmm", 256, 20, "reach", True, w_init, goal7)
+    g9_panda_trace("panda_pick", 256, 20, "pick", False, grasp_world(P, sc), goal7)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6_g7, g7_quat, g6_panda, g8, g10, g9):
+    for fn in (g1, g2, g3, g4, g5, g6_g7, g7_quat, g6_panda, g8, g10, g9, g9_panda):
         fn()
         print(fn.__name__, "ok")
     path = os.path.join(HERE, "ref_golden.npz")

@@ -162,3 +162,94 @@ class OracleSim:
     @property
     def _dof_state(self):
         return torch.from_numpy(self.worlds[:, [0, 4, 1, 5]].copy())
+
+
+PANDA_LINKS = {("panda", "panda_leftfinger"): "left", ("panda", "panda_rightfinger"): "right", ("cubeA", "box"): "cubeA",
+               ("cubeB", "box"): "cubeB"}
+
+
+class OraclePandaSim:
+    """K oracle panda worlds (oracle/panda_chain.c) behind the wrapper API the reference's panda plugins
+    use: dynamics of reactive_tamp.py:63-70 (set_dof_velocity_target_tensor, step, robot_pos / robot_vel =
+    dofs 0 and 1) and the getters of cost_functions.py:91-169 (finger / cube link states, cubeA
+    orientation, contact forces of table / shelf_stand / cubeB)."""
+
+    def __init__(self, K, world0, scene=None):
+        import oracle.panda as P
+        self.P = P
+        self.sc = scene or P.default_scene()
+        self.num_envs = K
+        self.dofs_per_robot = 9
+        self.world0 = np.array(world0, np.float32).reshape(-1)[:P.WORLD_FLOATS].copy()
+        self.worlds = np.tile(self.world0, (K, 1)).astype(np.float32)
+        self.u = np.zeros((K, 9), np.float32)
+        self._obs = None
+        lib = P.lib()
+        import ctypes as C
+        lib.m3o_panda_infer_held.argtypes = [C.POINTER(P.PandaScene), C.POINTER(C.c_float)]
+        self._lib, self._C = lib, C
+
+    def reset(self, world0=None):
+        """run_tamp (reactive_tamp.py:45-48): every environment takes the real world's state; whether the
+        cube is clamped between the pads is inferred from the geometry (the tensors carry no such bit)."""
+        P = self.P
+        if world0 is not None:
+            self.world0 = np.array(world0, np.float32).reshape(-1)[:P.WORLD_FLOATS].copy()
+        w = self.world0.copy()
+        self._lib.m3o_panda_infer_held(self._C.byref(self.sc), w.ctypes.data_as(self._C.POINTER(self._C.c_float)))
+        self.worlds[:] = w
+        self._obs = None
+
+    def _observe(self):
+        if self._obs is None:
+            self._obs = np.stack([self.P.observe(self.sc, self.worlds[i]) for i in range(self.num_envs)])
+        return self._obs
+
+    @property
+    def robot_pos(self):
+        return torch.from_numpy(self.worlds[:, [0, 1]].copy())
+
+    @property
+    def robot_vel(self):
+        return torch.from_numpy(self.worlds[:, [9, 10]].copy())
+
+    @property
+    def _dof_state(self):
+        d = np.zeros((self.num_envs, 18), np.float32)
+        d[:, 0::2] = self.worlds[:, 0:9]
+        d[:, 1::2] = self.worlds[:, 9:18]
+        return torch.from_numpy(d)
+
+    def get_actor_link_by_name(self, actor, link):
+        P, o = self.P, self._observe()
+        x = np.zeros((self.num_envs, 13), np.float32)
+        which = PANDA_LINKS[(actor, link)]
+        if which == "left":
+            x[:, 0:3], x[:, 3:7] = o[:, 0:3], o[:, 3:7]
+        elif which == "right":
+            x[:, 0:3] = o[:, 7:10]
+            x[:, 6] = 1.0    # (the costs read only the right finger's position)
+        elif which == "cubeA":
+            x[:] = self.worlds[:, P.W_CUBEA:P.W_CUBEA + 13]
+        else:
+            x[:] = self.worlds[:, P.W_CUBEB:P.W_CUBEB + 13]
+        return torch.from_numpy(x)
+
+    def get_actor_orientation_by_name(self, actor):
+        assert actor == "cubeA"
+        P = self.P
+        return torch.from_numpy(self.worlds[:, P.W_CUBEA + 3:P.W_CUBEA + 7].copy())
+
+    def get_actor_contact_forces_by_name(self, actor, link):
+        P = self.P
+        base = {"table": P.W_FT, "shelf_stand": P.W_FS, "cubeB": P.W_FB}[actor]
+        f = np.zeros((self.num_envs, 3), np.float32)
+        f[:, :2] = self.worlds[:, base:base + 2]
+        return torch.from_numpy(f)
+
+    def set_dof_velocity_target_tensor(self, u):
+        self.u = u.detach().numpy().astype(np.float32).reshape(self.num_envs, 9).copy()
+
+    def step(self):
+        self.P.step_batch(self.sc, self.worlds, self.u)
+        self._obs = None

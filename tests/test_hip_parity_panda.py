@@ -17,40 +17,7 @@ def raw31(P, w58):
     return np.concatenate([w[P.W_Q:P.W_Q + 18], w[P.W_CUBEA:P.W_CUBEA + 10], w[P.W_CUBEB:P.W_CUBEB + 3]])
 
 
-def grasp_world(P, sc, close_gripper=True, lift=0.0):
-    """A world in which the gripper holds cubeA (built with the oracle: IK + closing); with
-    close_gripper=False the open gripper is left around the cube (`lift` metres above the grasp
-    pose), so that rollouts grasp -- or just miss -- it on their own."""
-    w = P.init_world(1)
-    for _ in range(30):
-        P.step_batch(sc, w, np.zeros((1, 9), np.float32))
-    target = w[0, P.W_CUBEA:P.W_CUBEA + 3] + np.array([0, 0, sc.grasp_z + lift])
-    q = np.array([0, 0.3, 0, -2.2, 0, 2.5, 0.785, 0.04, 0.04], np.float32)
-
-    def feat(L):
-        return np.concatenate([L["pos"][8], 0.3 * L["az"][8], 0.3 * L["ay"][8]])
-
-    want = np.concatenate([target, 0.3 * np.array([0, 0, -1.0]), 0.3 * np.array([0, 1.0, 0])])
-    for _ in range(600):
-        L = P.fk(sc, q)
-        e = want - feat(L)
-        if np.linalg.norm(e) < 1e-4:
-            break
-        Jm = np.zeros((9, 7))
-        for j in range(7):
-            dq = q.copy(); dq[j] += 1e-3
-            Jm[:, j] = (feat(P.fk(sc, dq)) - feat(L)) / 1e-3
-        q[:7] += (np.linalg.pinv(Jm, rcond=1e-3) @ e * 0.5).astype(np.float32)
-        q[:7] = np.clip(q[:7], np.array(sc.qlo)[:7], np.array(sc.qhi)[:7])
-    w[0, P.W_Q:P.W_Q + 9] = q
-    w[0, P.W_QD:P.W_QD + 9] = 0
-    if not close_gripper:
-        return w[0].copy()
-    close = np.zeros((1, 9), np.float32); close[0, 7:] = -1.5
-    for _ in range(40):
-        P.step_batch(sc, w, close)
-    assert w[0, P.W_HELD] == 1.0
-    return w[0].copy()
+from tests.panda_worlds import grasp_world  # noqa: E402
 
 
 @pytest.mark.parametrize("task,mm,grip,held", [("reach", False, 1, False), ("reach", True, 1, False),
@@ -148,4 +115,38 @@ def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed):
     bad = np.argwhere(ch != opl.last["cost_h"])
     assert bad.size == 0, f"seed {seed}: {len(bad)} cost mismatches, first {bad[0]}"
     np.testing.assert_array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
+    eng.close()
+
+
+@pytest.mark.parametrize("tag,task,mm,grip", [("panda_reach", "reach", False, 1), ("panda_reachmm", "reach", True, 1),
+                                              ("panda_pick", "pick", False, 2)])
+def test_panda_command_traces_vs_reference_golden(golden, tag, task, mm, grip):
+    """G9 (panda): the HIP command() against five consecutive calls of the REFERENCE's own M3P2I + Objective
+    (tests/golden/make_golden.py g9_panda: the reference's planner + panda costs driven through their plugin
+    API; C4-shaped at K = 256, T = 20).  Bar: 1e-3 on the control output and the weights; the adapted,
+    persistent beta of the panda env (mppi.py:446-454) must follow the reference's call by call."""
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    K, T = 256, 20
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", multi_modal=mm, u_min=UMIN, u_max=UMAX,
+                                noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01))
+    eng.set_objective(task, goal, gripper_cmd=grip)
+    eng.set_noise(golden[f"g9_{tag}_delta"])
+    for call, w in enumerate(golden[f"g9_{tag}_world"]):
+        eng.set_world_panda_raw(raw31(P, w))
+        a = eng.command(sync_host=True)
+        np.testing.assert_allclose(a, golden[f"g9_{tag}_action"][call], atol=1e-3, err_msg=f"{tag} call {call}")
+        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), golden[f"g9_{tag}_weights"][call], atol=1e-3)
+        np.testing.assert_allclose(eng.buffer(L.BUF_MEAN).cpu().numpy(), golden[f"g9_{tag}_mean"][call], atol=1e-3)
+        np.testing.assert_allclose(eng.buffer(L.BUF_TOP_TRAJS).cpu().numpy()[:5], golden[f"g9_{tag}_top_trajs"][call][:5],
+                                   atol=1e-3)
+        info = eng.info()
+        if not mm:
+            assert info.beta == pytest.approx(float(golden[f"g9_{tag}_beta"][call]), rel=1e-5)
+        else:
+            assert info.pull_preference == int(golden[f"g9_{tag}_pref"][call])
+    np.testing.assert_allclose(eng.states.cpu().numpy(), golden[f"g9_{tag}_states_last"], atol=1e-3)
+    np.testing.assert_allclose(eng.actions.cpu().numpy(), golden[f"g9_{tag}_actions_last"], atol=1e-3)
     eng.close()

@@ -112,3 +112,33 @@ def test_cube_settles_on_table_and_can_be_grasped_and_lifted(P):
     for _ in range(100):
         P.step_batch(sc, w, release)
     assert w[0, P.W_HELD] == 0.0 and w[0, P.W_CUBEA + 2] == pytest.approx(1.05, abs=1e-5)  # fell back
+
+
+PANDA_TRACES = {"panda_reach": ("reach", False, 1), "panda_reachmm": ("reach", True, 1), "panda_pick": ("pick", False, 2)}
+
+
+@pytest.mark.parametrize("tag", list(PANDA_TRACES))
+def test_g9_panda_command_traces_vs_reference(golden, oracle, tag):
+    """G9 (panda): five consecutive command() calls of the REFERENCE's M3P2I + Objective (imported by
+    tests/golden/make_golden.py, the oracle's chain dynamics behind its wrapper API) vs the oracle's own
+    planner from the same worlds and noise: returned plan, weights, top trajectories, the persistent beta
+    the panda env adapts (mppi.py:446-454), gripper override (mppi.py:412-416)."""
+    import oracle.panda as P
+    task, mm, grip = PANDA_TRACES[tag]
+    K, T = 256, 20
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    cfg = P.make_cfg(K, T, multi_modal=mm, task=task, goal=goal, gripper_cmd=grip)
+    opl = P.OraclePandaPlanner(cfg, golden[f"g9_{tag}_delta"])
+    for call, w in enumerate(golden[f"g9_{tag}_world"]):
+        a = opl.command(w)
+        np.testing.assert_allclose(a, golden[f"g9_{tag}_action"][call], atol=1e-3, err_msg=f"{tag} call {call}")
+        np.testing.assert_allclose(opl.last["w"], golden[f"g9_{tag}_weights"][call], atol=1e-3)
+        np.testing.assert_allclose(opl.mean, golden[f"g9_{tag}_mean"][call], atol=1e-3)
+        if not mm:
+            assert opl.beta == pytest.approx(float(golden[f"g9_{tag}_beta"][call]), rel=1e-5)
+        top = opl.last["states"][opl.last["top_idx"]][:, :, [0, 2]]
+        np.testing.assert_allclose(top[:5], golden[f"g9_{tag}_top_trajs"][call][:5], atol=1e-3)
+        # the gripper override: fingers commanded open (reach) / closed (pick) in every sample
+        assert np.all(opl.last["actions"][:-1, :, 7:] == (1.5 if grip == 1 else -1.5))
+    np.testing.assert_allclose(opl.last["states"], golden[f"g9_{tag}_states_last"], atol=1e-3)
+    np.testing.assert_allclose(opl.last["actions"], golden[f"g9_{tag}_actions_last"], atol=1e-3)
