@@ -22,18 +22,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from m3p2i_aip_amd import compat  # noqa: E402
 
 
-def main(argv):
-    cn, ticks, out, overrides = "config_point", 2000, None, []
-    it = iter(argv)
-    for a in it:
-        if a in ("-cn", "--config-name"):
-            cn = next(it)
-        elif a == "--ticks":
-            ticks = int(next(it))
-        elif a == "--json":
-            out = next(it)
-        else:
-            overrides.append(a)
+def run(cn="config_point", overrides=(), ticks=2000):
+    """One closed-loop episode; returns the report dict (what main() prints)."""
+    overrides = list(overrides)
     compat.install(force_standins=True)
     from m3p2i_aip.planners.motion_planner import m3p2i
     from m3p2i_aip.planners.task_planner import task_planner
@@ -113,6 +104,25 @@ def main(argv):
         goal = real.get_actor_link_by_name("cubeB", "box")[0, :3].cpu()
         res["cube_to_goal_xy"] = float(torch.norm(cube[:2] - goal[:2]))
         res["cube_height_above_goal"] = float(cube[2] - goal[2])
+    real.stop_sim()
+    tamp.sim.stop_sim()
+    tamp.motion_planner._engine.close()
+    return res
+
+
+def main(argv):
+    cn, ticks, out, overrides = "config_point", 2000, None, []
+    it = iter(argv)
+    for a in it:
+        if a in ("-cn", "--config-name"):
+            cn = next(it)
+        elif a == "--ticks":
+            ticks = int(next(it))
+        elif a == "--json":
+            out = next(it)
+        else:
+            overrides.append(a)
+    res = run(cn, overrides, ticks)
     print(json.dumps(res))
     if out:
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
