@@ -5,7 +5,8 @@ import and run unchanged on this package.
 (`reactive_tamp.py:1-8`, `sim.py:1-6`).  Nothing of the reference is copied and Isaac Gym is
 not needed.  Launcher / RPC pieces (hydra, zerorpc) are outside the hot path (SURVEY.md
 section 8(f)); when the real packages are absent, small stand-ins cover exactly the calls the
-scripts make.
+scripts make (`hydra.main` composition of config_point / config_panda + key=value overrides;
+`zerorpc.Server / Client` over TCP + msgpack: m3p2i_aip_amd/rpc.py).
 
 Host-side helpers restated here (all O(1) per command, no data parallelism):
   PLANNER_SIMPLE / PLANNER_AIF_PANDA / AiAgent / adapt_act_sel / MDPIsCubeAtReal
@@ -165,19 +166,13 @@ def _hydra_standin():
 
 
 def _zerorpc_standin():
+    """`zerorpc` is not installed here: the Server / Client pair of m3p2i_aip_amd.rpc (same calls, a plain
+    TCP + msgpack transport) answers to the name, so reactive_tamp.py:89-94 and sim.py:29-49 run as two
+    processes."""
+    from . import rpc
     m = types.ModuleType("zerorpc")
-
-    class _NoRPC:
-        def __init__(self, *a, **k):
-            self.target = a[0] if a else None
-
-        def bind(self, *a, **k):
-            raise RuntimeError("zerorpc is not installed: the RPC transport of reactive_tamp.py:92-94 is "
-                               "outside this build's scope; call REACTIVE_TAMP.run_tamp() in-process")
-
-        connect = run = bind
-
-    m.Server = m.Client = _NoRPC
+    m.Server, m.Client = rpc.Server, rpc.Client
+    m.RemoteError, m.LostRemote = rpc.RemoteError, rpc.LostRemote
     return m
 
 

@@ -17,7 +17,7 @@ The K environments are K lanes of one HIP kernel (m3_sim_step).  The four state 
 ordinary torch CUDA tensors (torch owns the memory); the library keeps its own SoA copy and
 the two are synchronised exactly where the reference synchronises with PhysX: `set_*_state
 _tensor` uploads, `step()` refreshes.  There is no viewer (reactive_tamp.py passes
-viewer=False); viewer/keyboard entry points raise.
+viewer=False; sim.py's viewer=True runs headless with a warning); keyboard_control raises.
 """
 from __future__ import annotations
 
@@ -51,7 +51,10 @@ class IsaacGymWrapper:
                  viewer: bool = False, device: str = "cuda:0", cube_on_shelf: bool = False,
                  k_offset: int = 0, num_envs_global: int | None = None):
         if viewer or getattr(cfg, "viewer", False):
-            raise NotImplementedError("the HIP rollout simulator has no viewer")
+            # scripts/sim.py:19-27 asks for the viewer of its 1-env world; this build has none: the world
+            # runs headless (visualize_trajs / play_with_cube are no-ops), keyboard_control raises
+            import warnings
+            warnings.warn("IsaacGymWrapper(viewer=True): this build has no viewer, the world runs headless")
         if env_type not in scenes.ENVS:
             raise ValueError(f"unknown env_type {env_type!r}")
         self.cfg = cfg

@@ -1,0 +1,160 @@
+"""A small RPC transport with the part of the `zerorpc` API the reference's two scripts use
+(scripts/reactive_tamp.py:89-94 planner side, scripts/sim.py:29-49 world side):
+
+    server = Server(obj); server.bind("tcp://0.0.0.0:4242"); server.run()
+    client = Client(); client.connect("tcp://127.0.0.1:4242"); reply = client.any_method(*args)
+
+so that, when the real zerorpc (ZeroMQ + gevent) is not installed, `compat.install()` can register this
+module under the name `zerorpc` and the unchanged scripts run as two processes.  Wire format: one TCP
+connection per client, length-prefixed msgpack frames -- request [method, args], reply [error, result];
+`bytes` payloads (the scripts ship `torch.save` blobs, utils/data_transfer.py:4-12) travel as msgpack
+bin.  Like zerorpc's server on gevent, calls are served one at a time in the order they arrive
+(reactive_tamp.py's command() is never re-entered).  Only public methods of the served object are
+callable; there is no pickle on the wire.
+"""
+from __future__ import annotations
+
+import select
+import socket
+import struct
+
+import msgpack
+
+_HDR = struct.Struct("!I")
+MAX_FRAME = 1 << 30
+
+
+class RemoteError(RuntimeError):
+    """An exception raised by the served object, re-raised on the client (zerorpc.RemoteError)."""
+
+
+class LostRemote(RuntimeError):
+    """The peer went away (zerorpc.LostRemote)."""
+
+
+def _endpoint(ep: str):
+    if not ep.startswith("tcp://"):
+        raise ValueError(f"only tcp:// endpoints are supported, got {ep!r}")
+    host, _, port = ep[len("tcp://"):].rpartition(":")
+    return ("" if host in ("*", "0.0.0.0") else host), int(port)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
+        if not chunk:
+            raise LostRemote("connection closed by the peer")
+        buf += chunk
+    return bytes(buf)
+
+
+def _send(sock, obj):
+    payload = msgpack.packb(obj, use_bin_type=True)
+    sock.sendall(_HDR.pack(len(payload)) + payload)
+
+
+def _recv(sock):
+    (n,) = _HDR.unpack(_recv_exact(sock, _HDR.size))
+    if n > MAX_FRAME:
+        raise LostRemote(f"frame of {n} bytes refused")
+    return msgpack.unpackb(_recv_exact(sock, n), raw=False)
+
+
+class Server:
+    def __init__(self, methods=None, name=None, context=None, pool_size=None, heartbeat=None):
+        self._target = methods
+        self._listen = []
+        self._clients = []
+        self._running = False
+
+    def bind(self, endpoint):
+        host, port = _endpoint(endpoint)
+        s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        s.bind((host, port))
+        s.listen(8)
+        self._listen.append(s)
+        return s.getsockname()[1]
+
+    def _call(self, name, args):
+        if not isinstance(name, str) or name.startswith("_"):
+            raise AttributeError(f"no such method: {name!r}")
+        fn = getattr(self._target, name)
+        if not callable(fn):
+            raise AttributeError(f"{name!r} is not callable")
+        return fn(*args)
+
+    def serve_once(self, timeout=None):
+        """Wait for activity (up to `timeout` seconds) and serve what arrived; returns the number of calls."""
+        ready, _, _ = select.select(self._listen + self._clients, [], [], timeout)
+        served = 0
+        for s in ready:
+            if s in self._listen:
+                c, _ = s.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self._clients.append(c)
+                continue
+            try:
+                name, args = _recv(s)
+            except (LostRemote, ConnectionError, ValueError):
+                self._clients.remove(s)
+                s.close()
+                continue
+            try:
+                reply = [None, self._call(name, args)]
+            except Exception as e:  # the served object's exception goes back to the caller
+                reply = [f"{type(e).__name__}: {e}", None]
+            try:
+                _send(s, reply)
+            except (ConnectionError, OSError):
+                self._clients.remove(s)
+                s.close()
+            served += 1
+        return served
+
+    def run(self):
+        self._running = True
+        while self._running:
+            self.serve_once(0.5)
+
+    def stop(self):
+        self._running = False
+
+    def close(self):
+        self.stop()
+        for s in self._listen + self._clients:
+            s.close()
+        self._listen, self._clients = [], []
+
+
+class Client:
+    def __init__(self, connect_to=None, context=None, timeout=30, heartbeat=None, passive_heartbeat=False):
+        self._sock = None
+        self._timeout = timeout
+        if connect_to:
+            self.connect(connect_to)
+
+    def connect(self, endpoint, resolve=True):
+        host, port = _endpoint(endpoint)
+        self._sock = socket.create_connection((host or "127.0.0.1", port), timeout=self._timeout)
+        self._sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+
+    def close(self):
+        if self._sock is not None:
+            self._sock.close()
+            self._sock = None
+
+    def __call__(self, method, *args):
+        if self._sock is None:
+            raise LostRemote("not connected")
+        _send(self._sock, [method, list(args)])
+        err, result = _recv(self._sock)
+        if err is not None:
+            raise RemoteError(err)
+        return result
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return lambda *args: self(name, *args)

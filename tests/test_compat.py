@@ -52,6 +52,20 @@ def test_unchanged_reference_script_loads_on_the_shims():
             ns["REACTIVE_TAMP"](compat.make_config("config_point", ["mppi.num_samples=64"]))
 
 
+@pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="reference checkout not mounted")
+def test_unchanged_reference_sim_script_loads_on_the_shims():
+    """scripts/sim.py AS IS: its imports (isaacgym, hydra, zerorpc, skill_utils.check_and_apply_suction /
+    time_tracking, data_transfer) resolve and its hydra entry point is built; running it needs the GPU and
+    a planner process on tcp://127.0.0.1:4242 (tests/test_rpc_two_process_gpu.py exercises that
+    arrangement with this repository's own driver, since the reference's files do not travel)."""
+    from m3p2i_aip_amd import compat
+    compat.install(force_standins=True)
+    ns = runpy.run_path(REF_SCRIPT.replace("reactive_tamp.py", "sim.py"), run_name="reference_sim")
+    assert callable(ns["run_sim"]) and ns["check_and_apply_suction"] is compat.check_and_apply_suction
+    import zerorpc
+    assert ns["zerorpc"] is zerorpc and hasattr(zerorpc.Client(), "connect")
+
+
 @pytest.mark.gpu
 def test_reactive_tamp_wiring_through_compat_names_gpu():
     """reactive_tamp.py:22-61 written against the reference's module names, on the GPU."""

@@ -2,6 +2,8 @@
 (1-env "real world") and scripts/reactive_tamp.py:22-88 (planner side) without the RPC hop.
 
     python tools/closed_loop.py [-cn config_point|config_panda] [key=value ...] [--ticks N] [--json out]
+    python tools/closed_loop.py --serve tcp://127.0.0.1:4242 [...]      planner process (reactive_tamp.py's role)
+    python tools/closed_loop.py --connect tcp://127.0.0.1:4242 [...]    world process (sim.py's role), same overrides
 
 e.g.  python tools/closed_loop.py task=push goal=[-1,-1] mppi.num_samples=2000 mppi.horizon=30
       python tools/closed_loop.py task=push_pull multi_modal=True mppi.num_samples=4000 mppi.horizon=30
@@ -22,50 +24,113 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from m3p2i_aip_amd import compat  # noqa: E402
 
 
-def run(cn="config_point", overrides=(), ticks=2000):
-    """One closed-loop episode; returns the report dict (what main() prints)."""
+class Tamp:
+    """Planner side: scripts/reactive_tamp.py:22-88 (REACTIVE_TAMP) written against the reference's module
+    names.  `run_tamp` takes / returns tensors; the *_bytes methods are the RPC surface of the script
+    (torch.save blobs, utils/data_transfer.py)."""
+
+    def __init__(self, cfg):
+        from m3p2i_aip.planners.motion_planner import m3p2i
+        from m3p2i_aip.planners.task_planner import task_planner
+        import m3p2i_aip.utils.isaacgym_utils.isaacgym_wrapper as wrapper
+        from m3p2i_aip.planners.motion_planner.cost_functions import Objective
+        self.cfg = cfg
+        self.sim = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=cfg.mppi.num_samples,
+                                           viewer=False, device=cfg.mppi.device, cube_on_shelf=cfg.cube_on_shelf)
+        self.objective = Objective(cfg)
+        self.task_planner = task_planner.set_task_planner(cfg)
+        self.task_success = False
+        self.suction_active = False
+        self.motion_planner = m3p2i.M3P2I(cfg, dynamics=self.dynamics, running_cost=self.running_cost)
+
+    def dynamics(self, _, u, t=None):
+        self.sim.set_dof_velocity_target_tensor(u)
+        self.sim.step()
+        return torch.stack([self.sim.robot_pos[:, 0], self.sim.robot_vel[:, 0],
+                            self.sim.robot_pos[:, 1], self.sim.robot_vel[:, 1]], dim=1), u
+
+    def running_cost(self, _):
+        return self.objective.compute_cost(self.sim)
+
+    def run_tamp(self, dof_state, root_state):
+        self.sim._dof_state[:] = dof_state
+        self.sim._root_state[:] = root_state
+        self.sim.set_dof_state_tensor(self.sim._dof_state)
+        self.sim.set_actor_root_state_tensor(self.sim._root_state)
+        self.task_planner.update_plan(self.sim)
+        self.motion_planner.update_gripper_command(self.task_planner.task)
+        self.objective.update_objective(self.task_planner.task, self.task_planner.curr_goal)
+        self.suction_active = self.motion_planner.get_pull_preference()
+        self.task_success = bool(self.task_planner.check_task_success(self.sim))
+        if self.task_success:
+            return torch.zeros(self.sim.dofs_per_robot, device=self.cfg.mppi.device)
+        return self.motion_planner.command(self.sim._dof_state[0])[0]
+
+    # ---- what reactive_tamp.py serves over zerorpc (:43-61, 83-87) + a status call for this tool ----
+    def run_tamp_bytes(self, dof_bytes, root_bytes):
+        from m3p2i_aip.utils.data_transfer import bytes_to_torch, torch_to_bytes
+        dev = self.cfg.mppi.device
+        return torch_to_bytes(self.run_tamp(bytes_to_torch(dof_bytes).to(dev), bytes_to_torch(root_bytes).to(dev)))
+
+    def get_suction(self):
+        from m3p2i_aip.utils.data_transfer import torch_to_bytes
+        return torch_to_bytes(self.suction_active)
+
+    def get_trajs(self):
+        from m3p2i_aip.utils.data_transfer import torch_to_bytes
+        return torch_to_bytes(self.motion_planner.top_trajs)
+
+    def status(self):
+        return {"task": self.task_planner.task, "success": bool(self.task_success),
+                "goal": [float(x) for x in self.task_planner.curr_goal.float().cpu().reshape(-1).tolist()]}
+
+    def close(self):
+        self.sim.stop_sim()
+        self.motion_planner._engine.close()
+
+
+class RemoteTamp:
+    """World side's view of a Tamp served in another process (scripts/sim.py:29-49): same three calls."""
+
+    def __init__(self, endpoint, device):
+        import zerorpc   # the real package, or compat's stand-in (m3p2i_aip_amd/rpc.py)
+        self.c = zerorpc.Client(timeout=120)
+        self.c.connect(endpoint)
+        self.device = device
+        self.task_success, self.suction_active, self.task = False, False, None
+
+    def run_tamp(self, dof_state, root_state):
+        from m3p2i_aip.utils.data_transfer import bytes_to_torch, torch_to_bytes
+        a = bytes_to_torch(self.c.run_tamp_bytes(torch_to_bytes(dof_state), torch_to_bytes(root_state))).to(self.device)
+        self.suction_active = bytes_to_torch(self.c.get_suction())
+        st = self.c.status()
+        self.task, self.task_success, self.goal = st["task"], st["success"], st["goal"]
+        return a
+
+    def close(self):
+        self.c.close()
+
+
+def serve(cn, overrides, endpoint):
+    """Planner process: python tools/closed_loop.py --serve tcp://127.0.0.1:4242 [config overrides]."""
+    compat.install(force_standins=True)
+    import zerorpc
+    tamp = Tamp(compat.make_config(cn, list(overrides)))
+    server = zerorpc.Server(tamp)
+    server.bind(endpoint)
+    print("serving", endpoint, flush=True)
+    server.run()
+
+
+def run(cn="config_point", overrides=(), ticks=2000, connect=None):
+    """One closed-loop episode; returns the report dict (what main() prints).  connect = endpoint of a
+    planner served by `--serve` in another process (otherwise the planner lives in this process)."""
     overrides = list(overrides)
     compat.install(force_standins=True)
-    from m3p2i_aip.planners.motion_planner import m3p2i
-    from m3p2i_aip.planners.task_planner import task_planner
     import m3p2i_aip.utils.isaacgym_utils.isaacgym_wrapper as wrapper
-    from m3p2i_aip.planners.motion_planner.cost_functions import Objective
     from m3p2i_aip.utils.skill_utils import check_and_apply_suction
     cfg = compat.make_config(cn, overrides)
-
-    class Tamp:   # reactive_tamp.py:22-88
-        def __init__(self):
-            self.sim = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=cfg.mppi.num_samples,
-                                               viewer=False, device=cfg.mppi.device, cube_on_shelf=cfg.cube_on_shelf)
-            self.objective = Objective(cfg)
-            self.task_planner = task_planner.set_task_planner(cfg)
-            self.task_success = False
-            self.motion_planner = m3p2i.M3P2I(cfg, dynamics=self.dynamics, running_cost=self.running_cost)
-
-        def dynamics(self, _, u, t=None):
-            self.sim.set_dof_velocity_target_tensor(u)
-            self.sim.step()
-            return torch.stack([self.sim.robot_pos[:, 0], self.sim.robot_vel[:, 0],
-                                self.sim.robot_pos[:, 1], self.sim.robot_vel[:, 1]], dim=1), u
-
-        def running_cost(self, _):
-            return self.objective.compute_cost(self.sim)
-
-        def run_tamp(self, dof_state, root_state):
-            self.sim._dof_state[:] = dof_state
-            self.sim._root_state[:] = root_state
-            self.sim.set_dof_state_tensor(self.sim._dof_state)
-            self.sim.set_actor_root_state_tensor(self.sim._root_state)
-            self.task_planner.update_plan(self.sim)
-            self.motion_planner.update_gripper_command(self.task_planner.task)
-            self.objective.update_objective(self.task_planner.task, self.task_planner.curr_goal)
-            self.suction_active = self.motion_planner.get_pull_preference()
-            self.task_success = bool(self.task_planner.check_task_success(self.sim))
-            if self.task_success:
-                return torch.zeros(self.sim.dofs_per_robot, device=cfg.mppi.device)
-            return self.motion_planner.command(self.sim._dof_state[0])[0]
-
-    tamp = Tamp()
+    tamp = RemoteTamp(connect, cfg.mppi.device) if connect else Tamp(cfg)
     real = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=1, viewer=False, device=cfg.mppi.device,
                                    cube_on_shelf=cfg.cube_on_shelf)
     nu = real.dofs_per_robot
@@ -79,7 +144,7 @@ def run(cn="config_point", overrides=(), ticks=2000):
         action = tamp.run_tamp(real._dof_state, real._root_state)
         action_host = action.cpu()               # command() wall time incl. the action on the host
         lat.append(time.perf_counter() - t0)
-        task = tamp.task_planner.task
+        task = tamp.task if connect else tamp.task_planner.task
         if not timeline or timeline[-1][1] != task:
             timeline.append((i, task))
         if tamp.task_success:
@@ -91,12 +156,12 @@ def run(cn="config_point", overrides=(), ticks=2000):
             check_and_apply_suction(cfg, real, action.view(1, nu))
         real.step()
     res = dict(config=cn, overrides=overrides, K=cfg.mppi.num_samples, T=cfg.mppi.horizon,
-               ticks=i + 1, success=success_tick is not None,
+               ticks=i + 1, success=success_tick is not None, transport="rpc " + connect if connect else "in-process",
                sim_time_s=(i + 1) * cfg.isaacgym.dt, timeline=timeline,
                command_ms_p50=float(np.percentile(lat[5:], 50) * 1e3), command_ms_p99=float(np.percentile(lat[5:], 99) * 1e3),
                command_hz_mean=float(1.0 / np.mean(lat[5:])))
     if cfg.env_type == "point_env":
-        goal = tamp.task_planner.curr_goal.float().cpu()
+        goal = torch.tensor(tamp.goal) if connect else tamp.task_planner.curr_goal.float().cpu()
         who = real.robot_pos[0].cpu() if cfg.task == "navigation" else real.get_actor_position_by_name("box")[0, :2].cpu()
         res["final_pos_error"] = float(torch.norm(who - goal))
     else:
@@ -105,13 +170,12 @@ def run(cn="config_point", overrides=(), ticks=2000):
         res["cube_to_goal_xy"] = float(torch.norm(cube[:2] - goal[:2]))
         res["cube_height_above_goal"] = float(cube[2] - goal[2])
     real.stop_sim()
-    tamp.sim.stop_sim()
-    tamp.motion_planner._engine.close()
+    tamp.close()
     return res
 
 
 def main(argv):
-    cn, ticks, out, overrides = "config_point", 2000, None, []
+    cn, ticks, out, overrides, serve_ep, connect_ep = "config_point", 2000, None, [], None, None
     it = iter(argv)
     for a in it:
         if a in ("-cn", "--config-name"):
@@ -120,9 +184,15 @@ def main(argv):
             ticks = int(next(it))
         elif a == "--json":
             out = next(it)
+        elif a == "--serve":
+            serve_ep = next(it)
+        elif a == "--connect":
+            connect_ep = next(it)
         else:
             overrides.append(a)
-    res = run(cn, overrides, ticks)
+    if serve_ep:
+        return serve(cn, overrides, serve_ep)
+    res = run(cn, overrides, ticks, connect=connect_ep)
     print(json.dumps(res))
     if out:
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
