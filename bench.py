@@ -245,7 +245,10 @@ def closed_loop(r, ticks, device):
     """The headline planner in CLOSED loop: a 1-env "real world" (the same integrator at K = 1) is stepped
     with the first action of every plan and its state is what the next command() starts from -- the flow
     of scripts/sim.py:36-52 + reactive_tamp.py:43-60 in one process.  Nothing is read back on the host
-    inside the loop (the action stays on the device), so the commands pipeline as in the open-loop run."""
+    inside the loop (the action stays on the device), so the commands pipeline as in the open-loop run.
+    In one process the planner reads the world's state tensors in place (planner.attach(sim=real): the
+    fused rollout takes env 0 of the bound tensors), so the state hand-over of reactive_tamp.py:45-48 costs
+    nothing; over RPC it is two blobs per tick (tools/closed_loop.py --connect)."""
     from m3p2i_aip_amd import isaacgym_wrapper as wrapper
     from m3p2i_aip_amd.compat import check_and_apply_suction
     pl, sim, cfg = r["pl"], r["sim"], r["cfg"]
@@ -254,12 +257,12 @@ def closed_loop(r, ticks, device):
     point = cfg.env_type == "point_env"
     pull = cfg.task in ("pull", "push_pull")
 
+    pl.attach(sim=real)
+
     def tick(i):
         if point:
             real.update_dyn_obs(i)
-        sim._dof_state[:] = real._dof_state          # reactive_tamp.py:45-48 (device-to-device, broadcast)
-        sim._root_state[:] = real._root_state
-        a = pl.command(sim._dof_state[0])[0]
+        a = pl.command(real._dof_state[0])[0]
         real.set_dof_velocity_target_tensor(a.view(1, nu))
         if pull:
             cfg.suction_active = pl.get_pull_preference()   # one host sync per tick, as the reference's .item()
@@ -283,6 +286,7 @@ def closed_loop(r, ticks, device):
         who = real.robot_pos[0] if cfg.task == "navigation" else real.get_actor_position_by_name("box")[0, :2]
         out["final_pos_error_m"] = float(torch.norm(who - goal))
         out["sim_time_s"] = (10 + ticks) * cfg.isaacgym.dt
+    pl.attach(sim=sim)
     real.stop_sim()
     return out
 

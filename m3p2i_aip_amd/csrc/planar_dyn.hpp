@@ -515,9 +515,30 @@ enum : unsigned {
     G_NO_BOX_STATICS = G_RB | G_RD | G_RO | G_RW | G_BD  // everything but box/dyn-obs vs walls and obstacle
 };
 
+// -DM3_ABL_PHASES (experiments, tools/phase_breakdown.py): shader-clock time of every wave per phase of
+// the rollout -- 0 action assembly + prefetch, 1 broad-phase mask + dispatch, 2 forces + detection, 3 the
+// solver passes, 4 net force + integration, 5 task cost, 6 stores + accumulation
+#ifdef M3_ABL_PHASES
+__device__ unsigned long long g_phase[1024 * 8];
+struct PhaseClock {
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+    __device__ __forceinline__ void start() { last = __builtin_readcyclecounter(); }
+    template <int N> __device__ __forceinline__ void mark() {
+        const unsigned long long now = __builtin_readcyclecounter();
+        acc[N] += now - last;
+        last = now;
+    }
+};
+#define M3_PH(n) if (pc_) pc_->template mark<n>()
+#else
+struct PhaseClock {};
+#define M3_PH(n)
+#endif
+
 template <bool ALL_FORCES, unsigned M>
 __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& w, float ux, float uy,
-                                              bool form_dyn_force) {
+                                              bool form_dyn_force, PhaseClock* pc_ = nullptr) {
+    M3_PH(1);
     constexpr bool RB = M & G_RB, RD = M & G_RD, RO = M & G_RO, RW = M & G_RW, BW = M & G_BW,
                    DW = M & G_DW, BD = M & G_BD, BO = M & G_BO, DO = M & G_DO;
     constexpr bool ANY_RARE = (M & ~G_RB) != 0u, ANY_WALLS = RW || BW || DW, ANY_BOXES = BD || BO || DO;
@@ -568,6 +589,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     const bool on_boxes = s_bd1.on | s_bd2.on | s_bo1.on | s_bo2.on | s_do1.on | s_do2.on;
     const bool rare = s_rd.on | s_ro.on | on_walls | on_boxes;
 
+    M3_PH(2);
     // 3. velocity solve
     Vel v = {w.rvx, w.rvy, w.B.vx, w.B.vy, w.B.w, w.D.vx, w.D.vy, w.D.w};
     float ldx = 0.0f, ldy = 0.0f;
@@ -649,6 +671,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     w.rvx = v.rvx; w.rvy = v.rvy;
     w.B.vx = v.bvx; w.B.vy = v.bvy; w.B.w = v.bw;
     w.D.vx = v.dvx; w.D.vy = v.dvy; w.D.w = v.dw;
+    M3_PH(3);
 
     // net contact force on the dyn-obs (get_motion_cost reads it), slot order.  The cost sees only
     // the LAST substep's value (spec), and only the navigation cost reads it at all
@@ -688,16 +711,18 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     w.ry = w.ry + h * w.rvy;
     if (!skipB) integrate_box(w.B, h);   // (a wave whose boxes all rest: x + h * 0 == x)
     if (!skipD) integrate_box(w.D, h);
+    M3_PH(4);
 }
 
 #ifdef M3_ABL_COUNT
 __device__ unsigned int g_lvl[512];
 __device__ unsigned int g_cyc[64 * 16];
 #endif
+
 // one sim.step(): substeps x (forces, detect, solve, integrate)
 template <bool ALL_FORCES>
 __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, float ux, float uy,
-                                           bool need_dyn_force = true) {
+                                           bool need_dyn_force = true, PhaseClock* pc_ = nullptr) {
     for (int sub = 0; sub < sc.substeps; ++sub) {
         const bool form = need_dyn_force && sub == sc.substeps - 1;
         if constexpr (ALL_FORCES) {
@@ -722,12 +747,12 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
 #endif
             // the leanest instance that covers the mask
 #define M3_COVERS(set) ((m & ~(set)) == 0u)
-            if (m == 0u) point_substep<false, 0u>(sc, w, ux, uy, form);
-            else if (M3_COVERS(G_RB)) point_substep<false, G_RB>(sc, w, ux, uy, form);
-            else if (M3_COVERS(G_RB | G_RD)) point_substep<false, G_RB | G_RD>(sc, w, ux, uy, form);
-            else if (M3_COVERS(G_RB | G_RD | G_BD)) point_substep<false, G_RB | G_RD | G_BD>(sc, w, ux, uy, form);
-            else if (M3_COVERS(G_NO_BOX_STATICS)) point_substep<false, G_NO_BOX_STATICS>(sc, w, ux, uy, form);
-            else point_substep<false, G_ALL>(sc, w, ux, uy, form);
+            if (m == 0u) point_substep<false, 0u>(sc, w, ux, uy, form, pc_);
+            else if (M3_COVERS(G_RB)) point_substep<false, G_RB>(sc, w, ux, uy, form, pc_);
+            else if (M3_COVERS(G_RB | G_RD)) point_substep<false, G_RB | G_RD>(sc, w, ux, uy, form, pc_);
+            else if (M3_COVERS(G_RB | G_RD | G_BD)) point_substep<false, G_RB | G_RD | G_BD>(sc, w, ux, uy, form, pc_);
+            else if (M3_COVERS(G_NO_BOX_STATICS)) point_substep<false, G_NO_BOX_STATICS>(sc, w, ux, uy, form, pc_);
+            else point_substep<false, G_ALL>(sc, w, ux, uy, form, pc_);
 #ifdef M3_ABL_COUNT
             {
                 const unsigned long long dt_ = wall_clock64() - t0_;

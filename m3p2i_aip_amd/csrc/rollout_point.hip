@@ -114,6 +114,12 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const
 
     float J = 0.0f, S = 0.0f, g = 1.0f, pc = 0.0f;
     StepIn nxt = fetch(0);
+#ifdef M3_ABL_PHASES
+    PhaseClock clk, *pc_ = &clk;
+    clk.start();
+#else
+    PhaseClock* pc_ = nullptr;
+#endif
     for (int t = 0; t < T; ++t) {
         const StepIn in = nxt;
         if (t + 1 < T) nxt = fetch(t + 1);
@@ -137,11 +143,13 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const
         float u0 = a.u_scale * a0, u1 = a.u_scale * a1;                 // mppi.py:297
         if (a.sample_null_action && is_last) { u0 = 0.0f; u1 = 0.0f; }  // mppi.py:300-302
 
+        M3_PH(0);
         // ---- A6: one sim.step() ----
-        point_step<false>(sc, w, u0, u1, /*need_dyn_force=*/a.cp.task == 0);
+        point_step<false>(sc, w, u0, u1, /*need_dyn_force=*/a.cp.task == 0, pc_);
 
         // ---- A7/A8: running cost on the post-step state ----
         const float c = point_cost(a.cp, w, k);
+        M3_PH(5);
 
         // ---- outputs, time-major ----
         *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
@@ -158,7 +166,12 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const
             pc = pc + m0 * (a.lambda_ * (e0 - m0) * a.sigma_inv[0]);
             pc = pc + m1 * (a.lambda_ * (e1 - m1) * a.sigma_inv[1]);
         }
+        M3_PH(6);
     }
+#ifdef M3_ABL_PHASES
+    if (threadIdx.x == 0 && blockIdx.x < 1024)
+        for (int q = 0; q < 8; ++q) atomicAdd(&g_phase[blockIdx.x * 8 + q], clk.acc[q]);
+#endif
     a.J[i] = a.mode_simple ? (S + pc) : J;
     a.pend[0 * Kl + i] = w.fRx; a.pend[1 * Kl + i] = w.fRy;
     a.pend[2 * Kl + i] = w.fBx; a.pend[3 * Kl + i] = w.fBy;
@@ -380,6 +393,12 @@ void launch_sim_suction(const SimViews& v, float* world, int Kl, float kp, float
 
 }  // namespace m3
 
+#ifdef M3_ABL_PHASES
+extern "C" void m3_dbg_phases(unsigned long long* out, int reset) {
+    if (reset) { static unsigned long long z[1024 * 8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(m3::g_phase), z, sizeof(z)); }
+    else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(m3::g_phase), 1024 * 8 * sizeof(unsigned long long));
+}
+#endif
 #ifdef M3_ABL_COUNT
 extern "C" void m3_dbg_levels(unsigned int* out, int reset) {
     if (reset) { static unsigned int z[512]; (void)hipMemcpyToSymbol(HIP_SYMBOL(m3::g_lvl), z, sizeof(z)); }

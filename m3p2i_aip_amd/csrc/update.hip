@@ -1102,6 +1102,10 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
+// "regen" sharding: the action the rollout formed for GLOBAL sample k at time step t (mppi.py:381-416 +
+// :297-302, as in rollout_point.hip / rollout_panda.hip: same f32 operations, same order => the same
+// bits), from the sample's noise row and the replicated plan -- re-computed instead of communicated.
+// Halton-spline mode only (explicit noise table).
 // weighted action sums: sum_k w_k * actions[t][k][:] over the local shard, for the global
 // weights and (multi-modal) the two per-mode weight sets; plus row gathers.  Grid = T x n_chunk
 // workgroups (+1 for top-k stage B): each reads its slice of the action rows once (all nu
@@ -1125,20 +1129,35 @@ __device__ __forceinline__ void finalize_body(const UpdateArgs& a, float* sm);  
 // rollout_point.hip / rollout_panda.hip: same f32 operations, same order => the same bits), from the
 // sample's noise row and the replicated plan -- what the "regen" sharding recomputes instead of
 // communicating.  Halton-spline mode only (explicit noise table).
+// The plan rows a time step's actions are assembled from (wave-uniform: loaded once per workgroup)
 template <int NU>
-__device__ __forceinline__ void regen_action(const UpdateArgs& a, int k, int t, const float* drow, float (&e)[NU]) {
-    const int T = a.T;
-    const int ts = (t + 1 < T) ? t + 1 : T - 1;
+struct RegenRows {
+    float m1[NU], m2[NU], b1[NU], b2[NU];   // shifted mean of mode 1 (or the single mean) / mode 2, best rows
+};
+template <int NU>
+__device__ __forceinline__ void regen_rows(const UpdateArgs& a, int t, RegenRows<NU>& R) {
+    const int T = a.T, ts = (t + 1 < T) ? t + 1 : T - 1;   // _shift_action: mppi.py:266-273
+    const bool multi = a.multi_modal != 0;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        R.m1[j] = multi ? a.mean1[ts * NU + j] : a.mean[ts * NU + j];
+        R.m2[j] = multi ? a.mean2[ts * NU + j] : R.m1[j];
+        R.b1[j] = a.best1[ts * NU + j];
+        R.b2[j] = a.best2[ts * NU + j];
+    }
+}
+template <int NU>
+__device__ __forceinline__ void regen_action(const UpdateArgs& a, const RegenRows<NU>& R, int k, const float* drow,
+                                             float (&e)[NU]) {
     const bool multi = a.multi_modal != 0;
     const bool is_last = k == a.Kg - 1;
+    const bool first = k < a.half_g;
     const bool use_best = multi && (k == 0 || k == a.half_g);
-    const float* mptr = multi ? (k < a.half_g ? a.mean1 : a.mean2) : a.mean;
-    const float* bptr = (k == 0) ? a.best1 : a.best2;
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
         const float d = is_last ? 0.0f : drow[j];
-        float aj = fmaxf(fminf(mptr[ts * NU + j] + d * a.scale_tril[j], a.u_max[j]), a.u_min[j]);
-        if (use_best) aj = bptr[ts * NU + j];
+        float aj = fmaxf(fminf((first ? R.m1[j] : R.m2[j]) + d * a.scale_tril[j], a.u_max[j]), a.u_min[j]);
+        if (use_best) aj = (k == 0) ? R.b1[j] : R.b2[j];
         if (NU == 9 && j >= 7) {
             if (a.gripper_cmd == 1) aj = 1.5f;
             else if (a.gripper_cmd == 2) aj = -1.5f;
@@ -1147,6 +1166,13 @@ __device__ __forceinline__ void regen_action(const UpdateArgs& a, int k, int t, 
         if (a.sample_null_action && is_last) uj = 0.0f;
         e[j] = (a.u_scale != 1.0f) ? uj / a.u_scale : uj;
     }
+}
+// shard of global sample k (k < 2^24: exact in binary32; one multiply + a fix-up instead of an integer division)
+__device__ __forceinline__ int shard_of(int k, int Kls, float inv_Kls) {
+    int r = (int)((float)k * inv_Kls);
+    r -= (r * Kls > k) ? 1 : 0;
+    r += ((r + 1) * Kls <= k) ? 1 : 0;
+    return r;
 }
 
 template <int NU, bool REGEN>
@@ -1164,6 +1190,9 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     float acc[3][NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
+    RegenRows<NU> rows;
+    const float inv_Kls = 1.0f / (float)a.Kls;
+    if constexpr (REGEN) regen_rows<NU>(a, t, rows);
     // fixed trip count, clamped unconditional loads: all the loads of a workgroup's slice are in
     // flight together (conditional loads each became a branch region ending in s_waitcnt vmcnt(0))
     const int clen = wsum_chunk_len(Kl);
@@ -1179,7 +1208,7 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         float av[NU];
         if constexpr (REGEN) {
             // (Kl == Kg, k0 == 0 here) the sample's noise row lives in its shard's block
-            const int r = k / a.Kls, kk = k - r * a.Kls;
+            const int r = shard_of(k, a.Kls, inv_Kls), kk = k - r * a.Kls;
             const float* drow = a.noise_all + (((size_t)r * T + t) * a.Kls + kk) * NU;
             float dv[NU];
             if constexpr (NU == 2) {
@@ -1189,7 +1218,7 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
 #pragma unroll
                 for (int j = 0; j < NU; ++j) dv[j] = drow[j];
             }
-            regen_action<NU>(a, k, t, dv, av);
+            regen_action<NU>(a, rows, k, dv, av);
         } else if constexpr (NU == 2) {
             const float2 v = reinterpret_cast<const float2*>(act)[ic];
             av[0] = v.x; av[1] = v.y;
@@ -1251,7 +1280,7 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
                 float dv[NU], ev[NU];
 #pragma unroll
                 for (int q = 0; q < NU; ++q) dv[q] = drow[q];
-                regen_action<NU>(a, gi, t, dv, ev);
+                regen_action<NU>(a, rows, gi, dv, ev);
 #pragma unroll
                 for (int q = 0; q < NU; ++q) if (q == j) v = ev[q];
             } else {

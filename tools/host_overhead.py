@@ -2,7 +2,7 @@ import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, bench
 for K, T in ((64, 12), (2000, 30)):
-    pl, sim, obj = bench.build_tamp("point_env", "push", (-1.0, -1.0), False, K, 0, 1, T, "cuda:0")
+    pl, sim, obj, _cfg = bench.build_tamp("point_env", "push", (-1.0, -1.0), False, K, 0, 1, T, "cuda:0")
     from m3p2i_aip_amd import sampling
     pl._ensure_noise()
     state = sim._dof_state[0]

@@ -8,7 +8,7 @@ import bench
 NAMES = ["RB", "RD", "RO", "RW", "BW", "DW", "BD", "BO", "DO"]
 for name in sys.argv[1:] or ["push"]:
     env, task, goal, mm, K, T = bench.CONFIGS[name]
-    pl, sim, obj = bench.build_tamp(env, task, goal, mm, K, 0, 1, T, "cuda:0")
+    pl, sim, obj, _cfg = bench.build_tamp(env, task, goal, mm, K, 0, 1, T, "cuda:0")
     state = sim._dof_state[0]
     lib = ctypes.CDLL(os.environ["M3P2I_HIP_LIB"])
     buf = (ctypes.c_uint * 512)()

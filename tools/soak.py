@@ -11,7 +11,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 g = torch.Generator(device="cpu").manual_seed(7)
 for name in ("push", "hybrid", "panda"):
     env, task, goal, mm, K, T = bench.CONFIGS[name]
-    pl, sim, obj = bench.build_tamp(env, task, goal, mm, K, 0, 1, T, "cuda:0")
+    pl, sim, obj, _cfg = bench.build_tamp(env, task, goal, mm, K, 0, 1, T, "cuda:0")
     eng = pl._engine
     dof0 = sim._dof_state.clone()
     root0 = sim._root_state.clone()
