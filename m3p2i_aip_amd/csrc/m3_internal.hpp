@@ -61,6 +61,7 @@ struct UpdateArgs {
     int* wcount;      // [T] arrival counters of the k_wsum chunks + [T] the launch-wide one of the
                       // fused finalize (zero between launches)
     int fuse_finalize;  // k_wsum's last workgroup also does k_finalize's work (unsharded m3_command)
+    int ladder_spins;   // k_update_small: bound of the wait for the other workgroups' ladder points
     int n_chunk;      // k_wsum workgroups per time step
     int lds_floats;   // costs staged in dynamic LDS by k_weights (set by launch_weights)
     int Kg, Kl, k0, T, nu;

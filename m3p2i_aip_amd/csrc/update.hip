@@ -1537,8 +1537,9 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
                 int spins = 0, ok = 1;
                 while (__hip_atomic_load(&a.wcount[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 18)) { ok = 0; break; }
+                    if (++spins > a.ladder_spins) { ok = 0; break; }
                 }
+                if (a.ladder_spins == 0) ok = 0;   // (tests: force the give-up branch even when everyone has arrived)
                 s_walk[0][0] = __int_as_float(ok);
             }
             __syncthreads();
@@ -1767,7 +1768,12 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
         finalize_body<true>(a, sm_fin);
     }
 }
-void launch_update_small(const UpdateArgs& a, hipStream_t s) {
+void launch_update_small(const UpdateArgs& a_, hipStream_t s) {
+    // bounded wait of the in-launch ladder exchange (~20 ms); M3P2I_LADDER_SPINS=0 makes every workgroup
+    // give up at once and run all its passes itself (tests/test_hip_edge_cases.py: same decisions)
+    static const int spins = getenv("M3P2I_LADDER_SPINS") ? atoi(getenv("M3P2I_LADDER_SPINS")) : (1 << 18);
+    UpdateArgs a = a_;
+    a.ladder_spins = spins;
     const dim3 grid(a.T + a.n_cand);
     const size_t lds = (size_t)a.T * a.nu * sizeof(float);
     const bool multi = a.multi_modal && !a.mode_simple;

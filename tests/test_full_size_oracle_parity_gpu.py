@@ -1,0 +1,94 @@
+"""The BASELINE configs at their FULL sizes against the CPU oracle directly (not through properties): the
+one-launch update instantiations the bench configs actually run -- k_update_small<2,false,8> (C2, K=2000),
+<2,true,16> (C3, K=4000), <9,false,16> (C4 panda, K=4000), <2,false,64> (north-star, K=10000), <2,true,32>
+(a C5 shard, K=8000) -- and the large-K multi-launch path (C5 unsharded, K=64000).  The oracle (C, OpenMP)
+finishes a command at these sizes in milliseconds to a second.  Bars: rollout states / actions / costs
+bit-exact on the first call; control output and weights within 1e-3 (BASELINE.json north_star) on every call;
+multi-modal iteration counts equal."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+POINT = {
+    "C2_push_K2000": dict(K=2000, task="push", goal=(-1.0, -1.0), mm=False),
+    "C3_hybrid_K4000": dict(K=4000, task="push_pull", goal=(-3.75, -3.75), mm=True),
+    "northstar_push_K10000": dict(K=10000, task="push", goal=(-1.0, -1.0), mm=False),
+    "C5shard_hybrid_K8000": dict(K=8000, task="push_pull", goal=(-3.75, -3.75), mm=True),
+    "C5_hybrid_K64000": dict(K=64000, task="push_pull", goal=(-3.75, -3.75), mm=True),
+}
+
+
+def _smooth_noise(K, T, nu, seed):
+    g = torch.Generator().manual_seed(seed)
+    knots = torch.randn(K, nu, T // 4, generator=g)
+    d = torch.nn.functional.interpolate(knots, size=T, mode="linear", align_corners=True)
+    return d.permute(0, 2, 1).contiguous().numpy()
+
+
+@pytest.mark.parametrize("name", list(POINT))
+def test_point_env_full_size_vs_oracle(oracle, name):
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    c = POINT[name]
+    K, T = c["K"], 30
+    delta = _smooth_noise(K, T, 2, 21)
+    w0 = oracle.init_world(1)[0]
+    w0[0:2] = (0.05, 1.5)                      # next to the box: contacts and suction inside the horizon
+    opl = oracle.OraclePointPlanner(oracle.make_cfg(K, T, 2, task=c["task"], goal=c["goal"], multi_modal=c["mm"]), delta)
+    eng = HipEngine(make_config(K=K, T=T, nu=2, multi_modal=c["mm"], u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3]))
+    eng.set_objective(c["task"], c["goal"])
+    eng.set_noise(delta)
+    raw = np.concatenate([w0[[0, 1, 4, 5]], w0[7:14], w0[14:21]]).astype(np.float32)
+    eng.set_world_point_raw(raw)
+    for call in range(3):
+        a = eng.command(sync_host=True)
+        b = opl.command(w0)
+        if call == 0:
+            assert np.array_equal(eng.states.cpu().numpy(), opl.last["states"])
+            assert np.array_equal(eng.actions.cpu().numpy(), opl.last["actions"])
+            assert np.array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+            assert np.array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
+        np.testing.assert_allclose(a, b, atol=1e-3, err_msg=f"{name} call {call}")
+        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), opl.last["w"], atol=1e-3)
+        i, oi = eng.info(), opl.last["info"]
+        if c["mm"]:
+            np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS_1).cpu().numpy(), opl.last["w1"], atol=1e-3)
+            np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS_2).cpu().numpy(), opl.last["w2"], atol=1e-3)
+            assert (i.iters, i.iters_1, i.iters_2) == (oi.iters, oi.iters_1, oi.iters_2), f"{name} call {call}"
+            assert (i.best_idx_1, i.best_idx_2) == (oi.best_idx_1, K // 2 + oi.best_idx_2)
+            assert i.pull_preference == opl.pull_preference()
+        else:
+            assert i.best_idx == oi.best_idx
+        top = eng.buffer(L.BUF_TOP_IDX).cpu().numpy()
+        assert np.array_equal(np.sort(opl.last["J"][top]), np.sort(opl.last["J"])[:20]) or call > 0
+    eng.close()
+
+
+def test_panda_full_size_vs_oracle(oracle):
+    """C4: panda_env reach, K=4000, T=20 -- k_update_small<9,false,16> and the panda rollout at full size."""
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    K, T = 4000, 20
+    delta = _smooth_noise(K, T, 9, 22)
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    w0 = P.init_world(1)[0]
+    opl = P.OraclePandaPlanner(P.make_cfg(K, T, task="reach", goal=goal, gripper_cmd=1), delta)
+    eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", u_min=[-2.0] * 7 + [-1.5] * 2,
+                                u_max=[2.0] * 7 + [1.5] * 2, noise_sigma_diag=[10.0] * 7 + [0.8] * 2, lambda_=0.05,
+                                pre_height_diff=0.05, dt=0.01))
+    eng.set_objective("reach", goal, gripper_cmd=1)
+    eng.set_noise(delta)
+    eng.set_world_panda_raw(np.concatenate([w0[P.W_Q:P.W_Q + 18], w0[P.W_CUBEA:P.W_CUBEA + 10], w0[P.W_CUBEB:P.W_CUBEB + 3]]))
+    for call in range(3):
+        a = eng.command(sync_host=True)
+        b = opl.command(w0)
+        if call == 0:
+            assert np.array_equal(eng.states.cpu().numpy(), opl.last["states"])
+            assert np.array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+        np.testing.assert_allclose(a, b, atol=1e-3, err_msg=f"call {call}")
+        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), opl.last["w"], atol=1e-3)
+        assert eng.info().beta == pytest.approx(opl.beta, rel=1e-5)
+    eng.close()

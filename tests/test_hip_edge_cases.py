@@ -136,3 +136,49 @@ def test_large_k_sanity():
     st = eng.states
     assert st.shape == (K, T, 4) and torch.isfinite(st).all()
     eng.close()
+
+
+def test_ladder_exchange_give_up_branch_makes_the_same_decisions():
+    """k_update_small (multi-modal, K <= 8192): the T column workgroups share the beta-ladder evaluations
+    through memory and wait for each other with a BOUNDED spin; a workgroup whose wait runs out (other
+    kernels occupying the CUs) runs all its search passes itself.  M3P2I_LADDER_SPINS=0 forces that branch
+    in every workgroup: iteration counts, weights and plan must equal the normal run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from m3p2i_aip_amd import _lib as L
+from m3p2i_aip_amd.engine import HipEngine, make_config
+K, T = 4000, 30
+g = torch.Generator().manual_seed(3)
+knots = torch.randn(K, 2, T // 4, generator=g)
+delta = torch.nn.functional.interpolate(knots, size=T, mode="linear", align_corners=True).permute(0, 2, 1).contiguous().numpy()
+eng = HipEngine(make_config(K=K, T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3]))
+eng.set_objective("push_pull", (-3.75, -3.75))
+eng.set_noise(delta)
+eng.set_world_point_raw(np.array([0.0, 1.5, 0, 0, 0, 2, 1, 0, 0, 0, 0, -2, 2, 1, 0, 0, 0, 0], np.float32))
+out = []
+for _ in range(3):
+    a = eng.command(sync_host=True)
+    i = eng.info()
+    out.append(dict(iters=[i.iters, i.iters_1, i.iters_2], eta=[i.eta, i.eta_1, i.eta_2], action=a.tolist(),
+                    w=eng.buffer(L.BUF_WEIGHTS).cpu().numpy().tolist()))
+print("RESULT" + json.dumps(out))
+""" % root
+
+    def run(env_extra):
+        r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+
+    normal, gave_up = run({}), run({"M3P2I_LADDER_SPINS": "0"})
+    for a, b in zip(normal, gave_up):
+        assert a["iters"] == b["iters"] and min(a["iters"]) > 1
+        np.testing.assert_allclose(a["eta"], b["eta"], rtol=1e-6)
+        np.testing.assert_allclose(a["w"], b["w"], rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(a["action"], b["action"], atol=1e-6)
