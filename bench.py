@@ -265,7 +265,7 @@ def closed_loop(r, ticks, device):
         a = pl.command(real._dof_state[0])[0]
         real.set_dof_velocity_target_tensor(a.view(1, nu))
         if pull:
-            cfg.suction_active = pl.get_pull_preference()   # one host sync per tick, as the reference's .item()
+            cfg.suction_active = pl.pull_preference_tensor()   # stays on the device (the reference reads it back: .item())
             check_and_apply_suction(cfg, real, a.view(1, nu))
         real.step()
 

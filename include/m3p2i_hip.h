@@ -309,9 +309,11 @@ int m3_sim_suction_forces(m3_handle* h, float kp_suction, float* forces_dev);
 /* check_suction_condition + check_and_apply_suction (utils/skill_utils.py:36-56): per environment, the
  * robot is within 0.6 of the box and action . (robot - box) > 0; where that holds and apply != 0 the
  * suction pair becomes the pending body force of the next m3_sim_step.  action_dev f32 [Kl][2];
- * applied_dev i32 [Kl] (optional) receives the condition.  No host synchronisation. */
+ * applied_dev i32 [Kl] (optional) receives the condition.  enabled_dev (optional): one i32 on the device that
+ * must be non-zero for the suction to act -- cfg.suction_active (sim.py:44-47) taken straight from the
+ * planner's m3_info.pull_preference (M3_BUF_INFO) instead of through the host.  No host synchronisation. */
 int m3_sim_check_and_apply_suction(m3_handle* h, const float* action_dev, float kp_suction, int apply,
-                                   int* applied_dev);
+                                   int* applied_dev, const int* enabled_dev);
 
 
 #ifdef __cplusplus

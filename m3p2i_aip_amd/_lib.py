@@ -52,6 +52,10 @@ class Info(C.Structure):
                 ("pull_preference", C.c_int), ("calls", C.c_int)]
 
 
+INFO_WORDS = C.sizeof(Info) // 4
+INFO_PULL_PREFERENCE = Info.pull_preference.offset // 4   # index of the field in an int32 view of M3_BUF_INFO
+
+
 class Timing(C.Structure):
     _fields_ = [("rollout_ms", C.c_float), ("update_ms", C.c_float),
                 ("finalize_ms", C.c_float), ("total_ms", C.c_float)]
@@ -104,7 +108,7 @@ SYMBOLS = [
     ("m3_sim_step", C.c_int, [_H]),
     ("m3_cost", C.c_int, [_H, _FP]),
     ("m3_sim_suction_forces", C.c_int, [_H, C.c_float, _FP]),
-    ("m3_sim_check_and_apply_suction", C.c_int, [_H, _FP, C.c_float, C.c_int, C.c_void_p]),
+    ("m3_sim_check_and_apply_suction", C.c_int, [_H, _FP, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
 ]
 
 _lib = None

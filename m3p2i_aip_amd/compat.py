@@ -54,8 +54,17 @@ set_task_planner = task_planner.set_task_planner
 # The suction skill of the 1-env "real world" (scripts/sim.py:41-49).  The geometry lives in the HIP
 # library (m3_sim_suction_forces / m3_sim_check_and_apply_suction, csrc/rollout_point.hip:
 # k_sim_suction); what stays on the host is the part that only reads the config.
+def _device_gate(cfg):
+    """cfg.suction_active handed over as a device tensor (planner.pull_preference_tensor()): the kernel
+    reads it, the host never does."""
+    g = cfg.suction_active
+    return g if (torch.is_tensor(g) and g.is_cuda) else None
+
+
 def _suction_enabled(cfg):
-    return cfg.task in ("pull", "push_pull") and bool(cfg.suction_active)
+    if cfg.task not in ("pull", "push_pull"):
+        return False
+    return True if _device_gate(cfg) is not None else bool(cfg.suction_active)
 
 
 def calculate_suction(cfg, sim):
@@ -67,14 +76,18 @@ def check_suction_condition(cfg, sim, action):
     """bool for env 0 (one host sync, as the reference's .item())."""
     if not _suction_enabled(cfg):
         return False
-    return bool(sim._engine.sim_check_and_apply_suction(action, cfg.kp_suction, apply=False, want_flags=True)[0].item())
+    g = _device_gate(cfg)
+    return bool(sim._engine.sim_check_and_apply_suction(action, cfg.kp_suction, apply=False, want_flags=True,
+                                                        enabled=None if g is None else g.to(torch.int32).reshape(1))[0].item())
 
 
 def check_and_apply_suction(cfg, sim, action):
     """Stages the suction pair for the next sim.step() wherever the condition holds; enqueued on the
     stream, nothing is read back (the reference's "suction!!!" / "no suction..." prints are dropped)."""
     if _suction_enabled(cfg):
-        sim._engine.sim_check_and_apply_suction(action, cfg.kp_suction, apply=True)
+        g = _device_gate(cfg)
+        sim._engine.sim_check_and_apply_suction(action, cfg.kp_suction, apply=True,
+                                                enabled=None if g is None else g.to(torch.int32).reshape(1))
 
 
 def time_tracking(t, cfg):

@@ -1018,26 +1018,27 @@ extern "C" int m3_sim_step(m3_handle* h) {
     return M3_OK;
 }
 
-static int suction_impl(m3_handle* h, float kp, const float* action, int apply, float* forces, int* flags) {
+static int suction_impl(m3_handle* h, float kp, const float* action, int apply, float* forces, int* flags,
+                        const int* gate) {
     if (!h) return M3_ERR_BAD_ARG;
     if (h->cfg.env_type != M3_ENV_POINT) return fail(h, M3_ERR_UNSUPPORTED, "suction is a point_env skill (skill_utils.py:36-94)");
     if (!h->views_bound || !h->sim_world) return fail(h, M3_ERR_STATE, "suction: views not bound");
     const float thresh = (h->cfg.K_local == 1) ? 1.5f : 1.8f;   // skill_utils.py:75-82 (sim.num_envs == 1: real world)
     launch_sim_suction(h->views, h->sim_world, h->cfg.K_local, kp, thresh, 0.6f /* skill_utils.py:56 */, action, apply,
-                       forces, flags, h->stream);
+                       forces, flags, gate, h->stream);
     HIPCHK(h, hipGetLastError());
     return M3_OK;
 }
 
 extern "C" int m3_sim_suction_forces(m3_handle* h, float kp_suction, float* forces_dev) {
     if (!forces_dev) return fail(h, M3_ERR_BAD_ARG, "m3_sim_suction_forces: null argument");
-    return suction_impl(h, kp_suction, nullptr, 0, forces_dev, nullptr);
+    return suction_impl(h, kp_suction, nullptr, 0, forces_dev, nullptr, nullptr);
 }
 
 extern "C" int m3_sim_check_and_apply_suction(m3_handle* h, const float* action_dev, float kp_suction, int apply,
-                                              int* applied_dev) {
+                                              int* applied_dev, const int* enabled_dev) {
     if (!action_dev) return fail(h, M3_ERR_BAD_ARG, "m3_sim_check_and_apply_suction: null argument");
-    return suction_impl(h, kp_suction, action_dev, apply, nullptr, applied_dev);
+    return suction_impl(h, kp_suction, action_dev, apply, nullptr, applied_dev, enabled_dev);
 }
 
 extern "C" int m3_cost(m3_handle* h, float* cost) {

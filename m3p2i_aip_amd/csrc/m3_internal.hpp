@@ -183,7 +183,7 @@ void launch_sim_forces(const SimViews& v, float* world, const float* f /*[Kl][nB
 void launch_sim_cost(const CostParams& cp, float* world, int Kl, int k0, float* cost,
                      hipStream_t s);
 void launch_sim_suction(const SimViews& v, float* world, int Kl, float kp, float thresh, float reach,
-                        const float* action, int apply, float* forces, int* flags, hipStream_t s);
+                        const float* action, int apply, float* forces, int* flags, const int* gate, hipStream_t s);
 
 constexpr int NW = 28;  // floats per env in the step-mode SoA world (PointWorld fields)
 constexpr int NWP = 45; // same for the panda_env (PandaWorld fields)

@@ -357,10 +357,13 @@ void launch_sim_forces(const SimViews& v, float* world, const float* f, int Kl, 
 //   action != null : check_suction_condition -- robot within `reach` of the box and the commanded
 //                    velocity pointing away from it -- and, if `apply`, the force of above staged
 //                    as the pending external force of the next step (apply_rigid_body_force_tensors)
+//   gate != null   : a device flag (the planner's pull preference, m3_info.pull_preference) that must be
+//                    non-zero for the suction to act: cfg.suction_active without a host round trip
 __global__ void k_sim_suction(const SimViews v, float* wd, int Kl, float kp, float thresh, float reach,
-                              const float* action, int apply, float* forces, int* flags) {
+                              const float* action, int apply, float* forces, int* flags, const int* gate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Kl) return;
+    const bool enabled = gate ? (*gate != 0) : true;
     float* p = wd + i;
     const float ex = p[4 * Kl] - p[0 * Kl], ey = p[5 * Kl] - p[1 * Kl];   // robot -> box
     const float len = sqrtf(ex * ex + ey * ey);
@@ -378,7 +381,7 @@ __global__ void k_sim_suction(const SimViews v, float* wd, int Kl, float kp, flo
     }
     if (action) {
         const float along = action[2 * i] * (-ex) + action[2 * i + 1] * (-ey);   // action . (robot - box)
-        const bool pulling = len < reach && along > 0.0f;
+        const bool pulling = enabled && len < reach && along > 0.0f;
         if (flags) flags[i] = pulling ? 1 : 0;
         if (pulling && apply) {
             p[18 * Kl] = fx; p[19 * Kl] = fy; p[20 * Kl] = -fx; p[21 * Kl] = -fy;
@@ -386,9 +389,9 @@ __global__ void k_sim_suction(const SimViews v, float* wd, int Kl, float kp, flo
     }
 }
 void launch_sim_suction(const SimViews& v, float* world, int Kl, float kp, float thresh, float reach,
-                        const float* action, int apply, float* forces, int* flags, hipStream_t s) {
+                        const float* action, int apply, float* forces, int* flags, const int* gate, hipStream_t s) {
     hipLaunchKernelGGL(k_sim_suction, dim3((Kl + 255) / 256), dim3(256), 0, s, v, world, Kl, kp, thresh, reach,
-                       action, apply, forces, flags);
+                       action, apply, forces, flags, gate);
 }
 
 }  // namespace m3

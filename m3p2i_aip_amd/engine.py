@@ -251,6 +251,7 @@ class HipEngine:
             L.BUF_REDUCE: ((self.lib.m3_reduce_len(self._h),), "<f4"),
             L.BUF_NOISE: ((T, Kl, nu), "<f4"), L.BUF_PENDING_FORCE: ((4, Kl), "<f4"),
             L.BUF_SIM_WORLD: ((28 if c.env_type == L.ENV_POINT else 45, Kl), "<f4"),
+            L.BUF_INFO: ((L.INFO_WORDS,), "<i4"),
             L.BUF_RECORD: ((self.lib.m3_record_len(self._h),), "<f4"),
             L.BUF_RECORDS_ALL: ((Kg // Kl, self.lib.m3_record_len(self._h)), "<f4"),
         }[which]
@@ -323,15 +324,20 @@ class HipEngine:
         self._ck(self.lib.m3_sim_suction_forces(self._h, float(kp_suction), f.data_ptr()))
         return f
 
-    def sim_check_and_apply_suction(self, action, kp_suction, apply=True, want_flags=False):
+    def sim_check_and_apply_suction(self, action, kp_suction, apply=True, want_flags=False, enabled=None):
         """check_suction_condition (+ apply_rigid_body_force_tensors(calculate_suction) where it holds)
-        on the device, no host sync (skill_utils.py:36-56).  Returns the per-env condition (int32
-        device tensor) if want_flags."""
+        on the device, no host sync (skill_utils.py:36-56).  enabled: optional 1-element int32 device
+        tensor that gates the suction (the planner's pull preference).  Returns the per-env condition
+        (int32 device tensor) if want_flags."""
         a = action.to(device=self.device, dtype=torch.float32).reshape(self.cfg.K_local, 2).contiguous()
         flags = torch.empty(self.cfg.K_local, device=self.device, dtype=torch.int32) if want_flags else None
+        if enabled is not None:
+            assert enabled.is_cuda and enabled.dtype == torch.int32 and enabled.numel() == 1
+            self._gate = enabled   # keep alive until the kernel ran
         self._ck(self.lib.m3_sim_check_and_apply_suction(
             self._h, a.data_ptr(), float(kp_suction), int(bool(apply)),
-            C.c_void_p(flags.data_ptr()) if want_flags else None))
+            C.c_void_p(flags.data_ptr()) if want_flags else None,
+            C.c_void_p(enabled.data_ptr()) if enabled is not None else None))
         return flags
 
     def cost(self, out=None):

@@ -502,6 +502,14 @@ class M3P2I(MPPI):
         elif task == "pick":
             self.gripper_command = "close"
 
+    def pull_preference_tensor(self):
+        """The pull preference of the last command as a 1-element int32 DEVICE tensor (a view of the
+        library's m3_info), for consumers on the same GPU: no host synchronisation.  1 = pull."""
+        if not self.multi_modal:
+            return torch.full((1,), int(bool(self.suction_active)), dtype=torch.int32, device=self.device)
+        w = L.INFO_PULL_PREFERENCE
+        return self._engine.buffer(L.BUF_INFO)[w:w + 1]
+
     def get_pull_preference(self):
         if self.multi_modal:
             i = self._engine.info()   # one host sync, like the reference's two .item() calls

@@ -509,8 +509,36 @@ def g9_panda():
     g9_panda_trace("panda_pick", 256, 20, "pick", False, grasp_world(P, sc), goal7)
 
 
+# ---------------------------------------------------------------- G7 (skill side): the real world's suction
+def g7_skill():
+    """utils/skill_utils.py:36-94 as scripts/sim.py:41-49 calls them on its 1-env world: calculate_suction on
+    K = 64 environments (threshold 1.8) and on single environments (threshold 1.5), and
+    check_suction_condition for single environments with given actions."""
+    rng = np.random.default_rng(707)
+    K = 64
+    box = np.tile(np.array([[0.0, 2.0]], np.float32), (K, 1)) + rng.uniform(-0.2, 0.2, (K, 2)).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, K)
+    rad = rng.uniform(0.25, 0.9, K)          # both sides of 1/1.8 = 0.556 and of 1/1.5 = 0.667
+    robot = (box + np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1)).astype(np.float32)
+    cfg = point_cfg(K, 30, task="pull", goal=(0.0, 0.0))
+    sim = refshim.SynthSim(robot, np.zeros((K, 2), np.float32), box)
+    out["g7s_robot"], out["g7s_box"] = robot, box
+    out["g7s_forces_K64"] = ref.skill_utils.calculate_suction(cfg, sim).numpy().copy()
+    f1, cond, acts = [], [], []
+    for i in range(K):
+        s1 = refshim.SynthSim(robot[i:i + 1], np.zeros((1, 2), np.float32), box[i:i + 1])
+        f1.append(ref.skill_utils.calculate_suction(cfg, s1).numpy()[0].copy())
+        a = rng.uniform(-1, 1, 2).astype(np.float32)
+        acts.append(a)
+        cfg.task, cfg.suction_active = "pull", True
+        cond.append(bool(ref.skill_utils.check_suction_condition(cfg, s1, torch.from_numpy(a))))
+    out["g7s_forces_K1"] = np.stack(f1)
+    out["g7s_action"] = np.stack(acts)
+    out["g7s_condition"] = np.array(cond, np.int32)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6_g7, g7_quat, g6_panda, g8, g10, g9, g9_panda):
+    for fn in (g1, g2, g3, g4, g5, g6_g7, g7_quat, g6_panda, g8, g10, g9, g9_panda, g7_skill):
         fn()
         print(fn.__name__, "ok")
     path = os.path.join(HERE, "ref_golden.npz")

@@ -187,3 +187,55 @@ def test_panda_reactive_tamp_with_aif_task_planner_gpu():
     assert tasks[0] == "reach" and set(tasks) <= {"reach", "pick"}
     assert d1 < 0.5 * d0, (d0, d1)
     assert r.motion_planner.probe_result["fused"] is True
+
+
+@pytest.mark.gpu
+def test_device_suction_skill_matches_reference_golden_gpu(golden):
+    """calculate_suction / check_suction_condition / check_and_apply_suction of the 1-env real world
+    (utils/skill_utils.py:36-94, called by scripts/sim.py:41-49) run as a HIP kernel on the wrapper's
+    environments (m3_sim_suction_forces, m3_sim_check_and_apply_suction): forces and conditions against
+    values recorded from the reference's own functions (make_golden.py g7_skill)."""
+    import types
+    import numpy as np
+    import torch
+    from m3p2i_aip_amd import compat, _lib as L
+    from m3p2i_aip_amd import isaacgym_wrapper as wrapper
+    robot, box = golden["g7s_robot"], golden["g7s_box"]
+    K = robot.shape[0]
+    cfg = types.SimpleNamespace(task="pull", suction_active=True, kp_suction=400)
+
+    def world(n, rows):
+        sim = wrapper.IsaacGymWrapper(wrapper.IsaacGymConfig(dt=0.05), "point_env", num_envs=n, device="cuda:0")
+        sim._dof_state[:, 0] = torch.tensor(robot[rows, 0], device="cuda:0")
+        sim._dof_state[:, 2] = torch.tensor(robot[rows, 1], device="cuda:0")
+        bi = int(sim._get_actor_index_by_name("box"))
+        sim._root_state[:, bi, 0:2] = torch.tensor(box[rows], device="cuda:0")
+        sim.set_dof_state_tensor(sim._dof_state)
+        sim.set_actor_root_state_tensor(sim._root_state)
+        return sim
+
+    sim = world(K, slice(None))                                   # K > 1: threshold 1.8
+    f = compat.calculate_suction(cfg, sim).cpu().numpy()
+    np.testing.assert_allclose(f, golden["g7s_forces_K64"], rtol=1e-5, atol=1e-3)
+    sim.stop_sim()
+    hits = 0
+    for i in range(0, K, 3):                                      # 1-env worlds: threshold 1.5 + the condition
+        s1 = world(1, slice(i, i + 1))
+        np.testing.assert_allclose(compat.calculate_suction(cfg, s1).cpu().numpy()[0], golden["g7s_forces_K1"][i],
+                                   rtol=1e-5, atol=1e-3)
+        a = torch.tensor(golden["g7s_action"][i], device="cuda:0")
+        cond = compat.check_suction_condition(cfg, s1, a)
+        assert cond == bool(golden["g7s_condition"][i]), i
+        for gate in (True, torch.ones(1, dtype=torch.int32, device="cuda:0"), torch.zeros(1, dtype=torch.int32, device="cuda:0")):
+            s1._engine.buffer(L.BUF_SIM_WORLD)[18:22].zero_()
+            cfg.suction_active = gate
+            compat.check_and_apply_suction(cfg, s1, a)            # stages the pair as the next step's external force
+            pend = s1._engine.buffer(L.BUF_SIM_WORLD)[18:22, 0].cpu().numpy()
+            on = cond and (gate is True or bool(gate.item()))
+            want = golden["g7s_forces_K1"][i]
+            exp = np.concatenate([want[-1, :2], want[int(s1._get_actor_index_by_name("box")), :2]]) if on else np.zeros(4)
+            np.testing.assert_allclose(pend, exp, rtol=1e-5, atol=1e-3)
+        cfg.suction_active = True
+        hits += cond
+        s1.stop_sim()
+    assert 0 < hits < len(range(0, K, 3))
