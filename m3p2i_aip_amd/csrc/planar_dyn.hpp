@@ -512,7 +512,9 @@ enum : unsigned {
     G_BO = 128u,  // box - obstacle                    2
     G_DO = 256u,  // dyn-obs - obstacle                2
     G_ALL = 511u,
-    G_NO_BOX_STATICS = G_RB | G_RD | G_RO | G_RW | G_BD  // everything but box/dyn-obs vs walls and obstacle
+    G_NO_BOX_STATICS = G_RB | G_RD | G_RO | G_RW | G_BD,  // everything but box/dyn-obs vs walls and obstacle
+    G_CORNER = G_RB | G_RW | G_BW   // the box being pushed along / into the walls: the scene of a goal in a corner
+                                    // (config_point.yaml goal [-3.75, -3.75]) once the box gets there
 };
 
 // -DM3_ABL_PHASES (experiments, tools/phase_breakdown.py): shader-clock time of every wave per phase of
@@ -624,8 +626,10 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
             if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
         }
         const bool d_moving = ((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u;
-        if (!skipD) if (d_moving | rare) {
-            solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
+        // (skipD: the dyn-obs rests in every lane and no slot of this instance touches it -- its friction
+        // row is a no-op; the rarely-active slots below do not depend on it)
+        if ((!skipD && d_moving) | rare) {
+            if (!skipD) solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
             if constexpr (ANY_RARE) {
                 // one outer flag + two group flags: a pass in which no lane has any of these pays
                 // one skipped exec-mask branch (same solve order as the spec)
@@ -751,12 +755,15 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
             else if (M3_COVERS(G_RB)) point_substep<false, G_RB>(sc, w, ux, uy, form, pc_);
             else if (M3_COVERS(G_RB | G_RD)) point_substep<false, G_RB | G_RD>(sc, w, ux, uy, form, pc_);
             else if (M3_COVERS(G_RB | G_RD | G_BD)) point_substep<false, G_RB | G_RD | G_BD>(sc, w, ux, uy, form, pc_);
+#ifndef M3_ABL_NO_CORNER
+            else if (M3_COVERS(G_CORNER)) point_substep<false, G_CORNER>(sc, w, ux, uy, form, pc_);
+#endif
             else if (M3_COVERS(G_NO_BOX_STATICS)) point_substep<false, G_NO_BOX_STATICS>(sc, w, ux, uy, form, pc_);
             else point_substep<false, G_ALL>(sc, w, ux, uy, form, pc_);
 #ifdef M3_ABL_COUNT
             {
                 const unsigned long long dt_ = wall_clock64() - t0_;
-                const int cls_ = m == 0u ? 0 : M3_COVERS(G_RB) ? 1 : M3_COVERS(G_RB | G_RD) ? 2 : M3_COVERS(G_RB | G_RD | G_BD) ? 3 : M3_COVERS(G_NO_BOX_STATICS) ? 4 : 5;
+                const int cls_ = m == 0u ? 0 : M3_COVERS(G_RB) ? 1 : M3_COVERS(G_RB | G_RD) ? 2 : M3_COVERS(G_RB | G_RD | G_BD) ? 3 : M3_COVERS(G_CORNER) ? 6 : M3_COVERS(G_NO_BOX_STATICS) ? 4 : 5;
                 if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) {
                     atomicAdd(&g_cyc[blockIdx.x * 16 + cls_], (unsigned int)dt_);
                     atomicAdd(&g_cyc[blockIdx.x * 16 + 8 + cls_], 1u);
