@@ -1816,6 +1816,7 @@ bool update_small_applies(const UpdateArgs& a) {
 // order over ranks), so the plans stay identical across ranks.
 __global__ __launch_bounds__(256) void k_mix(const UpdateArgs a) {
     __shared__ float s_rho[MIX_MAX_RANKS];
+    __shared__ float s_soft[3];   // global minimum, -1/beta, 1/Z
     __shared__ int s_best_rank;
     __shared__ tkey s_key[MIX_MAX_RANKS * M3_TOPK];
     __shared__ int s_src[M3_TOPK];
@@ -1838,6 +1839,7 @@ __global__ __launch_bounds__(256) void k_mix(const UpdateArgs a) {
             Z += sr;
         }
         const float iz = 1.0f / Z;
+        s_soft[0] = m; s_soft[1] = nib; s_soft[2] = iz;
         float h0 = 0.0f, h1 = 0.0f;
         for (int r = 0; r < N; ++r) {
             s_rho[r] = s_rho[r] * iz;
@@ -1884,7 +1886,12 @@ __global__ __launch_bounds__(256) void k_mix(const UpdateArgs a) {
         for (int q = 0; q < nc; ++q) rank += (s_key[q] < my) ? 1 : 0;
         if (rank < M3_TOPK) {
             s_src[rank] = c;
-            a.top_idx[rank] = (int)(unsigned)my;
+            const VI win = key_vi(my);
+            a.top_idx[rank] = win.i;
+            // the weights buffer holds this rank's own shard; the top-k samples of OTHER ranks get their
+            // global weight too, so that weights[top_idx] (the reference's top_values, mppi.py:248) is
+            // complete on every rank
+            if (win.i < a.k0 || win.i >= a.k0 + a.Kl) a.w[win.i] = m3_exp(s_soft[1] * (win.v - s_soft[0])) * s_soft[2];
         }
     }
     __syncthreads();

@@ -244,6 +244,8 @@ class MPPI():
     best_traj_1 = property(lambda s: s._buf(L.BUF_BEST_1), lambda s, v: s._buf(L.BUF_BEST_1).copy_(v))
     best_traj_2 = property(lambda s: s._buf(L.BUF_BEST_2), lambda s, v: s._buf(L.BUF_BEST_2).copy_(v))
     U = property(lambda s: s._buf(L.BUF_MEAN), lambda s, v: s._buf(L.BUF_MEAN).copy_(v))
+    # [K] softmin weights.  Sharded single-mode planners (shard_mix) materialise their OWN shard's entries
+    # plus the global top-20's (top_values); the multi-modal protocols fill all K on every rank.
     weights = property(lambda s: s._buf(L.BUF_WEIGHTS))
     weights_1 = property(lambda s: s._buf(L.BUF_WEIGHTS_1))
     weights_2 = property(lambda s: s._buf(L.BUF_WEIGHTS_2))

@@ -250,6 +250,10 @@ def test_one_collective_shard_mix_equals_unsharded(golden, oracle, world, K, mod
             np.testing.assert_allclose(e.buffer(L.BUF_WEIGHTS)[r * Kl:(r + 1) * Kl].cpu().numpy(),
                                        full.buffer(L.BUF_WEIGHTS)[r * Kl:(r + 1) * Kl].cpu().numpy(),
                                        rtol=1e-3, atol=1e-8)
+            # ... plus the global top-k samples' weights wherever they live: planner.top_values
+            ti = e.buffer(L.BUF_TOP_IDX).long()
+            np.testing.assert_allclose(e.buffer(L.BUF_WEIGHTS)[ti].cpu().numpy(), full.buffer(L.BUF_WEIGHTS)[ti].cpu().numpy(),
+                                       rtol=1e-3, atol=1e-8)
             i = e.info()
             assert i.best_idx == fi.best_idx
             assert abs(i.eta - fi.eta) <= 1e-4 * fi.eta

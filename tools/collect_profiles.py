@@ -5,7 +5,7 @@ import json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-P = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "profiles/r01")
+P = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "profiles/r02")
 os.makedirs(P, exist_ok=True)
 NAMES = {"push": "push_K2000_T30", "hybrid": "hybrid_K4000_T30", "panda": "panda_K4000_T20", "northstar": "northstar_K10000_T30", "c5": "c5shard_K8000_T30"}
 
@@ -28,6 +28,14 @@ for c, n in NAMES.items():
     cp(f"prof_{c}/trace/bench_kernel_stats.csv", f"bench_{n}_kernel_stats.csv")
     cp(f"prof_{c}/summary.txt", f"bench_{n}_summary.txt")
     cp(f"cl_{c}.json", f"closed_loop_{n}.json")
+s = os.path.join(G, "bench_default.json")
+if os.path.exists(s):
+    json.dump(json.loads(open(s).read().strip().splitlines()[-1]), open(os.path.join(P, "bench_default_line.json"), "w"), indent=1)
+    print("copied bench_default_line.json")
+for f in ("collective_overhead_c5.json", "collective_overhead_push.json", "coop_rows_K2000.json", "phase_breakdown.json",
+          "mask_count_closed_loop.json", "closed_loop_perf.json"):
+    cp(f, f)
+cp("prof_emul/emul_kernel_stats.csv", "rank0_of_8_emulation_kernel_stats.csv")
 cp("host_overhead.txt", "host_overhead.txt")
 cp("iters_sweep.txt", "iters_sweep_push_K2000.txt")
 cp("k_sweep.json", "k_sweep_push_T30.json")
