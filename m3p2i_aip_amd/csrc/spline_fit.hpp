@@ -9,6 +9,12 @@
 // same operation order, validated against scipy itself (tests/test_spline_fit.py; on the GPU
 // tests/test_device_sampler_gpu.py).  All arithmetic is binary64 like FITPACK's.
 //
+// Provenance: FITPACK ("DIERCKX") is third-party numerical software by Paul Dierckx, distributed through
+// netlib (http://www.netlib.org/dierckx/) and shipped, compiled, inside SciPy under SciPy's BSD-3-Clause
+// licence terms.  It is NOT part of tud-amr/m3p2i-aip (the reference only calls it through scipy), and no
+// FITPACK source was available here (scipy ships the object code only): this file follows the algorithm as
+// published, and its agreement with the compiled library is a test, not an assumption.
+//
 // One call = one series of m points y[0..m) at abscissae x_i = i * m / (m - 1)  (np.linspace(0, m, m),
 // skill_utils/mppi_utils bspline), evaluated at n_out points linspace(0, m, n_out).
 #pragma once
