@@ -96,7 +96,9 @@ typedef struct {
     float u_min[M3_MAX_NU];
     float u_max[M3_MAX_NU];
     float noise_sigma_diag[M3_MAX_NU]; /* diagonal of cfg.mppi.noise_sigma */
-    float u_scale;
+    float u_scale;          /* mppi.py:297,421.  The update consumes actions / u_scale throughout; for u_scale != 1 the
+                               reference updates its distribution from the SCALED stack (mppi.py:313,331): a
+                               deviation, which is why the Python planner refuses u_scale != 1 */
     float gamma;            /* rollout_var_discount */
     float lambda_;
     float step_size_mean;   /* 0.98, mppi.py:178 */

@@ -279,16 +279,13 @@ class MPPI():
             return
         e = self._engine
         # (a one-collective multi-modal shard holds the rows of ALL samples: engine.needs_global_noise)
-        k0, k1 = (0, self.K) if getattr(e, "needs_global_noise", False) else (self.k_offset, self.k_offset + self.K_local)
-        if hasattr(e, "set_noise_knots"):
-            # device sampler: Halton knots on the host (K*nu*n_knots values, vectorised), the K*nu
-            # spline fits -- where the reference's ~1 s init goes -- one GPU thread each
-            e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree, k0, k1),
-                              self.degree, 0.5)
-            if self.relabel_samples and hasattr(e, "relabel_samples"):
-                e.relabel_samples()   # the sampler's row labels are arbitrary: wavefront-coherent ones
-        else:   # engines without the device sampler (the CPU test stand-in)
-            e.set_noise(sampling.halton_spline_delta(self.K, self.T, self.nu, self.knot_scale, self.degree, k0, k1))
+        k0, k1 = (0, self.K) if e.needs_global_noise else (self.k_offset, self.k_offset + self.K_local)
+        # device sampler: Halton knots on the host (K*nu*n_knots values, vectorised), the K*nu
+        # spline fits -- where the reference's ~1 s init goes -- one GPU thread each
+        e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree, k0, k1),
+                          self.degree, 0.5)
+        if self.relabel_samples:
+            e.relabel_samples()   # the sampler's row labels are arbitrary: wavefront-coherent ones
         self._have_noise = True
 
     @property
