@@ -269,29 +269,35 @@ def general_ori_cube2goal(cube_quat, goal_quat):
     return float(np.sum(1.0 - cos.max(axis=1)))
 
 
+def _as_goal_tensor(goal, device):
+    import torch
+    return goal if torch.is_tensor(goal) else torch.tensor(goal, device=device)
+
+
 class PLANNER_SIMPLE:
-    """task_planner.py:13-39."""
+    """The point_env "task planner" (behaves like task_planner.py:13-39): task and goal are the configured ones
+    for the whole run; all it decides is whether the task is done -- robot (navigation) or box (push / pull /
+    push_pull) within SUCCESS_RADIUS of the goal."""
+
+    SUCCESS_RADIUS = 0.1
 
     def __init__(self, cfg) -> None:
-        import torch
-        self.device = cfg.mppi.device
-        self.task = cfg.task
-        self.curr_goal = cfg.goal if torch.is_tensor(cfg.goal) else torch.tensor(cfg.goal, device=self.device)
-        self.dist_threshold = 0.1
+        self.device, self.task = cfg.mppi.device, cfg.task
+        self.curr_goal = _as_goal_tensor(cfg.goal, self.device)
+        self.dist_threshold = self.SUCCESS_RADIUS
 
     def update_plan(self, sim):
-        pass
+        """Nothing to re-plan: a single fixed task."""
 
     def reset_plan(self):
-        pass
+        """(kept for the interface: nothing to reset)"""
 
     def check_task_success(self, sim):
         import torch
-        box_pos = sim.get_actor_position_by_name("box")[0, :2]
         if self.task == "navigation":
             return torch.norm(sim.robot_pos[0, :] - self.curr_goal) < self.dist_threshold
         if self.task in ("push", "pull", "push_pull"):
-            return torch.norm(box_pos - self.curr_goal) <= self.dist_threshold
+            return torch.norm(sim.get_actor_position_by_name("box")[0, :2] - self.curr_goal) <= self.dist_threshold
         return False
 
 
