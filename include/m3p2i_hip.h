@@ -188,7 +188,9 @@ typedef enum {
                                top-k global indices | top-k trajectories [M3_TOPK][T][2] */
     M3_BUF_RECORDS_ALL = 23,/* f32 [K_global/K_local][record_len]: all-gather M3_BUF_RECORD into
                                this buffer between m3_update and m3_finalize (shard_mix) */
-    M3_BUF_COUNT = 24
+    M3_BUF_NOISE_ALL = 24,  /* f32 [K_global/K_local][T][Kl][nu]: every shard's noise block (one-collective
+                               multi-modal shards only; M3_BUF_NOISE is this rank's block of it) */
+    M3_BUF_COUNT = 25
 } m3_buffer_id;
 
 typedef struct m3_handle m3_handle;

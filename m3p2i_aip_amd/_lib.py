@@ -22,7 +22,7 @@ TASKS = {"navigation": 0, "push": 1, "pull": 2, "push_pull": 3, "reach": 4, "pic
 (BUF_STATES, BUF_ACTIONS, BUF_COST_HORIZON, BUF_TRAJ_COST, BUF_TRAJ_COST_ALL, BUF_WEIGHTS,
  BUF_WEIGHTS_1, BUF_WEIGHTS_2, BUF_MEAN, BUF_MEAN_1, BUF_MEAN_2, BUF_BEST, BUF_BEST_1,
  BUF_BEST_2, BUF_ACTION_OUT, BUF_TOP_IDX, BUF_TOP_TRAJS, BUF_REDUCE, BUF_NOISE,
- BUF_PENDING_FORCE, BUF_INFO, BUF_SIM_WORLD, BUF_RECORD, BUF_RECORDS_ALL, BUF_COUNT) = range(25)
+ BUF_PENDING_FORCE, BUF_INFO, BUF_SIM_WORLD, BUF_RECORD, BUF_RECORDS_ALL, BUF_NOISE_ALL, BUF_COUNT) = range(26)
 
 
 class Config(C.Structure):

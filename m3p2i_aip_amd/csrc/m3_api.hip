@@ -196,6 +196,7 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
         if (rc == M3_OK) {   // non-owning aliases (m3_destroy skips them)
             h->buf[M3_BUF_TRAJ_COST] = h->buf[M3_BUF_RECORD]; h->nbytes[M3_BUF_TRAJ_COST] = Kl * f;
             h->buf[M3_BUF_NOISE] = h->noise_all + (size_t)(c->k_offset / Kl) * T * Kl * nu; h->nbytes[M3_BUF_NOISE] = T * Kl * nu * f;
+            h->buf[M3_BUF_NOISE_ALL] = h->noise_all; h->nbytes[M3_BUF_NOISE_ALL] = T * Kg * nu * f;
         }
     } else if (c->shard_mix && Kl != Kg) {
         A(M3_BUF_RECORD, (long long)record_length((int)T, (int)nu) * f);
@@ -227,7 +228,7 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
 
 extern "C" void m3_destroy(m3_handle* h) {
     if (!h) return;
-    if (h->regen) h->buf[M3_BUF_TRAJ_COST] = h->buf[M3_BUF_NOISE] = nullptr;   // aliases
+    if (h->regen) h->buf[M3_BUF_TRAJ_COST] = h->buf[M3_BUF_NOISE] = h->buf[M3_BUF_NOISE_ALL] = nullptr;   // aliases
     for (int i = 0; i < M3_BUF_COUNT; ++i)
         if (h->buf[i]) (void)hipFree(h->buf[i]);
     if (h->noise_all) (void)hipFree(h->noise_all);

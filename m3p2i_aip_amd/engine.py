@@ -252,6 +252,7 @@ class HipEngine:
             L.BUF_NOISE: ((T, Kl, nu), "<f4"), L.BUF_PENDING_FORCE: ((4, Kl), "<f4"),
             L.BUF_SIM_WORLD: ((28 if c.env_type == L.ENV_POINT else 45, Kl), "<f4"),
             L.BUF_INFO: ((L.INFO_WORDS,), "<i4"),
+            L.BUF_NOISE_ALL: ((Kg // Kl, T, Kl, nu), "<f4"),
             L.BUF_RECORD: ((self.lib.m3_record_len(self._h),), "<f4"),
             L.BUF_RECORDS_ALL: ((Kg // Kl, self.lib.m3_record_len(self._h)), "<f4"),
         }[which]

@@ -184,3 +184,55 @@ def test_one_collective_shard_needs_the_global_noise_table():
     with pytest.raises(L.M3Error):   # in-kernel random noise cannot be re-generated from a table
         HipEngine(make_config(K=512, K_local=256, k_offset=0, shard_mix=True, sampling_random=True, **kw))
     e.close()
+
+
+def test_one_collective_shards_with_the_built_in_sampler_and_relabelling():
+    """The planner's own path: Halton knots of ALL samples on every rank, spline fits on the device, samples
+    relabelled into wavefront order (m3_relabel_samples).  Every rank relabels every shard's block itself --
+    the same deterministic procedure on the same inputs -- so all ranks must hold the SAME noise table, and
+    their plans must stay bit-identical call after call; the plan equals the unsharded, un-relabelled
+    handle's up to the order of f32 summation (same sample set, other labels)."""
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd import sampling
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    Kt, Nt = 2048, 4
+    kl = Kt // Nt
+    knots = sampling.halton_knots(Kt, T, 2)
+    kw = dict(T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+    full = HipEngine(make_config(K=Kt, **kw))
+    full.set_noise_knots(knots)
+    shards = [HipEngine(make_config(K=Kt, K_local=kl, k_offset=r * kl, shard_mix=True, **kw)) for r in range(Nt)]
+    for e in shards:
+        e.set_noise_knots(knots)        # all K rows
+        e.relabel_samples()
+    for e in [full] + shards:
+        e.set_objective("push_pull", (-3.75, -3.75))
+    for call in range(4):
+        for e in [full] + shards:
+            e.set_world_point_raw(_world(call))
+        full.command()
+        for e in shards:
+            e.rollout()
+            e.update()
+        allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])
+        for e in shards:
+            e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
+            e.finalize()
+        torch.cuda.synchronize()
+        tables = [e.buffer(L.BUF_NOISE_ALL) for e in shards]
+        for r, e in enumerate(shards):
+            assert torch.equal(tables[r], tables[0]), f"call {call}: rank {r} holds another noise table than rank 0"
+            assert torch.equal(e.buffer(L.BUF_NOISE), tables[0][r])          # its own block of it
+            for name in PLAN_BUFS + ("BUF_WEIGHTS", "BUF_TOP_IDX"):
+                b = getattr(L, name)
+                assert torch.equal(e.buffer(b), shards[0].buffer(b)), f"call {call}: ranks disagree on {name}"
+            np.testing.assert_allclose(e.buffer(L.BUF_ACTION_OUT).cpu().numpy(), full.buffer(L.BUF_ACTION_OUT).cpu().numpy(),
+                                       atol=1e-4, err_msg=f"call {call} rank {r}")
+        if call == 0:   # relabelled: the same sample SET (a permutation of the unsharded costs within each mode)
+            J = torch.cat([e.buffer(L.BUF_TRAJ_COST) for e in shards])
+            Jf = full.buffer(L.BUF_TRAJ_COST)
+            assert torch.equal(torch.sort(J[:Kt // 2]).values, torch.sort(Jf[:Kt // 2]).values)
+            assert torch.equal(torch.sort(J[Kt // 2:]).values, torch.sort(Jf[Kt // 2:]).values)
+            assert not torch.equal(J, Jf)     # ... and it really was relabelled
+    for e in shards + [full]:
+        e.close()
