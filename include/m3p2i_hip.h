@@ -236,6 +236,13 @@ int m3_set_noise_knots(m3_handle* h, const float* knots, int n_knots, int degree
 int m3_set_noise_global(m3_handle* h, const float* delta_all, int on_device);
 int m3_set_noise_knots_global(m3_handle* h, const float* knots_all, int n_knots, int degree, float smoothing,
                               int on_device);
+/* The WHOLE reference sampler on the device: Halton radical inverses (in-tree use_ghalton=False branch,
+ * mppi_utils.py:69-96) -> sqrt(2) erfinv(2u - 1) (:99-104) -> the smoothing spline of m3_set_noise_knots, for
+ * this shard's samples (all K_global for a one-collective multi-modal shard).  The uniform Halton values are
+ * bit-identical to the host sampler's; the Gaussian ones agree to ~1e-6 relative (device erff / expf / logf
+ * differ from the host's libm in the last ulp) -- so the planner's default stays m3_set_noise_knots with host
+ * knots, pinned bit for bit by golden G8; this entry (MPPIConfig.device_knots) removes the last host values. */
+int m3_set_noise_halton(m3_handle* h, int n_knots, int degree, float smoothing);
 int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd);
 /* Objective.multi_modal (cost_functions.py:9) for a sim_only handle, whose config does not
  * come from an MPPI object; refused on planner handles (fixed at m3_create) */

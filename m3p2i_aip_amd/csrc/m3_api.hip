@@ -468,6 +468,40 @@ extern "C" int m3_set_noise_knots_global(m3_handle* h, const float* knots_all, i
     return upload_knots(h, knots_all, h->cfg.K_global, h->noise_all, n_knots, degree, smoothing, on_device);
 }
 
+// the whole reference sampler on the device: Halton -> erfinv -> smoothing spline (no host values at all)
+extern "C" int m3_set_noise_halton(m3_handle* h, int n_knots, int degree, float smoothing) {
+    if (!h) return M3_ERR_BAD_ARG;
+    const m3_config& c = h->cfg;
+    if (c.sim_only) return fail(h, M3_ERR_STATE, "m3_set_noise_halton: handle was created sim_only");
+    const int ncol = c.nu * n_knots;
+    if (n_knots < 1 || ncol > 100) return fail(h, M3_ERR_SHAPE, "m3_set_noise_halton: nu * n_knots must be <= 100 (mppi_utils.py:81)");
+    int primes[100], np_ = 0;
+    for (int cand = 2; np_ < ncol; ++cand) {
+        bool is_p = true;
+        for (int q = 0; q < np_ && primes[q] * primes[q] <= cand; ++q)
+            if (cand % primes[q] == 0) { is_p = false; break; }
+        if (is_p) primes[np_++] = cand;
+    }
+    const long long rows = h->regen ? c.K_global : c.K_local;
+    const int k0 = h->regen ? 0 : c.k_offset;
+    float* knots = nullptr;
+    int* primes_dev = nullptr;
+    HIPCHK(h, hipMalloc((void**)&knots, (size_t)rows * ncol * sizeof(float)));
+    if (hipMalloc((void**)&primes_dev, ncol * sizeof(int)) != hipSuccess) { (void)hipFree(knots); return fail(h, M3_ERR_HIP, "m3_set_noise_halton: hipMalloc"); }
+    int rc = M3_OK;
+    if (hipMemcpyAsync(primes_dev, primes, ncol * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK) {
+        launch_halton_knots(knots, k0, (int)rows, ncol, primes_dev, h->stream);
+        // knots [rows][nu][n_knots] == [rows][ncol]: column j * n_knots + q is knot q of control dimension j
+        rc = upload_knots(h, knots, rows, h->regen ? h->noise_all : (float*)h->buf[M3_BUF_NOISE], n_knots, degree, smoothing, 1);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(knots);
+    (void)hipFree(primes_dev);
+    if (rc != M3_OK && h->err.empty()) h->err = "m3_set_noise_halton failed";
+    return rc;
+}
+
 extern "C" int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd) {
     if (!h) return M3_ERR_BAD_ARG;
     if (task < 0 || task > M3_TASK_IDLE) return fail(h, M3_ERR_BAD_ARG, "m3_set_objective: unknown task");

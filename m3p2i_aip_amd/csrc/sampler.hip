@@ -33,6 +33,63 @@ void launch_spline_noise(const float* knots, float* noise, int Kl, int nu, int n
                        degree, smoothing);
 }
 
+// ---- the knots themselves on the device (optional: m3_set_noise_halton) ------------------------
+// Gaussian Halton values of samples k0 .. k0 + n: van der Corput radical inverse of the index k + 1 in the
+// c-th prime (mppi_utils.py:69-96, the in-tree use_ghalton=False branch), accumulated in binary32 digit by
+// digit from the least significant one with the scale 1 / base^d carried in binary64 and rounded per digit --
+// the arithmetic of sampling.radical_inverse, bit for bit -- then sqrt(2) * erfinv(2u - 1) (mppi_utils.py:
+// 99-104).  erfinv is the rational approximation + two Newton steps torch's CPU kernel uses, on the device's
+// erff / expf / logf: those differ from glibc's in the last ulp, so the Gaussian values agree with the host
+// sampler to ~1e-6 relative, not bit for bit (which is why the planner's default keeps the host knots,
+// pinned by golden G8; MPPIConfig.device_knots opts in).
+__device__ __forceinline__ float dev_erfinv(float y) {
+    const float a[4] = {0.886226899f, -1.645349621f, 0.914624893f, -0.140543331f};
+    const float b[4] = {-2.118377725f, 1.442710462f, -0.329097515f, 0.012229801f};
+    const float c[4] = {-1.970840454f, -1.624906493f, 3.429567803f, 1.641345311f};
+    const float d[2] = {3.543889200f, 1.637067800f};
+    const float ya = fabsf(y);
+    if (ya > 1.0f) return __builtin_nanf("");
+    if (ya == 1.0f) return copysignf(__builtin_inff(), y);
+    float x;
+    if (ya <= 0.7f) {
+        const float z = y * y;
+        const float num = ((a[3] * z + a[2]) * z + a[1]) * z + a[0];
+        const float dem = (((b[3] * z + b[2]) * z + b[1]) * z + b[0]) * z + 1.0f;
+        x = y * num / dem;
+    } else {
+        const float z = sqrtf(-logf((1.0f - ya) / 2.0f));
+        const float num = ((c[3] * z + c[2]) * z + c[1]) * z + c[0];
+        const float dem = (d[1] * z + d[0]) * z + 1.0f;
+        x = copysignf(num, y) / dem;
+    }
+    const float two_over_sqrt_pi = 1.1283791670955126f;
+    x = x - (erff(x) - y) / (two_over_sqrt_pi * expf(-x * x));
+    x = x - (erff(x) - y) / (two_over_sqrt_pi * expf(-x * x));
+    return x;
+}
+
+__global__ void k_halton_knots(float* __restrict__ knots /*[n][ncol]*/, int k0, int n, int ncol, const int* __restrict__ primes) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n * ncol) return;
+    const int c = o % ncol;
+    unsigned rem = (unsigned)(k0 + o / ncol) + 1u;      // Halton indices start at 1
+    const unsigned base = (unsigned)primes[c];
+    float acc = 0.0f;
+    double scale = 1.0;
+    while (rem > 0u) {
+        scale /= (double)base;
+        acc += (float)scale * (float)(rem % base);
+        rem /= base;
+    }
+    const float u = 2.0f * acc - 1.0f;
+    knots[o] = 1.41421356237309515f * dev_erfinv(u);
+}
+
+void launch_halton_knots(float* knots, int k0, int n, int ncol, const int* primes_dev, hipStream_t s) {
+    const int total = n * ncol;
+    hipLaunchKernelGGL(k_halton_knots, dim3((total + 255) / 256), dim3(256), 0, s, knots, k0, n, ncol, primes_dev);
+}
+
 // ---- wavefront order of the samples (point_env rollout) ---------------------------------
 // The rollout kernel picks, per substep and per WAVE, the leanest dynamics instance that covers
 // every lane's nearby pairs (planar_dyn.hpp), so a wave costs the UNION of its 64 samples' contact

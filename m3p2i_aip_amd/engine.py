@@ -151,6 +151,10 @@ class HipEngine:
         assert k.ndim == 3 and k.shape[:2] == (rows, c.nu), k.shape
         self._ck(fn(self._h, k.ctypes.data, int(k.shape[2]), int(degree), float(smoothing), 0))
 
+    def set_noise_halton(self, n_knots, degree=2, smoothing=0.5):
+        """The whole Halton-spline sampler on the device (knots included): include/m3p2i_hip.h."""
+        self._ck(self.lib.m3_set_noise_halton(self._h, int(n_knots), int(degree), float(smoothing)))
+
     def set_objective(self, task, goal, gripper_cmd=0):
         t = L.TASKS[task] if isinstance(task, str) else int(task)
         g = [float(x) for x in (goal.detach().cpu().reshape(-1).tolist()

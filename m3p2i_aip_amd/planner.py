@@ -78,6 +78,7 @@ class MPPIConfig(object):
     world_size: int = 1               #   num_samples/world_size consecutive samples
     shard_mix: Optional[bool] = None  # None: one-collective protocol whenever it applies
     relabel_samples: bool = True      # generated noise rows into wavefront-coherent order (same sample set)
+    device_knots: bool = False        # Halton + erfinv knots on the device too (~1e-6 from the host sampler's)
 
 
 def _get(cfg, name, default=None):
@@ -282,8 +283,13 @@ class MPPI():
         k0, k1 = (0, self.K) if e.needs_global_noise else (self.k_offset, self.k_offset + self.K_local)
         # device sampler: Halton knots on the host (K*nu*n_knots values, vectorised), the K*nu
         # spline fits -- where the reference's ~1 s init goes -- one GPU thread each
-        e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree, k0, k1),
-                          self.degree, 0.5)
+        if bool(_get(self._top_cfg.mppi, "device_knots", False)):
+            if self.n_knots <= self.degree:
+                raise ValueError(f"horizon T={self.T} gives n_knots={self.n_knots}: the spline needs T >= {self.knot_scale * (self.degree + 1)}")
+            e.set_noise_halton(self.n_knots, self.degree, 0.5)     # ... and the knots on the device as well
+        else:
+            e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree, k0, k1),
+                              self.degree, 0.5)
         if self.relabel_samples:
             e.relabel_samples()   # the sampler's row labels are arbitrary: wavefront-coherent ones
         self._have_noise = True

@@ -60,3 +60,36 @@ def test_bad_knot_shapes_are_refused():
     with pytest.raises(L.M3Error):
         eng.set_noise_knots(np.zeros((64, 2, 65), np.float32))
     eng.close()
+
+
+@pytest.mark.parametrize("K,T,nu,k0,k1", [(2000, 30, 2, 0, 2000), (4000, 20, 9, 0, 4000), (4096, 30, 2, 1024, 2048)])
+def test_whole_sampler_on_the_device_agrees_with_the_host_sampler(K, T, nu, k0, k1):
+    """m3_set_noise_halton: Halton radical inverses + erfinv on the device as well (MPPIConfig.device_knots).
+    The Halton uniforms are the host's bit for bit (the knot signs and magnitudes below would scatter
+    otherwise); the Gaussian values go through the device's erff / expf / logf, so the final noise agrees with
+    the host sampler -- the reference's arithmetic, golden G8 -- to ~1e-5 absolute, not bit for bit."""
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd import sampling
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    env = "point_env" if nu == 2 else "panda_env"
+    kw = dict(u_min=[-1.0] * nu, u_max=[1.0] * nu, noise_sigma_diag=[1.0] * nu)
+    eng = HipEngine(make_config(K=K, K_local=k1 - k0, k_offset=k0, T=T, nu=nu, env_type=env, **kw))
+    eng.set_noise_halton(T // 4)
+    torch.cuda.synchronize()
+    dev = eng.buffer(L.BUF_NOISE).permute(1, 0, 2).cpu().numpy()
+    ref = sampling.halton_spline_delta(K, T, nu, k0=k0, k1=k1, workers=1).numpy()
+    assert np.isfinite(dev).all()
+    np.testing.assert_allclose(dev, ref, atol=3e-5, rtol=1e-5)
+    eng.close()
+
+
+def test_planner_with_device_knots_plans_like_the_default_sampler():
+    import bench
+    outs = []
+    for dk in (False, True):
+        pl, sim, obj, cfg = bench.build_tamp("point_env", "push", (-1.0, -1.0), False, 2000, 0, 1, 30, "cuda:0")
+        cfg.mppi.device_knots = dk
+        a = [pl.command(sim._dof_state[0]).clone() for _ in range(3)][-1]
+        outs.append(a.cpu().numpy())
+        pl._engine.close()
+    np.testing.assert_allclose(outs[1], outs[0], atol=2e-3)
