@@ -57,6 +57,54 @@ __global__ __launch_bounds__(64) void k_lane_gs(float* out, int passes, float ux
     if (i == 0) out[gridDim.x * 64] = (float)(t1 - t0);
 }
 
+// ---- A2: the same rows as ONE straight-line block per pass (no exec-mask regions: the rest test of the
+// friction row becomes a select, the contact row is unconditional), so that the scheduler may interleave the
+// independent drive / friction chains.  Same arithmetic per row => same numbers as A.
+__device__ __forceinline__ void friction_branch_free(const PointScene& sc, Vel& v, Fric& f, float m, float I, float Llin, float Lang) {
+    const bool moving = ((__float_as_uint(v.bvx) | __float_as_uint(v.bvy) | __float_as_uint(v.bw)) << 1) != 0u;
+    float nlx = f.lx + (-m * v.bvx), nly = f.ly + (-m * v.bvy);
+    const float mag2 = nlx * nlx + nly * nly;
+    const float scl = Llin * spec_rsqrt(mag2);
+    const bool sat = mag2 > Llin * Llin;
+    nlx = sat ? nlx * scl : nlx;
+    nly = sat ? nly * scl : nly;
+    float nla = clamp_sym(f.la + (-I * v.bw), Lang);
+    const float dvx = sc.invm_b * (nlx - f.lx), dvy = sc.invm_b * (nly - f.ly), dw = sc.invI_b * (nla - f.la);
+    v.bvx = moving ? v.bvx + dvx : v.bvx;
+    v.bvy = moving ? v.bvy + dvy : v.bvy;
+    v.bw = moving ? v.bw + dw : v.bw;
+    f.lx = moving ? nlx : f.lx; f.ly = moving ? nly : f.ly; f.la = moving ? nla : f.la;
+}
+template <bool INTERLEAVE>
+__global__ __launch_bounds__(64) void k_lane_gs_flat(float* out, int passes, float ux, float uy) {
+    const PointScene sc = make_scene();
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    Vel v = {0.3f + 1e-3f * i, 0.1f, 0.05f, 0.02f, 0.01f, 0.f, 0.f, 0.f};
+    Slot c;
+    prepare<ROBOT, BOXB>(sc, c, 0.0f, 1.0f, 0.f, 0.f, 0.05f + 1e-4f * i, -0.2f, -0.002f);
+    float ldx = 0.f, ldy = 0.f;
+    Fric fB = {0.f, 0.f, 0.f};
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < passes; ++it) {
+        if (INTERLEAVE) {
+            // friction first in program order, drive rows after it: they share no variable, so the order is
+            // free; the scheduler sees both chains in one block
+            friction_branch_free(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
+        }
+        float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
+        float l1 = clamp_sym(ldx + dl, sc.dmax);
+        v.rvx += sc.invm_r * (l1 - ldx); ldx = l1;
+        dl = -(((v.rvy - uy) + sc.gam * ldy) * sc.md);
+        l1 = clamp_sym(ldy + dl, sc.dmax);
+        v.rvy += sc.invm_r * (l1 - ldy); ldy = l1;
+        if (!INTERLEAVE) friction_branch_free(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
+        solve<ROBOT, BOXB>(sc, v, c, sc.mu_rb);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    out[i] = v.rvx + v.rvy + v.bvx + v.bvy + v.bw + c.ln + c.lt + fB.lx;
+    if (i == 0) out[gridDim.x * 64] = (float)(t1 - t0);
+}
+
 // ---- B / C: 8 lanes per sample, one generic row per lane ----------------------------------------
 #define DPP_XOR1 0xB1
 #define DPP_XOR2 0x4E
@@ -131,11 +179,13 @@ int main(int argc, char** argv) {
     hipMalloc(&d, (size_t)(K + 4096) * sizeof(float));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    struct { const char* name; int lanes_per_sample; } cfg[3] = {{"A lane/sample, Gauss-Seidel (product rows)", 1},
+    struct { const char* name; int lanes_per_sample; } cfg[5] = {{"A lane/sample, Gauss-Seidel (product rows)", 1},
                                                                 {"B 8 lanes/sample, block-Jacobi generic rows", 8},
-                                                                {"C 8 lanes/sample, coloured Gauss-Seidel", 8}};
+                                                                {"C 8 lanes/sample, coloured Gauss-Seidel", 8},
+                                                                {"A2 lane/sample, rows as one straight-line block (selects instead of exec-mask regions)", 1},
+                                                                {"A3 = A2 with the friction row ahead of the drive rows", 1}};
     printf("{\"K\": %d, \"passes\": %d, \"results\": [\n", K, passes);
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < 5; ++m) {
         const int waves = (K * cfg[m].lanes_per_sample + 63) / 64;
         float cyc = 0, ms = 0;
         for (int rep = 0; rep < 3; ++rep) {
@@ -143,14 +193,16 @@ int main(int argc, char** argv) {
             if (m == 0) hipLaunchKernelGGL(k_lane_gs, dim3(waves), dim3(64), 0, 0, d, passes, 1.0f, -0.5f);
             if (m == 1) hipLaunchKernelGGL(k_coop<true>, dim3(waves), dim3(64), 0, 0, d, passes, 1.0f, -0.5f);
             if (m == 2) hipLaunchKernelGGL(k_coop<false>, dim3(waves), dim3(64), 0, 0, d, passes, 1.0f, -0.5f);
+            if (m == 3) hipLaunchKernelGGL(k_lane_gs_flat<false>, dim3(waves), dim3(64), 0, 0, d, passes, 1.0f, -0.5f);
+            if (m == 4) hipLaunchKernelGGL(k_lane_gs_flat<true>, dim3(waves), dim3(64), 0, 0, d, passes, 1.0f, -0.5f);
             hipEventRecord(e1, 0);
             hipDeviceSynchronize();
             ms = ms_of(e0, e1);
-            hipMemcpy(&cyc, d + (m == 0 ? waves * 64 : waves * 8), sizeof(float), hipMemcpyDeviceToHost);
+            hipMemcpy(&cyc, d + (cfg[m].lanes_per_sample == 1 ? waves * 64 : waves * 8), sizeof(float), hipMemcpyDeviceToHost);
         }
         printf("  {\"mapping\": \"%s\", \"waves\": %d, \"cycles_per_pass_one_wave\": %.1f, \"kernel_us_for_K\": %.1f}%s\n",
-               cfg[m].name, waves, cyc / passes, ms * 1e3, m < 2 ? "," : "");
+               cfg[m].name, waves, cyc / passes, ms * 1e3, m < 4 ? "," : "");
     }
-    printf("], \"note\": \"cycles = s_memtime ticks (100 MHz) are NOT core clocks: compare the rows, and the kernel times\"}\n");
+    printf("], \"note\": \"clocks = __builtin_readcyclecounter ticks (shader clock: 360 passes x 378 ticks = 60 us); B and C use pyramid friction (and B is Jacobi): other numbers than A; A2 / A3 compute the same numbers as A\"}\n");
     return 0;
 }
