@@ -236,3 +236,46 @@ def test_one_collective_shards_with_the_built_in_sampler_and_relabelling():
             assert not torch.equal(J, Jf)     # ... and it really was relabelled
     for e in shards + [full]:
         e.close()
+
+
+def test_one_collective_protocol_panda_multi_modal():
+    """The re-generated actions of the panda_env (nine controls, gripper override mppi.py:412-416, best rows at
+    k = 0 and K/2): two shard handles of a multi-modal reach vs the unsharded handle."""
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    Kt, Nt, Tt = 512, 2, 20
+    kl = Kt // Nt
+    rng = np.random.default_rng(4)
+    delta = rng.standard_normal((Kt, Tt, 9)).astype(np.float32)
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    kw = dict(T=Tt, nu=9, env_type="panda_env", multi_modal=True, u_min=[-2.0] * 7 + [-1.5] * 2, u_max=[2.0] * 7 + [1.5] * 2,
+              noise_sigma_diag=[10.0] * 7 + [0.8] * 2, lambda_=0.05, pre_height_diff=0.05, dt=0.01)
+    full = HipEngine(make_config(K=Kt, **kw))
+    shards = [HipEngine(make_config(K=Kt, K_local=kl, k_offset=r * kl, shard_mix=True, **kw)) for r in range(Nt)]
+    for e in [full] + shards:
+        e.set_objective("reach", goal, gripper_cmd=1)
+        e.set_noise(delta)
+    for call in range(4):
+        full.command()
+        for e in shards:
+            e.rollout()
+            e.update()
+        allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])
+        for e in shards:
+            e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
+            e.finalize()
+        torch.cuda.synchronize()
+        fi = full.info()
+        for r, e in enumerate(shards):
+            i = e.info()
+            assert (i.iters, i.iters_1, i.iters_2, i.best_idx_1, i.best_idx_2) == (fi.iters, fi.iters_1, fi.iters_2, fi.best_idx_1, fi.best_idx_2)
+            for name in ("BUF_ACTION_OUT", "BUF_MEAN", "BUF_MEAN_1", "BUF_MEAN_2", "BUF_BEST_1", "BUF_BEST_2", "BUF_TOP_TRAJS"):
+                b = getattr(L, name)
+                assert torch.equal(e.buffer(b), shards[0].buffer(b))
+                np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), atol=5e-5, rtol=1e-4,
+                                           err_msg=f"call {call} rank {r} {name}")
+            assert torch.equal(e.buffer(L.BUF_TOP_IDX), full.buffer(L.BUF_TOP_IDX))
+            # the stored actions of the shard are what the other rank re-generates: gripper columns overridden
+            assert (e.actions[:, :, 7:] == 1.5).all() or r == Nt - 1
+    for e in shards + [full]:
+        e.close()
