@@ -1102,10 +1102,6 @@ void launch_weights(const UpdateArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// "regen" sharding: the action the rollout formed for GLOBAL sample k at time step t (mppi.py:381-416 +
-// :297-302, as in rollout_point.hip / rollout_panda.hip: same f32 operations, same order => the same
-// bits), from the sample's noise row and the replicated plan -- re-computed instead of communicated.
-// Halton-spline mode only (explicit noise table).
 // weighted action sums: sum_k w_k * actions[t][k][:] over the local shard, for the global
 // weights and (multi-modal) the two per-mode weight sets; plus row gathers.  Grid = T x n_chunk
 // workgroups (+1 for top-k stage B): each reads its slice of the action rows once (all nu
@@ -1118,7 +1114,10 @@ constexpr int WS_BATCH = 8;     // loads in flight per thread and array
 __host__ __device__ inline int wsum_chunk_len(int Kl) {
     const int unit = 2048;   // WS_BATCH * ST
     const int per32 = (((Kl + 31) / 32) + unit - 1) / unit * unit;
-    return per32 > 8192 ? per32 : 8192;
+#ifndef M3_WSUM_MIN_CHUNK
+#define M3_WSUM_MIN_CHUNK 8192
+#endif
+    return per32 > M3_WSUM_MIN_CHUNK ? per32 : M3_WSUM_MIN_CHUNK;
 }
 int wsum_chunks(int Kl) { const int L = wsum_chunk_len(Kl); return (Kl + L - 1) / L; }
 
@@ -1129,7 +1128,8 @@ __device__ __forceinline__ void finalize_body(const UpdateArgs& a, float* sm);  
 // rollout_point.hip / rollout_panda.hip: same f32 operations, same order => the same bits), from the
 // sample's noise row and the replicated plan -- what the "regen" sharding recomputes instead of
 // communicating.  Halton-spline mode only (explicit noise table).
-// The plan rows a time step's actions are assembled from (wave-uniform: loaded once per workgroup)
+//
+// The plan rows a time step's actions are assembled from (wave-uniform: loaded once per workgroup):
 template <int NU>
 struct RegenRows {
     float m1[NU], m2[NU], b1[NU], b2[NU];   // shifted mean of mode 1 (or the single mean) / mode 2, best rows

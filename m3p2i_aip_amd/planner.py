@@ -130,7 +130,12 @@ class MPPI():
         self.nu = len(noise_sigma)
         sig = torch.tensor(noise_sigma, dtype=torch.float32)
         if not torch.equal(sig, torch.diag(torch.diagonal(sig))):
-            raise NotImplementedError("only diagonal noise_sigma is supported (all reference configs are diagonal)")
+            # the reference's halton-spline path scales the Halton noise with sqrt(diag(noise_sigma)) and never
+            # reads the off-diagonal entries (mppi.py:175-176, 394); only MultivariateNormal sampling
+            # (sampling_method='random', mppi_mode='simple': mppi.py:129-131, 340, 481) uses the full matrix
+            if not (self.mppi_mode == "halton-spline" and self.sampling_method == "halton"):
+                raise NotImplementedError("a non-diagonal noise_sigma is only supported where the reference itself uses just "
+                                          "its diagonal (mppi_mode='halton-spline' with sampling_method='halton')")
         u_max, u_min = m.u_max, m.u_min
         if u_max and not u_min:
             u_min = [-float(x) for x in u_max]
