@@ -127,6 +127,14 @@ typedef struct {
                                  receiving them: bit-identical to the unsharded handle.  Needs the noise rows
                                  of all K_global samples on every rank (m3_set_noise_global /
                                  m3_set_noise_knots_global; 15 MB at K = 64000).
+                               2 = (multi-modal only) the same with each shard's minima and its eta(beta) sums on
+                                 the beta ladders added to the record: after the gather the searches walk the
+                                 MIXTURE of the shards' tables (eta(beta_j) = sum_r exp(-(m_r - m)/beta_j) eta_r(beta_j))
+                                 instead of re-evaluating all K costs -- passes over the gathered costs only when
+                                 a search leaves its ladder -- and one kernel forms weights, sums, best rows and the
+                                 plan: per-rank work after the collective halves.  Equal to the unsharded run up to
+                                 f32 rounding (plan <= 3e-5, same beta-search iteration counts), bit-identical
+                                 across ranks.
                                0 = gather + reduce, two collectives (all-gather TRAJ_COST, all-reduce REDUCE) */
     unsigned long long seed;
 } m3_config;

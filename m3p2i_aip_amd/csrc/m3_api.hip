@@ -136,6 +136,9 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
         if (c->multi_modal && !c->mode_simple && c->sampling_random)
             return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: one-collective multi-modal sharding re-generates the other ranks' "
                                                      "actions from the noise TABLE: not with sampling_random");
+        if (c->shard_mix == 2 && !(c->multi_modal && !c->mode_simple))
+            return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: shard_mix = 2 (ladder tables in the records) is a multi-modal protocol");
+        if (c->shard_mix < 0 || c->shard_mix > 2) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: shard_mix must be 0, 1 or 2");
         if (c->K_global % c->K_local != 0 || c->k_offset % c->K_local != 0 || c->K_global / c->K_local > MIX_MAX_RANKS)
             return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs equal shards (K_global = n * K_local, n <= 32)");
         if (c->K_local < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs K_local >= 20");
@@ -150,6 +153,7 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (!h) return fail(nullptr, M3_ERR_HIP, "m3_create: out of host memory");
     h->cfg = *c;
     h->regen = c->shard_mix && c->K_local != c->K_global && c->multi_modal && !c->mode_simple;
+    h->regen_fast = h->regen && c->shard_mix == 2;
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) {
         g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
@@ -744,6 +748,8 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.rank = c.k_offset / c.K_local;
     a.records_all = (const float*)h->buf[M3_BUF_RECORDS_ALL];
     a.rec_topj = a.rec_topi = nullptr;
+    a.rec_mins = a.rec_table = nullptr;
+    a.fast = 0;
     a.regen = 0;
     a.Jout = nullptr;
     a.Kls = c.K_local;
@@ -786,6 +792,11 @@ static int update_impl(m3_handle* h, bool fuse) {
         a.rec_topj = rec + regen_off_topj(c.K_local);
         a.rec_topi = rec + regen_off_topi(c.K_local);
         a.top_dst = rec + regen_off_trajs(c.K_local);
+        if (h->regen_fast) {   // ... and its minima + ladder table
+            a.fast = 1;
+            a.rec_mins = rec + regen_off_mins(c.K_local, c.T);
+            a.rec_table = rec + regen_off_table(c.K_local, c.T);
+        }
         launch_local_topk(a, h->stream);
         HIPCHK(h, hipGetLastError());
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
@@ -846,6 +857,18 @@ static int regen_finalize(m3_handle* h) {
     UpdateArgs a;
     fill_update_args(h, a);
     a.regen = 1;
+    if (h->regen_fast) {
+        // shard_mix = 2: k_search mixes the shards' ladder tables, then ONE kernel does the rest
+        if ((long long)c.T * c.nu > 2048) return fail(h, M3_ERR_UNSUPPORTED, "m3_finalize: shard_mix = 2 needs T * nu <= 2048");
+        a.fast = 1;
+        a.Kl = c.K_global; a.k0 = 0;
+        a.n_chunk = wsum_chunks(c.K_global);
+        a.top_dst = a.top_trajs;
+        a.fuse_finalize = 1;
+        launch_regen_fast(a, h->stream);
+        HIPCHK(h, hipGetLastError());
+        return M3_OK;
+    }
     a.Jout = (float*)h->buf[M3_BUF_TRAJ_COST_ALL];   // k_mins compacts the records' costs into it
     a.Kl = c.K_global; a.k0 = 0;           // the launches cover every sample
     a.n_chunk = wsum_chunks(c.K_global);

@@ -100,6 +100,10 @@ struct UpdateArgs {
     // the other ranks' samples are RE-GENERATED from the replicated noise table and plan instead of
     // being communicated (a_k[t] is a function of the global sample index: mppi.py:381-416)
     int regen;           // 1: the launch covers all K_global samples (Kl == Kg, k0 == 0 in this struct)
+    int fast;            // shard_mix = 2: the records carry per-rank minima + ladder tables; the search mixes them
+                         // instead of re-evaluating all K costs, and ONE kernel does weights + sums + finalize
+    float* rec_mins;     // this rank's record: minima [4] and ladder table [LAD_N][3] (pre-gather launch)
+    float* rec_table;
     int Kls;             // samples per shard (= per rank)
     int rec_len;         // floats per gathered record
     const float* noise_all;  // [n_ranks][T][Kls][nu]: every shard's noise block
@@ -122,12 +126,18 @@ __host__ __device__ inline int reduce_length(int T, int nu) { return 6 * T * nu 
 constexpr int REC_HDR = 48, REC_TOPJ = 8, REC_TOPI = 28;
 __host__ __device__ inline int record_length(int T, int nu) { return REC_HDR + reduce_length(T, nu); }
 constexpr int MIX_MAX_RANKS = 32;
+// beta ladders of the multi-modal search: 0.9^j (j = 0..63) and 1.2^j (j = 1..32), see update.hip
+constexpr int LAD_S = 64, LAD_G = 32, LAD_N = LAD_S + LAD_G;
 // regen record: [Kls] trajectory costs of the shard | [TOPK] its smallest costs | [TOPK] their global
-// indices (int bits) | [TOPK][T][2] their (x, y) trajectories; length padded to a multiple of 4 floats
+// indices (int bits) | [TOPK][T][2] their (x, y) trajectories | [4] the shard's minima (all / mode 1 /
+// mode 2 / pad) | [LAD_N][3] its eta(beta) sums on the ladders relative to those minima (the last two only
+// with shard_mix = 2); length padded to a multiple of 4 floats
 __host__ __device__ inline int regen_off_topj(int Kls) { return Kls; }
 __host__ __device__ inline int regen_off_topi(int Kls) { return Kls + M3_TOPK; }
 __host__ __device__ inline int regen_off_trajs(int Kls) { return Kls + 2 * M3_TOPK; }
-__host__ __device__ inline int regen_record_length(int Kls, int T) { return (Kls + 2 * M3_TOPK + M3_TOPK * T * 2 + 3) / 4 * 4; }
+__host__ __device__ inline int regen_off_mins(int Kls, int T) { return Kls + 2 * M3_TOPK + M3_TOPK * T * 2; }
+__host__ __device__ inline int regen_off_table(int Kls, int T) { return regen_off_mins(Kls, T) + 4; }
+__host__ __device__ inline int regen_record_length(int Kls, int T) { return (regen_off_table(Kls, T) + LAD_N * 3 + 3) / 4 * 4; }
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s);
@@ -154,6 +164,7 @@ bool update_small_applies(const UpdateArgs& a);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);
 void launch_mix(const UpdateArgs& a, hipStream_t s);
 void launch_local_topk(const UpdateArgs& a, hipStream_t s);
+void launch_regen_fast(const UpdateArgs& a, hipStream_t s);
 int rollout_lanes_for(int Kl);
 int mins_workgroups(int Kg);
 int topk_workgroups(int Kg);
@@ -234,6 +245,7 @@ struct m3_handle {
     int bind_nact = 0, bind_box = 0, bind_dyn = 0;
     bool have_noise = false;
     bool regen = false;            // one-collective multi-modal sharding (UpdateArgs::regen)
+    bool regen_fast = false;       // ... with per-rank ladder tables in the records (cfg.shard_mix == 2)
     float* noise_all = nullptr;    // regen: [n_ranks][T][Kl][nu]; buf[M3_BUF_NOISE] aliases this rank's block
     int* local_top_idx = nullptr;  // regen: top_idx of the local pre-gather selection (scratch)
     unsigned calls = 0;

@@ -41,9 +41,7 @@ namespace m3 {
 constexpr int WT_MAX = 1024;       // threads of k_weights for large K (16 wavefronts); 256 for small K
 constexpr int PREP_T = 256;        // threads of k_mins / a top-k stage-A workgroup
 constexpr int PREP_RPT = 16;       // costs per thread held in registers there
-constexpr int LAD_S = 64;          // shrink ladder: beta = 0.9^j, j = 0..63
-constexpr int LAD_G = 32;          // grow ladder:   beta = 1.2^j, j = 1..32
-constexpr int LAD_N = LAD_S + LAD_G;
+// (LAD_S = 64 shrink-ladder points 0.9^j, LAD_G = 32 grow-ladder points 1.2^j, LAD_N: m3_internal.hpp)
 constexpr int LAD_EL = 256;        // costs per k_ladder workgroup
 constexpr int WEIGHTS_LDS_MAX = 32768;  // costs staged in LDS by k_weights (128 KB of the CU's 160 KB)
 
@@ -52,6 +50,26 @@ constexpr int WEIGHTS_LDS_MAX = 32768;  // costs staged in LDS by k_weights (128
 // rounded expf.  The bar on the weights is 1e-3 and the same function is used for eta and
 // for the weights, so they still sum to one.
 __device__ __forceinline__ float m3_exp(float x) { return __expf(x); }
+
+// an optimisation barrier for a value: the compiler must take it as given
+__device__ __forceinline__ float uniform_f(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// shard of global sample k (k < 2^24: exact in binary32; one multiply + a fix-up instead of an integer division)
+__device__ __forceinline__ int shard_of(int k, int Kls, float inv_Kls) {
+    int r = (int)((float)k * inv_Kls);
+    r -= (r * Kls > k) ? 1 : 0;
+    r += ((r + 1) * Kls <= k) ? 1 : 0;
+    return r;
+}
+// trajectory cost of GLOBAL sample k: the contiguous array, or (shard_mix = 2) the head of its shard's
+// gathered record
+__device__ __forceinline__ float jcost(const UpdateArgs& a, int k) {
+    if (!a.fast) return a.Jall[k];
+    const int r = shard_of(k, a.Kls, 1.0f / (float)a.Kls);
+    return a.records_all[(size_t)r * a.rec_len + (k - r * a.Kls)];
+}
 
 // ---- wavefront (64-lane) reductions on the DPP cross-lane path ---------------------------
 // __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~100+ cycles each, six
@@ -510,6 +528,35 @@ __device__ __forceinline__ void topk_stage_b(const UpdateArgs& a) {
     __syncthreads();
     topk_finish(a, s_top, blockDim.x);
 }
+// shard_mix = 2: the global top-k is a subset of the union of the shards' own sorted top-k lists, which came
+// with the gathered records: rank counting over the N x TOPK candidates (keys are unique: the index is part
+// of the key), rows copied from the owners' records.  One workgroup.
+__device__ __forceinline__ void topk_merge_records(const UpdateArgs& a) {
+    __shared__ tkey s_key[MIX_MAX_RANKS * M3_TOPK];
+    __shared__ int s_src[M3_TOPK];
+    const int tid = threadIdx.x, nt = blockDim.x, N = a.n_ranks, nc = N * M3_TOPK, T = a.T;
+    for (int c = tid; c < nc; c += nt) {
+        const float* rec = a.records_all + (size_t)(c / M3_TOPK) * a.rec_len;
+        s_key[c] = vi_key(rec[regen_off_topj(a.Kls) + c % M3_TOPK], __float_as_int(rec[regen_off_topi(a.Kls) + c % M3_TOPK]));
+    }
+    __syncthreads();
+    for (int c = tid; c < nc; c += nt) {
+        const tkey my = s_key[c];
+        int rank = 0;
+#pragma unroll 4
+        for (int q = 0; q < nc; ++q) rank += (s_key[q] < my) ? 1 : 0;
+        if (rank < M3_TOPK) {
+            s_src[rank] = c;
+            a.top_idx[rank] = (int)(unsigned)my;
+        }
+    }
+    __syncthreads();
+    for (int o = tid; o < M3_TOPK * T * 2; o += nt) {
+        const int slot = o / (T * 2), c = s_src[slot];
+        a.top_trajs[o] = a.records_all[(size_t)(c / M3_TOPK) * a.rec_len + regen_off_trajs(a.Kls) + (c % M3_TOPK) * T * 2 + o % (T * 2)];
+    }
+}
+
 int weights_threads(int Kg);
 int mins_workgroups(int Kg) {
     const int per = PREP_T * PREP_RPT;
@@ -821,11 +868,33 @@ __global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
     __shared__ float s_tab[LAD_N * 3];
     __shared__ float s_part[3 * LAD_N * 3];
     if (blockIdx.x > 0) {  // workgroups 1..n_cand: top-k stage A, concurrent with the search
-        topk_stage_a(a, blockIdx.x - 1);
+        if (a.fast) topk_merge_records(a);   // (shard_mix = 2: the global top-k from the shards' own lists)
+        else topk_stage_a(a, blockIdx.x - 1);
         return;
     }
     const int Kg = a.Kg, half = a.half_g - a.kbase, tid = threadIdx.x, WT = blockDim.x;
     const float INF = __builtin_inff();
+    if (a.fast) {
+        // the records carry every shard's minima m_r and its ladder sums relative to them:
+        // eta(beta_j) = sum_r exp(-(m_r - m) / beta_j) eta_r(beta_j), m = min_r m_r  (rank order)
+        const int N = a.n_ranks, om = regen_off_mins(a.Kls, a.T), ot = regen_off_table(a.Kls, a.T);
+        if (tid < 3) {
+            float m = INF;
+            for (int r = 0; r < N; ++r) m = fminf(m, a.records_all[(size_t)r * a.rec_len + om + tid]);
+            s_mn[tid] = m;
+        }
+        __syncthreads();
+        for (int o = tid; o < LAD_N * 3; o += WT) {
+            const int j = o / 3, sx = o - 3 * j;
+            const float nib = -1.0f / ladder_beta(j), m = s_mn[sx];
+            float t = 0.0f;
+            for (int r = 0; r < N; ++r) {
+                const float* rec = a.records_all + (size_t)r * a.rec_len;
+                t += m3_exp(nib * (rec[om + sx] - m)) * rec[ot + o];
+            }
+            s_tab[o] = t;
+        }
+    } else {
     if (tid < 3) {
         float m = INF;
         for (int b = 0; b < a.n_mins; ++b) m = fminf(m, a.part_min[b * 3 + tid]);
@@ -852,6 +921,7 @@ __global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
             for (int g = 1; g < nseg; ++g) t += s_part[g * NT + q];
             s_tab[q] = t;
         }
+    }
     }
     __syncthreads();
     if (tid < 3) {  // the reference's rule on the table (m3p2i.py:35-51), as in k_weights
@@ -894,7 +964,7 @@ __global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
         float e[3] = {0.0f, 0.0f, 0.0f};
         const float n0 = -1.0f / b0, n1 = -1.0f / b1, n2 = -1.0f / b2;
         for (int k = tid; k < Kg; k += WT) {
-            const float v = a.Jall[k];
+            const float v = jcost(a, k);
             if (!d0) e[0] += m3_exp(n0 * (v - m0));
             if (k < half) { if (!d1) e[1] += m3_exp(n1 * (v - m1)); }
             else { if (!d2) e[2] += m3_exp(n2 * (v - m2)); }
@@ -1167,14 +1237,6 @@ __device__ __forceinline__ void regen_action(const UpdateArgs& a, const RegenRow
         e[j] = (a.u_scale != 1.0f) ? uj / a.u_scale : uj;
     }
 }
-// shard of global sample k (k < 2^24: exact in binary32; one multiply + a fix-up instead of an integer division)
-__device__ __forceinline__ int shard_of(int k, int Kls, float inv_Kls) {
-    int r = (int)((float)k * inv_Kls);
-    r -= (r * Kls > k) ? 1 : 0;
-    r += ((r + 1) * Kls <= k) ? 1 : 0;
-    return r;
-}
-
 template <int NU, bool REGEN>
 __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     __shared__ float red[3 * 16];
@@ -1350,12 +1412,225 @@ void launch_wsum(const UpdateArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((k_wsum<9, false>), grid, dim3(ST), lds, s, a);
 }
 
+// ---------------------------------------------------------------------------------------
+// shard_mix = 2, after the all-gather and k_search (which mixed the shards' ladder tables into beta, eta and the
+// minima): weights, weighted sums over ALL K samples with re-generated actions, the best rows, m3_info and
+// the finalize in ONE launch.  Grid = T x n_chunk workgroups as k_wsum.  Every workgroup forms the weights
+// of its samples itself from the costs in the gathered records (w = exp(-(J - m) / beta) / eta: the
+// expression of k_apply_weights); the chunk workgroups of time step 0 also store them and keep the half sums
+// / argmax keys of their chunk; the workgroup that finishes last combines those in chunk order, re-generates
+// the three best rows and runs the finalize.
+template <int NU>
+__global__ __launch_bounds__(ST) void k_regen_fast(const UpdateArgs a) {
+    __shared__ float red[3 * 16];
+    __shared__ VI redvi[16];
+    __shared__ float sred[3 * 9 * (ST / 64)];
+    const int tid = threadIdx.x, C = a.n_chunk, Kg = a.Kg, T = a.T, half = a.half_g;
+    const int t = blockIdx.x / C, c = blockIdx.x % C;
+    const float INF = __builtin_inff();
+    const SearchOut so = *a.srch;
+    const float i0 = uniform_f(1.0f / so.eta[0]), n0 = uniform_f(-1.0f / so.beta[0]);
+    const float i1 = uniform_f(1.0f / so.eta[1]), n1 = uniform_f(-1.0f / so.beta[1]);
+    const float i2 = uniform_f(1.0f / so.eta[2]), n2 = uniform_f(-1.0f / so.beta[2]);
+    RegenRows<NU> rows;
+    regen_rows<NU>(a, t, rows);
+    const float inv_Kls = 1.0f / (float)a.Kls;
+    float acc[3][NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
+    float hs[2] = {0.0f, 0.0f};
+    VI b0 = {INF, 0x7fffffff}, b1 = {INF, 0x7fffffff}, b2 = {INF, 0x7fffffff};
+    const int clen = wsum_chunk_len(Kg);
+    const int iend = min(Kg, (c + 1) * clen);
+    for (int ib = c * clen; ib < iend; ib += WS_BATCH * ST)
+#pragma unroll
+    for (int it = 0; it < WS_BATCH; ++it) {
+        const int i = ib + it * ST + tid;
+        const bool ok = i < iend;
+        const int k = ok ? i : (iend - 1);
+        const int r = shard_of(k, a.Kls, inv_Kls), kk = k - r * a.Kls;
+        const float v = a.records_all[(size_t)r * a.rec_len + kk];
+        const float* drow = a.noise_all + (((size_t)r * T + t) * a.Kls + kk) * NU;
+        float dv[NU], av[NU];
+        if constexpr (NU == 2) {
+            const float2 d2 = *reinterpret_cast<const float2*>(drow);
+            dv[0] = d2.x; dv[1] = d2.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) dv[j] = drow[j];
+        }
+        regen_action<NU>(a, rows, k, dv, av);
+        const bool first = k < half;
+        float w = i0 * m3_exp(n0 * (v - so.mn[0]));
+        float wh = (first ? i1 : i2) * m3_exp((first ? n1 : n2) * (v - (first ? so.mn[1] : so.mn[2])));
+        if (!ok) { w = 0.0f; wh = 0.0f; }
+        const float wa = first ? wh : 0.0f, wb = first ? 0.0f : wh;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            acc[0][j] += w * av[j];
+            acc[1][j] += wa * av[j];
+            acc[2][j] += wb * av[j];
+        }
+        if (t == 0 && ok) {   // (workgroup-uniform on t) the weights themselves, half sums, argmax keys
+            a.w[k] = w;
+            if (first) a.w1[k] = wh; else a.w2[k - half] = wh;
+            hs[0] += first ? w : 0.0f;
+            hs[1] += first ? 0.0f : w;
+            if (vi_less(-w, k, b0.v, b0.i)) { b0.v = -w; b0.i = k; }
+            if (first) { if (vi_less(-wh, k, b1.v, b1.i)) { b1.v = -wh; b1.i = k; } }
+            else { if (vi_less(-wh, k, b2.v, b2.i)) { b2.v = -wh; b2.i = k; } }
+        }
+    }
+    if (t == 0) {
+        block_sum<2>(hs, red);
+        b0 = block_argmin(b0, redvi);
+        b1 = block_argmin(b1, redvi);
+        b2 = block_argmin(b2, redvi);
+        if (tid < 8) {
+            const float val = tid == 0 ? hs[0] : tid == 1 ? hs[1] : tid == 2 ? b0.v : tid == 3 ? __int_as_float(b0.i)
+                            : tid == 4 ? b1.v : tid == 5 ? __int_as_float(b1.i) : tid == 6 ? b2.v : __int_as_float(b2.i);
+            __hip_atomic_store(a.apart + (size_t)c * 8 + tid, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    float* out = (C == 1) ? a.reduce : a.wpart + (size_t)c * 3 * T * NU;
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const float ws = wave_sum(acc[s3][j]);
+                if (lane == 0) sred[(s3 * NU + j) * (ST / 64) + wv] = ws;
+            }
+        __syncthreads();
+        if (tid < 3 * NU) {
+            float rv = 0.0f;
+#pragma unroll
+            for (int w = 0; w < ST / 64; ++w) rv += sred[tid * (ST / 64) + w];
+            const int s3 = tid / NU, j = tid % NU;
+            __hip_atomic_store(&out[s3 * T * NU + t * NU + j], rv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    bool t_last = true;
+    if (C > 1) {   // chunk combine of this time step (as in k_wsum)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(&a.wcount[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = ticket == C - 1;
+            if (is_last) a.wcount[t] = 0;
+            red[47] = __int_as_float(is_last);
+        }
+        __syncthreads();
+        t_last = __float_as_int(red[47]) != 0;
+        if (t_last && tid < 3 * NU) {
+            const int which = tid / NU, j = tid % NU;
+            float sum = 0.0f;
+            for (int cc = 0; cc < C; ++cc)
+                sum += __hip_atomic_load(&a.wpart[((size_t)cc * 3 + which) * T * NU + t * NU + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.reduce[reduce_off_psum(which, T, NU) + t * NU + j], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!t_last) return;
+    // the workgroup that completed its time step takes the launch-wide ticket; the last one finishes the command
+    extern __shared__ float sm_fin[];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(&a.wcount[T], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int is_last = ticket == T - 1;
+        if (is_last) a.wcount[T] = 0;
+        red[46] = __int_as_float(is_last);
+    }
+    __syncthreads();
+    if (!__float_as_int(red[46])) return;
+    // (a) half sums and argmax keys of time step 0's chunks, in chunk order (every chunk workgroup of t = 0
+    // stored its eight values before it arrived at its time step's ticket)
+    __shared__ int s_best[3];
+    if (tid == 0) {
+        float h0 = 0.0f, h1 = 0.0f;
+        VI c0 = {INF, 0x7fffffff}, c1 = c0, c2 = c0;
+        for (int cc = 0; cc < C; ++cc) {
+            float x[8];
+            for (int q = 0; q < 8; ++q) x[q] = __hip_atomic_load(a.apart + (size_t)cc * 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h0 += x[0]; h1 += x[1];
+            if (vi_less(x[2], __float_as_int(x[3]), c0.v, c0.i)) { c0.v = x[2]; c0.i = __float_as_int(x[3]); }
+            if (vi_less(x[4], __float_as_int(x[5]), c1.v, c1.i)) { c1.v = x[4]; c1.i = __float_as_int(x[5]); }
+            if (vi_less(x[6], __float_as_int(x[7]), c2.v, c2.i)) { c2.v = x[6]; c2.i = __float_as_int(x[7]); }
+        }
+        m3_info* f = a.info;
+        f->best_idx = c0.i; f->best_idx_1 = c1.i; f->best_idx_2 = c2.i;
+        f->wsum_push = h0; f->wsum_pull = h1;
+        f->pull_preference = h1 > h0;
+        s_best[0] = c0.i; s_best[1] = c1.i; s_best[2] = c2.i;
+    }
+    __syncthreads();
+    // (b) the best rows: actions of the three argmax samples, re-generated for every time step
+    for (int o = tid; o < 3 * T; o += ST) {
+        const int which = o / T, tt = o - which * T, gi = s_best[which];
+        RegenRows<NU> rr;
+        regen_rows<NU>(a, tt, rr);
+        float dv[NU], ev[NU];
+        const int r = gi / a.Kls, kk = gi - r * a.Kls;
+        const float* drow = a.noise_all + (((size_t)r * T + tt) * a.Kls + kk) * NU;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) dv[j] = drow[j];
+        regen_action<NU>(a, rr, gi, dv, ev);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a.reduce[reduce_off_best(which, T, NU) + tt * NU + j] = ev[j];
+    }
+    __threadfence();
+    __syncthreads();
+    finalize_body<true>(a, sm_fin);
+}
+void launch_regen_fast(const UpdateArgs& a, hipStream_t s) {
+    // workgroup 0: the searches on the mixed ladder tables; workgroup 1: the global top-k from the shards' lists
+    hipLaunchKernelGGL(k_search, dim3(2), dim3(WT_MAX), 0, s, a);
+    const dim3 grid(a.T * a.n_chunk);
+    const size_t lds = (size_t)a.T * a.nu * sizeof(float);
+    if (a.nu == 2) hipLaunchKernelGGL(k_regen_fast<2>, grid, dim3(ST), lds, s, a);
+    else hipLaunchKernelGGL(k_regen_fast<9>, grid, dim3(ST), lds, s, a);
+}
+
 // the shard's own top-k before the collective ("regen" sharding): stage A per 4096 costs, the last
 // workgroup to finish merges (as the top-k workgroups of k_update_small)
+constexpr int LREC_WG = 32;   // extra workgroups of the pre-gather launch that evaluate the shard's ladder table
 template <int RPT>
 __global__ __launch_bounds__(PREP_T) void k_local_topk(const UpdateArgs a) {
     __shared__ int s_lastb;
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= a.n_cand) {
+        // shard_mix = 2: this shard's minima (all / mode 1 / mode 2) and its eta(beta) sums relative to them for
+        // the ladder points w, w + LREC_WG, ...; the costs are read from memory (L2) per point
+        __shared__ float red[3 * 16];
+        const int w = blockIdx.x - a.n_cand, Kn = a.Kg, half = a.half_g - a.kbase;   // k < half <=> mode 1
+        const float INF = __builtin_inff();
+        float mn[3] = {INF, INF, INF};
+        for (int k = tid; k < Kn; k += PREP_T) {
+            const float v = a.Jall[k];
+            mn[0] = fminf(mn[0], v);
+            if (k < half) mn[1] = fminf(mn[1], v); else mn[2] = fminf(mn[2], v);
+        }
+        block_min<3>(mn, red);
+        if (w == 0 && tid < 4) a.rec_mins[tid] = tid < 3 ? mn[tid] : 0.0f;
+        for (int p = w; p < LAD_N; p += LREC_WG) {
+            const float nib = uniform_f(-1.0f / ladder_beta(p));
+            float e[3] = {0.0f, 0.0f, 0.0f};
+            for (int k = tid; k < Kn; k += PREP_T) {
+                const float v = a.Jall[k];
+                e[0] += m3_exp(nib * (v - mn[0]));
+                const bool first = k < half;
+                const float xh = m3_exp(nib * (v - (first ? mn[1] : mn[2])));
+                e[1] += first ? xh : 0.0f;
+                e[2] += first ? 0.0f : xh;
+            }
+            block_sum<3>(e, red);
+            if (tid < 3) a.rec_table[p * 3 + tid] = e[tid];
+            __syncthreads();
+        }
+        return;
+    }
     topk_stage_a<RPT>(a, blockIdx.x);
     if (a.n_cand > 1) {
         __threadfence();
@@ -1374,8 +1649,9 @@ __global__ __launch_bounds__(PREP_T) void k_local_topk(const UpdateArgs a) {
 }
 void launch_local_topk(const UpdateArgs& a, hipStream_t s) {
     // up to 8192 costs: ONE workgroup with 32 rows per thread (no second stage, no ticket)
-    if (a.n_cand == 1 && a.Kg > PREP_T * 16) hipLaunchKernelGGL(k_local_topk<32>, dim3(1), dim3(PREP_T), 0, s, a);
-    else hipLaunchKernelGGL(k_local_topk<16>, dim3(a.n_cand), dim3(PREP_T), 0, s, a);
+    const int extra = a.fast ? LREC_WG : 0;   // + the ladder-table workgroups
+    if (a.n_cand == 1 && a.Kg > PREP_T * 16) hipLaunchKernelGGL(k_local_topk<32>, dim3(1 + extra), dim3(PREP_T), 0, s, a);
+    else hipLaunchKernelGGL(k_local_topk<16>, dim3(a.n_cand + extra), dim3(PREP_T), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1393,11 +1669,6 @@ void launch_local_topk(const UpdateArgs& a, hipStream_t s) {
 // Workgroup 0 also stores the weights and m3_info, workgroup T is the top-k stage, the last
 // workgroup to finish does the mean update / filter (same hand-off as in k_wsum) and writes the
 // adapted beta -- after every workgroup has read the old one.
-// an optimisation barrier for a value: the compiler must take it as given
-__device__ __forceinline__ float uniform_f(float v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
 template <int NU, bool MULTI, int JR>
 __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
     constexpr int WT = 256, NS = MULTI ? 3 : 1;   // JR rows of 256 costs per thread: K <= JR * 256

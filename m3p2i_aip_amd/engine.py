@@ -58,7 +58,7 @@ def make_config(K, T, nu=2, env_type="point_env", multi_modal=False, mode_simple
     c.substeps, c.solver_iters = int(substeps), int(solver_iters)
     c.cube_on_shelf = int(bool(cube_on_shelf))
     c.sim_only = int(bool(sim_only))
-    c.shard_mix = int(bool(shard_mix))
+    c.shard_mix = int(shard_mix)   # 0: gather + reduce; 1 (True): one collective; 2: ... with ladder tables (multi-modal)
     c.seed = int(seed)
     return c
 

@@ -76,7 +76,7 @@ class MPPIConfig(object):
     fused: Optional[bool] = None      # None: probe the callbacks on the first command
     rank: int = 0                     # sample sharding: this process owns
     world_size: int = 1               #   num_samples/world_size consecutive samples
-    shard_mix: Optional[bool] = None  # None: one-collective protocol whenever it applies
+    shard_mix: Optional[int] = None   # None: one-collective protocol whenever it applies (multi-modal: 2); 1 / 2 / False
     relabel_samples: bool = True      # generated noise rows into wavefront-coherent order (same sample set)
     device_knots: bool = False        # Halton + erfinv knots on the device too (~1e-6 from the host sampler's)
 
@@ -185,6 +185,10 @@ class MPPI():
         if sm and not can_mix:
             raise ValueError("shard_mix=True with multi_modal needs sampling_method='halton' (a noise table)")
         self.shard_mix = bool(world > 1 and can_mix and (True if sm is None else sm))
+        # multi-modal: shard_mix=2 (default) adds per-shard ladder tables to the records -- half the per-rank work
+        # after the collective, equal to the unsharded run up to f32 rounding; shard_mix=True/1 keeps the
+        # bit-identical variant (all K costs re-evaluated on every rank)
+        self._shard_mix_level = 0 if not self.shard_mix else (1 if single else (2 if sm in (None, 2) else 1))
         self.relabel_samples = bool(_get(m, "relabel_samples", True))
         self._engine = ENGINE_CLS(make_config(
             K=self.K, K_local=self.K_local, k_offset=self.k_offset, T=self.T, nu=self.nu,
@@ -199,7 +203,7 @@ class MPPI():
             pre_height_diff=float(_get(cfg, "pre_height_diff", 0) or 0),
             dt=float(_get(isaac, "dt", 0.05 if self.env_type == "point_env" else 0.01)),
             substeps=int(_get(isaac, "substeps", 2)), seed=self.seed_val, device=dev.index or 0,
-            cube_on_shelf=bool(_get(cfg, "cube_on_shelf", False)), shard_mix=self.shard_mix))
+            cube_on_shelf=bool(_get(cfg, "cube_on_shelf", False)), shard_mix=self._shard_mix_level))
         self._fused = _get(m, "fused", None)
         self._sim = None
         self._objective = None

@@ -36,7 +36,7 @@ class OracleEngine:
         self.mix = bool(c.shard_mix) and Kl != Kg and not self.regen
         self.HDR, self.RL = 48, 48 + 6 * T * nu + L.TOPK * T * 2   # record layout: m3_internal.hpp
         if self.regen:   # {costs of the shard | top-k costs | top-k global indices | top-k trajectories}, padded to 4
-            self.RL = (Kl + 2 * L.TOPK + L.TOPK * T * 2 + 3) // 4 * 4
+            self.RL = (Kl + 2 * L.TOPK + L.TOPK * T * 2 + 4 + 96 * 3 + 3) // 4 * 4   # (+ minima, ladder table: shard_mix 2)
             self.np[L.BUF_RECORD] = np.zeros(self.RL, f)
             self.np[L.BUF_RECORDS_ALL] = np.zeros((Kg // Kl, self.RL), f)
             self.np[L.BUF_TRAJ_COST] = self.np[L.BUF_RECORD][:Kl]     # alias, as in the library

@@ -14,8 +14,9 @@ and HIP-event time of each collective on the stream.
   --emulate-rank-of N   additionally: rank 0's share of an N-rank run of the config (K_global = N x K),
                         on this one GPU -- its real kernel sequence (rollout of K samples, records, the update
                         on all N x K costs) with the collectives as world_size-1 RCCL calls into rank 0's slot;
-                        the other ranks' records / costs are filled once with shifted copies.  Both protocols:
-                        one collective (cfg.shard_mix) and all-gather + all-reduce.  What is missing vs a real
+                        the other ranks' records / costs are filled once with shifted copies.  All three protocols:
+                        one collective (shard_mix 2, the default, and 1, the bit-identical variant) and all-gather
+                        + all-reduce.  What is missing vs a real
                         node: the xGMI wire time of the collective, nothing else.
 """
 import argparse
@@ -49,7 +50,7 @@ def emulate_rank(name, N, steps):
     from m3p2i_aip_amd import _lib as L
     env, task, goal, mm, K, T = bench.CONFIGS[name]
     res = {}
-    for label, mix in (("one_collective", True), ("gather_reduce", False)):
+    for label, mix in (("one_collective", None), ("one_collective_exact", 1), ("gather_reduce", False)):
         from m3p2i_aip_amd import isaacgym_wrapper as wrapper
         from m3p2i_aip_amd.cost_functions import Objective
         from m3p2i_aip_amd.planner import M3P2I, MPPIConfig
@@ -84,6 +85,8 @@ def emulate_rank(name, N, steps):
                 R[r, :K] += 0.37 * r
                 R[r, K:K + 20] += 0.37 * r
                 R[r, K + 20:K + 40].view(torch.int32).add_(r * K)
+                om = K + 40 + 40 * T                      # the shard's minima (shard_mix = 2 records): shifted alike
+                R[r, om:om + 3] += 0.37 * r
         else:
             J = e.buffer(L.BUF_TRAJ_COST_ALL)
             for r in range(1, N):
