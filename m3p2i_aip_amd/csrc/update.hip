@@ -539,6 +539,7 @@ __device__ __forceinline__ void topk_merge_records(const UpdateArgs& a) {
         const float* rec = a.records_all + (size_t)(c / M3_TOPK) * a.rec_len;
         s_key[c] = vi_key(rec[regen_off_topj(a.Kls) + c % M3_TOPK], __float_as_int(rec[regen_off_topi(a.Kls) + c % M3_TOPK]));
     }
+    if (tid < M3_TOPK) s_src[tid] = 0;   // (records with duplicated keys -- never from real shards -- must not leave a slot unset)
     __syncthreads();
     for (int c = tid; c < nc; c += nt) {
         const tkey my = s_key[c];
@@ -1572,13 +1573,15 @@ __global__ __launch_bounds__(ST) void k_regen_fast(const UpdateArgs a) {
         RegenRows<NU> rr;
         regen_rows<NU>(a, tt, rr);
         float dv[NU], ev[NU];
-        const int r = gi / a.Kls, kk = gi - r * a.Kls;
+        const bool valid = gi >= 0 && gi < Kg;     // (no argmax at all when every weight is NaN: zero rows then)
+        const int gc = valid ? gi : 0;
+        const int r = gc / a.Kls, kk = gc - r * a.Kls;
         const float* drow = a.noise_all + (((size_t)r * T + tt) * a.Kls + kk) * NU;
 #pragma unroll
         for (int j = 0; j < NU; ++j) dv[j] = drow[j];
-        regen_action<NU>(a, rr, gi, dv, ev);
+        regen_action<NU>(a, rr, gc, dv, ev);
 #pragma unroll
-        for (int j = 0; j < NU; ++j) a.reduce[reduce_off_best(which, T, NU) + tt * NU + j] = ev[j];
+        for (int j = 0; j < NU; ++j) a.reduce[reduce_off_best(which, T, NU) + tt * NU + j] = valid ? ev[j] : 0.0f;
     }
     __threadfence();
     __syncthreads();
@@ -1602,31 +1605,81 @@ __global__ __launch_bounds__(PREP_T) void k_local_topk(const UpdateArgs a) {
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= a.n_cand) {
         // shard_mix = 2: this shard's minima (all / mode 1 / mode 2) and its eta(beta) sums relative to them for
-        // the ladder points w, w + LREC_WG, ...; the costs are read from memory (L2) per point
+        // the ladder points w, w + LREC_WG, ...
         __shared__ float red[3 * 16];
         const int w = blockIdx.x - a.n_cand, Kn = a.Kg, half = a.half_g - a.kbase;   // k < half <=> mode 1
         const float INF = __builtin_inff();
+        // up to 8192 costs live in registers (32 rows of 256, all loads in flight at once); beyond that
+        // they are re-read from memory (L2) per ladder point, eight loads in flight
+        constexpr int LR = 32;
+        const bool in_regs = Kn <= LR * PREP_T;
+        float rv[LR];
+        if (in_regs) {
+#pragma unroll
+            for (int e = 0; e < LR; ++e) {
+                const int k = e * PREP_T + tid;
+                const float jv = a.Jall[min(k, Kn - 1)];
+                rv[e] = (k < Kn) ? jv : INF;
+            }
+        }
         float mn[3] = {INF, INF, INF};
-        for (int k = tid; k < Kn; k += PREP_T) {
-            const float v = a.Jall[k];
-            mn[0] = fminf(mn[0], v);
-            if (k < half) mn[1] = fminf(mn[1], v); else mn[2] = fminf(mn[2], v);
+        if (in_regs) {
+#pragma unroll
+            for (int e = 0; e < LR; ++e) {
+                const bool first = e * PREP_T + tid < half;
+                mn[0] = fminf(mn[0], rv[e]);
+                mn[1] = fminf(mn[1], first ? rv[e] : INF);
+                mn[2] = fminf(mn[2], first ? INF : rv[e]);
+            }
+        } else {
+            for (int k0 = 0; k0 < Kn; k0 += 8 * PREP_T) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = a.Jall[min(k0 + u * PREP_T + tid, Kn - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * PREP_T + tid;
+                    const float x = (k < Kn) ? v[u] : INF;
+                    mn[0] = fminf(mn[0], x);
+                    if (k < half) mn[1] = fminf(mn[1], x); else mn[2] = fminf(mn[2], x);
+                }
+            }
         }
         block_min<3>(mn, red);
         if (w == 0 && tid < 4) a.rec_mins[tid] = tid < 3 ? mn[tid] : 0.0f;
         for (int p = w; p < LAD_N; p += LREC_WG) {
             const float nib = uniform_f(-1.0f / ladder_beta(p));
-            float e[3] = {0.0f, 0.0f, 0.0f};
-            for (int k = tid; k < Kn; k += PREP_T) {
-                const float v = a.Jall[k];
-                e[0] += m3_exp(nib * (v - mn[0]));
-                const bool first = k < half;
-                const float xh = m3_exp(nib * (v - (first ? mn[1] : mn[2])));
-                e[1] += first ? xh : 0.0f;
-                e[2] += first ? 0.0f : xh;
+            float e3[3] = {0.0f, 0.0f, 0.0f};
+            if (in_regs) {
+#pragma unroll
+                for (int e = 0; e < LR; ++e) {   // rows past the end hold +inf: exp(-inf) = 0 ...
+                    const int k = e * PREP_T + tid;
+                    const bool ok = k < Kn, first = k < half;
+                    e3[0] += m3_exp(nib * (rv[e] - mn[0]));
+                    // ... but not against the +inf minimum of a mode this shard has no sample of (inf - inf)
+                    const float xh = m3_exp(nib * (rv[e] - (first ? mn[1] : mn[2])));
+                    e3[1] += (ok && first) ? xh : 0.0f;
+                    e3[2] += (ok && !first) ? xh : 0.0f;
+                }
+            } else {
+                for (int k0 = 0; k0 < Kn; k0 += 8 * PREP_T) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = a.Jall[min(k0 + u * PREP_T + tid, Kn - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int k = k0 + u * PREP_T + tid;
+                        const bool ok = k < Kn, first = k < half;
+                        const float x0 = m3_exp(nib * (v[u] - mn[0]));
+                        const float xh = m3_exp(nib * (v[u] - (first ? mn[1] : mn[2])));
+                        e3[0] += ok ? x0 : 0.0f;
+                        e3[1] += (ok && first) ? xh : 0.0f;
+                        e3[2] += (ok && !first) ? xh : 0.0f;
+                    }
+                }
             }
-            block_sum<3>(e, red);
-            if (tid < 3) a.rec_table[p * 3 + tid] = e[tid];
+            block_sum<3>(e3, red);
+            if (tid < 3) a.rec_table[p * 3 + tid] = e3[tid];
             __syncthreads();
         }
         return;
@@ -2140,6 +2193,7 @@ __global__ __launch_bounds__(256) void k_mix(const UpdateArgs a) {
         const float* rec = R + (size_t)(c / M3_TOPK) * L;
         s_key[c] = vi_key(rec[REC_TOPJ + c % M3_TOPK], __float_as_int(rec[REC_TOPI + c % M3_TOPK]));
     }
+    if (tid < M3_TOPK) s_src[tid] = 0;   // (duplicated keys -- never from real shards -- must not leave a slot unset)
     __syncthreads();
     // weighted sums and the best rows (mode sets 1, 2 are unused in single-mode MPPI)
     const int n = T * nu, br = s_best_rank;

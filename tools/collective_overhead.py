@@ -87,6 +87,12 @@ def emulate_rank(name, N, steps):
                 R[r, K + 20:K + 40].view(torch.int32).add_(r * K)
                 om = K + 40 + 40 * T                      # the shard's minima (shard_mix = 2 records): shifted alike
                 R[r, om:om + 3] += 0.37 * r
+                if r >= N // 2:                           # a rank of the second half holds mode-2 samples only
+                    tab = R[r, om + 4:om + 4 + 96 * 3].view(96, 3)
+                    tab[:, 2] = tab[:, 1]
+                    tab[:, 1] = 0.0
+                    R[r, om + 2] = R[r, om + 1]
+                    R[r, om + 1] = float("inf")
         else:
             J = e.buffer(L.BUF_TRAJ_COST_ALL)
             for r in range(1, N):
