@@ -14,14 +14,17 @@ only the importance-weight update couples them.  Defaul
 
   multi-modal M3P2I (the on-the-fly beta search needs eta(beta) over ALL samples at every pass,
   m3p2i.py:24-64 -- a reduce of weight sums would only be exact for a fixed beta)
-    rollout -> update (the shard's own top-20 into its record)
-      -> all_gather  record = {J of the shard [K/N] | top-20 costs, indices, trajectories}
-    finalize (every rank now holds all K costs: the UNSHARDED update kernels on them -- same beta
-              search, same weights, bit for bit -- and the weighted action sums over all K samples with
-              the other ranks' actions RE-GENERATED from the replicated noise table and plan (a_k[t] is
-              a function of the global sample index, mppi.py:381-416) instead of communicated.)
-    Every rank holds the noise rows of all K samples (15 MB at K = 64000, init only).  Results are
-    bit-identical to the single-GPU run of the same K (tests/test_c5_sharded_gpu.py).
+    rollout -> update (the shard's own top-20, minima and ladder sums eta_r(beta_j) into its record)
+      -> all_gather  record = {J of the shard [K/N] | top-20 costs, indices, trajectories | minima, ladder table}
+    finalize (the searches walk the MIXTURE of the shards' ladder tables -- passes over the gathered costs
+              only if a search leaves its ladder --, then one kernel forms the weights of all K samples, the
+              weighted action sums with the other ranks' actions RE-GENERATED from the replicated noise
+              table and plan (a_k[t] is a function of the global sample index, mppi.py:381-416) instead of
+              communicated, the best rows and the plan.)
+    Every rank holds the noise rows of all K samples (15 MB at K = 64000, init only).  Equal to the
+    single-GPU run of the same K up to f32 rounding (same iteration counts, plan <= 3e-5), identical on every
+    rank; MPPIConfig.shard_mix = 1 selects the variant that re-evaluates all K costs with the unsharded kernels
+    and is bit-identical to the single-GPU run (tests/test_c5_sharded_gpu.py).
 
 Fallback protocol (shard_mix=False; also the multi-modal path with sampling_method='random', whose
 in-kernel noise has no table): two collectives,
