@@ -3,20 +3,24 @@
     python -m m3p2i_aip_amd.build [--force]
 
 -ffp-contract=off / no fast-math: the dynamics are specified as a fixed sequence of IEEE
-binary32 operations so that the CPU oracle can check them bit-for-bit.
+binary32 operations so that the CPU oracle can check them bit-for-bit.  Every source is its own
+translation unit (no relocatable device code): they are compiled in parallel and linked into one .so.
 """
 from __future__ import annotations
 
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libm3p2i_hip.so")
-SOURCES = ["rollout_point.hip", "rollout_panda.hip", "update.hip", "sampler.hip", "m3_api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+OBJ = os.path.join(HERE, "_obj")   # object files (git- and gpurun-ignored)
+SOURCES = ["rollout_point.hip", "rollout_point_task0.hip", "rollout_point_task1.hip", "rollout_point_task2.hip",
+           "rollout_point_task3.hip", "rollout_panda.hip", "update.hip", "sampler.hip", "m3_api.hip"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+          "-Wno-unused-function"]
 
 
 def _stale():
@@ -28,16 +32,29 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, extra_flags=(), out=OUT):
+    if not force and out == OUT and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    objdir = OBJ if out == OUT else os.path.join(OBJ, os.path.basename(out) + ".d")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc] + CFLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return OUT
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
+    return out
 
 
 if __name__ == "__main__":

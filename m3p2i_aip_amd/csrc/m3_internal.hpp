@@ -141,6 +141,10 @@ __host__ __device__ inline int regen_record_length(int Kls, int T) { return (reg
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s);
+void launch_rollout_point_nav(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s);
+void launch_rollout_point_push(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s);
+void launch_rollout_point_pull(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s);
+void launch_rollout_point_pushpull(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s);
 void launch_transpose_noise(const float* src_ktn, float* dst_tkn, int K, int T, int nu,
                             hipStream_t s);
 void launch_spline_noise(const float* knots, float* noise, int Kl, int nu, int n_knots, int T, int degree,

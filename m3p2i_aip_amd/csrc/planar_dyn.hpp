@@ -521,7 +521,7 @@ enum : unsigned {
 // the rollout -- 0 action assembly + prefetch, 1 broad-phase mask + dispatch, 2 forces + detection, 3 the
 // solver passes, 4 net force + integration, 5 task cost, 6 stores + accumulation
 #ifdef M3_ABL_PHASES
-__device__ unsigned long long g_phase[1024 * 8];
+static __device__ unsigned long long g_phase[1024 * 8];
 struct PhaseClock {
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
     __device__ __forceinline__ void start() { last = __builtin_readcyclecounter(); }
@@ -719,8 +719,8 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
 }
 
 #ifdef M3_ABL_COUNT
-__device__ unsigned int g_lvl[512];
-__device__ unsigned int g_cyc[64 * 16];
+static __device__ unsigned int g_lvl[512];
+static __device__ unsigned int g_cyc[64 * 16];
 #endif
 
 // one sim.step(): substeps x (forces, detect, solve, integrate)

@@ -1,181 +1,8 @@
-// rollout_point.hip -- fused MPPI rollout kernel for the point_env (gfx950).
-//
-// One launch = the whole hot loop of MPPI._compute_rollout_costs (mppi.py:296-315) for all K
-// samples: action assembly (mppi.py:381-416 / :335-347), T x { velocity-servo + contact
-// dynamics step (replaces reactive_tamp.py:63-70 -> Isaac Gym), task cost
-// (cost_functions.py:19-89,158-169), discounted accumulation (mppi_utils.py:106-113) }.
-// The reference issues ~180 (push) to ~540 (push_pull) aten launches + one PhysX step PER
-// TIME STEP for this; here the T-loop runs inside the kernel with the world in registers.
-//
-// Mapping: one lane per sample, 64-lane workgroups (one wavefront) so that K = 2000 spreads
-// over 32 CUs.  HBM layout is time-major ([T][K][c]) so lane i writes address base + i*c*4:
-// every store of the wave is one contiguous 256 B .. 1 KiB segment -- no LDS staging needed.
-// Algorithmic traffic per state-step (nu = 2): read delta 8 B, write state 16 B + action
-// 8 B + cost 4 B = 36 B (28 B with in-kernel noise); the update pass re-reads actions (8 B).
-#include "m3_internal.hpp"
+// rollout_point.hip -- point_env rollout: launch dispatch, the all-modes instance of the kernel
+// (rollout_point_kernel.hpp), the noise transpose and the step-mode (IsaacGymWrapper-like) kernels.
+#include "rollout_point_kernel.hpp"
 
 namespace m3 {
-
-// ---- counter-based noise stream (spec: DESIGN.md "Noise stream"; mirrors the oracle) ----
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long& x) {
-    unsigned long long z = (x += 0x9E3779B97F4A7C15ULL);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ unsigned rotl32(unsigned x, int k) { return (x << k) | (x >> (32 - k)); }
-__device__ __forceinline__ unsigned xoshiro128pp(unsigned (&s)[4]) {
-    const unsigned result = rotl32(s[0] + s[3], 7) + s[0];
-    const unsigned t = s[1] << 9;
-    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = rotl32(s[3], 11);
-    return result;
-}
-// standard-normal pair for (seed, call, k, t, pair)
-__device__ __forceinline__ void gauss_pair(unsigned long long seed, unsigned call, unsigned k,
-                                           unsigned t, unsigned pair, float& z0, float& z1) {
-    unsigned long long x = seed ^ (0xD1B54A32D192ED03ULL * (unsigned long long)(call + 1u));
-    x ^= ((unsigned long long)k << 32) | ((unsigned long long)t << 8) | (unsigned long long)pair;
-    const unsigned long long a = splitmix64(x), b = splitmix64(x);
-    unsigned s[4] = {(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
-    const unsigned r0 = xoshiro128pp(s), r1 = xoshiro128pp(s);
-    const float u0 = ((float)(r0 >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float u1 = (float)(r1 >> 8) * (1.0f / 16777216.0f);
-    const float rad = sqrtf(-2.0f * logf(u0));
-    const float ang = 6.28318530717958647692f * u1;
-    z0 = rad * cosf(ang);
-    z1 = rad * sinf(ang);
-}
-
-__device__ __forceinline__ void load_world(const float* p, PointWorld& w) {
-    w.rx = p[0]; w.ry = p[1]; w.rvx = p[2]; w.rvy = p[3];
-    w.B.x = p[4]; w.B.y = p[5]; w.B.c = p[6]; w.B.s = p[7]; w.B.vx = p[8]; w.B.vy = p[9]; w.B.w = p[10];
-    w.D.x = p[11]; w.D.y = p[12]; w.D.c = p[13]; w.D.s = p[14]; w.D.vx = p[15]; w.D.vy = p[16]; w.D.w = p[17];
-    w.fcDx = w.fcDy = w.fcBx = w.fcBy = w.fcRx = w.fcRy = 0.0f;
-}
-
-// env 0 of the wrapper's tensors -> world (yaw from the (0,0,qz,qw) quaternion);
-// dof_state row = [x, vx, y, vy] (isaacgym_wrapper.py:120-126), root row = pos3 quat4 vel3 ang3
-__device__ __forceinline__ void load_world_from_sim(const float* dof, const float* root, int box,
-                                                    int dyn, PointWorld& w) {
-    w.rx = dof[0]; w.ry = dof[2]; w.rvx = dof[1]; w.rvy = dof[3];
-    const float* r = root + (size_t)box * 13;
-    float qz = r[5], qw = r[6];
-    w.B.x = r[0]; w.B.y = r[1]; w.B.c = 1.0f - 2.0f * (qz * qz); w.B.s = 2.0f * (qz * qw);
-    w.B.vx = r[7]; w.B.vy = r[8]; w.B.w = r[12];
-    r = root + (size_t)dyn * 13;
-    qz = r[5]; qw = r[6];
-    w.D.x = r[0]; w.D.y = r[1]; w.D.c = 1.0f - 2.0f * (qz * qz); w.D.s = 2.0f * (qz * qw);
-    w.D.vx = r[7]; w.D.vy = r[8]; w.D.w = r[12];
-    w.fcDx = w.fcDy = w.fcBx = w.fcBy = w.fcRx = w.fcRy = 0.0f;
-}
-
-// Launch geometry: 64-thread workgroups (one wavefront) of which `lanes` are active
-// (default 64 = one lane per sample; lanes = 1 is the north_star's literal "one wavefront
-// per sample" and was measured 2-9x slower, see rollout_lanes_for below).
-__global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const PointScene sc) {
-    const int slot = blockIdx.x * a.lanes + threadIdx.x;
-    if ((int)threadIdx.x >= a.lanes || slot >= a.Kl) return;
-    const int i = a.order ? a.order[slot] : slot;
-    const int Kl = a.Kl, T = a.T;
-    const int k = a.k0 + i;  // global sample index
-    PointWorld w;
-    if (a.sim_dof) load_world_from_sim(a.sim_dof, a.sim_root, a.sim_box, a.sim_dyn, w);
-    else load_world(a.world0, w);
-    w.fRx = a.pend[0 * Kl + i]; w.fRy = a.pend[1 * Kl + i];
-    w.fBx = a.pend[2 * Kl + i]; w.fBy = a.pend[3 * Kl + i];
-
-    const bool is_last = (k == a.Kg - 1);
-    const bool first_half = k < a.cp.half_K;
-    const float* mptr = a.mean;
-    if (a.multi_modal && !a.mode_simple) mptr = first_half ? a.mean1 : a.mean2;
-
-    // Inputs of step t+1 are fetched before step t is simulated: with one wavefront per SIMD
-    // nothing else hides the ~1-2 us HBM/L2 latency of a load whose result is needed at once
-    // (measured: SQ_WAIT_ANY was a third of the kernel's wave-cycles).
-    struct StepIn { float d0, d1, m0, m1, b0, b1; };
-    const bool halton = !a.mode_simple;
-    const bool use_best = halton && a.multi_modal && (k == 0 || k == a.cp.half_K);
-    const float* bptr = (k == 0) ? a.best1 : a.best2;
-    auto fetch = [&](int t) {
-        StepIn in;
-        in.d0 = in.d1 = in.b0 = in.b1 = 0.0f;
-        if (!a.sampling_random) {
-            const float2 dd = *reinterpret_cast<const float2*>(a.delta + ((size_t)t * Kl + slot) * 2);
-            in.d0 = dd.x; in.d1 = dd.y;
-        }
-        // torch.roll(U, -1): mppi.py:221 / _shift_action: mppi.py:266-273
-        const int ts = a.mode_simple ? ((t + 1 == T) ? 0 : t + 1) : ((t + 1 < T) ? t + 1 : T - 1);
-        in.m0 = mptr[ts * 2 + 0]; in.m1 = mptr[ts * 2 + 1];
-        if (use_best) { in.b0 = bptr[ts * 2 + 0]; in.b1 = bptr[ts * 2 + 1]; }
-        return in;
-    };
-
-    float J = 0.0f, S = 0.0f, g = 1.0f, pc = 0.0f;
-    StepIn nxt = fetch(0);
-#ifdef M3_ABL_PHASES
-    PhaseClock clk, *pc_ = &clk;
-    clk.start();
-#else
-    PhaseClock* pc_ = nullptr;
-#endif
-    for (int t = 0; t < T; ++t) {
-        const StepIn in = nxt;
-        if (t + 1 < T) nxt = fetch(t + 1);
-        // ---- A4 / A13: perturbed action for this (k, t) ----
-        float d0 = in.d0, d1 = in.d1;
-        if (a.sampling_random) {
-            gauss_pair(a.seed, a.call, (unsigned)k, (unsigned)t, 0u, d0, d1);
-            d0 *= a.scale_tril[0]; d1 *= a.scale_tril[1];  // N(0, Sigma): mppi.py:481 / :340
-        }
-        float a0, a1;
-        const float m0 = in.m0, m1 = in.m1;
-        if (a.mode_simple) {
-            a0 = fmaxf(fminf(m0 + d0, a.u_max[0]), a.u_min[0]);  // mppi.py:343-345
-            a1 = fmaxf(fminf(m1 + d1, a.u_max[1]), a.u_min[1]);
-        } else {
-            if (is_last) { d0 = 0.0f; d1 = 0.0f; }      // mppi.py:392
-            a0 = fmaxf(fminf(m0 + d0 * a.scale_tril[0], a.u_max[0]), a.u_min[0]);  // :394-405
-            a1 = fmaxf(fminf(m1 + d1 * a.scale_tril[1], a.u_max[1]), a.u_min[1]);
-            if (use_best) { a0 = in.b0; a1 = in.b1; }  // mppi.py:407-409
-        }
-        float u0 = a.u_scale * a0, u1 = a.u_scale * a1;                 // mppi.py:297
-        if (a.sample_null_action && is_last) { u0 = 0.0f; u1 = 0.0f; }  // mppi.py:300-302
-
-        M3_PH(0);
-        // ---- A6: one sim.step() ----
-        point_step<false>(sc, w, u0, u1, /*need_dyn_force=*/a.cp.task == 0, pc_);
-
-        // ---- A7/A8: running cost on the post-step state ----
-        const float c = point_cost(a.cp, w, k);
-        M3_PH(5);
-
-        // ---- outputs, time-major ----
-        *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
-            make_float4(w.rx, w.rvx, w.ry, w.rvy);                      // reactive_tamp.py:66-69
-        // mppi.py:421 (x / 1 == x exactly: the usual u_scale = 1 skips two IEEE divisions per step)
-        float e0 = u0, e1 = u1;
-        if (a.u_scale != 1.0f) { e0 = u0 / a.u_scale; e1 = u1 / a.u_scale; }   // wave-uniform branch
-        *reinterpret_cast<float2*>(a.actions + ((size_t)t * Kl + i) * 2) = make_float2(e0, e1);
-        a.cost_h[(size_t)t * Kl + i] = c;                               // mppi.py:310
-        J = J + g * c;                                                  // mppi_utils.py:106-113
-        S = S + c;                                                      // mppi.py:309
-        g = g * a.gamma;
-        if (a.mode_simple) {  // perturbation cost, mppi.py:355-362 (diagonal Sigma)
-            pc = pc + m0 * (a.lambda_ * (e0 - m0) * a.sigma_inv[0]);
-            pc = pc + m1 * (a.lambda_ * (e1 - m1) * a.sigma_inv[1]);
-        }
-        M3_PH(6);
-    }
-#ifdef M3_ABL_PHASES
-    if (threadIdx.x == 0 && blockIdx.x < 1024)
-        for (int q = 0; q < 8; ++q) atomicAdd(&g_phase[blockIdx.x * 8 + q], clk.acc[q]);
-#endif
-    a.J[i] = a.mode_simple ? (S + pc) : J;
-    a.pend[0 * Kl + i] = w.fRx; a.pend[1 * Kl + i] = w.fRy;
-    a.pend[2 * Kl + i] = w.fBx; a.pend[3 * Kl + i] = w.fBy;
-}
 
 // lanes per wavefront.  MEASURED on MI355X (tools/lanes_sweep.py, DESIGN.md "Lanes per
 // wavefront"): full 64-lane waves are never slower -- K=2000: 0.38 ms at 64 lanes vs 0.83 ms
@@ -190,7 +17,21 @@ int rollout_lanes_for(int Kl) {
 
 void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s) {
     const int blocks = (a.Kl + a.lanes - 1) / a.lanes;
-    hipLaunchKernelGGL(k_rollout_point, dim3(blocks), dim3(64), 0, s, a, sc);
+#if defined(M3_ABL_GENERAL_ONLY) || defined(M3_ABL_COUNT) || defined(M3_ABL_PHASES)   // (experiments: one kernel for all modes;
+    // the instrumented builds keep their counters in this translation unit)
+    const bool general = true;
+#else
+    // push_pull without multi_modal is refused upstream (m3_rollout); a task outside 0..3 cannot reach here
+    const bool general = a.sampling_random || a.mode_simple || a.cp.task < 0 || a.cp.task > 3 ||
+                         (a.cp.task == 3 && !a.multi_modal);
+#endif
+    if (general) { hipLaunchKernelGGL((k_rollout_point<true, -1>), dim3(blocks), dim3(64), 0, s, a, sc); return; }
+    switch (a.cp.task) {   // the reference's default sampler: one instance per task (rollout_point_task*.hip)
+        case 0: launch_rollout_point_nav(a, sc, blocks, s); break;
+        case 1: launch_rollout_point_push(a, sc, blocks, s); break;
+        case 2: launch_rollout_point_pull(a, sc, blocks, s); break;
+        default: launch_rollout_point_pushpull(a, sc, blocks, s); break;
+    }
 }
 
 // delta [K][T][nu] (reference layout) -> [T][K][nu]
