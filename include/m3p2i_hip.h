@@ -52,7 +52,7 @@ extern "C" {
 
 #define M3_MAX_NU 9
 #define M3_TOPK 20
-#define M3_ABI_VERSION 2
+#define M3_ABI_VERSION 3
 
 typedef enum {
     M3_OK = 0,
@@ -96,9 +96,9 @@ typedef struct {
     float u_min[M3_MAX_NU];
     float u_max[M3_MAX_NU];
     float noise_sigma_diag[M3_MAX_NU]; /* diagonal of cfg.mppi.noise_sigma */
-    float u_scale;          /* mppi.py:297,421.  The update consumes actions / u_scale throughout; for u_scale != 1 the
-                               reference updates its distribution from the SCALED stack (mppi.py:313,331): a
-                               deviation, which is why the Python planner refuses u_scale != 1 */
+    float u_scale;          /* mppi.py:297.  M3_BUF_ACTIONS holds the SCALED controls u_scale * a (what the dynamics
+                               got and what the reference's distribution update consumes, mppi.py:313-331); the
+                               division of mppi.py:353 / :420 only concerns the attribute a caller reads */
     float gamma;            /* rollout_var_discount */
     float lambda_;
     float step_size_mean;   /* 0.98, mppi.py:178 */
@@ -136,6 +136,21 @@ typedef struct {
                                  f32 rounding (plan <= 3e-5, same beta-search iteration counts), bit-identical
                                  across ranks.
                                0 = gather + reduce, two collectives (all-gather TRAJ_COST, all-reduce REDUCE) */
+    /* ---- the MPPIConfig switches no shipped config turns on (mppi.py:39-54); zero = the defaults ---- */
+    int noise_abs_cost;     /* mppi.py:366-367: |noise| in the action cost (read in simple mode only, as in the reference) */
+    int update_cov;         /* mppi.py:201, :508-516: after every command of a single-mode halton-spline planner
+                               cov_action <- 0.3 cov_action + 0.7 mean_t sum_k w_k (a_k - mean)^2 + 0.005 and
+                               scale_tril = sqrt(cov_action) (M3_BUF_COV: the rollout reads its scale from there).
+                               Ignored for multi_modal / simple mode, exactly as the reference ignores it there
+                               (m3p2i.py:66-92 and mppi.py:220-233 have no such branch); unsharded handles only */
+    int full_sigma;         /* 0: noise_sigma = diag(noise_sigma_diag).  1: noise_sigma_full is the matrix; its
+                               diagonal must equal noise_sigma_diag.  Only the paths where the reference uses the whole
+                               matrix read it: MultivariateNormal sampling (sampling_random / simple mode,
+                               mppi.py:129-131, :340, :481) through its Cholesky factor and the action cost
+                               (mppi.py:128, :366-372) through its inverse, both formed in binary64 and rounded to f32;
+                               the Halton noise is scaled by sqrt(diag) alone (mppi.py:175-176, :394) */
+    float noise_mu[M3_MAX_NU];                         /* mppi.py:127-131: mean of the sampled noise */
+    float noise_sigma_full[M3_MAX_NU * M3_MAX_NU];     /* row-major [nu][nu] */
     unsigned long long seed;
 } m3_config;
 
@@ -198,7 +213,9 @@ typedef enum {
                                this buffer between m3_update and m3_finalize (shard_mix) */
     M3_BUF_NOISE_ALL = 24,  /* f32 [K_global/K_local][T][Kl][nu]: every shard's noise block (one-collective
                                multi-modal shards only; M3_BUF_NOISE is this rank's block of it) */
-    M3_BUF_COUNT = 25
+    M3_BUF_COV = 25,        /* f32 [2][nu]: cov_action | scale_tril (mppi.py:175-176; rewritten by every command
+                               when update_cov is on) */
+    M3_BUF_COUNT = 26
 } m3_buffer_id;
 
 typedef struct m3_handle m3_handle;

@@ -10,7 +10,7 @@ import os
 
 MAX_NU = 9
 TOPK = 20
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M3P2I_HIP_LIB") or os.path.join(_HERE, "lib", "libm3p2i_hip.so")
@@ -22,7 +22,8 @@ TASKS = {"navigation": 0, "push": 1, "pull": 2, "push_pull": 3, "reach": 4, "pic
 (BUF_STATES, BUF_ACTIONS, BUF_COST_HORIZON, BUF_TRAJ_COST, BUF_TRAJ_COST_ALL, BUF_WEIGHTS,
  BUF_WEIGHTS_1, BUF_WEIGHTS_2, BUF_MEAN, BUF_MEAN_1, BUF_MEAN_2, BUF_BEST, BUF_BEST_1,
  BUF_BEST_2, BUF_ACTION_OUT, BUF_TOP_IDX, BUF_TOP_TRAJS, BUF_REDUCE, BUF_NOISE,
- BUF_PENDING_FORCE, BUF_INFO, BUF_SIM_WORLD, BUF_RECORD, BUF_RECORDS_ALL, BUF_NOISE_ALL, BUF_COUNT) = range(26)
+ BUF_PENDING_FORCE, BUF_INFO, BUF_SIM_WORLD, BUF_RECORD, BUF_RECORDS_ALL, BUF_NOISE_ALL, BUF_COV,
+ BUF_COUNT) = range(27)
 
 
 class Config(C.Structure):
@@ -36,7 +37,9 @@ class Config(C.Structure):
                 ("gamma", C.c_float), ("lambda_", C.c_float), ("step_size_mean", C.c_float),
                 ("kp_suction", C.c_float), ("pre_height_diff", C.c_float), ("dt", C.c_float),
                 ("substeps", C.c_int), ("solver_iters", C.c_int), ("cube_on_shelf", C.c_int),
-                ("sim_only", C.c_int), ("shard_mix", C.c_int), ("seed", C.c_ulonglong)]
+                ("sim_only", C.c_int), ("shard_mix", C.c_int), ("noise_abs_cost", C.c_int),
+                ("update_cov", C.c_int), ("full_sigma", C.c_int), ("noise_mu", C.c_float * MAX_NU),
+                ("noise_sigma_full", C.c_float * (MAX_NU * MAX_NU)), ("seed", C.c_ulonglong)]
 
 
 class PointWorld(C.Structure):

@@ -148,10 +148,52 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
             return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad noise_sigma / bounds");
     if (!(c->gamma > 0.0f) || !(c->u_scale != 0.0f) || (c->mode_simple && !(c->lambda_ > 0.0f)))
         return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad gamma / u_scale / lambda_");
+    // noise_sigma with off-diagonal entries: Cholesky factor (MultivariateNormal, mppi.py:129-131) and inverse
+    // (mppi.py:128) in binary64, rounded to f32 (for a diagonal matrix: sqrtf / 1.0f/x bit for bit)
+    double chol[M3_MAX_NU * M3_MAX_NU] = {}, sinv[M3_MAX_NU * M3_MAX_NU] = {};
+    if (c->full_sigma) {
+        const int n = c->nu;
+        for (int i = 0; i < n; ++i) {
+            if (c->noise_sigma_full[i * n + i] != c->noise_sigma_diag[i])
+                return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: diagonal of noise_sigma_full != noise_sigma_diag");
+            for (int j = 0; j < i; ++j)
+                if (c->noise_sigma_full[i * n + j] != c->noise_sigma_full[j * n + i])
+                    return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: noise_sigma_full is not symmetric");
+        }
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double s = (double)c->noise_sigma_full[i * n + j];
+                for (int q = 0; q < j; ++q) s -= chol[i * n + q] * chol[j * n + q];
+                if (i == j) {
+                    if (!(s > 0.0)) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: noise_sigma_full is not positive definite");
+                    chol[i * n + i] = std::sqrt(s);
+                } else chol[i * n + j] = s / chol[j * n + j];
+            }
+        // Sigma^-1 = L^-T L^-1
+        double li[M3_MAX_NU * M3_MAX_NU] = {};
+        for (int j = 0; j < n; ++j) {
+            li[j * n + j] = 1.0 / chol[j * n + j];
+            for (int i = j + 1; i < n; ++i) {
+                double s = 0.0;
+                for (int q = j; q < i; ++q) s -= chol[i * n + q] * li[q * n + j];
+                li[i * n + j] = s / chol[i * n + i];
+            }
+        }
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double s = 0.0;
+                for (int q = (i > j ? i : j); q < n; ++q) s += li[q * n + i] * li[q * n + j];
+                sinv[i * n + j] = s;
+            }
+    }
+    const bool single_halton = !c->multi_modal && !c->mode_simple;
+    if (c->update_cov && single_halton && c->K_local != c->K_global)
+        return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: update_cov needs an unsharded handle");
 
     m3_handle* h = new (std::nothrow) m3_handle();
     if (!h) return fail(nullptr, M3_ERR_HIP, "m3_create: out of host memory");
     h->cfg = *c;
+    h->cov_active = c->update_cov && single_halton && !c->sim_only;   // (elsewhere the reference ignores the flag)
     h->regen = c->shard_mix && c->K_local != c->K_global && c->multi_modal && !c->mode_simple;
     h->regen_fast = h->regen && c->shard_mix == 2;
     hipError_t e = hipSetDevice(c->device);
@@ -190,6 +232,18 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (!h->regen) A(M3_BUF_NOISE, T * Kl * nu * f);
     A(M3_BUF_PENDING_FORCE, 4 * Kl * f);
     A(M3_BUF_INFO, sizeof(m3_info));
+    A(M3_BUF_COV, 2 * nu * f);
+    if (rc == M3_OK) {   // cov_action = diag(noise_sigma), scale_tril = sqrt(cov_action): mppi.py:175-176
+        float cv[2 * M3_MAX_NU];
+        for (int j = 0; j < nu; ++j) { cv[j] = c->noise_sigma_diag[j]; cv[nu + j] = std::sqrt(c->noise_sigma_diag[j]); }
+        if (hipMemcpy(h->buf[M3_BUF_COV], cv, (size_t)(2 * nu * f), hipMemcpyHostToDevice) != hipSuccess) rc = M3_ERR_HIP;
+    }
+    if (rc == M3_OK && c->full_sigma) {
+        float mats[2 * M3_MAX_NU * M3_MAX_NU];
+        for (int i = 0; i < nu * nu; ++i) { mats[i] = (float)chol[i]; mats[nu * nu + i] = (float)sinv[i]; }
+        if (hipMalloc((void**)&h->noise_mats, (size_t)(2 * nu * nu * f)) != hipSuccess ||
+            hipMemcpy(h->noise_mats, mats, (size_t)(2 * nu * nu * f), hipMemcpyHostToDevice) != hipSuccess) rc = M3_ERR_HIP;
+    }
     if (h->regen) {
         const long long rl = regen_record_length((int)Kl, (int)T);
         A(M3_BUF_RECORD, rl * f);
@@ -236,6 +290,7 @@ extern "C" void m3_destroy(m3_handle* h) {
     for (int i = 0; i < M3_BUF_COUNT; ++i)
         if (h->buf[i]) (void)hipFree(h->buf[i]);
     if (h->noise_all) (void)hipFree(h->noise_all);
+    if (h->noise_mats) (void)hipFree(h->noise_mats);
     if (h->local_top_idx) (void)hipFree(h->local_top_idx);
     if (h->world0_dev) (void)hipFree(h->world0_dev);
     if (h->topk_cand) (void)hipFree(h->topk_cand);
@@ -664,6 +719,10 @@ extern "C" int m3_rollout(m3_handle* h) {
         a.sigma_inv[j] = 1.0f / c.noise_sigma_diag[j];       // mppi.py:128 (diagonal)
     }
     a.u_scale = c.u_scale; a.gamma = c.gamma; a.lambda_ = c.lambda_;
+    a.noise_abs_cost = c.noise_abs_cost; a.full_sigma = c.full_sigma;
+    for (int j = 0; j < c.nu; ++j) a.noise_mu[j] = c.noise_mu[j];
+    a.noise_mats = h->noise_mats;
+    a.scale_dev = h->cov_active ? (const float*)h->buf[M3_BUF_COV] + c.nu : nullptr;
     a.seed = c.seed; a.call = h->calls;
     fill_cost_params(h, a.cp);
     std::memcpy(a.world0, h->world0, sizeof(a.world0));
@@ -884,6 +943,17 @@ static int regen_finalize(m3_handle* h) {
     return M3_OK;
 }
 
+// MPPIConfig.update_cov: the covariance update that follows the mean update (mppi.py:508-516)
+static int after_finalize(m3_handle* h) {
+    if (!h->cov_active) return M3_OK;
+    const m3_config& c = h->cfg;
+    launch_cov_update((const float*)h->buf[M3_BUF_ACTIONS], (const float*)h->buf[M3_BUF_WEIGHTS],
+                      (const float*)h->buf[M3_BUF_MEAN], h->wpart, (float*)h->buf[M3_BUF_COV], c.K_local, c.T, c.nu,
+                      h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
 extern "C" int m3_finalize(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     if (h->regen) {
@@ -898,6 +968,8 @@ extern "C" int m3_finalize(m3_handle* h) {
     if (mix_mode(h)) launch_mix(a, h->stream);  // records -> the REDUCE buffer an all-reduce would hold, + finalize
     else launch_finalize(a, h->stream);
     HIPCHK(h, hipGetLastError());
+    const int rc = after_finalize(h);
+    if (rc != M3_OK) return rc;
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     h->calls += 1;
     return M3_OK;
@@ -911,7 +983,8 @@ extern "C" int m3_update_finalize(m3_handle* h) {
         const int rc = m3_update(h);
         return rc != M3_OK ? rc : m3_finalize(h);
     }
-    const int rc = update_impl(h, true);
+    int rc = update_impl(h, true);
+    if (rc == M3_OK) rc = after_finalize(h);
     if (rc != M3_OK) return rc;
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     h->calls += 1;

@@ -18,6 +18,11 @@ struct RolloutArgs {
     int gripper_cmd;
     float u_min[M3_MAX_NU], u_max[M3_MAX_NU], scale_tril[M3_MAX_NU], sigma_inv[M3_MAX_NU];
     float u_scale, gamma, lambda_;
+    // the MPPIConfig switches no shipped config turns on (general kernel instance only)
+    int noise_abs_cost, full_sigma;
+    float noise_mu[M3_MAX_NU];
+    const float* noise_mats;  // device [2][nu][nu]: Cholesky factor | inverse of noise_sigma (full_sigma)
+    const float* scale_dev;   // device [nu] scale_tril when update_cov rewrites it every command, else null
     unsigned long long seed;
     unsigned call;
     CostParams cp;
@@ -167,6 +172,8 @@ void launch_update_small(const UpdateArgs& a, hipStream_t s);
 bool update_small_applies(const UpdateArgs& a);
 void launch_finalize(const UpdateArgs& a, hipStream_t s);
 void launch_mix(const UpdateArgs& a, hipStream_t s);
+void launch_cov_update(const float* actions, const float* w, const float* mean, float* part, float* cov, int K, int T,
+                       int nu, hipStream_t s);
 void launch_local_topk(const UpdateArgs& a, hipStream_t s);
 void launch_regen_fast(const UpdateArgs& a, hipStream_t s);
 int rollout_lanes_for(int Kl);
@@ -248,6 +255,8 @@ struct m3_handle {
     const float* bind_root = nullptr;
     int bind_nact = 0, bind_box = 0, bind_dyn = 0;
     bool have_noise = false;
+    bool cov_active = false;       // cfg.update_cov on a single-mode halton-spline planner (mppi.py:508-516)
+    float* noise_mats = nullptr;   // device [2][nu][nu]: chol(noise_sigma) | noise_sigma^-1 (cfg.full_sigma)
     bool regen = false;            // one-collective multi-modal sharding (UpdateArgs::regen)
     bool regen_fast = false;       // ... with per-rank ladder tables in the records (cfg.shard_mix == 2)
     float* noise_all = nullptr;    // regen: [n_ranks][T][Kl][nu]; buf[M3_BUF_NOISE] aliases this rank's block

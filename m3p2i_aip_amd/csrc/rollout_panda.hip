@@ -60,7 +60,8 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         a.u_min[j] = in_vgpr(a_.u_min[j]); a.u_max[j] = in_vgpr(a_.u_max[j]);
-        a.scale_tril[j] = in_vgpr(a_.scale_tril[j]);
+        // (update_cov rewrites the scale on the device after every command: mppi.py:516)
+        a.scale_tril[j] = in_vgpr(a_.scale_dev ? a_.scale_dev[j] : a_.scale_tril[j]);
         sc.a[j] = in_vgpr(sc_.a[j]); sc.rden[j] = in_vgpr(sc_.rden[j]); sc.dv[j] = in_vgpr(sc_.dv[j]);
     }
     const int Kl = a.Kl, T = a.T;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
             float uj = a.u_scale * aj;                                                 // :297
             if (a.sample_null_action && is_last) uj = 0.0f;                            // :300-302
             u[j] = uj;
-            e[j] = uj / a.u_scale;                                                     // :421
+            e[j] = uj;                                     // :313 (the update consumes the scaled stack)
         }
         PandaObs obs;
         panda_step<FORCES, true>(sc, w, u, obs, hp, &trav);

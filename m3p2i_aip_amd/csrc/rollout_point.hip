@@ -23,7 +23,7 @@ void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_
 #else
     // push_pull without multi_modal is refused upstream (m3_rollout); a task outside 0..3 cannot reach here
     const bool general = a.sampling_random || a.mode_simple || a.cp.task < 0 || a.cp.task > 3 ||
-                         (a.cp.task == 3 && !a.multi_modal);
+                         (a.cp.task == 3 && !a.multi_modal) || a.scale_dev != nullptr /* update_cov */;
 #endif
     if (general) { hipLaunchKernelGGL((k_rollout_point<true, -1>), dim3(blocks), dim3(64), 0, s, a, sc); return; }
     switch (a.cp.task) {   // the reference's default sampler: one instance per task (rollout_point_task*.hip)

@@ -88,7 +88,10 @@ __device__ __forceinline__ void load_world_from_sim(const float* dof, const floa
 template <bool GENERAL, int TASK>
 __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a_, const PointScene sc) {
     RolloutArgs a = a_;
-    if constexpr (!GENERAL) { a.sampling_random = 0; a.mode_simple = 0; }
+    if constexpr (!GENERAL) {
+        a.sampling_random = 0; a.mode_simple = 0;
+        a.noise_abs_cost = 0; a.full_sigma = 0; a.scale_dev = nullptr;   // (the host routes those to the general instance)
+    }
     if constexpr (TASK >= 0) {
         a.cp.task = TASK;
         if constexpr (TASK == 3) { a.multi_modal = 1; a.cp.multi_modal = 1; }
@@ -130,6 +133,16 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a_, cons
         return in;
     };
 
+    // the MPPIConfig switches no shipped config turns on (general instance only): scale_tril rewritten by
+    // update_cov (mppi.py:516), Cholesky factor / inverse of a non-diagonal noise_sigma (mppi.py:128-131)
+    if (a.scale_dev) { a.scale_tril[0] = a.scale_dev[0]; a.scale_tril[1] = a.scale_dev[1]; }
+    float L10 = 0.0f, L00 = a.scale_tril[0], L11 = a.scale_tril[1];
+    float S00 = a.sigma_inv[0], S01 = 0.0f, S10 = 0.0f, S11 = a.sigma_inv[1];
+    if (a.full_sigma) {
+        L00 = a.noise_mats[0]; L10 = a.noise_mats[2]; L11 = a.noise_mats[3];
+        S00 = a.noise_mats[4]; S01 = a.noise_mats[5]; S10 = a.noise_mats[6]; S11 = a.noise_mats[7];
+    }
+
     float J = 0.0f, S = 0.0f, g = 1.0f, pc = 0.0f;
     StepIn nxt = fetch(0);
 #ifdef M3_ABL_PHASES
@@ -143,9 +156,13 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a_, cons
         if (t + 1 < T) nxt = fetch(t + 1);
         // ---- A4 / A13: perturbed action for this (k, t) ----
         float d0 = in.d0, d1 = in.d1;
-        if (a.sampling_random) {
-            gauss_pair(a.seed, a.call, (unsigned)k, (unsigned)t, 0u, d0, d1);
-            d0 *= a.scale_tril[0]; d1 *= a.scale_tril[1];  // N(0, Sigma): mppi.py:481 / :340
+        if (a.sampling_random) {   // N(noise_mu, noise_sigma) = mu + L z: mppi.py:129-131, :340 / :481
+            float z0, z1;
+            gauss_pair(a.seed, a.call, (unsigned)k, (unsigned)t, 0u, z0, z1);
+            d0 = a.noise_mu[0] + L00 * z0;
+            float acc = L11 * z1;
+            if (a.full_sigma) acc = L10 * z0 + acc;
+            d1 = a.noise_mu[1] + acc;
         }
         float a0, a1;
         const float m0 = in.m0, m1 = in.m1;
@@ -172,17 +189,22 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a_, cons
         // ---- outputs, time-major ----
         *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
             make_float4(w.rx, w.rvx, w.ry, w.rvy);                      // reactive_tamp.py:66-69
-        // mppi.py:421 (x / 1 == x exactly: the usual u_scale = 1 skips two IEEE divisions per step)
-        float e0 = u0, e1 = u1;
-        if (a.u_scale != 1.0f) { e0 = u0 / a.u_scale; e1 = u1 / a.u_scale; }   // wave-uniform branch
+        // mppi.py:313: the stack the distribution update consumes holds the SCALED controls (:329-331, :355);
+        // the division of :353 / :420 only touches the attribute the caller reads (planner.actions)
+        const float e0 = u0, e1 = u1;
         *reinterpret_cast<float2*>(a.actions + ((size_t)t * Kl + i) * 2) = make_float2(e0, e1);
         a.cost_h[(size_t)t * Kl + i] = c;                               // mppi.py:310
         J = J + g * c;                                                  // mppi_utils.py:106-113
         S = S + c;                                                      // mppi.py:309
         g = g * a.gamma;
-        if (a.mode_simple) {  // perturbation cost, mppi.py:355-362 (diagonal Sigma)
-            pc = pc + m0 * (a.lambda_ * (e0 - m0) * a.sigma_inv[0]);
-            pc = pc + m1 * (a.lambda_ * (e1 - m1) * a.sigma_inv[1]);
+        if (a.mode_simple) {  // perturbation cost, mppi.py:355-372: sum U * ((lambda * noise) @ Sigma^-1)
+            float n0 = e0 - m0, n1 = e1 - m1;
+            if (a.noise_abs_cost) { n0 = fabsf(n0); n1 = fabsf(n1); }      // :366-367
+            const float l0 = a.lambda_ * n0, l1 = a.lambda_ * n1;
+            float c0 = l0 * S00, c1 = l1 * S11;
+            if (a.full_sigma) { c0 = c0 + l1 * S10; c1 = l0 * S01 + c1; }
+            pc = pc + m0 * c0;
+            pc = pc + m1 * c1;
         }
         M3_PH(6);
     }

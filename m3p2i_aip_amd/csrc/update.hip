@@ -1235,7 +1235,7 @@ __device__ __forceinline__ void regen_action(const UpdateArgs& a, const RegenRow
         }
         float uj = a.u_scale * aj;
         if (a.sample_null_action && is_last) uj = 0.0f;
-        e[j] = (a.u_scale != 1.0f) ? uj / a.u_scale : uj;
+        e[j] = uj;   // mppi.py:313
     }
 }
 template <int NU, bool REGEN>
@@ -2320,6 +2320,47 @@ __global__ __launch_bounds__(256) void k_finalize(const UpdateArgs a) {
 }
 void launch_finalize(const UpdateArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), a.T * a.nu * sizeof(float), s, a);
+}
+
+// ---- MPPIConfig.update_cov (mppi.py:201-203, :508-516; off in every shipped config) ----
+// delta = actions - mean_action (the NEW mean); cov_update = mean_t sum_k w_k delta^2 per control dimension;
+// cov_action <- (1 - 0.7) cov_action + 0.7 cov_update; += 0.005; scale_tril = sqrt(cov_action).
+// Two small launches after the finalize (one workgroup per time step, then one thread per dimension): the
+// kernel boundary orders the partial sums, nothing on the default path changes.
+__global__ __launch_bounds__(256) void k_cov_partial(const float* __restrict__ actions, const float* __restrict__ w,
+                                                     const float* __restrict__ mean, float* __restrict__ part,
+                                                     int K, int nu) {
+    __shared__ float lds[M3_MAX_NU * 16];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    float acc[M3_MAX_NU];
+    float m[M3_MAX_NU];
+#pragma unroll
+    for (int j = 0; j < M3_MAX_NU; ++j) { acc[j] = 0.0f; m[j] = j < nu ? mean[t * nu + j] : 0.0f; }
+    for (int k = tid; k < K; k += 256) {
+        const float wk = w[k];
+        const float* row = actions + ((size_t)t * K + k) * nu;
+#pragma unroll
+        for (int j = 0; j < M3_MAX_NU; ++j)
+            if (j < nu) { const float d = row[j] - m[j]; acc[j] = acc[j] + wk * (d * d); }
+    }
+    block_sum<M3_MAX_NU>(acc, lds);
+    if (tid < nu) part[t * nu + tid] = acc[tid];
+}
+__global__ void k_cov_apply(const float* __restrict__ part, float* __restrict__ cov /* [2][nu] */, int T, int nu) {
+    const int j = threadIdx.x;
+    if (j >= nu) return;
+    float s = 0.0f;
+    for (int t = 0; t < T; ++t) s = s + part[t * nu + j];
+    const float upd = s / (float)T;                                       // torch.mean(..., dim=0)
+    float c = (float)(1.0 - 0.7) * cov[j] + 0.7f * upd;                   // mppi.py:514 (step_size_cov = 0.7)
+    c = c + 0.005f;                                                       // :515 (kappa)
+    cov[j] = c;
+    cov[nu + j] = sqrtf(c);                                               // :516
+}
+void launch_cov_update(const float* actions, const float* w, const float* mean, float* part, float* cov, int K, int T,
+                       int nu, hipStream_t s) {
+    hipLaunchKernelGGL(k_cov_partial, dim3(T), dim3(256), 0, s, actions, w, mean, part, K, nu);
+    hipLaunchKernelGGL(k_cov_apply, dim3(1), dim3(64), 0, s, (const float*)part, cov, T, nu);
 }
 
 }  // namespace m3

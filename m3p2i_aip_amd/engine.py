@@ -30,7 +30,10 @@ def make_config(K, T, nu=2, env_type="point_env", multi_modal=False, mode_simple
                 u_per_command=None, u_min=None, u_max=None, noise_sigma_diag=None, u_scale=1.0,
                 gamma=0.95, lambda_=1.0, kp_suction=400.0, pre_height_diff=0.05, dt=None,
                 substeps=2, solver_iters=6, seed=0, device=0, K_local=None, k_offset=0,
-                cube_on_shelf=False, sim_only=False, shard_mix=False) -> L.Config:
+                cube_on_shelf=False, sim_only=False, shard_mix=False, noise_mu=None, noise_sigma=None,
+                noise_abs_cost=False, update_cov=False) -> L.Config:
+    """noise_sigma: the full [nu][nu] matrix (sets noise_sigma_diag too; full_sigma when it has off-diagonal
+    entries)."""
     lib = L.load()
     c = L.Config()
     env = L.ENV_POINT if env_type in ("point_env", 0) else L.ENV_PANDA
@@ -58,6 +61,17 @@ def make_config(K, T, nu=2, env_type="point_env", multi_modal=False, mode_simple
     c.substeps, c.solver_iters = int(substeps), int(solver_iters)
     c.cube_on_shelf = int(bool(cube_on_shelf))
     c.sim_only = int(bool(sim_only))
+    if noise_sigma is not None:
+        for i in range(nu):
+            c.noise_sigma_diag[i] = float(noise_sigma[i][i])
+            for j in range(nu):
+                c.noise_sigma_full[i * nu + j] = float(noise_sigma[i][j])
+                if i != j and float(noise_sigma[i][j]) != 0.0:
+                    c.full_sigma = 1
+    if noise_mu is not None:
+        for j in range(nu):
+            c.noise_mu[j] = float(noise_mu[j])
+    c.noise_abs_cost, c.update_cov = int(bool(noise_abs_cost)), int(bool(update_cov))
     c.shard_mix = int(shard_mix)   # 0: gather + reduce; 1 (True): one collective; 2: ... with ladder tables (multi-modal)
     c.seed = int(seed)
     return c
@@ -257,6 +271,7 @@ class HipEngine:
             L.BUF_SIM_WORLD: ((28 if c.env_type == L.ENV_POINT else 45, Kl), "<f4"),
             L.BUF_INFO: ((L.INFO_WORDS,), "<i4"),
             L.BUF_NOISE_ALL: ((Kg // Kl, T, Kl, nu), "<f4"),
+            L.BUF_COV: ((2, nu), "<f4"),
             L.BUF_RECORD: ((self.lib.m3_record_len(self._h),), "<f4"),
             L.BUF_RECORDS_ALL: ((Kg // Kl, self.lib.m3_record_len(self._h)), "<f4"),
         }[which]

@@ -100,17 +100,12 @@ class MPPI():
             raise ValueError(f"unknown mppi_mode {self.mppi_mode!r}")
         if self.sampling_method not in ("halton", "random"):
             raise ValueError(f"unknown sampling_method {self.sampling_method!r}")
-        if _get(m, "update_cov", False):
-            raise NotImplementedError("update_cov=True (flagged '!! weird' in mppi.py:199) is not supported")
-        if _get(m, "noise_abs_cost", False):
-            raise NotImplementedError("noise_abs_cost=True is not supported")
-        if _get(m, "U_init", None) is not None or float(_get(m, "u_init", 0.0) or 0.0) != 0.0:
-            raise NotImplementedError("U_init / u_init != 0 are not supported (no reference config sets them); "
-                                      "install a warm start with planner.mean_action = ... instead")
-        if float(_get(m, "u_scale", 1) or 1) != 1.0:
-            # the reference updates its distribution from the u_scale-d stack and divides afterwards
-            # (mppi.py:313,331,420); the kernels keep the unscaled actions throughout
-            raise NotImplementedError("u_scale != 1 is not supported (every reference config uses 1)")
+        # U_init / u_init are accepted and ignored: the reference stores both and never reads them
+        # (mppi.py:122-123, :132-133 -- the one use is commented out; tests/golden: g9_opt_dead).  A warm start
+        # is installed with planner.mean_action = ... (planner.U in simple mode), as with the reference.
+        self.noise_abs_cost = bool(_get(m, "noise_abs_cost", False))     # mppi.py:116, :366-367 (simple mode)
+        self.update_cov = bool(_get(m, "update_cov", False))             # mppi.py:201, :508-516 ("!! weird")
+        self.step_size_cov, self.kappa = 0.7, 0.005                      # mppi.py:202-203
 
         self.K = int(m.num_samples)
         self.half_K = int(self.K / 2)
@@ -129,13 +124,12 @@ class MPPI():
         noise_sigma = [list(map(float, r)) for r in noise_sigma]
         self.nu = len(noise_sigma)
         sig = torch.tensor(noise_sigma, dtype=torch.float32)
-        if not torch.equal(sig, torch.diag(torch.diagonal(sig))):
-            # the reference's halton-spline path scales the Halton noise with sqrt(diag(noise_sigma)) and never
-            # reads the off-diagonal entries (mppi.py:175-176, 394); only MultivariateNormal sampling
-            # (sampling_method='random', mppi_mode='simple': mppi.py:129-131, 340, 481) uses the full matrix
-            if not (self.mppi_mode == "halton-spline" and self.sampling_method == "halton"):
-                raise NotImplementedError("a non-diagonal noise_sigma is only supported where the reference itself uses just "
-                                          "its diagonal (mppi_mode='halton-spline' with sampling_method='halton')")
+        # a non-diagonal noise_sigma: the halton-spline path scales the Halton noise with sqrt(diag(noise_sigma))
+        # and never reads the off-diagonal entries (mppi.py:175-176, :394); MultivariateNormal sampling
+        # (sampling_method='random', mppi_mode='simple': mppi.py:129-131, :340, :481) and the action cost
+        # (mppi.py:128, :366-372) use the whole matrix -- the library takes it as noise_sigma_full
+        noise_mu = _get(m, "noise_mu", None)
+        noise_mu = [0.0] * self.nu if not noise_mu else list(map(float, noise_mu))     # mppi.py:120-121
         u_max, u_min = m.u_max, m.u_min
         if u_max and not u_min:
             u_min = [-float(x) for x in u_max]
@@ -144,13 +138,12 @@ class MPPI():
         if not u_max:
             raise ValueError("u_min/u_max are required (mppi.py:135-136)")
         self.noise_sigma = sig.to(m.device)
-        self.noise_mu = torch.zeros(self.nu, device=m.device)
+        self.noise_mu = torch.tensor(noise_mu, dtype=torch.float32, device=m.device)
         self.noise_sigma_inv = torch.inverse(sig).to(m.device)
         self.u_max = torch.tensor(list(map(float, u_max)), device=m.device)
         self.u_min = torch.tensor(list(map(float, u_min)), device=m.device)
         self.u_scale = float(m.u_scale)
-        self.cov_action = torch.diagonal(self.noise_sigma, 0)
-        self.scale_tril = torch.sqrt(self.cov_action)
+        self._cov0 = torch.diagonal(self.noise_sigma, 0)
         self.knot_scale, self.degree, self.seed_val = 4, 2, int(_get(m, "seed_val", 0) or 0)
         self.n_knots = self.T // self.knot_scale
         self.step_size_mean = 0.98
@@ -203,7 +196,13 @@ class MPPI():
             pre_height_diff=float(_get(cfg, "pre_height_diff", 0) or 0),
             dt=float(_get(isaac, "dt", 0.05 if self.env_type == "point_env" else 0.01)),
             substeps=int(_get(isaac, "substeps", 2)), seed=self.seed_val, device=dev.index or 0,
-            cube_on_shelf=bool(_get(cfg, "cube_on_shelf", False)), shard_mix=self._shard_mix_level))
+            cube_on_shelf=bool(_get(cfg, "cube_on_shelf", False)), shard_mix=self._shard_mix_level,
+            noise_mu=noise_mu, noise_sigma=noise_sigma, noise_abs_cost=self.noise_abs_cost,
+            update_cov=self.update_cov))
+        if self.mppi_mode == "simple":
+            # mppi.py:129-134: U starts as T draws of N(noise_mu, noise_sigma) from torch's global generator
+            dist = torch.distributions.MultivariateNormal(self.noise_mu.cpu(), covariance_matrix=sig)
+            self.U = dist.sample((self.T,)).to(**self.tensor_args)
         self._fused = _get(m, "fused", None)
         self._sim = None
         self._objective = None
@@ -260,11 +259,28 @@ class MPPI():
     weights_1 = property(lambda s: s._buf(L.BUF_WEIGHTS_1))
     weights_2 = property(lambda s: s._buf(L.BUF_WEIGHTS_2))
     states = property(lambda s: s._engine.states)        # [K_local, T, 4] strided view
-    actions = property(lambda s: s._engine.actions)      # [K_local, T, nu]
+    @property
+    def actions(self):
+        """[K_local, T, nu] controls of the last rollout as the reference leaves them in `self.actions`: the stack
+        handed to the dynamics divided by u_scale (mppi.py:353, :420; the library keeps the scaled stack, which is
+        what the distribution update consumes, mppi.py:313-331)."""
+        a = self._engine.actions
+        return a if self.u_scale == 1.0 else a / self.u_scale
+
     top_trajs = property(lambda s: s._buf(L.BUF_TOP_TRAJS))
     top_idx = property(lambda s: s._buf(L.BUF_TOP_IDX).to(torch.int64))
     top_values = property(lambda s: s.weights[s.top_idx])
     cost_total = property(lambda s: s._buf(L.BUF_TRAJ_COST))
+
+    # cov_action / scale_tril (mppi.py:175-176): constants unless update_cov rewrites them after every command of
+    # a single-mode halton-spline planner (mppi.py:508-516; the library keeps both in M3_BUF_COV)
+    @property
+    def cov_action(self):
+        return self._buf(L.BUF_COV)[0] if self.update_cov else self._cov0
+
+    @property
+    def scale_tril(self):
+        return self._buf(L.BUF_COV)[1] if self.update_cov else torch.sqrt(self._cov0)
 
     @property
     def beta(self):
@@ -437,7 +453,7 @@ class MPPI():
                 u[last] = 0.0
             state, u = self._dynamics(state, u, t)
             c = self._running_cost(state)
-            A[t].copy_(u / self.u_scale)
+            A[t].copy_(u)        # mppi.py:313: the scaled controls, as the update consumes them
             S[t].copy_(state[:, :4])
             C[t].copy_(c)
             J = J + gs * c
@@ -473,7 +489,7 @@ class MPPI():
         # both legs must start from the same warm start (means, best trajectories, pending suction
         # forces, adapted beta): snapshot it, run the fused leg, put it back, run the step leg
         keep = [L.BUF_MEAN, L.BUF_MEAN_1, L.BUF_MEAN_2, L.BUF_BEST, L.BUF_BEST_1, L.BUF_BEST_2,
-                L.BUF_PENDING_FORCE]
+                L.BUF_PENDING_FORCE, L.BUF_COV]
         saved = [self._buf(b).clone() for b in keep]
         beta0 = self._engine.info().beta
         self._command_fused()

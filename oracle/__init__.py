@@ -58,7 +58,9 @@ class Cfg(C.Structure):
                 ("step_size_mean", C.c_float), ("task", C.c_int), ("goal", C.c_float * 7),
                 ("kp_suction", C.c_float), ("suction_thresh", C.c_float),
                 ("gripper_cmd", C.c_int), ("pre_height_diff", C.c_float),
-                ("tilt_cos_theta", C.c_float)]
+                ("tilt_cos_theta", C.c_float), ("noise_abs_cost", C.c_int), ("full_sigma", C.c_int),
+                ("noise_mu", C.c_float * MAX_NU), ("chol", C.c_float * (MAX_NU * MAX_NU)),
+                ("sigma_inv_full", C.c_float * (MAX_NU * MAX_NU))]
 
 
 class UpdateInfo(C.Structure):
@@ -122,6 +124,7 @@ def load():
     lib.m3o_simple_update.argtypes = [C.POINTER(Cfg), FP, FP, FP, FP, FP]
     lib.m3o_gauss.argtypes = [C.c_ulonglong, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
     lib.m3o_gauss.restype = C.c_float
+    lib.m3o_noise_fill.argtypes = [C.POINTER(Cfg), C.c_ulonglong, C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.m3o_gauss_fill.argtypes = [C.c_ulonglong, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int,
                                    FP]
     lib.m3o_ori_cube2goal.argtypes = [FP, FP]
@@ -147,7 +150,9 @@ def make_cfg(K, T, nu=2, multi_modal=False, env_type="point_env", task="push", g
              u_min=None, u_max=None, noise_sigma_diag=None, u_scale=1.0, gamma=0.95,
              lambda_=1.0, sample_null_action=True, mode_simple=False, filter_u=True,
              u_per_command=1, kp_suction=400.0, gripper_cmd=0, pre_height_diff=0.05,
-             suction_thresh=None) -> Cfg:
+             suction_thresh=None, noise_mu=None, noise_sigma=None, noise_abs_cost=False) -> Cfg:
+    """noise_sigma: the full [nu][nu] matrix (overrides noise_sigma_diag); its Cholesky factor and inverse are
+    formed in binary64 and rounded to f32 -- for a diagonal matrix that is sqrtf / 1.0f/x bit for bit."""
     c = Cfg()
     c.K, c.T, c.nu = int(K), int(T), int(nu)
     c.multi_modal = int(bool(multi_modal))
@@ -160,8 +165,20 @@ def make_cfg(K, T, nu=2, multi_modal=False, env_type="point_env", task="push", g
         u_min = [-3.0] * nu
     if u_max is None:
         u_max = [3.0] * nu
+    if noise_sigma is not None:
+        sig = np.array(noise_sigma, np.float32).astype(np.float64)
+        noise_sigma_diag = [float(sig[j, j]) for j in range(nu)]
+        if np.any(sig != np.diag(np.diag(sig))):
+            c.full_sigma = 1
+            L, inv = np.linalg.cholesky(sig).astype(np.float32), np.linalg.inv(sig).astype(np.float32)
+            for i in range(nu):
+                for j in range(nu):
+                    c.chol[i * nu + j], c.sigma_inv_full[i * nu + j] = float(L[i, j]), float(inv[i, j])
     if noise_sigma_diag is None:
         noise_sigma_diag = [3.0] * nu
+    c.noise_abs_cost = int(bool(noise_abs_cost))
+    for j in range(nu):
+        c.noise_mu[j] = float(noise_mu[j]) if noise_mu is not None else 0.0
     for j in range(nu):
         c.u_min[j], c.u_max[j] = float(u_min[j]), float(u_max[j])
         c.scale_tril[j] = float(np.sqrt(np.float32(noise_sigma_diag[j])))
@@ -316,6 +333,13 @@ def gauss_fill(seed, call, K, T, nu, k0=0):
     return out
 
 
+def noise_fill(cfg, seed, call, K, k0=0):
+    """[K, T, nu] draws of N(noise_mu, noise_sigma) from the build's stream (mppi.py:129-131, :340, :481)."""
+    out = np.zeros((K, cfg.T, cfg.nu), np.float32)
+    load().m3o_noise_fill(C.byref(cfg), seed, call, k0, K, _fp(out))
+    return out
+
+
 def ori_cube2goal(qc, qg):
     return load().m3o_ori_cube2goal(_fp(f32(qc)), _fp(f32(qg)))
 
@@ -333,8 +357,11 @@ class OraclePointPlanner:
     Supports sharding (rank, world_size) so gloo tests can exercise the N>1 host logic.
     """
 
-    def __init__(self, cfg: Cfg, delta=None, scene=None, seed=0):
+    def __init__(self, cfg: Cfg, delta=None, scene=None, seed=0, update_cov=False):
         self.cfg = cfg
+        # mppi.py:201-203, :508-516 (single-mode halton-spline only: the multi-modal update has no such branch)
+        self.update_cov = bool(update_cov) and not cfg.multi_modal and not cfg.mode_simple
+        self.cov_action = np.array([np.float32(cfg.scale_tril[j]) ** 2 for j in range(cfg.nu)], np.float32)
         self.sc = scene or default_scene()
         K, T, nu = cfg.K, cfg.T, cfg.nu
         self.delta = None if delta is None else f32(delta).copy()
@@ -359,8 +386,8 @@ class OraclePointPlanner:
             self.mean1, self.mean2 = shift(self.mean1), shift(self.mean2)
             self.best1, self.best2 = shift(self.best1), shift(self.best2)
         if self.delta is None:  # sampling_method == 'random' (mppi.py:386-387,481; quirk Q4)
-            st = np.array([cfg.scale_tril[j] for j in range(nu)], np.float32)
-            delta = gauss_fill(self.seed, self.calls, K, T, nu) * st
+            delta = noise_fill(cfg, self.seed, self.calls, K)
+            delta[-1] = 0.0      # mppi.py:392
         else:
             delta = self.delta
         act = assemble_actions(cfg, delta, self.mean, self.mean1, self.mean2, self.best1,
@@ -376,6 +403,14 @@ class OraclePointPlanner:
             self.best2 = r["actions"][K // 2 + info.best_idx_2].copy()
         else:
             self.best = r["actions"][info.best_idx].copy()
+        if self.update_cov:
+            d = (r["actions"] - self.mean[None]).astype(np.float64)      # delta of mppi.py:506 (new mean)
+            upd = ((w.astype(np.float64)[:, None, None] * d * d).sum(axis=0).mean(axis=0)).astype(np.float32)
+            f = np.float32
+            self.cov_action = (f(1.0 - 0.7) * self.cov_action + f(0.7) * upd).astype(f)   # :514
+            self.cov_action = (self.cov_action + f(0.005)).astype(f)                      # :515
+            for j in range(nu):
+                cfg.scale_tril[j] = float(np.sqrt(self.cov_action[j]))                    # :516
         action = self.mean.copy()
         top_idx, top_val = topk(w, min(20, K))
         top_trajs = r["states"][top_idx][:, :, [0, 2]]
@@ -390,8 +425,7 @@ class OraclePointPlanner:
         cfg = self.cfg
         K, T, nu = cfg.K, cfg.T, cfg.nu
         self.U = np.roll(self.U, -1, axis=0)  # mppi.py:221
-        st = np.array([cfg.scale_tril[j] for j in range(nu)], np.float32)
-        noise = gauss_fill(self.seed, self.calls, K, T, nu) * st  # mppi.py:340
+        noise = noise_fill(cfg, self.seed, self.calls, K)  # mppi.py:340
         lo = np.array([cfg.u_min[j] for j in range(nu)], np.float32)
         hi = np.array([cfg.u_max[j] for j in range(nu)], np.float32)
         act = np.maximum(np.minimum(self.U[None] + noise, hi), lo).astype(np.float32)

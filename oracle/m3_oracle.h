@@ -110,6 +110,13 @@ typedef struct {
     int gripper_cmd;       /* 0 undefined, 1 open, 2 close (m3p2i.py:10-14) */
     float pre_height_diff; /* config_panda.yaml:9 */
     float tilt_cos_theta;  /* cost_functions.py:13 */
+    /* the MPPIConfig switches no shipped config turns on (mppi.py:39-54) */
+    int noise_abs_cost;    /* mppi.py:366-367 */
+    int full_sigma;        /* 1: noise_sigma has off-diagonal entries: chol / sigma_inv_full are used where the
+                              reference uses the whole matrix (MultivariateNormal :129-131, the action cost :366-372) */
+    float noise_mu[M3O_MAX_NU];                        /* mppi.py:127 */
+    float chol[M3O_MAX_NU * M3O_MAX_NU];               /* row-major lower Cholesky factor of noise_sigma */
+    float sigma_inv_full[M3O_MAX_NU * M3O_MAX_NU];     /* mppi.py:128 */
 } m3o_cfg;
 
 /* A4: delta[K,T,nu] (global) -> act[(k1-k0),T,nu] for global samples k0..k1-1.
@@ -177,6 +184,7 @@ float m3o_gauss(unsigned long long seed, unsigned call, unsigned k, unsigned t, 
 
 void m3o_gauss_fill(unsigned long long seed, unsigned call, int k0, int n, int T, int nu,
                     float* out);
+void m3o_noise_fill(const m3o_cfg* cfg, unsigned long long seed, unsigned call, int k0, int n, float* out);
 
 /* ---- panda_env: "Panda chain spec v1"  ---- */
 typedef struct {

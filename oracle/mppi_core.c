@@ -179,8 +179,9 @@ void m3o_point_rollout(const m3o_cfg* cfg, const m3o_point_scene* sc,
             st[0] = w.R.x; st[1] = w.R.vx; st[2] = w.R.y; st[3] = w.R.vy; /* :66-69 */
             float c = m3o_point_cost(cfg, &w, k);         /* reactive_tamp.py:72-73 */
             cost_h[(size_t)i * T + t] = c;                /* mppi.py:310 */
-            for (int d = 0; d < 2; ++d)                   /* mppi.py:313 then :421 */
-                actions[((size_t)i * T + t) * nu + d] = u[d] / cfg->u_scale;
+            for (int d = 0; d < 2; ++d)                   /* mppi.py:313: the SCALED controls are what the */
+                actions[((size_t)i * T + t) * nu + d] = u[d];   /* update consumes (:329-331); :353,:420 */
+                                                          /* divide only the attribute the caller reads  */
             j = j + g * c;                                /* mppi_utils.py:106-113, col 0 */
             s = s + c;                                    /* mppi.py:309 */
             g = g * cfg->gamma;
@@ -383,8 +384,8 @@ void m3o_shift(float* seq, int T, int nu) {
 
 /* simple mode: mppi.py:220-233 with _compute_total_cost_batch_simple :335-363.
  * cost_total = S + mean(S)  (aliasing quirk Q1, mppi.py:284,325)
- *            + sum_{t,j} U * lambda * noise * sigma_inv   (:358-362, diagonal Sigma)
- * noise = perturbed - U (after clamping, :355) */
+ *            + sum_{t,j} U * ((lambda * noise) @ sigma_inv)   (:358-372; |noise| with noise_abs_cost)
+ * noise = perturbed - U (after clamping, :355; `perturbed` holds the u_scale-d controls, :311) */
 void m3o_simple_update(const m3o_cfg* cfg, const float* S, const float* perturbed, float* U,
                        float* cost_total, float* w) {
     const int K = cfg->K, T = cfg->T, nu = cfg->nu, n = T * nu;
@@ -393,10 +394,21 @@ void m3o_simple_update(const m3o_cfg* cfg, const float* S, const float* perturbe
     float meanS = (float)(ms / (double)K);
     for (int k = 0; k < K; ++k) {
         double pc = 0.0;
-        for (int i = 0; i < n; ++i) {
-            float noise = perturbed[(size_t)k * n + i] - U[i];
-            float ac = cfg->lambda_ * noise * cfg->sigma_inv[i % nu];
-            pc += (double)(U[i] * ac);
+        for (int t = 0; t < T; ++t) {
+            float ln[M3O_MAX_NU];
+            for (int j = 0; j < nu; ++j) {
+                float noise = perturbed[(size_t)k * n + t * nu + j] - U[t * nu + j];
+                if (cfg->noise_abs_cost) noise = fabsf(noise);           /* :366-367 */
+                ln[j] = cfg->lambda_ * noise;
+            }
+            for (int j = 0; j < nu; ++j) {
+                float ac;
+                if (cfg->full_sigma) {                                    /* (lambda * noise) @ Sigma^-1 */
+                    ac = ln[0] * cfg->sigma_inv_full[0 * nu + j];
+                    for (int i = 1; i < nu; ++i) ac = ac + ln[i] * cfg->sigma_inv_full[i * nu + j];
+                } else ac = ln[j] * cfg->sigma_inv[j];
+                pc += (double)(U[t * nu + j] * ac);
+            }
         }
         cost_total[k] = (S[k] + meanS) + (float)pc;
     }
@@ -460,6 +472,25 @@ void m3o_gauss_fill(unsigned long long seed, unsigned call, int k0, int n, int T
             for (int j = 0; j < nu; ++j)
                 out[((size_t)i * T + t) * nu + j] =
                     m3o_gauss(seed, call, (unsigned)(k0 + i), (unsigned)t, (unsigned)j);
+}
+
+/* N(noise_mu, noise_sigma) draws of the stream (MultivariateNormal(...).sample, mppi.py:129-131, :340, :481):
+ * d_j = mu_j + sum_{i<=j} L[j][i] z_i, accumulated i = 0, 1, .. (diagonal Sigma: mu_j + scale_tril_j z_j) */
+void m3o_noise_fill(const m3o_cfg* cfg, unsigned long long seed, unsigned call, int k0, int n, float* out) {
+    const int T = cfg->T, nu = cfg->nu;
+    for (int i = 0; i < n; ++i)
+        for (int t = 0; t < T; ++t) {
+            float z[M3O_MAX_NU];
+            for (int j = 0; j < nu; ++j) z[j] = m3o_gauss(seed, call, (unsigned)(k0 + i), (unsigned)t, (unsigned)j);
+            for (int j = 0; j < nu; ++j) {
+                float acc;
+                if (cfg->full_sigma) {
+                    acc = cfg->chol[j * nu + 0] * z[0];
+                    for (int q = 1; q <= j; ++q) acc = acc + cfg->chol[j * nu + q] * z[q];
+                } else acc = z[j] * cfg->scale_tril[j];
+                out[((size_t)i * T + t) * nu + j] = cfg->noise_mu[j] + acc;
+            }
+        }
 }
 
 /* ------------------------------------------------------------------------------------

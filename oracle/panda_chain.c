@@ -443,7 +443,7 @@ void m3o_panda_rollout(const m3o_cfg* cfg, const m3o_panda_scene* sc, const m3o_
             m3o_panda_observe(sc, &w, &o);
             float c = m3o_panda_cost_obs(cfg, &o, k);
             cost_h[(size_t)i * T + t] = c;
-            for (int d = 0; d < nu; ++d) actions[((size_t)i * T + t) * nu + d] = u[d] / cfg->u_scale;
+            for (int d = 0; d < nu; ++d) actions[((size_t)i * T + t) * nu + d] = u[d];   /* mppi.py:313 (scaled, as the update sees it) */
             j = j + g * c;
             g = g * cfg->gamma;
         }

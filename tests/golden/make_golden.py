@@ -369,7 +369,7 @@ def halton_delta(K, T, nu):
     return delta
 
 
-def g9_trace(tag, cfg, ncalls, world0, closed_loop=True, noise_stream=False, seed=7):
+def g9_trace(tag, cfg, ncalls, world0, closed_loop=True, noise_stream=False, seed=7, extra=None):
     """reactive_tamp.py wiring (:22-41, :43-73) around the reference planner."""
     K, T = cfg.mppi.num_samples, cfg.mppi.horizon
     sim = refshim.OracleSim(K, world0)
@@ -393,16 +393,28 @@ def g9_trace(tag, cfg, ncalls, world0, closed_loop=True, noise_stream=False, see
     if noise_stream:
         # replace torch's global RNG draw (mppi.py:340 / :481) by the build's counter-based
         # stream so both sides see identical noise: N(0, Sigma) = z * sqrt(diag Sigma)
+        # (noise_mu + L z with L = chol(noise_sigma), accumulated in the order DESIGN.md section 5 fixes;
+        # for the diagonal default this is z * sqrt(3) bit for bit)
+        sig = np.array(cfg.mppi.noise_sigma, np.float64)
+        Lc = np.linalg.cholesky(sig).astype(np.float32)
+        mu = np.array(cfg.mppi.noise_mu or [0.0, 0.0], np.float32)
+
         class Dist:
             def sample(self, shape):
                 z = O.gauss_fill(seed, calls[0], K, T, 2)
-                return torch.from_numpy(z * np.sqrt(np.float32(3.0)))
+                d = np.zeros_like(z)
+                for j in range(2):
+                    acc = Lc[j, 0] * z[..., 0] if j else Lc[0, 0] * z[..., 0]
+                    if j:
+                        acc = (acc + Lc[1, 1] * z[..., 1]).astype(np.float32)
+                    d[..., j] = (mu[j] + acc).astype(np.float32)
+                return torch.from_numpy(d)
 
         pl.noise_dist = Dist()
         if cfg.mppi.mppi_mode == "simple":
             pl.U = torch.zeros(T, 2)  # reference draws U from the global RNG (mppi.py:134)
     sc = O.default_scene()
-    acts, ws, tops, prefs, worlds, means, Js = [], [], [], [], [], [], []
+    acts, ws, tops, prefs, worlds, means, Js, extras = [], [], [], [], [], [], [], []
     for call in range(ncalls):
         worlds.append(real[0].copy())
         sim.reset(real[0])
@@ -419,8 +431,12 @@ def g9_trace(tag, cfg, ncalls, world0, closed_loop=True, noise_stream=False, see
             means.append(pl.mean_action.numpy().copy())
             Js.append(pl.total_costs.numpy().copy() if hasattr(pl, "total_costs") and
                       not cfg.multi_modal else np.zeros(K, np.float32))
+        if extra is not None:
+            extras.append(extra(pl))
         if closed_loop:
             O.step_batch(sc, real, a[0:1].numpy())
+    if extras:
+        out[f"g9_{tag}_extra"] = np.stack(extras)
     out[f"g9_{tag}_world"] = np.stack(worlds)
     out[f"g9_{tag}_action"] = np.stack(acts)
     out[f"g9_{tag}_weights"] = np.stack(ws)
@@ -454,6 +470,41 @@ def g9():
     # halton-spline + random sampling (quirk Q4: noise scaled twice)
     cfg = point_cfg(128, 12, task="navigation", goal=(-3.0, 3.0), sampling="random")
     g9_trace("navr", cfg, 4, w0, noise_stream=True)
+
+
+# ---------------------------------------------------------------- G11 the optional branches of command()
+def g11():
+    """Reference traces of the MPPIConfig switches no shipped config turns on (mppi.py:39-54): u_scale != 1
+    (:297 -- the distribution update consumes the SCALED stack, :313,:331), U_init / u_init (dead: :122-123,
+    :132-133), noise_mu and a non-diagonal noise_sigma (MultivariateNormal, :129-131), noise_abs_cost
+    (:366-367), update_cov (:508-516)."""
+    w0 = O.init_world(1)[0]
+    w1 = w0.copy()
+    w1[0], w1[1] = 0.1, 1.45
+    cfg = point_cfg(256, 30, task="push", goal=(-1.0, 3.0))
+    cfg.mppi.u_scale = 0.5
+    g9_trace("opt_uscale", cfg, 4, w1)
+    cfg = point_cfg(256, 30, task="push", goal=(-1.0, 3.0))
+    cfg.mppi.U_init = [[1.0, -1.0]] * 30
+    cfg.mppi.u_init = 0.7
+    g9_trace("opt_dead", cfg, 3, w1)
+    cfg = point_cfg(256, 30, task="push", goal=(-1.0, 3.0))
+    cfg.mppi.update_cov = True
+    g9_trace("opt_cov", cfg, 5, w1, extra=lambda pl: pl.scale_tril.numpy().copy())
+    # simple mode: |noise| action cost, scaled controls, biased full-covariance noise
+    cfg = point_cfg(100, 10, task="navigation", goal=(-3.0, 3.0), mode="simple", sampling="random",
+                    filter_u=True, u_per_command=10)
+    cfg.mppi.noise_abs_cost = True
+    cfg.mppi.u_scale = 0.8
+    cfg.mppi.noise_mu = [0.3, -0.2]
+    cfg.mppi.noise_sigma = [[3.0, 1.0], [1.0, 2.0]]
+    g9_trace("opt_abs", cfg, 4, w0, noise_stream=True)
+    # halton-spline + random sampling with the same noise distribution (the sample is scaled once more by
+    # sqrt(diag Sigma), quirk Q4)
+    cfg = point_cfg(128, 12, task="navigation", goal=(-3.0, 3.0), sampling="random")
+    cfg.mppi.noise_mu = [0.3, -0.2]
+    cfg.mppi.noise_sigma = [[3.0, 1.0], [1.0, 2.0]]
+    g9_trace("opt_navr", cfg, 4, w0, noise_stream=True)
 
 
 # ---------------------------------------------------------------- G9 (panda): full command() traces
@@ -538,7 +589,7 @@ def g7_skill():
 
 
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6_g7, g7_quat, g6_panda, g8, g10, g9, g9_panda, g7_skill):
+    for fn in (g1, g2, g3, g4, g5, g6_g7, g7_quat, g6_panda, g8, g10, g9, g9_panda, g7_skill, g11):
         fn()
         print(fn.__name__, "ok")
     path = os.path.join(HERE, "ref_golden.npz")

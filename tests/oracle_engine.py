@@ -29,7 +29,12 @@ class OracleEngine:
             L.BUF_TOP_IDX: np.zeros(L.TOPK, np.int32), L.BUF_TOP_TRAJS: np.zeros((L.TOPK, T, 2), f),
             L.BUF_REDUCE: np.zeros(6 * T * nu + L.TOPK * T * 2, f),
             L.BUF_PENDING_FORCE: np.zeros((4, Kl), f),
+            L.BUF_COV: np.array([[c.noise_sigma_diag[j] for j in range(nu)],
+                                 [np.sqrt(f(c.noise_sigma_diag[j])) for j in range(nu)]], f),   # cov_action | scale_tril
         }
+        if c.mode_simple or c.sampling_random:
+            raise NotImplementedError("OracleEngine: halton-spline planners with an explicit noise table only")
+        self.cov_active = bool(c.update_cov) and not c.multi_modal
         for b in range(L.BUF_MEAN, L.BUF_ACTION_OUT + 1):
             self.np[b] = np.zeros((T, nu), f)
         self.regen = bool(c.shard_mix) and Kl != Kg and bool(c.multi_modal) and not c.mode_simple
@@ -101,11 +106,14 @@ class OracleEngine:
 
     def _ocfg(self):
         c = self.cfg
-        return O.make_cfg(self.Kg, self.T, self.nu, multi_modal=bool(c.multi_modal), task=self.task,
-                          goal=self.goal, u_min=list(c.u_min)[:self.nu], u_max=list(c.u_max)[:self.nu],
-                          noise_sigma_diag=list(c.noise_sigma_diag)[:self.nu], u_scale=c.u_scale,
-                          gamma=c.gamma, lambda_=c.lambda_, sample_null_action=bool(c.sample_null_action),
-                          filter_u=bool(c.filter_u), kp_suction=c.kp_suction)
+        o = O.make_cfg(self.Kg, self.T, self.nu, multi_modal=bool(c.multi_modal), task=self.task,
+                       goal=self.goal, u_min=list(c.u_min)[:self.nu], u_max=list(c.u_max)[:self.nu],
+                       noise_sigma_diag=list(c.noise_sigma_diag)[:self.nu], u_scale=c.u_scale,
+                       gamma=c.gamma, lambda_=c.lambda_, sample_null_action=bool(c.sample_null_action),
+                       filter_u=bool(c.filter_u), kp_suction=c.kp_suction)
+        for j in range(self.nu):
+            o.scale_tril[j] = float(self.np[L.BUF_COV][1, j])    # (update_cov rewrites it: mppi.py:516)
+        return o
 
     def _world0(self):
         dof, root, bi, di = self.bound
@@ -290,6 +298,14 @@ class OracleEngine:
         if getattr(self, "_action_out", None) is not None:
             self._action_out.copy_(self.t[L.BUF_ACTION_OUT])
         n[L.BUF_TOP_TRAJS][...] = red[6 * T * nu:].reshape(L.TOPK, T, 2)
+        if self.cov_active:   # mppi.py:508-516 (as oracle.OraclePointPlanner)
+            assert self.Kl == self.Kg
+            f = np.float32
+            d = (n[L.BUF_ACTIONS] - n[L.BUF_MEAN][:, None, :]).astype(np.float64)      # [T, K, nu]
+            upd = (n[L.BUF_WEIGHTS].astype(np.float64)[None, :, None] * d * d).sum(axis=1).mean(axis=0).astype(f)
+            cov = (f(1.0 - 0.7) * n[L.BUF_COV][0] + f(0.7) * upd).astype(f)
+            n[L.BUF_COV][0] = (cov + f(0.005)).astype(f)
+            n[L.BUF_COV][1] = np.sqrt(n[L.BUF_COV][0])
         self.calls += 1
 
     def set_action_out(self, tensor):

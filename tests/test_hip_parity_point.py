@@ -33,6 +33,14 @@ G9 = {
     "nav": dict(K=100, T=10, task="navigation", goal=(-3.0, 3.0), mode_simple=True,
                 u_per_command=10, lambda_=0.5),
     "navr": dict(K=128, T=12, task="navigation", goal=(-3.0, 3.0)),
+    # the MPPIConfig switches no shipped config turns on (reference traces: make_golden.py g11)
+    "opt_uscale": dict(K=256, T=30, task="push", goal=(-1.0, 3.0), u_scale=0.5),
+    "opt_cov": dict(K=256, T=30, task="push", goal=(-1.0, 3.0), update_cov=True),
+    "opt_abs": dict(K=100, T=10, task="navigation", goal=(-3.0, 3.0), mode_simple=True, u_per_command=10,
+                    lambda_=0.5, u_scale=0.8, noise_mu=[0.3, -0.2], noise_sigma=[[3.0, 1.0], [1.0, 2.0]],
+                    noise_abs_cost=True),
+    "opt_navr": dict(K=128, T=12, task="navigation", goal=(-3.0, 3.0), noise_mu=[0.3, -0.2],
+                     noise_sigma=[[3.0, 1.0], [1.0, 2.0]]),
 }
 
 
@@ -42,12 +50,15 @@ def make_pair(oracle, golden, tag, seed=7):
     task, goal = kw.pop("task"), kw.pop("goal")
     K, T = kw.pop("K"), kw.pop("T")
     delta = golden[f"g9_{tag}_delta"] if f"g9_{tag}_delta" in golden else None
+    update_cov = kw.pop("update_cov", False)
     ocfg = oracle.make_cfg(K, T, 2, task=task, goal=goal, **kw)
-    opl = oracle.OraclePointPlanner(ocfg, delta, seed=seed)
+    opl = oracle.OraclePointPlanner(ocfg, delta, seed=seed, update_cov=update_cov)
     eng = _engine(K=K, T=T, nu=2, multi_modal=kw.get("multi_modal", False),
                   mode_simple=kw.get("mode_simple", False), sampling_random=delta is None,
                   u_per_command=kw.get("u_per_command"), lambda_=kw.get("lambda_", 1.0),
-                  u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3], seed=seed)
+                  u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3], seed=seed,
+                  u_scale=kw.get("u_scale", 1.0), noise_mu=kw.get("noise_mu"), noise_sigma=kw.get("noise_sigma"),
+                  noise_abs_cost=kw.get("noise_abs_cost", False), update_cov=update_cov)
     eng.set_objective(task, goal)
     if delta is not None:
         eng.set_noise(delta)
@@ -87,6 +98,10 @@ def test_command_traces_vs_reference_and_oracle(golden, oracle, tag):
                 np.testing.assert_allclose(st, opl.last["states"], atol=1e-4)
                 np.testing.assert_allclose(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"],
                                            rtol=1e-5, atol=1e-4)
+        if f"g9_{tag}_extra" in golden:     # update_cov: scale_tril after the call (mppi.py:516)
+            np.testing.assert_allclose(eng.buffer(L.BUF_COV).cpu().numpy()[1], golden[f"g9_{tag}_extra"][call], rtol=1e-4)
+            np.testing.assert_allclose(eng.buffer(L.BUF_COV).cpu().numpy()[1], [opl.cfg.scale_tril[j] for j in range(2)],
+                                       rtol=1e-4)
         info = eng.info()
         if G9[tag].get("multi_modal"):
             assert info.pull_preference == int(golden[f"g9_{tag}_pref"][call])

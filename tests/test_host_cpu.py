@@ -109,8 +109,8 @@ def test_objective_goal_host_copy_is_cached_until_the_goal_changes():
 
 def test_non_diagonal_noise_sigma_uses_its_diagonal_in_halton_spline_mode():
     """mppi.py:175-176: scale_tril = sqrt(diagonal(noise_sigma)) -- the reference's halton-spline path never
-    reads the off-diagonal entries, so a full matrix plans exactly like its diagonal; the modes that sample
-    from MultivariateNormal(noise_sigma) are refused for a non-diagonal matrix."""
+    reads the off-diagonal entries, so a full matrix plans exactly like its diagonal; the whole matrix travels to the
+    library (noise_sigma_full) for the modes that sample from MultivariateNormal(noise_sigma)."""
     from types import SimpleNamespace
     import pytest
     import torch
@@ -126,10 +126,8 @@ def test_non_diagonal_noise_sigma_uses_its_diagonal_in_halton_spline_mode():
                                            pre_height_diff=0.0, task="push", goal=[0.0, 0.0], cube_on_shelf=False, mppi=m))
         full, diag = make([[3.0, 0.7], [0.7, 2.0]]), make([[3.0, 0.0], [0.0, 2.0]])
         assert torch.equal(full.scale_tril, diag.scale_tril)
-        assert list(full._engine.cfg.noise_sigma_diag)[:2] == [3.0, 2.0]
-        with pytest.raises(NotImplementedError):
-            make([[3.0, 0.7], [0.7, 2.0]], sampling_method="random")
-        with pytest.raises(NotImplementedError):
-            make([[3.0, 0.7], [0.7, 2.0]], mppi_mode="simple")
+        c = full._engine.cfg
+        assert list(c.noise_sigma_diag)[:2] == [3.0, 2.0] and c.full_sigma == 1 and diag._engine.cfg.full_sigma == 0
+        assert [round(v, 6) for v in list(c.noise_sigma_full)[:4]] == [3.0, 0.7, 0.7, 2.0]
     finally:
         P.ENGINE_CLS = old

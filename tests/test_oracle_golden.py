@@ -182,14 +182,24 @@ G9 = {
     "nav": dict(K=100, T=10, task="navigation", goal=(-3.0, 3.0), mode_simple=True,
                 u_per_command=10, lambda_=0.5),
     "navr": dict(K=128, T=12, task="navigation", goal=(-3.0, 3.0)),
+    # the MPPIConfig switches no shipped config turns on (reference traces: make_golden.py g11)
+    "opt_uscale": dict(K=256, T=30, task="push", goal=(-1.0, 3.0), u_scale=0.5),
+    "opt_dead": dict(K=256, T=30, task="push", goal=(-1.0, 3.0)),            # U_init / u_init: dead parameters
+    "opt_cov": dict(K=256, T=30, task="push", goal=(-1.0, 3.0), update_cov=True),
+    "opt_abs": dict(K=100, T=10, task="navigation", goal=(-3.0, 3.0), mode_simple=True, u_per_command=10,
+                    lambda_=0.5, u_scale=0.8, noise_mu=[0.3, -0.2], noise_sigma=[[3.0, 1.0], [1.0, 2.0]],
+                    noise_abs_cost=True),
+    "opt_navr": dict(K=128, T=12, task="navigation", goal=(-3.0, 3.0), noise_mu=[0.3, -0.2],
+                     noise_sigma=[[3.0, 1.0], [1.0, 2.0]]),
 }
 
 
 def g9_planner(oracle, golden, tag, seed=7):
     kw = dict(G9[tag])
+    update_cov = kw.pop("update_cov", False)
     cfg = oracle.make_cfg(kw.pop("K"), kw.pop("T"), 2, **kw)
     delta = golden[f"g9_{tag}_delta"] if f"g9_{tag}_delta" in golden else None
-    return cfg, oracle.OraclePointPlanner(cfg, delta, seed=seed)
+    return cfg, oracle.OraclePointPlanner(cfg, delta, seed=seed, update_cov=update_cov)
 
 
 @pytest.mark.parametrize("tag", list(G9))
@@ -213,6 +223,8 @@ def test_g9_command_traces(golden, oracle, tag):
             assert pl.pull_preference() == int(golden[f"g9_{tag}_pref"][call]) or \
                 not cfg.multi_modal
         # top-20 trajectories: compare as sets of rows (ties in weights may reorder)
+        if f"g9_{tag}_extra" in golden:      # update_cov: scale_tril after the call (mppi.py:516)
+            np.testing.assert_allclose([cfg.scale_tril[j] for j in range(2)], golden[f"g9_{tag}_extra"][call], rtol=1e-4)
         ref_top = golden[f"g9_{tag}_top_trajs"][call]
         got = pl.last["top_trajs"]
         assert got.shape == ref_top.shape
@@ -225,6 +237,15 @@ def test_g9_command_traces(golden, oracle, tag):
     # (ulp 1.2e-4) two correct implementations differ by ~2e-3 there (torch's cumsum is not
     # bit-reproducible by a sequential sum).  The returned control stays within 1e-4.
     tol = 5e-3 if cfg.multi_modal else 5e-4
-    np.testing.assert_allclose(pl.last["actions"], golden[f"g9_{tag}_actions_last"], atol=tol)
+    # (the reference's `actions` attribute is the scaled stack divided by u_scale, mppi.py:353 / :420)
+    np.testing.assert_allclose(pl.last["actions"] / np.float32(cfg.u_scale), golden[f"g9_{tag}_actions_last"], atol=tol)
     ds = np.abs(pl.last["states"] - golden[f"g9_{tag}_states_last"]).max(axis=(1, 2))
     assert np.quantile(ds, 0.5) < 1e-3 and ds.max() < 2e-2
+
+
+def test_u_init_parameters_are_dead_in_the_reference(golden):
+    """MPPIConfig.U_init / u_init are stored and never read (mppi.py:122-123, :132-133, the use is commented
+    out): a reference planner given both produces the trace of one without."""
+    n = golden["g9_opt_dead_action"].shape[0]
+    for key in ("action", "weights", "mean", "top_trajs"):
+        np.testing.assert_array_equal(golden[f"g9_opt_dead_{key}"], golden[f"g9_pushc_{key}"][:n])
