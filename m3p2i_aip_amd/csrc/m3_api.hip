@@ -122,8 +122,6 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (c->env_type == M3_ENV_POINT && c->nu != 2) return fail(nullptr, M3_ERR_SHAPE, "m3_create: point_env needs nu == 2");
     if (c->env_type == M3_ENV_PANDA && c->nu != 9) return fail(nullptr, M3_ERR_SHAPE, "m3_create: panda_env needs nu == 9");
     if (c->env_type != M3_ENV_POINT && c->env_type != M3_ENV_PANDA) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: bad env_type");
-    if (c->env_type == M3_ENV_PANDA && (c->mode_simple || c->sampling_random))
-        return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: panda_env supports mppi_mode='halton-spline' with explicit noise only");
     if (!c->sim_only) {
         if (c->K_global < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: K must be >= 20 (torch.topk(weights, 20), mppi.py:248)");
         if (c->filter_u && (c->mode_simple ? c->u_per_command : c->T) < 9)

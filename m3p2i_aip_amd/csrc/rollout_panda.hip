@@ -7,6 +7,7 @@
 // state (reactive_tamp.py:66-70), so states stay [T][K][4]; actions are [T][K][9].
 // Algorithmic traffic per state-step: delta 36 B read; state 16 + action 36 + cost 4 B written.
 #include "m3_internal.hpp"
+#include "noise_stream.hpp"
 #include "panda_dyn.hpp"
 
 namespace m3 {
@@ -45,7 +46,11 @@ __device__ __forceinline__ float in_vgpr(float v) {   // keep a uniform value in
     return v;
 }
 
-template <bool FORCES>
+// GENERAL = false: the reference's default sampler (halton-spline noise table), the path of every BASELINE
+// config.  GENERAL = true adds what no shipped config turns on: the in-kernel random stream with a noise mean and a
+// full covariance (sampling_method = 'random', mppi.py:129-131, :481; quirk Q4: that sample is scaled by
+// sqrt(diag Sigma) once more) and mppi_mode = 'simple' (mppi.py:220-233, :335-372).
+template <bool FORCES, bool GENERAL>
 __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, const PandaArgs pa,
                                                       const PandaScene sc_) {
     const int i = blockIdx.x * 64 + threadIdx.x;
@@ -57,6 +62,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
     // one wave per SIMD, so they are parked there once.
     RolloutArgs a = a_;
     PandaScene sc = sc_;
+    if constexpr (!GENERAL) { a.sampling_random = 0; a.mode_simple = 0; a.full_sigma = 0; a.noise_abs_cost = 0; }
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         a.u_min[j] = in_vgpr(a_.u_min[j]); a.u_max[j] = in_vgpr(a_.u_max[j]);
@@ -74,37 +80,61 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
 
     const bool is_last = (k == a.Kg - 1);
     const bool first_half = k < pa.cp.half_K;
+    const bool halton = !a.mode_simple;
     const float* mptr = a.mean;
-    if (a.multi_modal) mptr = first_half ? a.mean1 : a.mean2;
+    if (a.multi_modal && halton) mptr = first_half ? a.mean1 : a.mean2;
 
     // inputs of step t+1 are fetched before step t is simulated (one wavefront per SIMD: nothing
     // else hides the latency of a load that is consumed at once)
-    const bool use_best = a.multi_modal && (k == 0 || k == pa.cp.half_K);
+    const bool use_best = halton && a.multi_modal && (k == 0 || k == pa.cp.half_K);
     const float* bptr = (k == 0) ? a.best1 : a.best2;
     float nd[9], nm[9];
     auto fetch = [&](int t) {
-        const int ts = (t + 1 < T) ? t + 1 : T - 1;  // _shift_action: mppi.py:266-273
+        // _shift_action: mppi.py:266-273; simple mode: torch.roll(U, -1), mppi.py:221
+        const int ts = a.mode_simple ? ((t + 1 == T) ? 0 : t + 1) : ((t + 1 < T) ? t + 1 : T - 1);
         const float* dptr = a.delta + ((size_t)t * Kl + i) * 9;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            nd[j] = dptr[j];
+            nd[j] = a.sampling_random ? 0.0f : dptr[j];
             nm[j] = use_best ? bptr[ts * 9 + j] : mptr[ts * 9 + j];
         }
     };
     fetch(0);
-    float J = 0.0f, g = 1.0f;
+    float J = 0.0f, g = 1.0f, S = 0.0f, pc = 0.0f;
     for (int t = 0; t < T; ++t) {
         float cd[9], cm[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) { cd[j] = nd[j]; cm[j] = nm[j]; }
         if (t + 1 < T) fetch(t + 1);
+        if constexpr (GENERAL) {
+            if (a.sampling_random) {   // N(noise_mu, noise_sigma) = mu + L z (noise_stream.hpp; order as the oracle)
+                float z[10];
+#pragma unroll
+                for (int p = 0; p < 5; ++p) gauss_pair(a.seed, a.call, (unsigned)k, (unsigned)t, (unsigned)p, z[2 * p], z[2 * p + 1]);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    float acc;
+                    if (a.full_sigma) {
+                        acc = a.noise_mats[j * 9 + 0] * z[0];
+#pragma unroll
+                        for (int q = 1; q <= j; ++q) acc = acc + a.noise_mats[j * 9 + q] * z[q];
+                    } else acc = z[j] * a_.scale_tril[j];   // (the configured scale, not update_cov's)
+                    cd[j] = a.noise_mu[j] + acc;
+                }
+            }
+        }
         float u[9], e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            const float d = is_last ? 0.0f : cd[j];                                    // mppi.py:392
-            float aj = fmaxf(fminf(cm[j] + d * a.scale_tril[j], a.u_max[j]), a.u_min[j]);
-            if (use_best) aj = cm[j];                                                  // :407-409
-            if (j >= 7) {                                                              // :412-416
+            float aj;
+            if (GENERAL && a.mode_simple) {
+                aj = fmaxf(fminf(cm[j] + cd[j], a.u_max[j]), a.u_min[j]);             // mppi.py:341-345
+            } else {
+                const float d = is_last ? 0.0f : cd[j];                                // mppi.py:392
+                aj = fmaxf(fminf(cm[j] + d * a.scale_tril[j], a.u_max[j]), a.u_min[j]);
+                if (use_best) aj = cm[j];                                              // :407-409
+            }
+            if (j >= 7) {                                                              // :412-416 / :346-350
                 if (a.gripper_cmd == 1) aj = 1.5f;
                 else if (a.gripper_cmd == 2) aj = -1.5f;
             }
@@ -124,13 +154,39 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         a.cost_h[(size_t)t * Kl + i] = c;
         J = J + g * c;
         g = g * a.gamma;
+        if constexpr (GENERAL) {
+            if (a.mode_simple) {   // mppi.py:309 and the perturbation cost :355-372: sum U * ((lambda * noise) @ Sigma^-1)
+                S = S + c;
+                float ln[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    float n = e[j] - cm[j];
+                    if (a.noise_abs_cost) n = fabsf(n);
+                    ln[j] = a.lambda_ * n;
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    float ac;
+                    if (a.full_sigma) {
+                        ac = ln[0] * a.noise_mats[81 + 0 * 9 + j];
+#pragma unroll
+                        for (int q = 1; q < 9; ++q) ac = ac + ln[q] * a.noise_mats[81 + q * 9 + j];
+                    } else ac = ln[j] * a.sigma_inv[j];
+                    pc = pc + cm[j] * ac;
+                }
+            }
+        }
     }
-    a.J[i] = J;
+    a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
 }
 
 void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
-    if (pa.cp.task == 5) hipLaunchKernelGGL(k_rollout_panda<true>, dim3((a.Kl + 63) / 64), dim3(64), 0, s, a, pa, sc);
-    else hipLaunchKernelGGL(k_rollout_panda<false>, dim3((a.Kl + 63) / 64), dim3(64), 0, s, a, pa, sc);
+    const dim3 grid((a.Kl + 63) / 64), block(64);
+    if (a.sampling_random || a.mode_simple) {
+        if (pa.cp.task == 5) hipLaunchKernelGGL((k_rollout_panda<true, true>), grid, block, 0, s, a, pa, sc);
+        else hipLaunchKernelGGL((k_rollout_panda<false, true>), grid, block, 0, s, a, pa, sc);
+    } else if (pa.cp.task == 5) hipLaunchKernelGGL((k_rollout_panda<true, false>), grid, block, 0, s, a, pa, sc);
+    else hipLaunchKernelGGL((k_rollout_panda<false, false>), grid, block, 0, s, a, pa, sc);
 }
 
 // ======================= step mode ======================================================

@@ -16,40 +16,9 @@
 // 8 B + cost 4 B = 36 B (28 B with in-kernel noise); the update pass re-reads actions (8 B).
 #pragma once
 #include "m3_internal.hpp"
+#include "noise_stream.hpp"
 
 namespace m3 {
-
-// ---- counter-based noise stream (spec: DESIGN.md "Noise stream"; mirrors the oracle) ----
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long& x) {
-    unsigned long long z = (x += 0x9E3779B97F4A7C15ULL);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ unsigned rotl32(unsigned x, int k) { return (x << k) | (x >> (32 - k)); }
-__device__ __forceinline__ unsigned xoshiro128pp(unsigned (&s)[4]) {
-    const unsigned result = rotl32(s[0] + s[3], 7) + s[0];
-    const unsigned t = s[1] << 9;
-    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = rotl32(s[3], 11);
-    return result;
-}
-// standard-normal pair for (seed, call, k, t, pair)
-__device__ __forceinline__ void gauss_pair(unsigned long long seed, unsigned call, unsigned k,
-                                           unsigned t, unsigned pair, float& z0, float& z1) {
-    unsigned long long x = seed ^ (0xD1B54A32D192ED03ULL * (unsigned long long)(call + 1u));
-    x ^= ((unsigned long long)k << 32) | ((unsigned long long)t << 8) | (unsigned long long)pair;
-    const unsigned long long a = splitmix64(x), b = splitmix64(x);
-    unsigned s[4] = {(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
-    const unsigned r0 = xoshiro128pp(s), r1 = xoshiro128pp(s);
-    const float u0 = ((float)(r0 >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float u1 = (float)(r1 >> 8) * (1.0f / 16777216.0f);
-    const float rad = sqrtf(-2.0f * logf(u0));
-    const float ang = 6.28318530717958647692f * u1;
-    z0 = rad * cosf(ang);
-    z1 = rad * sinf(ang);
-}
 
 __device__ __forceinline__ void load_world(const float* p, PointWorld& w) {
     w.rx = p[0]; w.ry = p[1]; w.rvx = p[2]; w.rvy = p[3];
@@ -135,9 +104,10 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a_, cons
 
     // the MPPIConfig switches no shipped config turns on (general instance only): scale_tril rewritten by
     // update_cov (mppi.py:516), Cholesky factor / inverse of a non-diagonal noise_sigma (mppi.py:128-131)
-    if (a.scale_dev) { a.scale_tril[0] = a.scale_dev[0]; a.scale_tril[1] = a.scale_dev[1]; }
+    // (the sampling distribution keeps the configured covariance: only scale_tril is rewritten, mppi.py:129-131 vs :516)
     float L10 = 0.0f, L00 = a.scale_tril[0], L11 = a.scale_tril[1];
     float S00 = a.sigma_inv[0], S01 = 0.0f, S10 = 0.0f, S11 = a.sigma_inv[1];
+    if (a.scale_dev) { a.scale_tril[0] = a.scale_dev[0]; a.scale_tril[1] = a.scale_dev[1]; }
     if (a.full_sigma) {
         L00 = a.noise_mats[0]; L10 = a.noise_mats[2]; L11 = a.noise_mats[3];
         S00 = a.noise_mats[4]; S01 = a.noise_mats[5]; S10 = a.noise_mats[6]; S11 = a.noise_mats[7];

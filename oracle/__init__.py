@@ -176,6 +176,9 @@ def make_cfg(K, T, nu=2, multi_modal=False, env_type="point_env", task="push", g
                     c.chol[i * nu + j], c.sigma_inv_full[i * nu + j] = float(L[i, j]), float(inv[i, j])
     if noise_sigma_diag is None:
         noise_sigma_diag = [3.0] * nu
+    for j in range(nu):      # diagonal of the Cholesky factor: the sampling scale of a diagonal noise_sigma
+        if not c.full_sigma:
+            c.chol[j * nu + j] = float(np.sqrt(np.float32(noise_sigma_diag[j])))
     c.noise_abs_cost = int(bool(noise_abs_cost))
     for j in range(nu):
         c.noise_mu[j] = float(noise_mu[j]) if noise_mu is not None else 0.0
@@ -392,7 +395,7 @@ class OraclePointPlanner:
             delta = self.delta
         act = assemble_actions(cfg, delta, self.mean, self.mean1, self.mean2, self.best1,
                                self.best2)
-        r = point_rollout(cfg, self.sc, world0, act, self.pend)
+        r = self._rollout(world0, act)
         w, w1, w2, info = update_weights(cfg, r["J"], self.beta)
         self.beta = info.beta
         ps = partial_sums(cfg, w, w1, w2, r["actions"])
@@ -421,6 +424,9 @@ class OraclePointPlanner:
                          act=act, action=action)
         return action
 
+    def _rollout(self, world0, act):
+        return point_rollout(self.cfg, self.sc, world0, act, self.pend)
+
     def _command_simple(self, world0):
         cfg = self.cfg
         K, T, nu = cfg.K, cfg.T, cfg.nu
@@ -429,7 +435,9 @@ class OraclePointPlanner:
         lo = np.array([cfg.u_min[j] for j in range(nu)], np.float32)
         hi = np.array([cfg.u_max[j] for j in range(nu)], np.float32)
         act = np.maximum(np.minimum(self.U[None] + noise, hi), lo).astype(np.float32)
-        r = point_rollout(cfg, self.sc, world0, act, self.pend)
+        if cfg.env_type == 1 and cfg.gripper_cmd:                      # mppi.py:346-350
+            act[:, :, 7:] = 1.5 if cfg.gripper_cmd == 1 else -1.5
+        r = self._rollout(world0, act)
         self.U, ct, w = simple_update(cfg, r["S"], r["actions"], self.U)
         action = self.U[:cfg.u_per_command].copy()
         top_idx, _ = topk(w, min(20, K))

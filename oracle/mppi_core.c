@@ -487,7 +487,8 @@ void m3o_noise_fill(const m3o_cfg* cfg, unsigned long long seed, unsigned call, 
                 if (cfg->full_sigma) {
                     acc = cfg->chol[j * nu + 0] * z[0];
                     for (int q = 1; q <= j; ++q) acc = acc + cfg->chol[j * nu + q] * z[q];
-                } else acc = z[j] * cfg->scale_tril[j];
+                } else acc = z[j] * cfg->chol[j * nu + j];   /* (= the configured sqrt(sigma_jj): scale_tril may have
+                                                                been rewritten by update_cov, the distribution not) */
                 out[((size_t)i * T + t) * nu + j] = cfg->noise_mu[j] + acc;
             }
         }

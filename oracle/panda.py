@@ -123,38 +123,18 @@ def rollout(cfg, sc, world0, act, k0=0, k1=None):
     return dict(states=states, actions=actions, cost_h=cost_h, J=J)
 
 
-class OraclePandaPlanner:
-    """command() for panda_env on the oracle (halton-spline mode), mirrors OraclePointPlanner."""
+class OraclePandaPlanner(O.OraclePointPlanner):
+    """command() for panda_env on the oracle: OraclePointPlanner (mppi.py:211-264 + m3p2i.py:66-92, halton-spline
+    with a noise table or the in-kernel stream, simple mode, update_cov) with the chain rollout in place of the
+    planar one."""
 
-    def __init__(self, cfg, delta, scene=None):
-        self.cfg, self.sc = cfg, scene or default_scene()
-        self.delta = O.f32(delta).copy()
-        self.delta[-1] = 0.0
-        z = lambda: np.zeros((cfg.T, 9), np.float32)
-        self.mean, self.mean1, self.mean2, self.best, self.best1, self.best2 = z(), z(), z(), z(), z(), z()
-        self.beta = 1.0
-        self.last = {}
+    def __init__(self, cfg, delta=None, scene=None, seed=0, update_cov=False):
+        super().__init__(cfg, delta, scene or default_scene(), seed=seed, update_cov=update_cov)
 
-    def command(self, world0):
-        cfg = self.cfg
-        K = cfg.K
-        self.mean = O.shift(self.mean)
-        if cfg.multi_modal:
-            self.mean1, self.mean2 = O.shift(self.mean1), O.shift(self.mean2)
-            self.best1, self.best2 = O.shift(self.best1), O.shift(self.best2)
-        act = O.assemble_actions(cfg, self.delta, self.mean, self.mean1, self.mean2, self.best1, self.best2)
-        r = rollout(cfg, self.sc, world0, act)
-        w, w1, w2, info = O.update_weights(cfg, r["J"], self.beta)
-        self.beta = info.beta
-        ps = O.partial_sums(cfg, w, w1, w2, r["actions"])
-        self.mean = O.mean_update(cfg, self.mean, ps[0])
-        if cfg.multi_modal:
-            self.mean1, self.mean2 = ps[1].copy(), ps[2].copy()
-            self.best1 = r["actions"][info.best_idx_1].copy()
-            self.best2 = r["actions"][K // 2 + info.best_idx_2].copy()
-        else:
-            self.best = r["actions"][info.best_idx].copy()
-        action = O.savgol9(self.mean) if cfg.filter_u else self.mean.copy()
-        top_idx, _ = O.topk(w, 20)
-        self.last = dict(r, w=w, w1=w1, w2=w2, info=info, act=act, action=action, top_idx=top_idx)
-        return action
+    def _rollout(self, world0, act):
+        r = rollout(self.cfg, self.sc, world0, act)
+        s = np.zeros(self.cfg.K, np.float32)
+        for t in range(self.cfg.T):          # mppi.py:309: cost_samples += c, in order
+            s = (s + r["cost_h"][:, t]).astype(np.float32)
+        r["S"] = s
+        return r

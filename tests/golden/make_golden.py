@@ -369,6 +369,20 @@ def halton_delta(K, T, nu):
     return delta
 
 
+class StreamDist:
+    """Stands in for the planner's MultivariateNormal (mppi.py:129-131): N(noise_mu, noise_sigma) draws of the
+    build's counter-based stream -- noise_mu + L z with L = chol(noise_sigma), accumulated in the order
+    DESIGN.md section 5 fixes (for the diagonal default: z * sqrt(sigma) bit for bit)."""
+
+    def __init__(self, cfg, nu, seed, calls):
+        m = cfg.mppi
+        self.K, self.seed, self.calls = m.num_samples, seed, calls
+        self.ocfg = O.make_cfg(m.num_samples, m.horizon, nu, noise_mu=m.noise_mu or None, noise_sigma=m.noise_sigma)
+
+    def sample(self, shape):
+        return torch.from_numpy(O.noise_fill(self.ocfg, self.seed, self.calls[0], self.K))
+
+
 def g9_trace(tag, cfg, ncalls, world0, closed_loop=True, noise_stream=False, seed=7, extra=None):
     """reactive_tamp.py wiring (:22-41, :43-73) around the reference planner."""
     K, T = cfg.mppi.num_samples, cfg.mppi.horizon
@@ -393,24 +407,7 @@ def g9_trace(tag, cfg, ncalls, world0, closed_loop=True, noise_stream=False, see
     if noise_stream:
         # replace torch's global RNG draw (mppi.py:340 / :481) by the build's counter-based
         # stream so both sides see identical noise: N(0, Sigma) = z * sqrt(diag Sigma)
-        # (noise_mu + L z with L = chol(noise_sigma), accumulated in the order DESIGN.md section 5 fixes;
-        # for the diagonal default this is z * sqrt(3) bit for bit)
-        sig = np.array(cfg.mppi.noise_sigma, np.float64)
-        Lc = np.linalg.cholesky(sig).astype(np.float32)
-        mu = np.array(cfg.mppi.noise_mu or [0.0, 0.0], np.float32)
-
-        class Dist:
-            def sample(self, shape):
-                z = O.gauss_fill(seed, calls[0], K, T, 2)
-                d = np.zeros_like(z)
-                for j in range(2):
-                    acc = Lc[j, 0] * z[..., 0] if j else Lc[0, 0] * z[..., 0]
-                    if j:
-                        acc = (acc + Lc[1, 1] * z[..., 1]).astype(np.float32)
-                    d[..., j] = (mu[j] + acc).astype(np.float32)
-                return torch.from_numpy(d)
-
-        pl.noise_dist = Dist()
+        pl.noise_dist = StreamDist(cfg, 2, seed, calls)
         if cfg.mppi.mppi_mode == "simple":
             pl.U = torch.zeros(T, 2)  # reference draws U from the global RNG (mppi.py:134)
     sc = O.default_scene()
@@ -505,10 +502,29 @@ def g11():
     cfg.mppi.noise_mu = [0.3, -0.2]
     cfg.mppi.noise_sigma = [[3.0, 1.0], [1.0, 2.0]]
     g9_trace("opt_navr", cfg, 4, w0, noise_stream=True)
+    # the same switches on the panda_env (C4-shaped, reduced K)
+    import oracle.panda as P
+    goal7 = [0.2, 0.2, 1.115, 0.0, 0.0, 0.0, 1.0]
+    wp = P.init_world(1)[0]
+    g9_panda_trace("panda_opt_cov", 256, 20, "reach", False, wp, goal7, ncalls=4, mppi_kw=dict(update_cov=True),
+                   extra=lambda pl: pl.scale_tril.numpy().copy())
+    sig = [[0.0] * 9 for _ in range(9)]
+    for i in range(7):
+        sig[i][i] = 10.0
+    sig[7][7] = sig[8][8] = 0.8
+    sig[0][1] = sig[1][0] = 4.0
+    sig[2][5] = sig[5][2] = -3.0
+    mu = [0.2, -0.1, 0.0, 0.1, 0.0, 0.0, -0.2, 0.0, 0.0]
+    g9_panda_trace("panda_opt_rand", 128, 12, "reach", False, wp, goal7, ncalls=4, noise_stream=True,
+                   mppi_kw=dict(sampling_method="random", noise_mu=mu, noise_sigma=sig))
+    g9_panda_trace("panda_opt_simple", 128, 12, "reach", False, wp, goal7, ncalls=4, noise_stream=True,
+                   mppi_kw=dict(mppi_mode="simple", sampling_method="random", noise_mu=mu, noise_sigma=sig,
+                                noise_abs_cost=True, u_scale=0.9, u_per_command=12))
 
 
 # ---------------------------------------------------------------- G9 (panda): full command() traces
-def g9_panda_trace(tag, K, T, task, multi_modal, world0, goal7, ncalls=5):
+def g9_panda_trace(tag, K, T, task, multi_modal, world0, goal7, ncalls=5, mppi_kw=None, noise_stream=False, seed=7,
+                   extra=None):
     """The reference's M3P2I + Objective driven through their plugin API on the panda_env (C4-shaped, reduced
     K), the oracle's chain dynamics behind the wrapper API: pins, in ONE reference trace, what G2 / G5 / G6b
     pin piecewise -- the gripper override (mppi.py:412-416), the persistent adapted beta (mppi.py:446-454),
@@ -516,6 +532,9 @@ def g9_panda_trace(tag, K, T, task, multi_modal, world0, goal7, ncalls=5):
     Closed loop: the first action of every plan steps the 1-env world (scripts/sim.py:41-52)."""
     import oracle.panda as P
     cfg = panda_cfg(K, T, multi_modal=multi_modal)
+    for k, v in (mppi_kw or {}).items():
+        setattr(cfg.mppi, k, v)
+    simple = cfg.mppi.mppi_mode == "simple"
     sim = refshim.OraclePandaSim(K, world0)
     obj = ref.cost_functions.Objective(cfg)
     obj.update_objective(task, torch.from_numpy(np.array(goal7, np.float32)))
@@ -527,22 +546,39 @@ def g9_panda_trace(tag, K, T, task, multi_modal, world0, goal7, ncalls=5):
 
     pl = make_planner(cfg, dynamics=dynamics, running_cost=lambda _: obj.compute_cost(sim))
     pl.update_gripper_command(task)      # reactive_tamp.py:78
-    pl.delta = halton_delta(K, T, 9)
-    out[f"g9_{tag}_delta"] = pl.delta.numpy().copy()
+    calls = [0]
+    if noise_stream:     # the build's counter-based stream in place of torch's global generator (as g9_trace)
+        pl.noise_dist = StreamDist(cfg, 9, seed, calls)
+        if simple:
+            pl.U = torch.zeros(T, 9)
+    else:
+        pl.delta = halton_delta(K, T, 9)
+        out[f"g9_{tag}_delta"] = pl.delta.numpy().copy()
     sc = P.default_scene()
     real = np.array(world0, np.float32).reshape(1, -1).copy()
-    rec = {k: [] for k in ("world", "action", "weights", "top_trajs", "mean", "beta", "pref")}
+    rec = {k: [] for k in ("world", "action", "weights", "top_trajs", "mean", "beta", "pref", "J")}
+    extras = []
     for call in range(ncalls):
         rec["world"].append(real[0].copy())
         sim.reset(real[0])
         a = pl.command(sim._dof_state[0])
+        calls[0] += 1
         rec["action"].append(a.numpy().copy())
         rec["weights"].append(pl.weights.numpy().copy())
         rec["top_trajs"].append(pl.top_trajs.numpy().copy())
-        rec["mean"].append(pl.mean_action.numpy().copy())
+        rec["mean"].append((pl.U if simple else pl.mean_action).numpy().copy())
         rec["beta"].append(float(pl.beta))
         rec["pref"].append(int(pl.get_pull_preference()))
-        P.step_batch(sc, real, a[0:1].numpy())
+        rec["J"].append(pl.cost_total.numpy().copy() if simple else np.zeros(K, np.float32))
+        if extra is not None:
+            extras.append(extra(pl))
+        u1 = np.zeros((1, 9), np.float32)
+        u1[0] = a[0].numpy()
+        P.step_batch(sc, real, u1)
+    if not simple:
+        rec.pop("J")
+    if extras:
+        out[f"g9_{tag}_extra"] = np.stack(extras)
     for k, v in rec.items():
         out[f"g9_{tag}_{k}"] = np.array(v, np.int32 if k == "pref" else np.float32) if k in ("beta", "pref") else np.stack(v)
     out[f"g9_{tag}_states_last"] = pl.states.numpy().copy()

@@ -150,3 +150,53 @@ def test_panda_command_traces_vs_reference_golden(golden, tag, task, mm, grip):
     np.testing.assert_allclose(eng.states.cpu().numpy(), golden[f"g9_{tag}_states_last"], atol=1e-3)
     np.testing.assert_allclose(eng.actions.cpu().numpy(), golden[f"g9_{tag}_actions_last"], atol=1e-3)
     eng.close()
+
+
+@pytest.mark.parametrize("tag", ["panda_opt_cov", "panda_opt_rand", "panda_opt_simple"])
+def test_panda_option_traces_vs_reference_golden(golden, oracle, tag):
+    """The MPPIConfig switches no shipped config turns on, on the panda_env (make_golden.py g11): update_cov;
+    sampling_method='random' with a noise mean and a non-diagonal noise_sigma; mppi_mode='simple' with
+    noise_abs_cost and u_scale != 1 -- HIP command() vs the reference's own planner and vs the oracle."""
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    from tests.test_oracle_panda import PANDA_OPT, panda_opt_planner
+    kw = dict(PANDA_OPT[tag])
+    ocfg, opl = panda_opt_planner(golden, tag)
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    delta = golden[f"g9_{tag}_delta"] if f"g9_{tag}_delta" in golden else None
+    simple = bool(kw.get("mode_simple"))
+    eng = HipEngine(make_config(K=kw["K"], T=kw["T"], nu=9, env_type="panda_env", u_min=UMIN, u_max=UMAX,
+                                noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01, seed=7,
+                                mode_simple=simple, sampling_random=delta is None, u_per_command=kw.get("u_per_command"),
+                                u_scale=kw.get("u_scale", 1.0), noise_mu=kw.get("noise_mu"), noise_sigma=kw.get("noise_sigma"),
+                                noise_abs_cost=kw.get("noise_abs_cost", False), update_cov=kw.get("update_cov", False)))
+    eng.set_objective("reach", goal, gripper_cmd=1)
+    if delta is not None:
+        eng.set_noise(delta)
+    for call, w in enumerate(golden[f"g9_{tag}_world"]):
+        if simple and call:
+            # lambda_ = 0.05 makes the softmin of simple mode (mppi.py:226: exp(-(J - min) / lambda_)) amplify one
+            # f32 ulp of a trajectory cost of ~60 into 1e-4 of a weight; left alone, two correct implementations
+            # drift apart by ~1e-3 per warm-started call (the reference itself carries cost_total + mean(S), quirk
+            # Q1).  Every call therefore starts from the REFERENCE's previous U: four independent comparisons.
+            eng.set_plan(L.BUF_MEAN, golden[f"g9_{tag}_mean"][call - 1])
+            opl.U = golden[f"g9_{tag}_mean"][call - 1].copy()
+        eng.set_world_panda_raw(raw31(P, w))
+        a = eng.command(sync_host=True)
+        a_orc = opl.command(w)
+        rows = golden[f"g9_{tag}_action"][call].shape[0]
+        np.testing.assert_allclose(a[:rows], golden[f"g9_{tag}_action"][call], atol=1e-3, err_msg=f"{tag} call {call}")
+        np.testing.assert_allclose(a[:rows], a_orc, atol=1e-3)
+        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), golden[f"g9_{tag}_weights"][call], atol=1e-3)
+        np.testing.assert_allclose(eng.buffer(L.BUF_MEAN).cpu().numpy(), golden[f"g9_{tag}_mean"][call], atol=1e-3)
+        if not simple:
+            assert eng.info().beta == pytest.approx(float(golden[f"g9_{tag}_beta"][call]), rel=1e-5)
+        if f"g9_{tag}_extra" in golden:
+            np.testing.assert_allclose(eng.buffer(L.BUF_COV).cpu().numpy()[1], golden[f"g9_{tag}_extra"][call], rtol=1e-4)
+        if call == 0 and delta is not None:     # same inputs: the rollout is bit-identical to the oracle's
+            np.testing.assert_array_equal(eng.states.cpu().numpy(), opl.last["states"])
+            np.testing.assert_array_equal(eng.actions.cpu().numpy(), opl.last["actions"])
+    np.testing.assert_allclose(eng.states.cpu().numpy(), golden[f"g9_{tag}_states_last"], atol=1e-3)
+    np.testing.assert_allclose(eng.actions.cpu().numpy() / np.float32(ocfg.u_scale), golden[f"g9_{tag}_actions_last"], atol=1e-3)
+    eng.close()

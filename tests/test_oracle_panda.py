@@ -142,3 +142,49 @@ def test_g9_panda_command_traces_vs_reference(golden, oracle, tag):
         assert np.all(opl.last["actions"][:-1, :, 7:] == (1.5 if grip == 1 else -1.5))
     np.testing.assert_allclose(opl.last["states"], golden[f"g9_{tag}_states_last"], atol=1e-3)
     np.testing.assert_allclose(opl.last["actions"], golden[f"g9_{tag}_actions_last"], atol=1e-3)
+
+
+PANDA_SIG = [[0.0] * 9 for _ in range(9)]
+for _i in range(7):
+    PANDA_SIG[_i][_i] = 10.0
+PANDA_SIG[7][7] = PANDA_SIG[8][8] = 0.8
+PANDA_SIG[0][1] = PANDA_SIG[1][0] = 4.0
+PANDA_SIG[2][5] = PANDA_SIG[5][2] = -3.0
+PANDA_MU = [0.2, -0.1, 0.0, 0.1, 0.0, 0.0, -0.2, 0.0, 0.0]
+# the MPPIConfig switches no shipped config turns on, on the panda_env (reference traces: make_golden.py g11)
+PANDA_OPT = {
+    "panda_opt_cov": dict(K=256, T=20, update_cov=True),
+    "panda_opt_rand": dict(K=128, T=12, noise_mu=PANDA_MU, noise_sigma=PANDA_SIG),
+    "panda_opt_simple": dict(K=128, T=12, mode_simple=True, u_per_command=12, lambda_=0.05, noise_mu=PANDA_MU,
+                             noise_sigma=PANDA_SIG, noise_abs_cost=True, u_scale=0.9),
+}
+
+
+def panda_opt_planner(golden, tag, seed=7):
+    import oracle.panda as P
+    kw = dict(PANDA_OPT[tag])
+    update_cov = kw.pop("update_cov", False)
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    cfg = P.make_cfg(kw.pop("K"), kw.pop("T"), task="reach", goal=goal, gripper_cmd=1, **kw)
+    delta = golden[f"g9_{tag}_delta"] if f"g9_{tag}_delta" in golden else None
+    return cfg, P.OraclePandaPlanner(cfg, delta, seed=seed, update_cov=update_cov)
+
+
+@pytest.mark.parametrize("tag", list(PANDA_OPT))
+def test_g11_panda_option_traces_vs_reference(golden, oracle, tag):
+    """update_cov; sampling_method='random' with a noise mean and a non-diagonal noise_sigma; mppi_mode='simple'
+    with noise_abs_cost and u_scale != 1 -- the reference's planner on the panda_env vs the oracle's."""
+    cfg, opl = panda_opt_planner(golden, tag)
+    for call, w in enumerate(golden[f"g9_{tag}_world"]):
+        a = opl.command(w)
+        np.testing.assert_allclose(a, golden[f"g9_{tag}_action"][call], atol=1e-3, err_msg=f"{tag} call {call}")
+        np.testing.assert_allclose(opl.last["w"], golden[f"g9_{tag}_weights"][call], atol=1e-3)
+        np.testing.assert_allclose(opl.U if cfg.mode_simple else opl.mean, golden[f"g9_{tag}_mean"][call], atol=1e-3)
+        if cfg.mode_simple:
+            np.testing.assert_allclose(opl.last["cost_total"], golden[f"g9_{tag}_J"][call], rtol=1e-5, atol=1e-3)
+        else:
+            assert opl.beta == pytest.approx(float(golden[f"g9_{tag}_beta"][call]), rel=1e-5)
+        if f"g9_{tag}_extra" in golden:
+            np.testing.assert_allclose([cfg.scale_tril[j] for j in range(9)], golden[f"g9_{tag}_extra"][call], rtol=1e-4)
+    np.testing.assert_allclose(opl.last["states"], golden[f"g9_{tag}_states_last"], atol=1e-3)
+    np.testing.assert_allclose(opl.last["actions"] / np.float32(cfg.u_scale), golden[f"g9_{tag}_actions_last"], atol=1e-3)

@@ -32,16 +32,18 @@ class Tamp:
         return self.objective.compute_cost(self.sim)
 
 
-def make_cfg(K, T, multi_modal=False, fused=None):
+def make_cfg(K, T, multi_modal=False, fused=None, **mppi_kw):
     from m3p2i_aip_amd.isaacgym_wrapper import IsaacGymConfig
     from m3p2i_aip_amd.planner import MPPIConfig
     sig = [[0.0] * 9 for _ in range(9)]
     for i in range(7):
         sig[i][i] = 10.0
     sig[7][7] = sig[8][8] = 0.8
-    m = MPPIConfig(num_samples=K, horizon=T, nx=18, device="cuda:0", lambda_=0.05,
-                   u_min=[-2.0] * 7 + [-1.5] * 2, u_max=[2.0] * 7 + [1.5] * 2, noise_sigma=sig,
-                   u_per_command=T, sample_null_action=True, filter_u=True, fused=fused)
+    kw = dict(num_samples=K, horizon=T, nx=18, device="cuda:0", lambda_=0.05,
+              u_min=[-2.0] * 7 + [-1.5] * 2, u_max=[2.0] * 7 + [1.5] * 2, noise_sigma=sig,
+              u_per_command=T, sample_null_action=True, filter_u=True, fused=fused)
+    kw.update(mppi_kw)
+    m = MPPIConfig(**kw)
     return SimpleNamespace(env_type="panda_env", multi_modal=multi_modal, suction_active=False, kp_suction=0,
                            pre_height_diff=0.05, task="reactive_pick", cube_on_shelf=False, mppi=m,
                            isaacgym=IsaacGymConfig(dt=0.01))
@@ -110,3 +112,57 @@ def test_fused_step_and_oracle_agree(oracle, task, mm):
     ref = np.stack([opl.command(w0) for _ in range(3)])
     np.testing.assert_allclose(outs["fused"][0], ref, atol=1e-3)
     np.testing.assert_allclose(outs["fused"][1], opl.last["w"], atol=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["panda_opt_rand", "panda_opt_simple", "panda_opt_cov"])
+def test_panda_planner_options_match_reference_traces(golden, tag):
+    """The Python mirror on the panda_env with sampling_method='random' (noise mean, non-diagonal noise_sigma),
+    mppi_mode='simple' (noise_abs_cost, u_scale != 1) and update_cov, against the reference's own planner
+    (make_golden.py g11; in-kernel stream = the recorded noise for the same seed)."""
+    from tests.test_oracle_panda import PANDA_OPT
+    from tests.test_hip_parity_panda import raw31
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    kw = dict(PANDA_OPT[tag])
+    K, T = kw.pop("K"), kw.pop("T")
+    simple = kw.pop("mode_simple", False)
+    delta = golden[f"g9_{tag}_delta"] if f"g9_{tag}_delta" in golden else None
+    opt = dict(kw)
+    if delta is None:
+        opt["sampling_method"] = "random"
+    if simple:
+        opt["mppi_mode"] = "simple"
+    cfg = make_cfg(K, T, fused=True, **opt)
+    cfg.mppi.seed_val = 7
+    tamp = Tamp(cfg)
+    pl = tamp.motion_planner
+    if delta is not None:
+        pl.set_noise(delta)
+    if simple:
+        pl.U = torch.zeros(T, 9, device="cuda:0")
+    goal = torch.tensor([0.2, 0.2, 1.115, 0, 0, 0, 1.0])
+    pl.update_gripper_command("reach")
+    tamp.objective.update_objective("reach", goal)
+    sim = tamp.sim
+    ia, ib = int(sim._get_actor_index_by_name("cubeA")), int(sim._get_actor_index_by_name("cubeB"))
+    for call, w in enumerate(golden[f"g9_{tag}_world"]):
+        if simple and call:     # (see test_panda_option_traces_vs_reference_golden: every call from the reference's U)
+            pl.U = torch.from_numpy(golden[f"g9_{tag}_mean"][call - 1]).to("cuda:0")
+        # run_tamp (reactive_tamp.py:45-48): the real world's state of this call into the wrapper's tensors
+        dof = torch.zeros(1, 18)
+        dof[0, 0::2] = torch.from_numpy(w[P.W_Q:P.W_Q + 9])
+        dof[0, 1::2] = torch.from_numpy(w[P.W_Q + 9:P.W_Q + 18])
+        root = sim._root_state[0:1].clone().cpu()
+        root[0, ia, 0:10] = torch.from_numpy(w[P.W_CUBEA:P.W_CUBEA + 10])
+        root[0, ib, 0:3] = torch.from_numpy(w[P.W_CUBEB:P.W_CUBEB + 3])
+        sim._dof_state[:] = dof.to("cuda:0")
+        sim._root_state[:] = root.to("cuda:0")
+        sim.set_dof_state_tensor(sim._dof_state)
+        sim.set_actor_root_state_tensor(sim._root_state)
+        a = pl.command(sim._dof_state[0])
+        np.testing.assert_allclose(a.cpu().numpy(), golden[f"g9_{tag}_action"][call], atol=1e-3, err_msg=f"{tag} {call}")
+        np.testing.assert_allclose(pl.weights.cpu().numpy(), golden[f"g9_{tag}_weights"][call], atol=1e-3)
+        np.testing.assert_allclose((pl.U if simple else pl.mean_action).cpu().numpy(), golden[f"g9_{tag}_mean"][call], atol=1e-3)
+        if f"g9_{tag}_extra" in golden:
+            np.testing.assert_allclose(pl.scale_tril.cpu().numpy(), golden[f"g9_{tag}_extra"][call], rtol=1e-4)
+    np.testing.assert_allclose(pl.actions.cpu().numpy(), golden[f"g9_{tag}_actions_last"], atol=1e-3)
