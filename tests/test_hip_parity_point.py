@@ -172,6 +172,21 @@ def test_api_errors_are_loud(oracle):
     with pytest.raises(L.M3Error):
         eng.set_objective("reach", (0, 0))             # not a point_env task
     eng.close()
+    # noise_sigma_full must be a covariance matrix with the configured diagonal
+    with pytest.raises(L.M3Error):
+        HipEngine(make_config(K=64, T=12, sampling_random=True, noise_sigma=[[3.0, 4.0], [4.0, 3.0]]))   # not positive definite
+    c = make_config(K=64, T=12, sampling_random=True, noise_sigma=[[3.0, 1.0], [1.0, 2.0]])
+    c.noise_sigma_full[1] = 0.5                                                                         # not symmetric
+    with pytest.raises(L.M3Error):
+        HipEngine(c)
+    c = make_config(K=64, T=12, sampling_random=True, noise_sigma=[[3.0, 1.0], [1.0, 2.0]])
+    c.noise_sigma_diag[0] = 2.0                                                                         # diagonals disagree
+    with pytest.raises(L.M3Error):
+        HipEngine(c)
+    with pytest.raises(L.M3Error):   # update_cov on a sharded single-mode handle would need one more reduction
+        HipEngine(make_config(K=128, T=12, K_local=64, k_offset=0, update_cov=True))
+    # ... while the modes in which the reference ignores the flag take it silently (m3p2i.py:66-92 has no such branch)
+    HipEngine(make_config(K=128, T=12, K_local=64, k_offset=0, update_cov=True, multi_modal=True)).close()
 
 
 @pytest.mark.parametrize("task,goal,mm", [("push", (-1, -1), False), ("push_pull", (-3.75, -3.75), True)])
