@@ -268,6 +268,10 @@ int m3_set_noise_knots_global(m3_handle* h, const float* knots_all, int n_knots,
  * differ from the host's libm in the last ulp) -- so the planner's default stays m3_set_noise_knots with host
  * knots, pinned bit for bit by golden G8; this entry (MPPIConfig.device_knots) removes the last host values. */
 int m3_set_noise_halton(m3_handle* h, int n_knots, int degree, float smoothing);
+/* sampling_random / simple mode: the draws of N(noise_mu, noise_sigma) that the NEXT m3_rollout generates in
+ * registers (MultivariateNormal(...).sample((K, T)), mppi.py:340 / :481), written to M3_BUF_NOISE for a caller
+ * that runs the rollout itself (the planner's STEP mode: user dynamics / running_cost callables) */
+int m3_sample_noise(m3_handle* h);
 int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd);
 /* Objective.multi_modal (cost_functions.py:9) for a sim_only handle, whose config does not
  * come from an MPPI object; refused on planner handles (fixed at m3_create) */
@@ -277,6 +281,9 @@ int m3_set_plan(m3_handle* h, int which, const float* host_values);
 /* the persistent softmin temperature (MPPI.beta, mppi.py:184; adapted by the panda_env's single-mode
  * update, mppi.py:446-454): together with m3_set_plan this restores a saved warm start */
 int m3_set_beta(m3_handle* h, float beta);
+/* the number of finished commands (m3_info.calls) = the index of the next command in the in-kernel noise stream;
+ * with m3_set_plan / m3_set_beta this restores a saved planner state exactly */
+int m3_set_call_count(m3_handle* h, unsigned calls);
 int m3_reset(m3_handle* h); /* zero means/best/pending forces, beta = 1, call counter = 0 */
 /* Where m3_finalize writes the returned plan (`action`, mppi.py:257-263): a caller-owned device
  * buffer of [T][nu] floats ([u_per_command][nu] in simple mode), or NULL for the library's

@@ -83,6 +83,8 @@ SYMBOLS = [
     ("m3_set_noise_global", C.c_int, [_H, _FP, C.c_int]),
     ("m3_set_noise_knots_global", C.c_int, [_H, _FP, C.c_int, C.c_int, C.c_float, C.c_int]),
     ("m3_set_noise_halton", C.c_int, [_H, C.c_int, C.c_int, C.c_float]),
+    ("m3_sample_noise", C.c_int, [_H]),
+    ("m3_set_call_count", C.c_int, [_H, C.c_uint]),
     ("m3_set_objective", C.c_int, [_H, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int]),
     ("m3_set_multi_modal", C.c_int, [_H, C.c_int]),
     ("m3_set_plan", C.c_int, [_H, C.c_int, _FP]),

@@ -559,6 +559,23 @@ extern "C" int m3_set_noise_halton(m3_handle* h, int n_knots, int degree, float 
     return rc;
 }
 
+extern "C" int m3_sample_noise(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    const m3_config& c = h->cfg;
+    if (c.sim_only || !(c.sampling_random || c.mode_simple))
+        return fail(h, M3_ERR_STATE, "m3_sample_noise: the handle has a noise table (sampling_random == 0)");
+    if (h->regen) return fail(h, M3_ERR_STATE, "m3_sample_noise: not on a one-collective multi-modal shard");
+    RolloutArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.Kg = c.K_global; a.Kl = c.K_local; a.k0 = c.k_offset; a.T = c.T; a.nu = c.nu;
+    a.full_sigma = c.full_sigma; a.noise_mats = h->noise_mats;
+    for (int j = 0; j < c.nu; ++j) { a.noise_mu[j] = c.noise_mu[j]; a.scale_tril[j] = std::sqrt(c.noise_sigma_diag[j]); }
+    a.seed = c.seed; a.call = h->calls;
+    launch_sample_noise(a, (float*)h->buf[M3_BUF_NOISE], h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
 extern "C" int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd) {
     if (!h) return M3_ERR_BAD_ARG;
     if (task < 0 || task > M3_TASK_IDLE) return fail(h, M3_ERR_BAD_ARG, "m3_set_objective: unknown task");
@@ -600,6 +617,12 @@ extern "C" int m3_set_beta(m3_handle* h, float beta) {
     HIPCHK(h, hipMemcpyAsync((char*)h->buf[M3_BUF_INFO] + offsetof(m3_info, beta), &beta, sizeof(float),
                              hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));   // `beta` is a stack value
+    return M3_OK;
+}
+
+extern "C" int m3_set_call_count(m3_handle* h, unsigned calls) {
+    if (!h) return M3_ERR_BAD_ARG;
+    h->calls = calls;
     return M3_OK;
 }
 

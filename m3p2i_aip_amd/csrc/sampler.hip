@@ -8,6 +8,7 @@
 // (spline_fit.hpp, bit-identical to scipy's FITPACK) and writes its T values straight into the
 // time-major noise buffer [T][K_local][nu] the rollout kernel reads.
 #include "m3_internal.hpp"
+#include "noise_stream.hpp"
 #include "spline_fit.hpp"
 
 #include <hipcub/hipcub.hpp>
@@ -212,6 +213,27 @@ void launch_gather_rows(const float* src, const int* order, float* dst, int Kl, 
     int blocks = (rows * Kl + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, s, src, order, dst, Kl, rows);
+}
+
+// ---- m3_sample_noise: the in-kernel stream of the rollout kernels, materialised (STEP mode) ----
+__global__ __launch_bounds__(256) void k_sample_noise(const RolloutArgs a, float* __restrict__ out /* [T][Kl][nu] */) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= a.T * a.Kl) return;
+    const int t = o / a.Kl, i = o % a.Kl, nu = a.nu;
+    float z[M3_MAX_NU + 1];
+    for (int p = 0; p < (nu + 1) / 2; ++p)
+        gauss_pair(a.seed, a.call, (unsigned)(a.k0 + i), (unsigned)t, (unsigned)p, z[2 * p], z[2 * p + 1]);
+    for (int j = 0; j < nu; ++j) {   // as rollout_point_kernel.hpp / rollout_panda.hip
+        float acc;
+        if (a.full_sigma) {
+            acc = a.noise_mats[j * nu + 0] * z[0];
+            for (int q = 1; q <= j; ++q) acc = acc + a.noise_mats[j * nu + q] * z[q];
+        } else acc = z[j] * a.scale_tril[j];
+        out[(size_t)o * nu + j] = a.noise_mu[j] + acc;
+    }
+}
+void launch_sample_noise(const RolloutArgs& a, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sample_noise, dim3((a.T * a.Kl + 255) / 256), dim3(256), 0, s, a, out);
 }
 
 }  // namespace m3

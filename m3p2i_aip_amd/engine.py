@@ -165,6 +165,15 @@ class HipEngine:
         assert k.ndim == 3 and k.shape[:2] == (rows, c.nu), k.shape
         self._ck(fn(self._h, k.ctypes.data, int(k.shape[2]), int(degree), float(smoothing), 0))
 
+    def set_call_count(self, calls):
+        self._ck(self.lib.m3_set_call_count(self._h, int(calls)))
+
+    def sample_noise(self):
+        """sampling_random / simple mode: this command's N(noise_mu, noise_sigma) draws into BUF_NOISE (what the
+        fused rollout generates in registers) -- for the planner's STEP mode."""
+        self._ck(self.lib.m3_sample_noise(self._h))
+        return self.buffer(L.BUF_NOISE)
+
     def set_noise_halton(self, n_knots, degree=2, smoothing=0.5):
         """The whole Halton-spline sampler on the device (knots included): include/m3p2i_hip.h."""
         self._ck(self.lib.m3_set_noise_halton(self._h, int(n_knots), int(degree), float(smoothing)))

@@ -412,9 +412,17 @@ class MPPI():
         e = self._engine
         ks = torch.arange(k0, k0 + Kl, device=self.device)
         if self.mppi_mode == "simple" or self.sampling_method == "random":
-            raise NotImplementedError("STEP mode with in-kernel random sampling: set the noise explicitly "
-                                      "(planner.set_noise) or use the fused path")
-        delta = self.delta.clone()
+            # MultivariateNormal(noise_mu, noise_sigma).sample((K, T)) (mppi.py:340 / :481): this command's draws
+            # of the stream the fused kernel generates in registers
+            delta = e.sample_noise().permute(1, 0, 2).clone()
+        else:
+            delta = self.delta.clone()
+        if self.mppi_mode == "simple":      # mppi.py:341-350
+            U = torch.roll(self.U, -1, dims=0)                                   # :221
+            act = torch.max(torch.min(U.unsqueeze(0) + delta, self.u_max), self.u_min)
+            if self.env_type == "panda_env" and self.gripper_command in ("open", "close"):
+                act[:, :, 7:] = 1.5 if self.gripper_command == "open" else -1.5
+            return act
         delta[ks == self.K - 1] = 0.0
         shift = torch.clamp(torch.arange(1, T + 1, device=self.device), max=T - 1)
         scaled = delta * self.scale_tril.view(1, 1, nu)
@@ -444,7 +452,7 @@ class MPPI():
         A, S, C = self._buf(L.BUF_ACTIONS), self._buf(L.BUF_STATES), self._buf(L.BUF_COST_HORIZON)
         state = self.state.view(1, -1).repeat(Kl, 1) if self.state.shape != (Kl, self.nx) else self.state
         J = torch.zeros(Kl, **self.tensor_args)
-        g = 1.0
+        Ssum = torch.zeros(Kl, **self.tensor_args)
         gs = torch.ones((), **self.tensor_args)
         last = self.K - 1 - self.k_offset
         for t in range(T):
@@ -457,7 +465,16 @@ class MPPI():
             S[t].copy_(state[:, :4])
             C[t].copy_(c)
             J = J + gs * c
+            Ssum = Ssum + c                             # mppi.py:309
             gs = gs * self.gamma
+        if self.mppi_mode == "simple":
+            # mppi.py:355-362: noise = perturbed_action (the scaled controls, :311) - U; cost_total += sum U * action_cost
+            # (cost_total also carries + mean(S) through the aliasing of :284, a shift the softmin cancels)
+            U = torch.roll(self.U, -1, dims=0)
+            noise = A.permute(1, 0, 2) - U.unsqueeze(0)
+            if self.noise_abs_cost:
+                noise = noise.abs()                                              # :366-367
+            J = Ssum + torch.sum(U.unsqueeze(0) * ((self.lambda_ * noise) @ self.noise_sigma_inv), dim=(1, 2))
         self._buf(L.BUF_TRAJ_COST).copy_(J)
         out = self._next_action_slot()
         self._update_exchange_finalize()
@@ -478,8 +495,7 @@ class MPPI():
         the user's callbacks, and keep the fused path only if both produced the same costs."""
         can_fuse = (self._sim is not None and self._objective is not None and self.F is not None
                     and self.running_cost is not None and self._objective.task is not None)
-        can_step = self.F is not None and self.running_cost is not None and \
-            self.mppi_mode != "simple" and self.sampling_method != "random"
+        can_step = self.F is not None and self.running_cost is not None
         if can_fuse and not can_step:
             self._fused = True
             return self._command_fused()
@@ -491,12 +507,14 @@ class MPPI():
         keep = [L.BUF_MEAN, L.BUF_MEAN_1, L.BUF_MEAN_2, L.BUF_BEST, L.BUF_BEST_1, L.BUF_BEST_2,
                 L.BUF_PENDING_FORCE, L.BUF_COV]
         saved = [self._buf(b).clone() for b in keep]
-        beta0 = self._engine.info().beta
+        info0 = self._engine.info()
+        beta0, calls0 = info0.beta, info0.calls
         self._command_fused()
         Jf = self._buf(L.BUF_TRAJ_COST).clone()
         for b, v in zip(keep, saved):
             self._buf(b).copy_(v)
         self._engine.set_beta(beta0)
+        self._engine.set_call_count(calls0)    # (the in-kernel noise stream is keyed by the command index)
         out = self._command_step()
         Js = self._buf(L.BUF_TRAJ_COST)
         same = bool(torch.allclose(Jf, Js, rtol=1e-5, atol=1e-4))

@@ -99,6 +99,9 @@ class OracleEngine:
     def set_beta(self, beta):
         self.beta = float(beta)
 
+    def set_call_count(self, calls):
+        self.calls = int(calls)
+
     def reset(self):
         for b in list(range(L.BUF_MEAN, L.BUF_ACTION_OUT + 1)) + [L.BUF_PENDING_FORCE]:
             self.np[b][...] = 0
@@ -319,6 +322,7 @@ class OracleEngine:
 
     def info(self):
         i = L.Info()
+        i.calls = self.calls
         s = self._info
         if s is not None:
             i.wsum_push, i.wsum_pull, i.beta = s.wsum_push, s.wsum_pull, s.beta

@@ -165,35 +165,49 @@ def test_wrapper_getters_and_step(oracle):
     assert np.abs(worlds[:, 11:13]).max() > 0.1   # the box really got pushed
 
 
-@pytest.mark.parametrize("tag", ["nav", "opt_abs"])
-def test_simple_mode_planner_matches_reference_traces(golden, tag):
+@pytest.mark.parametrize("mode", ["fused", "step", "auto"])
+@pytest.mark.parametrize("tag", ["nav", "opt_abs", "navr", "opt_navr"])
+def test_simple_mode_planner_matches_reference_traces(golden, tag, mode):
     """mppi_mode='simple' through the Python mirror (mppi.py:220-233, :335-372): C1, and the same with
     noise_abs_cost, u_scale != 1, a noise mean and a non-diagonal noise_sigma.  The reference trace was recorded
     with its MultivariateNormal replaced by the build's counter-based stream (make_golden.py g9_trace), which is
     what the kernel draws from for the same seed."""
-    opt = dict(noise_abs_cost=True, u_scale=0.8, noise_mu=[0.3, -0.2], noise_sigma=[[3.0, 1.0], [1.0, 2.0]]) \
-        if tag == "opt_abs" else {}
-    cfg = make_cfg(100, 10, "navigation", (-3.0, 3.0), fused=True, mppi_mode="simple", sampling_method="random",
-                   u_per_command=10, **opt)
+    fused = {"fused": True, "step": False, "auto": None}[mode]
+    simple = tag in ("nav", "opt_abs")
+    opt = dict(noise_mu=[0.3, -0.2], noise_sigma=[[3.0, 1.0], [1.0, 2.0]]) if tag.startswith("opt_") else {}
+    if tag == "opt_abs":
+        opt.update(noise_abs_cost=True, u_scale=0.8)
+    if simple:     # C1: K = 100, T = 10, mppi_mode 'simple'
+        cfg = make_cfg(100, 10, "navigation", (-3.0, 3.0), fused=fused, mppi_mode="simple", sampling_method="random",
+                       u_per_command=10, **opt)
+    else:          # halton-spline with sampling_method 'random' (quirk Q4: the sample is scaled twice)
+        cfg = make_cfg(128, 12, "navigation", (-3.0, 3.0), fused=fused, sampling_method="random", **opt)
+    T = cfg.mppi.horizon
     cfg.mppi.seed_val = 7
     torch.manual_seed(3)
     tamp = Tamp(cfg)
     pl = tamp.motion_planner
-    # mppi.py:134: U starts as T draws of N(noise_mu, noise_sigma); the trace was recorded from U = 0
-    assert pl.U.shape == (10, 2) and float(pl.U.abs().max()) > 0.0
-    pl.U = torch.zeros(10, 2, device="cuda:0")
+    if simple:
+        # mppi.py:134: U starts as T draws of N(noise_mu, noise_sigma); the trace was recorded from U = 0
+        assert pl.U.shape == (T, 2) and float(pl.U.abs().max()) > 0.0
+        pl.U = torch.zeros(T, 2, device="cuda:0")
     tamp.objective.update_objective("navigation", [-3.0, 3.0])
     worlds = golden[f"g9_{tag}_world"]
     for call in range(worlds.shape[0]):
         dof, root = world_to_tensors(tamp.sim, worlds[call])
         tamp.sim._dof_state[:] = dof
         tamp.sim._root_state[:] = root
+        tamp.sim.set_dof_state_tensor(tamp.sim._dof_state)              # run_tamp, reactive_tamp.py:45-48
+        tamp.sim.set_actor_root_state_tensor(tamp.sim._root_state)
         action = pl.command(tamp.sim._dof_state[0])
         np.testing.assert_allclose(action.cpu().numpy(), golden[f"g9_{tag}_action"][call], atol=1e-3)
         np.testing.assert_allclose(pl.weights.cpu().numpy(), golden[f"g9_{tag}_weights"][call], atol=1e-3)
         np.testing.assert_allclose(pl.U.cpu().numpy(), golden[f"g9_{tag}_mean"][call], atol=1e-3)
-        # (the reference's cost_total carries + mean_k(S) through an aliasing quirk, SURVEY Q1; the softmin is
-        # shift-invariant and the library leaves it out: compare relative to the minimum)
-        ct, ref = pl.cost_total.cpu().numpy(), golden[f"g9_{tag}_J"][call]
-        np.testing.assert_allclose(ct - ct.min(), ref - ref.min(), rtol=1e-5, atol=2e-3)
+        if simple:
+            # (the reference's cost_total carries + mean_k(S) through an aliasing quirk, SURVEY Q1; the softmin is
+            # shift-invariant and the library leaves it out: compare relative to the minimum)
+            ct, ref = pl.cost_total.cpu().numpy(), golden[f"g9_{tag}_J"][call]
+            np.testing.assert_allclose(ct - ct.min(), ref - ref.min(), rtol=1e-5, atol=2e-3)
+    if mode == "auto":
+        assert pl.probe_result["fused"] is True, pl.probe_result
     np.testing.assert_allclose(pl.actions.cpu().numpy(), golden[f"g9_{tag}_actions_last"], atol=5e-4)
