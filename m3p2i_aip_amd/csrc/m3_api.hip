@@ -1,6 +1,7 @@
 // m3_api.hip -- C-ABI of libm3p2i_hip.so (see include/m3p2i_hip.h for what each entry
 // point replaces in the reference).  Host code only: argument checking, buffer ownership,
 // launch sequencing on the handle's HIP stream.
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -262,8 +263,8 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (rc == M3_OK && hipMalloc((void**)&h->topk_cand, (size_t)topk_workgroups((int)Kg) * M3_TOPK * sizeof(VI)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->part_min, (size_t)mins_workgroups((int)Kg) * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->lad, (size_t)ladder_workgroups((int)Kg) * 96 * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
-    if (rc == M3_OK && hipMalloc((void**)&h->wpart, (size_t)wsum_chunks((int)(h->regen ? Kg : Kl)) * 3 * T * nu * f) != hipSuccess) rc = M3_ERR_HIP;
-    if (rc == M3_OK && hipMalloc((void**)&h->apart, (size_t)(16 + apply_workgroups((int)Kg) * 8) * f) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->wpart, (size_t)(h->regen ? std::max(wsum_chunks((int)Kg), regen_chunks((int)Kg)) : wsum_chunks((int)Kl)) * 3 * T * nu * f) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->apart, (size_t)(16 + std::max(apply_workgroups((int)Kg), h->regen ? regen_chunks((int)Kg) : 0) * 8) * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->wcount, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMemset(h->wcount, 0, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK) {
@@ -938,7 +939,7 @@ static int regen_finalize(m3_handle* h) {
     fill_update_args(h, a);
     a.regen = 1;
     if (h->regen_fast) {
-        // shard_mix = 2: k_search mixes the shards' ladder tables, then ONE kernel does the rest
+        // shard_mix = 2: k_search mixes the shards' ladder tables, k_regen_part / k_regen_done do the rest
         if ((long long)c.T * c.nu > 2048) return fail(h, M3_ERR_UNSUPPORTED, "m3_finalize: shard_mix = 2 needs T * nu <= 2048");
         a.fast = 1;
         a.Kl = c.K_global; a.k0 = 0;

@@ -1421,8 +1421,20 @@ void launch_wsum(const UpdateArgs& a, hipStream_t s) {
 // expression of k_apply_weights); the chunk workgroups of time step 0 also store them and keep the half sums
 // / argmax keys of their chunk; the workgroup that finishes last combines those in chunk order, re-generates
 // the three best rows and runs the finalize.
+// Two launches: k_regen_part -- T x n_chunk workgroups of 2048 samples each, nothing but partial sums (no arrival
+// tickets: with 32 chunks per time step their serialised atomics on one address cost more than the sums) -- and
+// k_regen_done, one workgroup that adds the partials in chunk order, combines the half sums / argmax keys,
+// re-generates the three best rows and runs the finalize.  (One launch with tickets, 8192-sample chunks: 29 us at
+// K = 64000; this pair: see DESIGN.md section 7.)
+int regen_chunk_len(int Kg) {          // 2048 = WS_BATCH * ST samples, more beyond 64 chunks per time step
+    const int unit = WS_BATCH * ST;
+    const int per64 = (((Kg + 63) / 64) + unit - 1) / unit * unit;
+    return per64 > unit ? per64 : unit;
+}
+int regen_chunks(int Kg) { const int L = regen_chunk_len(Kg); return (Kg + L - 1) / L; }
+
 template <int NU>
-__global__ __launch_bounds__(ST) void k_regen_fast(const UpdateArgs a) {
+__global__ __launch_bounds__(ST) void k_regen_part(const UpdateArgs a, const int clen) {
     __shared__ float red[3 * 16];
     __shared__ VI redvi[16];
     __shared__ float sred[3 * 9 * (ST / 64)];
@@ -1441,7 +1453,6 @@ __global__ __launch_bounds__(ST) void k_regen_fast(const UpdateArgs a) {
     for (int j = 0; j < NU; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
     float hs[2] = {0.0f, 0.0f};
     VI b0 = {INF, 0x7fffffff}, b1 = {INF, 0x7fffffff}, b2 = {INF, 0x7fffffff};
-    const int clen = wsum_chunk_len(Kg);
     const int iend = min(Kg, (c + 1) * clen);
     for (int ib = c * clen; ib < iend; ib += WS_BATCH * ST)
 #pragma unroll
@@ -1490,84 +1501,74 @@ __global__ __launch_bounds__(ST) void k_regen_fast(const UpdateArgs a) {
         if (tid < 8) {
             const float val = tid == 0 ? hs[0] : tid == 1 ? hs[1] : tid == 2 ? b0.v : tid == 3 ? __int_as_float(b0.i)
                             : tid == 4 ? b1.v : tid == 5 ? __int_as_float(b1.i) : tid == 6 ? b2.v : __int_as_float(b2.i);
-            __hip_atomic_store(a.apart + (size_t)c * 8 + tid, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.apart[(size_t)c * 8 + tid] = val;
         }
     }
-    float* out = (C == 1) ? a.reduce : a.wpart + (size_t)c * 3 * T * NU;
-    {
-        const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
+    for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
-            for (int j = 0; j < NU; ++j) {
-                const float ws = wave_sum(acc[s3][j]);
-                if (lane == 0) sred[(s3 * NU + j) * (ST / 64) + wv] = ws;
-            }
-        __syncthreads();
-        if (tid < 3 * NU) {
-            float rv = 0.0f;
-#pragma unroll
-            for (int w = 0; w < ST / 64; ++w) rv += sred[tid * (ST / 64) + w];
-            const int s3 = tid / NU, j = tid % NU;
-            __hip_atomic_store(&out[s3 * T * NU + t * NU + j], rv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < NU; ++j) {
+            const float ws = wave_sum(acc[s3][j]);
+            if (lane == 0) sred[(s3 * NU + j) * (ST / 64) + wv] = ws;
         }
-        __syncthreads();
+    __syncthreads();
+    if (tid < 3 * NU) {
+        float rv = 0.0f;
+#pragma unroll
+        for (int w = 0; w < ST / 64; ++w) rv += sred[tid * (ST / 64) + w];
+        const int s3 = tid / NU, j = tid % NU;
+        a.wpart[((size_t)c * 3 + s3) * T * NU + t * NU + j] = rv;
     }
-    bool t_last = true;
-    if (C > 1) {   // chunk combine of this time step (as in k_wsum)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            const int ticket = __hip_atomic_fetch_add(&a.wcount[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int is_last = ticket == C - 1;
-            if (is_last) a.wcount[t] = 0;
-            red[47] = __int_as_float(is_last);
-        }
-        __syncthreads();
-        t_last = __float_as_int(red[47]) != 0;
-        if (t_last && tid < 3 * NU) {
-            const int which = tid / NU, j = tid % NU;
-            float sum = 0.0f;
-            for (int cc = 0; cc < C; ++cc)
-                sum += __hip_atomic_load(&a.wpart[((size_t)cc * 3 + which) * T * NU + t * NU + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&a.reduce[reduce_off_psum(which, T, NU) + t * NU + j], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (!t_last) return;
-    // the workgroup that completed its time step takes the launch-wide ticket; the last one finishes the command
+}
+
+template <int NU>
+__global__ __launch_bounds__(ST) void k_regen_done(const UpdateArgs a) {
     extern __shared__ float sm_fin[];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const int ticket = __hip_atomic_fetch_add(&a.wcount[T], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int is_last = ticket == T - 1;
-        if (is_last) a.wcount[T] = 0;
-        red[46] = __int_as_float(is_last);
-    }
-    __syncthreads();
-    if (!__float_as_int(red[46])) return;
-    // (a) half sums and argmax keys of time step 0's chunks, in chunk order (every chunk workgroup of t = 0
-    // stored its eight values before it arrived at its time step's ticket)
     __shared__ int s_best[3];
-    if (tid == 0) {
-        float h0 = 0.0f, h1 = 0.0f;
-        VI c0 = {INF, 0x7fffffff}, c1 = c0, c2 = c0;
-        for (int cc = 0; cc < C; ++cc) {
-            float x[8];
-            for (int q = 0; q < 8; ++q) x[q] = __hip_atomic_load(a.apart + (size_t)cc * 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            h0 += x[0]; h1 += x[1];
-            if (vi_less(x[2], __float_as_int(x[3]), c0.v, c0.i)) { c0.v = x[2]; c0.i = __float_as_int(x[3]); }
-            if (vi_less(x[4], __float_as_int(x[5]), c1.v, c1.i)) { c1.v = x[4]; c1.i = __float_as_int(x[5]); }
-            if (vi_less(x[6], __float_as_int(x[7]), c2.v, c2.i)) { c2.v = x[6]; c2.i = __float_as_int(x[7]); }
+    __shared__ float s_part[64 * 8];
+    const int tid = threadIdx.x, C = a.n_chunk, Kg = a.Kg, T = a.T;
+    const float INF = __builtin_inff();
+    // (every load of this workgroup is a first touch of a line another workgroup wrote: they are issued eight at
+    // a time and added afterwards, in chunk order -- a dependent load per chunk was 20 us of latency here)
+    for (int o = tid; o < C * 8; o += ST) s_part[o] = a.apart[o];
+    // (a) the partial sums in chunk order
+    for (int o = tid; o < 3 * T * NU; o += ST) {
+        const int which = o / (T * NU), rem = o - which * T * NU;
+        float sum = 0.0f;
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            float p[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cc = min(c0 + q, C - 1);
+                p[q] = a.wpart[((size_t)cc * 3 + which) * T * NU + rem];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += (c0 + q < C) ? p[q] : 0.0f;
         }
-        m3_info* f = a.info;
-        f->best_idx = c0.i; f->best_idx_1 = c1.i; f->best_idx_2 = c2.i;
-        f->wsum_push = h0; f->wsum_pull = h1;
-        f->pull_preference = h1 > h0;
-        s_best[0] = c0.i; s_best[1] = c1.i; s_best[2] = c2.i;
+        a.reduce[reduce_off_psum(which, T, NU) + rem] = sum;
     }
     __syncthreads();
-    // (b) the best rows: actions of the three argmax samples, re-generated for every time step
+    // (b) half sums and argmax keys of time step 0's chunks: lane cc of the first wavefront holds chunk cc
+    // (C <= 64), fixed reduction tree
+    if (tid < 64) {
+        const bool on = tid < C;
+        const float* x = s_part + (size_t)(on ? tid : 0) * 8;
+        const float h0 = wave_sum(on ? x[0] : 0.0f), h1 = wave_sum(on ? x[1] : 0.0f);
+        const VI none = {INF, 0x7fffffff};
+        const VI c0 = wave_argmin(on ? VI{x[2], __float_as_int(x[3])} : none);
+        const VI c1 = wave_argmin(on ? VI{x[4], __float_as_int(x[5])} : none);
+        const VI c2 = wave_argmin(on ? VI{x[6], __float_as_int(x[7])} : none);
+        if (tid == 0) {
+            m3_info* f = a.info;
+            f->best_idx = c0.i; f->best_idx_1 = c1.i; f->best_idx_2 = c2.i;
+            f->wsum_push = h0; f->wsum_pull = h1;
+            f->pull_preference = h1 > h0;
+            s_best[0] = c0.i; s_best[1] = c1.i; s_best[2] = c2.i;
+        }
+    }
+    __syncthreads();
+    // (c) the best rows: actions of the three argmax samples, re-generated for every time step
     for (int o = tid; o < 3 * T; o += ST) {
         const int which = o / T, tt = o - which * T, gi = s_best[which];
         RegenRows<NU> rr;
@@ -1583,22 +1584,30 @@ __global__ __launch_bounds__(ST) void k_regen_fast(const UpdateArgs a) {
 #pragma unroll
         for (int j = 0; j < NU; ++j) a.reduce[reduce_off_best(which, T, NU) + tt * NU + j] = valid ? ev[j] : 0.0f;
     }
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
-    finalize_body<true>(a, sm_fin);
+    finalize_body<false>(a, sm_fin);
 }
-void launch_regen_fast(const UpdateArgs& a, hipStream_t s) {
+void launch_regen_fast(const UpdateArgs& a_, hipStream_t s) {
     // workgroup 0: the searches on the mixed ladder tables; workgroup 1: the global top-k from the shards' lists
-    hipLaunchKernelGGL(k_search, dim3(2), dim3(WT_MAX), 0, s, a);
+    hipLaunchKernelGGL(k_search, dim3(2), dim3(WT_MAX), 0, s, a_);
+    UpdateArgs a = a_;
+    const int clen = regen_chunk_len(a.Kg);
+    a.n_chunk = regen_chunks(a.Kg);
     const dim3 grid(a.T * a.n_chunk);
     const size_t lds = (size_t)a.T * a.nu * sizeof(float);
-    if (a.nu == 2) hipLaunchKernelGGL(k_regen_fast<2>, grid, dim3(ST), lds, s, a);
-    else hipLaunchKernelGGL(k_regen_fast<9>, grid, dim3(ST), lds, s, a);
+    if (a.nu == 2) {
+        hipLaunchKernelGGL(k_regen_part<2>, grid, dim3(ST), 0, s, a, clen);
+        hipLaunchKernelGGL(k_regen_done<2>, dim3(1), dim3(ST), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(k_regen_part<9>, grid, dim3(ST), 0, s, a, clen);
+        hipLaunchKernelGGL(k_regen_done<9>, dim3(1), dim3(ST), lds, s, a);
+    }
 }
 
 // the shard's own top-k before the collective ("regen" sharding): stage A per 4096 costs, the last
 // workgroup to finish merges (as the top-k workgroups of k_update_small)
-constexpr int LREC_WG = 32;   // extra workgroups of the pre-gather launch that evaluate the shard's ladder table
+constexpr int LREC_WG = 96;   // extra workgroups of the pre-gather launch that evaluate the shard's ladder table: one per ladder point (32 of them, three points each: 11.4 us at 8000 costs)
 template <int RPT>
 __global__ __launch_bounds__(PREP_T) void k_local_topk(const UpdateArgs a) {
     __shared__ int s_lastb;

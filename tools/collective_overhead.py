@@ -50,7 +50,10 @@ def emulate_rank(name, N, steps):
     from m3p2i_aip_amd import _lib as L
     env, task, goal, mm, K, T = bench.CONFIGS[name]
     res = {}
+    only = os.environ.get("M3P2I_EMUL_PROTOCOLS")      # (profiling runs: one protocol at a time)
     for label, mix in (("one_collective", None), ("one_collective_exact", 1), ("gather_reduce", False)):
+        if only and label not in only.split(","):
+            continue
         from m3p2i_aip_amd import isaacgym_wrapper as wrapper
         from m3p2i_aip_amd.cost_functions import Objective
         from m3p2i_aip_amd.planner import M3P2I, MPPIConfig
