@@ -383,6 +383,17 @@ def main():
             line["collective_ms"] = r["collective_ms"]
     delta_np = pl.delta.contiguous().cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
+    if world > 1 and extras and name != "push":
+        # the N = 1 headline's workload (C2: push, 2000 samples per GPU, single-mode) weak-scaled over the same
+        # ranks (one collective per command): value(N) / (N x the N = 1 line's value) is a like-for-like efficiency
+        rw = run_config("push", args, world, rank, device, dist, args.steps, args.warmup, latency=False,
+                        time_collectives=True)
+        if rank == 0:
+            b = brief(rw)
+            b["n_gpus"], b["collective_ms"] = world, rw["collective_ms"]
+            b["workload"] += f" ({rw['K_local']}/GPU, sharded x{world}: BASELINE configs[1] weak-scaled)"
+            line["other_configs"] = {"push_weak": b}
+        rw["pl"]._engine.close()
     if world > 1 and extras and not share:
         # the same per-GPU workload on ONE GPU, unsharded (rank 0, after the distributed run; the other
         # ranks wait at the barrier below)

@@ -32,3 +32,8 @@ def test_bench_with_two_ranks(config, mode):
     assert d["collective_ms"]["per_command"] == 1.0 and d["collective_ms"]["total"] > 0
     assert d["value"] > 0 and abs(d["value"] - 1024 * 30 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+    if config is None:   # the N = 1 headline's workload weak-scaled over the same ranks rides along
+        w = d["other_configs"]["push_weak"]
+        assert w["n_gpus"] == 2 and w["collective_ms"]["per_command"] == 1.0 and "K=4000" in w["workload"] and w["value"] > 0
+    else:
+        assert "other_configs" not in d
