@@ -855,24 +855,23 @@ __global__ __launch_bounds__(NTHR) void k_weights(const UpdateArgs a) {
 //   -> k_apply_weights: every workgroup normalises 4096 costs, keeps its half sums and argmax
 //   keys; the last one to finish (write-through partials + relaxed agent ticket) combines them in
 //   workgroup order and fills m3_info.  Same values as k_weights; half sums in a different order.
-struct SearchOut {   // device scratch, written by k_search
-    float beta[3], eta[3], mn[3];
-};
 constexpr int AP_T = 256, AP_RPT = 16;  // 4096 costs per workgroup (few workgroups: their tickets serialise on one
                                         // address, ~0.3 us each); <= 256 workgroups (K <= 1M)
 int apply_workgroups(int Kg) { return (Kg + AP_T * AP_RPT - 1) / (AP_T * AP_RPT); }
 
-__global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
+struct SearchOut {   // device scratch, written by k_search
+    float beta[3], eta[3], mn[3];
+};
+// The three beta searches (all K / mode 1 / mode 2, m3p2i.py:24-64) of a workgroup of any size: minima, the eta table
+// on both beta ladders (mixed from the shards' tables when a.fast, summed from k_ladder's partials otherwise), the
+// reference's rule on the table, passes over the costs only for a search that leaves its ladder or reverses.
+// Every thread returns with the result; `publish`: thread 0 also writes a.srch and the diagnostics of m3_info.
+__device__ __forceinline__ void search_body(const UpdateArgs& a, SearchOut& out, bool publish) {
     __shared__ float red[3 * 16];
     __shared__ float s_beta[3], s_eta[3], s_mn[3];
     __shared__ int s_done[3], s_it[3];
     __shared__ float s_tab[LAD_N * 3];
     __shared__ float s_part[3 * LAD_N * 3];
-    if (blockIdx.x > 0) {  // workgroups 1..n_cand: top-k stage A, concurrent with the search
-        if (a.fast) topk_merge_records(a);   // (shard_mix = 2: the global top-k from the shards' own lists)
-        else topk_stage_a(a, blockIdx.x - 1);
-        return;
-    }
     const int Kg = a.Kg, half = a.half_g - a.kbase, tid = threadIdx.x, WT = blockDim.x;
     const float INF = __builtin_inff();
     if (a.fast) {
@@ -982,7 +981,8 @@ __global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
         }
         __syncthreads();
     }
-    if (tid == 0) {
+    for (int sx = 0; sx < 3; ++sx) { out.beta[sx] = s_beta[sx]; out.eta[sx] = s_eta[sx]; out.mn[sx] = s_mn[sx]; }
+    if (publish && tid == 0) {
         SearchOut* o = a.srch;
         for (int s = 0; s < 3; ++s) { o->beta[s] = s_beta[s]; o->eta[s] = s_eta[s]; o->mn[s] = s_mn[s]; }
         m3_info* f = a.info;
@@ -990,6 +990,15 @@ __global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
         f->iters = s_it[0]; f->iters_1 = s_it[1]; f->iters_2 = s_it[2];
         f->beta_1 = s_beta[1]; f->beta_2 = s_beta[2];   // diagnostics; info->beta stays (m3p2i.py:58-60)
     }
+}
+__global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
+    if (blockIdx.x > 0) {  // workgroups 1..n_cand: top-k stage A, concurrent with the search
+        if (a.fast) topk_merge_records(a);   // (shard_mix = 2: the global top-k from the shards' own lists)
+        else topk_stage_a(a, blockIdx.x - 1);
+        return;
+    }
+    SearchOut so;
+    search_body(a, so, true);
 }
 
 // MULTI = false: single-mode MPPI with K > 16384 (beyond every reference config, but the rollout's
@@ -1439,38 +1448,60 @@ __global__ __launch_bounds__(ST) void k_regen_part(const UpdateArgs a, const int
     __shared__ VI redvi[16];
     __shared__ float sred[3 * 9 * (ST / 64)];
     const int tid = threadIdx.x, C = a.n_chunk, Kg = a.Kg, T = a.T, half = a.half_g;
+    if ((int)blockIdx.x == T * C) {   // the extra workgroup: the global top-k from the shards' own lists
+        topk_merge_records(a);
+        return;
+    }
     const int t = blockIdx.x / C, c = blockIdx.x % C;
     const float INF = __builtin_inff();
-    const SearchOut so = *a.srch;
+    const float inv_Kls = 1.0f / (float)a.Kls;
+    const int iend = min(Kg, (c + 1) * clen);
+    // this workgroup's costs and noise rows (the first batch: all of them up to K = 131072) are requested BEFORE
+    // the search, whose table loads and serial walk would otherwise sit in front of their latency
+    float v8[WS_BATCH], d8[WS_BATCH][NU];
+    auto load_batch = [&](int ib) {
+#pragma unroll
+        for (int it = 0; it < WS_BATCH; ++it) {
+            const int k = min(ib + it * ST + tid, iend - 1);
+            const int r = shard_of(k, a.Kls, inv_Kls), kk = k - r * a.Kls;
+            v8[it] = a.records_all[(size_t)r * a.rec_len + kk];
+            const float* drow = a.noise_all + (((size_t)r * T + t) * a.Kls + kk) * NU;
+            if constexpr (NU == 2) {
+                const float2 d2 = *reinterpret_cast<const float2*>(drow);
+                d8[it][0] = d2.x; d8[it][1] = d2.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) d8[it][j] = drow[j];
+            }
+        }
+    };
+    load_batch(c * clen);
+    // the beta searches on the MIXTURE of the shards' ladder tables, by every workgroup for itself (a few hundred
+    // exps and a serial walk: cheaper than a launch of its own in front of this one; same code, same data => the
+    // same result in every workgroup); workgroup 0 publishes it
+    SearchOut so;
+    search_body(a, so, blockIdx.x == 0);
     const float i0 = uniform_f(1.0f / so.eta[0]), n0 = uniform_f(-1.0f / so.beta[0]);
     const float i1 = uniform_f(1.0f / so.eta[1]), n1 = uniform_f(-1.0f / so.beta[1]);
     const float i2 = uniform_f(1.0f / so.eta[2]), n2 = uniform_f(-1.0f / so.beta[2]);
     RegenRows<NU> rows;
     regen_rows<NU>(a, t, rows);
-    const float inv_Kls = 1.0f / (float)a.Kls;
     float acc[3][NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
     float hs[2] = {0.0f, 0.0f};
     VI b0 = {INF, 0x7fffffff}, b1 = {INF, 0x7fffffff}, b2 = {INF, 0x7fffffff};
-    const int iend = min(Kg, (c + 1) * clen);
-    for (int ib = c * clen; ib < iend; ib += WS_BATCH * ST)
+    for (int ib = c * clen; ib < iend; ib += WS_BATCH * ST) {
+    if (ib != c * clen) load_batch(ib);
 #pragma unroll
     for (int it = 0; it < WS_BATCH; ++it) {
         const int i = ib + it * ST + tid;
         const bool ok = i < iend;
         const int k = ok ? i : (iend - 1);
-        const int r = shard_of(k, a.Kls, inv_Kls), kk = k - r * a.Kls;
-        const float v = a.records_all[(size_t)r * a.rec_len + kk];
-        const float* drow = a.noise_all + (((size_t)r * T + t) * a.Kls + kk) * NU;
+        const float v = v8[it];
         float dv[NU], av[NU];
-        if constexpr (NU == 2) {
-            const float2 d2 = *reinterpret_cast<const float2*>(drow);
-            dv[0] = d2.x; dv[1] = d2.y;
-        } else {
 #pragma unroll
-            for (int j = 0; j < NU; ++j) dv[j] = drow[j];
-        }
+        for (int j = 0; j < NU; ++j) dv[j] = d8[it][j];
         regen_action<NU>(a, rows, k, dv, av);
         const bool first = k < half;
         float w = i0 * m3_exp(n0 * (v - so.mn[0]));
@@ -1492,6 +1523,7 @@ __global__ __launch_bounds__(ST) void k_regen_part(const UpdateArgs a, const int
             if (first) { if (vi_less(-wh, k, b1.v, b1.i)) { b1.v = -wh; b1.i = k; } }
             else { if (vi_less(-wh, k, b2.v, b2.i)) { b2.v = -wh; b2.i = k; } }
         }
+    }
     }
     if (t == 0) {
         block_sum<2>(hs, red);
@@ -1589,12 +1621,10 @@ __global__ __launch_bounds__(ST) void k_regen_done(const UpdateArgs a) {
     finalize_body<false>(a, sm_fin);
 }
 void launch_regen_fast(const UpdateArgs& a_, hipStream_t s) {
-    // workgroup 0: the searches on the mixed ladder tables; workgroup 1: the global top-k from the shards' lists
-    hipLaunchKernelGGL(k_search, dim3(2), dim3(WT_MAX), 0, s, a_);
     UpdateArgs a = a_;
     const int clen = regen_chunk_len(a.Kg);
     a.n_chunk = regen_chunks(a.Kg);
-    const dim3 grid(a.T * a.n_chunk);
+    const dim3 grid(a.T * a.n_chunk + 1);   // + the top-k merge
     const size_t lds = (size_t)a.T * a.nu * sizeof(float);
     if (a.nu == 2) {
         hipLaunchKernelGGL(k_regen_part<2>, grid, dim3(ST), 0, s, a, clen);

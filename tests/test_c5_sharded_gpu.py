@@ -291,3 +291,47 @@ def test_one_collective_protocol_panda_multi_modal(level):
             assert (e.actions[:, :, 7:] == 1.5).all() or r == Nt - 1
     for e in shards + [full]:
         e.close()
+
+
+@pytest.mark.parametrize("scale", [1e-5, 1.0, 1e8])
+@pytest.mark.parametrize("Kt,Nt", [(16384, 4), (2048, 2)])
+def test_one_collective_fast_protocol_on_synthetic_costs(Kt, Nt, scale):
+    """shard_mix = 2 with cost spreads of 1e-5 and 1e+8, which drive the beta searches (m3p2i.py:24-64) far beyond the
+    shards' precomputed ladder tables: every workgroup of k_regen_part then continues with passes over the gathered
+    costs (search_body's fallback), and all of them -- and all ranks -- must arrive at the same beta / eta / weights
+    as the reference's rule evaluated in float64 on the whole cost vector."""
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    from tests.test_update_on_synthetic_costs_gpu import search
+    kl, Ts = Kt // Nt, 12
+    kw = dict(T=Ts, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+    shards = [HipEngine(make_config(K=Kt, K_local=kl, k_offset=r * kl, shard_mix=2, **kw)) for r in range(Nt)]
+    rng = np.random.default_rng(int(Kt + np.log10(scale) * 7))
+    J = (scale * np.abs(rng.standard_normal(Kt))).astype(np.float32)
+    delta = rng.standard_normal((Kt, Ts, 2)).astype(np.float32)
+    for r, e in enumerate(shards):
+        e.set_noise(delta)
+        e.set_objective("push_pull", (-3.75, -3.75))
+        e.rollout()                                              # (fills states / actions; its costs are replaced)
+        e.buffer(L.BUF_TRAJ_COST).copy_(torch.from_numpy(J[r * kl:(r + 1) * kl]))
+        e.update()
+    allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])
+    for e in shards:
+        e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
+        e.finalize()
+    torch.cuda.synchronize()
+    half = Kt // 2
+    info = shards[0].info()
+    for buf, JJ, eta, iters in ((L.BUF_WEIGHTS, J, info.eta, info.iters), (L.BUF_WEIGHTS_1, J[:half], info.eta_1, info.iters_1),
+                                (L.BUF_WEIGHTS_2, J[half:], info.eta_2, info.iters_2)):
+        w_ref, eta_ref, beta_ref, it_ref = search(JJ)
+        assert 3.0 <= eta <= 10.0 and abs(iters - it_ref) <= 1, (eta, iters, it_ref)
+        if iters == it_ref:
+            np.testing.assert_allclose(shards[0].buffer(buf).cpu().numpy(), w_ref, rtol=5e-3, atol=1e-7)
+    if scale != 1.0:     # beyond the 0.9-ladder (64 points) / the 1.2-ladder (32 points): the fallback passes ran
+        assert info.iters > (65 if scale < 1.0 else 34), info.iters
+    for e in shards[1:]:
+        for name in PLAN_BUFS + ("BUF_WEIGHTS", "BUF_WEIGHTS_1", "BUF_WEIGHTS_2", "BUF_TOP_IDX"):
+            assert torch.equal(e.buffer(getattr(L, name)), shards[0].buffer(getattr(L, name))), name
+    for e in shards:
+        e.close()
