@@ -340,10 +340,16 @@ int m3_sim_bind_views(m3_handle* h, float* dof_state, float* root_state,
                       float* rigid_body_state, float* net_contact_force, int n_actors,
                       int n_bodies);
 int m3_sim_pull_state(m3_handle* h); /* views -> internal state (set_*_state_tensor) */
+/* update_dyn_obs (isaacgym_wrapper.py:205-220): root position of one actor of every environment shifted by
+ * (dx, dy, dz) in the bound root_state view, followed by m3_sim_pull_state -- one launch (point_env) */
+int m3_sim_shift_actor(m3_handle* h, int actor, float dx, float dy, float dz);
 int m3_sim_push_state(m3_handle* h); /* internal state -> views (refresh_*) */
 int m3_sim_set_velocity_target(m3_handle* h, const float* u_dev /* [Kl][nu] */);
 int m3_sim_apply_body_forces(m3_handle* h, const float* f_dev /* [Kl][nB][3] */);
 int m3_sim_step(m3_handle* h);       /* one step(): dt with substeps, then push views */
+/* m3_sim_set_velocity_target(h, u) + m3_sim_step(h) in one launch: the targets are read from u (device,
+ * [K_local][nu]) when the step runs and stay in force for later steps */
+int m3_sim_step_with_target(m3_handle* h, const float* u);
 int m3_cost(m3_handle* h, float* cost_dev /* [Kl] */); /* Objective.compute_cost */
 /* the 1-env "real world" of scripts/sim.py:41-49 (point_env), evaluated on the device:
  * calculate_suction (utils/skill_utils.py:59-94): forces_dev f32 [Kl][nB][3] is overwritten with the

@@ -108,6 +108,8 @@ SYMBOLS = [
     ("m3_get_timing", C.c_int, [_H, C.POINTER(Timing)]),
     ("m3_sim_bind_views", C.c_int, [_H, _FP, _FP, _FP, _FP, C.c_int, C.c_int]),
     ("m3_sim_pull_state", C.c_int, [_H]),
+    ("m3_sim_shift_actor", C.c_int, [_H, C.c_int, C.c_float, C.c_float, C.c_float]),
+    ("m3_sim_step_with_target", C.c_int, [_H, C.c_void_p]),
     ("m3_sim_push_state", C.c_int, [_H]),
     ("m3_sim_set_velocity_target", C.c_int, [_H, _FP]),
     ("m3_sim_apply_body_forces", C.c_int, [_H, _FP]),

@@ -1130,6 +1130,16 @@ extern "C" int m3_sim_pull_state(m3_handle* h) {
     return M3_OK;
 }
 
+extern "C" int m3_sim_shift_actor(m3_handle* h, int actor, float dx, float dy, float dz) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->views_bound) return fail(h, M3_ERR_STATE, "m3_sim_shift_actor: views not bound");
+    if (h->cfg.env_type != M3_ENV_POINT) return fail(h, M3_ERR_UNSUPPORTED, "m3_sim_shift_actor: point_env (its dyn-obs walks; the panda_env's offset is zero)");
+    if (actor < 0 || actor >= h->views.n_actors) return fail(h, M3_ERR_SHAPE, "m3_sim_shift_actor: actor index out of range");
+    launch_sim_shift_pull(h->views, h->sim_world, h->cfg.K_local, actor, dx, dy, dz, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
 extern "C" int m3_sim_push_state(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     if (!h->views_bound) return fail(h, M3_ERR_STATE, "m3_sim_push_state: views not bound");
@@ -1157,18 +1167,25 @@ extern "C" int m3_sim_apply_body_forces(m3_handle* h, const float* f) {
     return M3_OK;
 }
 
-extern "C" int m3_sim_step(m3_handle* h) {
-    if (!h) return M3_ERR_BAD_ARG;
+static int sim_step_impl(m3_handle* h, const float* u) {
     if (!h->views_bound) return fail(h, M3_ERR_STATE, "m3_sim_step: views not bound");
     if (h->cfg.env_type == M3_ENV_POINT) {
-        launch_sim_step(h->scene, h->sim_world, h->sim_u, h->cfg.K_local, h->stream);
-        launch_sim_push(h->views, h->sim_world, h->cfg.K_local, h->stream);
+        launch_sim_step(h->scene, h->views, h->sim_world, u, h->sim_u, h->cfg.K_local, h->stream);
     } else {
-        launch_psim_step(h->pscene, h->sim_world, h->sim_u, h->cfg.K_local, h->stream);
-        launch_psim_push(h->pscene, h->views, h->sim_world, h->cfg.K_local, h->stream);
+        launch_psim_step(h->pscene, h->views, h->sim_world, u, h->sim_u, h->cfg.K_local, h->stream);
     }
     HIPCHK(h, hipGetLastError());
     return M3_OK;
+}
+
+extern "C" int m3_sim_step(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    return sim_step_impl(h, h->sim_u);
+}
+
+extern "C" int m3_sim_step_with_target(m3_handle* h, const float* u) {
+    if (!h || !u) return M3_ERR_BAD_ARG;
+    return sim_step_impl(h, u);
 }
 
 static int suction_impl(m3_handle* h, float kp, const float* action, int apply, float* forces, int* flags,

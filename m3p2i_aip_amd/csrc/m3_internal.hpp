@@ -200,9 +200,10 @@ struct SimViews {
     int table_body, shelf_body;             // panda_env only
 };
 void launch_sim_pull(const SimViews& v, float* world /*[NW][Kl]*/, int Kl, hipStream_t s);
+void launch_sim_shift_pull(const SimViews& v, float* world, int Kl, int actor, float dx, float dy, float dz, hipStream_t s);
 void launch_sim_push(const SimViews& v, const float* world, int Kl, hipStream_t s);
-void launch_sim_step(const PointScene& sc, float* world, const float* u /*[Kl][2]*/, int Kl,
-                     hipStream_t s);
+void launch_sim_step(const PointScene& sc, const SimViews& v, float* world, const float* u /*[Kl][2]*/, float* u_keep,
+                     int Kl, hipStream_t s);   // step + refresh of the views
 void launch_sim_forces(const SimViews& v, float* world, const float* f /*[Kl][nB][3]*/, int Kl,
                        hipStream_t s);
 void launch_sim_cost(const CostParams& cp, float* world, int Kl, int k0, float* cost,
@@ -220,7 +221,8 @@ struct PandaArgs {
     PandaCostParams cp;
 };
 void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s);
-void launch_psim_step(const PandaScene& sc, float* world, const float* u, int Kl, hipStream_t s);
+void launch_psim_step(const PandaScene& sc, const SimViews& v, float* world, const float* u, float* u_keep, int Kl,
+                      hipStream_t s);
 void launch_psim_pull(const PandaScene& sc, const SimViews& v, float* world, int Kl, hipStream_t s);
 void launch_psim_push(const PandaScene& sc, const SimViews& v, const float* world, int Kl, hipStream_t s);
 void launch_psim_cost(const PandaScene& sc, const PandaCostParams& cp, const float* world, int Kl, int k0,

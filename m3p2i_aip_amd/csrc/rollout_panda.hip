@@ -225,40 +225,8 @@ __device__ __forceinline__ void psoa_store(float* wd, int Kl, int i, const Panda
     p[43 * Kl] = w.f_cubeB[0]; p[44 * Kl] = w.f_cubeB[1];
 }
 
-__global__ __launch_bounds__(64) void k_psim_step(const PandaScene sc, float* wd, const float* u, int Kl) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= Kl) return;
-    PandaWorld w;
-    psoa_load(wd, Kl, i, w);
-    float uu[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) uu[j] = u[(size_t)i * 9 + j];
-    PandaObs obs;
-    panda_step(sc, w, uu, obs);
-    psoa_store(wd, Kl, i, w);
-}
-void launch_psim_step(const PandaScene& sc, float* world, const float* u, int Kl, hipStream_t s) {
-    hipLaunchKernelGGL(k_psim_step, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, world, u, Kl);
-}
-
-__global__ __launch_bounds__(64) void k_psim_pull(const PandaScene sc, const SimViews v, float* wd, int Kl) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= Kl) return;
-    PandaWorld w;
-    panda_world_from_sim(v.dof_state + (size_t)i * 18, v.root_state + (size_t)i * v.n_actors * 13,
-                         v.box_actor, v.dyn_actor, w);  // box_actor = cubeA, dyn_actor = cubeB here
-    panda_infer_held(sc, w);
-    psoa_store(wd, Kl, i, w);
-}
-void launch_psim_pull(const PandaScene& sc, const SimViews& v, float* world, int Kl, hipStream_t s) {
-    hipLaunchKernelGGL(k_psim_pull, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, v, world, Kl);
-}
-
-__global__ __launch_bounds__(64) void k_psim_push(const PandaScene sc, const SimViews v, const float* wd, int Kl) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= Kl) return;
-    PandaWorld w;
-    psoa_load(wd, Kl, i, w);
+// SoA world of environment i -> the wrapper's views (link poses through the forward kinematics)
+__device__ __forceinline__ void panda_push_views(const PandaScene& sc, const SimViews& v, int i, const PandaWorld& w) {
     if (v.dof_state) {
         float* d = v.dof_state + (size_t)i * 18;
 #pragma unroll
@@ -296,6 +264,51 @@ __global__ __launch_bounds__(64) void k_psim_push(const PandaScene sc, const Sim
         f[v.shelf_body * 3 + 0] = w.f_shelf[0]; f[v.shelf_body * 3 + 1] = w.f_shelf[1];
         f[v.dyn_body * 3 + 0] = w.f_cubeB[0]; f[v.dyn_body * 3 + 1] = w.f_cubeB[1];
     }
+}
+
+// one sim.step() of every environment and the refresh of the wrapper's views in the same launch
+__global__ __launch_bounds__(64) void k_psim_step(const PandaScene sc, const SimViews v, float* wd, const float* u,
+                                                  float* u_keep, int Kl) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= Kl) return;
+    PandaWorld w;
+    psoa_load(wd, Kl, i, w);
+    float uu[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) uu[j] = u[(size_t)i * 9 + j];
+    if (u_keep != u) {   // (targets taken from the caller's tensor: kept for the steps after this one)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) u_keep[(size_t)i * 9 + j] = uu[j];
+    }
+    PandaObs obs;
+    panda_step(sc, w, uu, obs);
+    psoa_store(wd, Kl, i, w);
+    panda_push_views(sc, v, i, w);
+}
+void launch_psim_step(const PandaScene& sc, const SimViews& v, float* world, const float* u, float* u_keep, int Kl,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_psim_step, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, v, world, u, u_keep, Kl);
+}
+
+__global__ __launch_bounds__(64) void k_psim_pull(const PandaScene sc, const SimViews v, float* wd, int Kl) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= Kl) return;
+    PandaWorld w;
+    panda_world_from_sim(v.dof_state + (size_t)i * 18, v.root_state + (size_t)i * v.n_actors * 13,
+                         v.box_actor, v.dyn_actor, w);  // box_actor = cubeA, dyn_actor = cubeB here
+    panda_infer_held(sc, w);
+    psoa_store(wd, Kl, i, w);
+}
+void launch_psim_pull(const PandaScene& sc, const SimViews& v, float* world, int Kl, hipStream_t s) {
+    hipLaunchKernelGGL(k_psim_pull, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, v, world, Kl);
+}
+
+__global__ __launch_bounds__(64) void k_psim_push(const PandaScene sc, const SimViews v, const float* wd, int Kl) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= Kl) return;
+    PandaWorld w;
+    psoa_load(wd, Kl, i, w);
+    panda_push_views(sc, v, i, w);
 }
 void launch_psim_push(const PandaScene& sc, const SimViews& v, const float* world, int Kl, hipStream_t s) {
     hipLaunchKernelGGL(k_psim_push, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, v, world, Kl);

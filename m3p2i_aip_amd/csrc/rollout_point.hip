@@ -78,18 +78,64 @@ __device__ __forceinline__ void soa_store(float* wd, int Kl, int i, const PointW
     p[26 * Kl] = w.fcRx; p[27 * Kl] = w.fcRy;
 }
 
-__global__ __launch_bounds__(64) void k_sim_step(const PointScene sc, float* wd, const float* u,
-                                                 int Kl) {
+__device__ __forceinline__ void write_body13(float* r, float x, float y, float c, float s,
+                                             float vx, float vy, float wz) {
+    // yaw (c, s) -> quaternion (0, 0, sin(th/2), cos(th/2)) with cos(th/2) >= 0
+    float qw = sqrtf(fmaxf(0.5f * (1.0f + c), 0.0f));
+    float qz;
+    if (qw > 1e-4f) qz = s / (2.0f * qw);
+    else { qz = 1.0f; qw = 0.0f; }
+    r[0] = x; r[1] = y;  // r[2] (z) is left as set at init
+    r[3] = 0.0f; r[4] = 0.0f; r[5] = qz; r[6] = qw;
+    r[7] = vx; r[8] = vy; r[9] = 0.0f;
+    r[10] = 0.0f; r[11] = 0.0f; r[12] = wz;
+}
+
+// SoA world of environment i -> the wrapper's views (what a refresh_*_tensor call of Isaac Gym does)
+__device__ __forceinline__ void push_views(const SimViews& v, int i, const PointWorld& w) {
+    if (v.dof_state) {
+        *reinterpret_cast<float4*>(v.dof_state + (size_t)i * 4) = make_float4(w.rx, w.rvx, w.ry, w.rvy);
+    }
+    if (v.root_state) {
+        float* base = v.root_state + (size_t)i * v.n_actors * 13;
+        write_body13(base + v.box_actor * 13, w.B.x, w.B.y, w.B.c, w.B.s, w.B.vx, w.B.vy, w.B.w);
+        write_body13(base + v.dyn_actor * 13, w.D.x, w.D.y, w.D.c, w.D.s, w.D.vx, w.D.vy, w.D.w);
+        // (fixed base of the robot: stays at its init pose)
+    }
+    if (v.rigid_body_state) {
+        float* base = v.rigid_body_state + (size_t)i * v.n_bodies * 13;
+        write_body13(base + v.box_body * 13, w.B.x, w.B.y, w.B.c, w.B.s, w.B.vx, w.B.vy, w.B.w);
+        write_body13(base + v.dyn_body * 13, w.D.x, w.D.y, w.D.c, w.D.s, w.D.vx, w.D.vy, w.D.w);
+        // robot links: plane (fixed), link_x (x only), link_y (x, y)
+        write_body13(base + (v.robot_body - 1) * 13, w.rx, 0.0f, 1.0f, 0.0f, w.rvx, 0.0f, 0.0f);
+        write_body13(base + v.robot_body * 13, w.rx, w.ry, 1.0f, 0.0f, w.rvx, w.rvy, 0.0f);
+    }
+    if (v.net_contact_force) {
+        float* f = v.net_contact_force + (size_t)i * v.n_bodies * 3;
+        f[v.box_body * 3 + 0] = w.fcBx; f[v.box_body * 3 + 1] = w.fcBy;
+        f[v.dyn_body * 3 + 0] = w.fcDx; f[v.dyn_body * 3 + 1] = w.fcDy;
+        f[v.robot_body * 3 + 0] = w.fcRx; f[v.robot_body * 3 + 1] = w.fcRy;
+    }
+}
+
+// one sim.step() of every environment and the refresh of the wrapper's views in the same launch
+// (u_keep != u: the targets come from the caller's tensor and are kept for the steps after this one, as a
+// set_dof_velocity_target_tensor in front of the step would have done)
+__global__ __launch_bounds__(64) void k_sim_step(const PointScene sc, const SimViews v, float* wd, const float* u,
+                                                 float* u_keep, int Kl) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= Kl) return;
     PointWorld w;
     soa_load(wd, Kl, i, w);
     const float2 uu = *reinterpret_cast<const float2*>(u + (size_t)i * 2);
+    if (u_keep != u) *reinterpret_cast<float2*>(u_keep + (size_t)i * 2) = uu;
     point_step<true>(sc, w, uu.x, uu.y);
     soa_store(wd, Kl, i, w);
+    push_views(v, i, w);
 }
-void launch_sim_step(const PointScene& sc, float* world, const float* u, int Kl, hipStream_t s) {
-    hipLaunchKernelGGL(k_sim_step, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, world, u, Kl);
+void launch_sim_step(const PointScene& sc, const SimViews& v, float* world, const float* u, float* u_keep, int Kl,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_sim_step, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, v, world, u, u_keep, Kl);
 }
 
 __global__ void k_sim_cost(const CostParams cp, float* wd, int Kl, int k0, float* cost) {
@@ -108,9 +154,7 @@ void launch_sim_cost(const CostParams& cp, float* world, int Kl, int k0, float* 
 
 // wrapper views (AoS, torch-owned) -> SoA world.  dof_state row = [x, vx, y, vy]
 // (isaacgym_wrapper.py:120-126); root_state row = pos3 quat4(xyzw) linvel3 angvel3 (:102-104)
-__global__ void k_sim_pull(const SimViews v, float* wd, int Kl) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Kl) return;
+__device__ __forceinline__ void pull_env(const SimViews& v, float* wd, int Kl, int i) {
     float* p = wd + i;
     const float* d = v.dof_state + (size_t)i * 4;
     p[0 * Kl] = d[0]; p[1 * Kl] = d[2]; p[2 * Kl] = d[1]; p[3 * Kl] = d[3];
@@ -124,21 +168,25 @@ __global__ void k_sim_pull(const SimViews v, float* wd, int Kl) {
         p[(o + 4) * Kl] = r[7]; p[(o + 5) * Kl] = r[8]; p[(o + 6) * Kl] = r[12];
     }
 }
+__global__ void k_sim_pull(const SimViews v, float* wd, int Kl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Kl) return;
+    pull_env(v, wd, Kl, i);
+}
+// update_dyn_obs (isaacgym_wrapper.py:205-220): one actor's root position shifted in the wrapper's root_state
+// view + set_actor_root_state_tensor, in one launch
+__global__ void k_sim_shift_pull(const SimViews v, float* wd, int Kl, int actor, float dx, float dy, float dz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Kl) return;
+    float* r = v.root_state + ((size_t)i * v.n_actors + actor) * 13;
+    r[0] = r[0] + dx; r[1] = r[1] + dy; r[2] = r[2] + dz;
+    pull_env(v, wd, Kl, i);
+}
+void launch_sim_shift_pull(const SimViews& v, float* world, int Kl, int actor, float dx, float dy, float dz, hipStream_t s) {
+    hipLaunchKernelGGL(k_sim_shift_pull, dim3((Kl + 255) / 256), dim3(256), 0, s, v, world, Kl, actor, dx, dy, dz);
+}
 void launch_sim_pull(const SimViews& v, float* world, int Kl, hipStream_t s) {
     hipLaunchKernelGGL(k_sim_pull, dim3((Kl + 255) / 256), dim3(256), 0, s, v, world, Kl);
-}
-
-__device__ __forceinline__ void write_body13(float* r, float x, float y, float c, float s,
-                                             float vx, float vy, float wz) {
-    // yaw (c, s) -> quaternion (0, 0, sin(th/2), cos(th/2)) with cos(th/2) >= 0
-    float qw = sqrtf(fmaxf(0.5f * (1.0f + c), 0.0f));
-    float qz;
-    if (qw > 1e-4f) qz = s / (2.0f * qw);
-    else { qz = 1.0f; qw = 0.0f; }
-    r[0] = x; r[1] = y;  // r[2] (z) is left as set at init
-    r[3] = 0.0f; r[4] = 0.0f; r[5] = qz; r[6] = qw;
-    r[7] = vx; r[8] = vy; r[9] = 0.0f;
-    r[10] = 0.0f; r[11] = 0.0f; r[12] = wz;
 }
 
 __global__ void k_sim_push(const SimViews v, const float* wd, int Kl) {
@@ -146,30 +194,7 @@ __global__ void k_sim_push(const SimViews v, const float* wd, int Kl) {
     if (i >= Kl) return;
     PointWorld w;
     soa_load(wd, Kl, i, w);
-    if (v.dof_state) {
-        *reinterpret_cast<float4*>(v.dof_state + (size_t)i * 4) = make_float4(w.rx, w.rvx, w.ry, w.rvy);
-    }
-    if (v.root_state) {
-        float* base = v.root_state + (size_t)i * v.n_actors * 13;
-        write_body13(base + v.box_actor * 13, w.B.x, w.B.y, w.B.c, w.B.s, w.B.vx, w.B.vy, w.B.w);
-        write_body13(base + v.dyn_actor * 13, w.D.x, w.D.y, w.D.c, w.D.s, w.D.vx, w.D.vy, w.D.w);
-        float* rr = base + v.robot_actor * 13;  // fixed base of the robot: stays at init pose
-        (void)rr;
-    }
-    if (v.rigid_body_state) {
-        float* base = v.rigid_body_state + (size_t)i * v.n_bodies * 13;
-        write_body13(base + v.box_body * 13, w.B.x, w.B.y, w.B.c, w.B.s, w.B.vx, w.B.vy, w.B.w);
-        write_body13(base + v.dyn_body * 13, w.D.x, w.D.y, w.D.c, w.D.s, w.D.vx, w.D.vy, w.D.w);
-        // robot links: plane (fixed), link_x (x only), link_y (x, y)
-        write_body13(base + (v.robot_body - 1) * 13, w.rx, 0.0f, 1.0f, 0.0f, w.rvx, 0.0f, 0.0f);
-        write_body13(base + v.robot_body * 13, w.rx, w.ry, 1.0f, 0.0f, w.rvx, w.rvy, 0.0f);
-    }
-    if (v.net_contact_force) {
-        float* f = v.net_contact_force + (size_t)i * v.n_bodies * 3;
-        f[v.box_body * 3 + 0] = w.fcBx; f[v.box_body * 3 + 1] = w.fcBy;
-        f[v.dyn_body * 3 + 0] = w.fcDx; f[v.dyn_body * 3 + 1] = w.fcDy;
-        f[v.robot_body * 3 + 0] = w.fcRx; f[v.robot_body * 3 + 1] = w.fcRy;
-    }
+    push_views(v, i, w);
 }
 void launch_sim_push(const SimViews& v, const float* world, int Kl, hipStream_t s) {
     hipLaunchKernelGGL(k_sim_push, dim3((Kl + 255) / 256), dim3(256), 0, s, v, world, Kl);

@@ -330,13 +330,21 @@ class HipEngine:
     def sim_pull_state(self):
         self._ck(self.lib.m3_sim_pull_state(self._h))
 
+    def sim_shift_actor(self, actor, dx, dy, dz=0.0):
+        """root position of one actor of every environment += (dx, dy, dz) in the bound view, then the state
+        upload -- one launch (update_dyn_obs)."""
+        self._ck(self.lib.m3_sim_shift_actor(self._h, int(actor), float(dx), float(dy), float(dz)))
+
     def sim_push_state(self):
         self._ck(self.lib.m3_sim_push_state(self._h))
 
     def sim_set_velocity_target(self, u):
+        """The targets are handed to the next sim_step() (one launch instead of a copy + a step); the tensor is
+        kept alive until then, and an in-place change of it in between -- which a copy at this point would not
+        have seen -- is refused there."""
         u = u.to(torch.float32).contiguous()
         assert u.is_cuda and tuple(u.shape) == (self.cfg.K_local, self.cfg.nu), u.shape
-        self._ck(self.lib.m3_sim_set_velocity_target(self._h, u.data_ptr()))
+        self._pending_u = (u, u._version)
 
     def sim_apply_body_forces(self, f):
         f = f.to(torch.float32).contiguous()
@@ -344,7 +352,16 @@ class HipEngine:
         self._ck(self.lib.m3_sim_apply_body_forces(self._h, f.data_ptr()))
 
     def sim_step(self):
-        self._ck(self.lib.m3_sim_step(self._h))
+        pending = getattr(self, "_pending_u", None)
+        if pending is None:
+            self._ck(self.lib.m3_sim_step(self._h))      # the targets of the last set call stay in force
+            return
+        u, version = pending
+        self._pending_u = None
+        if u._version != version:
+            raise RuntimeError("the velocity-target tensor was modified in place between "
+                               "set_dof_velocity_target_tensor() and step(): pass a clone")
+        self._ck(self.lib.m3_sim_step_with_target(self._h, u.data_ptr()))
 
     def sim_suction_forces(self, kp_suction):
         """calculate_suction on the device: [K_local, n_bodies, 3] body forces (skill_utils.py:59-94)."""

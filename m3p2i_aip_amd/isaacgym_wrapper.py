@@ -197,15 +197,16 @@ class IsaacGymWrapper:
 
     def update_dyn_obs(self, i, period=100):
         """The dyn-obs of the point_env walks 1 cm per tick along the diagonal, forth for half a period and
-        back (isaacgym_wrapper.py:205-220); in the panda_env the offset is zero.  One in-place add on a
-        slice view + the state upload: no index tensors, no host round trip."""
-        if getattr(self, "_dyn_obs_step", None) is None:
+        back (isaacgym_wrapper.py:205-220); in the panda_env the offset is zero (the state is uploaded unchanged).
+        The shift of the root_state row and the state upload are one launch: no index tensors, no host round trip."""
+        if getattr(self, "_dyn_obs_row", None) is None:
             self._dyn_obs_row = [a.name for a in self.env_cfg].index("dyn-obs")
-            step = [0.01, 0.01, 0.0] if self.env_type == "point_env" else [0.0, 0.0, 0.0]
-            self._dyn_obs_step = torch.tensor(step, dtype=torch.float32, device=self.device)
         forth = period / 4 < i % period < period / 4 * 3
-        self._root_state[:, self._dyn_obs_row, :3].add_(self._dyn_obs_step, alpha=1.0 if forth else -1.0)
-        self.set_actor_root_state_tensor(self._root_state)
+        if self.env_type == "point_env":
+            d = 0.01 if forth else -0.01
+            self._engine.sim_shift_actor(self._dyn_obs_row, d, d, 0.0)
+        else:
+            self.set_actor_root_state_tensor(self._root_state)
 
     def step(self):
         self._engine.sim_step()

@@ -163,6 +163,40 @@ def test_wrapper_getters_and_step(oracle):
     link = sim.get_actor_link_by_name("point_robot", "link_y").cpu().numpy()
     np.testing.assert_array_equal(link[:, :2], worlds[:, 0:2])
     assert np.abs(worlds[:, 11:13]).max() > 0.1   # the box really got pushed
+    # velocity targets stay in force until they are set again (two steps, one set) ...
+    u = rng.uniform(-3, 3, (K, 2)).astype(np.float32)
+    sim.set_dof_velocity_target_tensor(torch.from_numpy(u).cuda())
+    for _ in range(2):
+        sim.step()
+        oracle.step_batch(sc, worlds, u)
+    np.testing.assert_array_equal(sim.robot_pos.cpu().numpy(), worlds[:, 0:2])
+    # ... and the hand-over of the target tensor to step() (one launch for both) refuses a tensor that was changed
+    # in place in between -- a copy at set time would not have seen the change
+    t = torch.from_numpy(u).cuda()
+    sim.set_dof_velocity_target_tensor(t)
+    t.mul_(0.5)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        sim.step()
+
+
+def test_update_dyn_obs_walks_the_obstacle_like_the_reference(oracle):
+    """isaacgym_wrapper.py:205-220: the dyn-obs of the point_env moves 1 cm per tick along the diagonal, forth while
+    period/4 < i % period < 3 period/4, back otherwise; the shift lands in the root_state view AND in the simulated
+    world (the next step() starts from it, and a robot standing in its way is pushed by it)."""
+    from m3p2i_aip_amd.isaacgym_wrapper import IsaacGymConfig, IsaacGymWrapper
+    sim = IsaacGymWrapper(IsaacGymConfig(dt=0.05), "point_env", num_envs=3, device="cuda:0")
+    row = int(sim._get_actor_index_by_name("dyn-obs"))
+    pos = sim._root_state[0, row, :3].clone()
+    zero = torch.zeros(3, 2, device="cuda:0")
+    for i in range(130):
+        sim.update_dyn_obs(i)
+        off = torch.tensor([0.01, 0.01, 0.0], device="cuda:0")
+        pos = pos + off if 25 < i % 100 < 75 else pos - off
+        if i % 10 == 0:
+            sim.set_dof_velocity_target_tensor(zero)
+            sim.step()          # the world carries the shifted obstacle through a step (nothing touches it here)
+        torch.testing.assert_close(sim._root_state[:, row, :3], pos.expand(3, 3), atol=2e-6, rtol=0)
+    torch.testing.assert_close(sim.get_actor_position_by_name("dyn-obs"), pos.expand(3, 3), atol=2e-6, rtol=0)
 
 
 @pytest.mark.parametrize("mode", ["fused", "step", "auto"])
