@@ -1761,19 +1761,21 @@ void launch_local_topk(const UpdateArgs& a, hipStream_t s) {
 // Workgroup 0 also stores the weights and m3_info, workgroup T is the top-k stage, the last
 // workgroup to finish does the mean update / filter (same hand-off as in k_wsum) and writes the
 // adapted beta -- after every workgroup has read the old one.
-template <int NU, bool MULTI, int JR>
-__global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
-    constexpr int WT = 256, NS = MULTI ? 3 : 1;   // JR rows of 256 costs per thread: K <= JR * 256
+template <int NU, bool MULTI, int JR, int WT = 256>
+__global__ __launch_bounds__(WT) void k_update_small(const UpdateArgs a) {
+    constexpr int NS = MULTI ? 3 : 1, NW = WT / 64;   // JR rows of WT costs per thread: K <= JR * WT
     __shared__ float red[3 * 16];
     __shared__ VI redvi[16];
     __shared__ float sred[3 * 9 * (WT / 64)];
-    __shared__ float s_part[2][3 * 4];
+    __shared__ float s_part[2][3 * NW];
     const int T = a.T, tid = threadIdx.x, Kg = a.Kg;
     if ((int)blockIdx.x >= T) {  // top-k workgroups, concurrent with the column workgroups
         // one per 4096 costs; with more than one, the last of them to finish merges the lists (stage
         // B): candidates out through agent-scope fences (off the command's critical path), a ticket
         __shared__ int s_lastb;
-        topk_stage_a(a, blockIdx.x - T);
+        if (tid >= PREP_T) return;   // (512-thread instances: the top-k stage is written for PREP_T threads ...
+        if constexpr (WT > PREP_T) topk_stage_a<32>(a, blockIdx.x - T);   // ... and ONE workgroup selects from all K <= 8192 costs)
+        else topk_stage_a(a, blockIdx.x - T);
         if (a.n_cand > 1) {
             __threadfence();
             __syncthreads();
@@ -1881,12 +1883,12 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
                 }
                 e0 = wave_sum(e0); e1 = wave_sum(e1); e2 = wave_sum(e2);
                 float* buf = s_part[nbuf & 1];
-                if (lane == 0) { buf[0 * 4 + wv] = e0; buf[1 * 4 + wv] = e1; buf[2 * 4 + wv] = e2; }
+                if (lane == 0) { buf[0 * NW + wv] = e0; buf[1 * NW + wv] = e1; buf[2 * NW + wv] = e2; }
                 __syncthreads();
                 if (tid < 3) {
                     float et = 0.0f;
 #pragma unroll
-                    for (int w = 0; w < WT / 64; ++w) et += buf[tid * 4 + w];   // wave order, as in a pass
+                    for (int w = 0; w < WT / 64; ++w) et += buf[tid * NW + w];   // wave order, as in a pass
                     __hip_atomic_store(&a.lad[p * 3 + tid], et, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -1976,13 +1978,13 @@ __global__ __launch_bounds__(256) void k_update_small(const UpdateArgs a) {
             }
             e0 = wave_sum(e0); e1 = wave_sum(e1); e2 = wave_sum(e2);
             float* buf = s_part[pass & 1];
-            if (lane == 0) { buf[0 * 4 + wv] = e0; buf[1 * 4 + wv] = e1; buf[2 * 4 + wv] = e2; }
+            if (lane == 0) { buf[0 * NW + wv] = e0; buf[1 * NW + wv] = e1; buf[2 * NW + wv] = e2; }
             __syncthreads();
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) {
                 float et = 0.0f;
 #pragma unroll
-                for (int w = 0; w < WT / 64; ++w) et += buf[s3 * 4 + w];   // wave order, as block_sum
+                for (int w = 0; w < WT / 64; ++w) et += buf[s3 * NW + w];   // wave order, as block_sum
                 if (!done[s3]) {
                     eta[s3] = et;
                     iters[s3] += 1;
@@ -2147,7 +2149,18 @@ void launch_update_small(const UpdateArgs& a_, hipStream_t s) {
         else hipLaunchKernelGGL((k_update_small<NU_, MULTI_, 16>), grid, dim3(256), lds, s, a);              \
     } while (0)
     if (a.nu == 2) {
-        if (multi && rows > 16) hipLaunchKernelGGL((k_update_small<2, true, 32>), grid, dim3(256), lds, s, a);
+        // multi-modal with more than 2048 costs: 512-thread workgroups (half the register rows per thread: every
+        // per-row loop of the kernel -- loads, ladder points, weights, sums -- halves; C3 24.2 -> 22.4 us, K = 8000
+        // 33 -> 27.7 us).  Single mode measured no gain (panda -1 %) or a loss (C2: +10 us on the command although
+        // the kernel itself is not slower -- the wider workgroups delay the next rollout's dispatch).
+        static const bool wide = getenv("M3P2I_UPDATE_WT256") == nullptr;   // (experiments: the 256-thread instances)
+        if (multi && wide && rows > 8) {   // 512 threads per workgroup, ONE top-k workgroup (32 rows of 256 costs)
+            a.n_cand = 1;
+            const dim3 grid1(a.T + 1);
+            if (rows > 16) hipLaunchKernelGGL((k_update_small<2, true, 16, 512>), grid1, dim3(512), lds, s, a);
+            else hipLaunchKernelGGL((k_update_small<2, true, 8, 512>), grid1, dim3(512), lds, s, a);
+        }
+        else if (multi && rows > 16) hipLaunchKernelGGL((k_update_small<2, true, 32>), grid, dim3(256), lds, s, a);
         else if (multi) M3_LAUNCH_SMALL(2, true);
         else if (rows <= 16) M3_LAUNCH_SMALL(2, false);
         else if (rows <= 32) hipLaunchKernelGGL((k_update_small<2, false, 32>), grid, dim3(256), lds, s, a);

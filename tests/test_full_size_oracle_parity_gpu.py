@@ -63,6 +63,10 @@ def test_point_env_full_size_vs_oracle(oracle, name):
             assert i.best_idx == oi.best_idx
         top = eng.buffer(L.BUF_TOP_IDX).cpu().numpy()
         assert np.array_equal(np.sort(opl.last["J"][top]), np.sort(opl.last["J"])[:20]) or call > 0
+        # top_trajs = states[top_idx][:, :, [0, 2]] of THIS handle's rollout (mppi.py:248-254), every call
+        Jh = eng.buffer(L.BUF_TRAJ_COST).cpu().numpy()
+        assert np.array_equal(np.sort(Jh[top]), np.sort(Jh)[:20])
+        np.testing.assert_array_equal(eng.buffer(L.BUF_TOP_TRAJS).cpu().numpy(), eng.states.cpu().numpy()[top][:, :, [0, 2]])
     eng.close()
 
 
