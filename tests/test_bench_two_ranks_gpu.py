@@ -37,3 +37,29 @@ def test_bench_with_two_ranks(config, mode):
         assert w["n_gpus"] == 2 and w["collective_ms"]["per_command"] == 1.0 and "K=4000" in w["workload"] and w["value"] > 0
     else:
         assert "other_configs" not in d
+
+
+def test_bench_single_gpu_line_contract():
+    """`python bench.py` (N = 1): ONE JSON line with the driver's keys, the BASELINE configs[1] workload as the
+    headline, `roofline` and `cpu_baseline` objects, the other configs and the closed-loop figure riding along."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 5 and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "K=2000" in d["config"]["workload"] and "T=30" in d["config"]["workload"] and "task=push" in d["config"]["workload"]
+    assert abs(d["value"] - 2000 * 30 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["bytes_per_launch"] == 36 * 2000 * 30
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["reference_shaped"]["value"] > 0
+    assert set(d["other_configs"]) == {"northstar", "hybrid", "panda", "c5shard"}
+    assert all(v["value"] > 0 for v in d["other_configs"].values()), d["other_configs"]
+    assert d["closed_loop"]["ms_per_step"] > d["ms_per_step"] and d["closed_loop"]["final_pos_error_m"] < 0.5
