@@ -51,14 +51,18 @@ CONFIGS = {
     "panda": ("panda_env", "reach", (0.0,) * 7, False, 4000, 20),          # BASELINE configs[3]
     "northstar": ("point_env", "push", (-1.0, -1.0), False, 10000, 30),    # north_star target point
     "c5": ("point_env", "push_pull", (-3.75, -3.75), True, 8000, 30),      # BASELINE configs[4] = 8 x this (--gpus 8)
+    # BASELINE configs[0], the reference's own CPU-runnable case: navigation, K = 100, T = 10 -- too short for the
+    # Halton spline (T >= 12), so mppi_mode 'simple' with in-kernel random noise
+    "c1": ("point_env", "navigation", (-3.0, 3.0), False, 100, 10),
 }
+SIMPLE_MODE = {"c1"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # rollout kernel, per state-step: delta read (4*nu) + state 16 + action 4*nu + cost 4 written
 BYTES_PER_STATE_STEP_ROLLOUT = {"point_env": 36, "panda_env": 92}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")  # PMC FETCH/WRITE_SIZE per launch
 
 
-def build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device):
+def build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device, simple=False):
     from m3p2i_aip_amd import isaacgym_wrapper as wrapper
     from m3p2i_aip_amd.cost_functions import Objective
     from m3p2i_aip_amd.planner import M3P2I, MPPIConfig
@@ -66,7 +70,7 @@ def build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device):
         m = MPPIConfig(num_samples=K_global, horizon=T, nx=4, device=device, lambda_=0.5,
                        u_min=[-3.0, -3.0], u_max=[3.0, 3.0], noise_sigma=[[3.0, 0.0], [0.0, 3.0]],
                        u_per_command=T, sample_null_action=True, filter_u=True, fused=True, rank=rank,
-                       world_size=world)
+                       world_size=world, **(dict(mppi_mode="simple", sampling_method="random") if simple else {}))
         dt = 0.05
     else:
         sig = [[0.0] * 9 for _ in range(9)]
@@ -153,7 +157,8 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
     env, task, goal, multi_modal, K_cfg, T = CONFIGS[name]
     K_local = K_local or K_cfg
     K_global = K_local * world
-    pl, sim, obj, cfg = build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device)
+    pl, sim, obj, cfg = build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device,
+                                   simple=name in SIMPLE_MODE)
     # synthetic noise: the reference's Halton-spline sampler for this rank's rows of the global
     # sample set, generated by the planner on its first command() (device sampler; init only, not
     # the hot path).  NOT tiled -- duplicated samples would make the reference's beta search
@@ -218,19 +223,20 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
             lat.append(time.perf_counter() - t1)
         lat_ms = np.asarray(lat) * 1e3
     rollout_ms = float(np.mean(tr))
-    alg_bytes = BYTES_PER_STATE_STEP_ROLLOUT[env] * K_local * T
+    # (in-kernel noise: no delta read, 8 B fewer per state-step)
+    alg_bytes = (BYTES_PER_STATE_STEP_ROLLOUT[env] - (8 if name in SIMPLE_MODE else 0)) * K_local * T
     achieved = alg_bytes / (rollout_ms * 1e-3) / 1e9
     return dict(pl=pl, sim=sim, cfg=cfg, env=env, task=task, goal=goal, multi_modal=multi_modal, K_local=K_local,
                 K_global=K_global, T=T, wall=wall, steps=steps, value=K_global * T * steps / wall,
                 ms_per_step=wall / steps * 1e3, rollout_ms=rollout_ms, update_ms=float(np.mean(tu)),
                 finalize_ms=float(np.mean(tf)), alg_bytes=alg_bytes, achieved=achieved, lat_ms=lat_ms,
-                collective_ms=coll_ms)
+                collective_ms=coll_ms, simple=name in SIMPLE_MODE)
 
 
 def brief(r):
     """Entry of `other_configs`."""
     out = {"workload": f"{r['env']} task={r['task']} K={r['K_global']} T={r['T']} "
-                       f"{'multi-modal' if r['multi_modal'] else 'single-mode'}",
+                       f"{'multi-modal' if r['multi_modal'] else 'single-mode'}" + (" simple mode, in-kernel noise" if r.get("simple") else ""),
            "steps": r["steps"], "ms_per_step": r["ms_per_step"], "command_hz": 1e3 / r["ms_per_step"],
            "value": r["value"], "unit": "state-steps/s",
            "kernel_ms": {"rollout": r["rollout_ms"], "update": r["update_ms"], "finalize": r["finalize_ms"]},
@@ -361,7 +367,8 @@ def main():
             "scaling": "weak", "vs_baseline": None,   # BASELINE.md holds no published number for this metric
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{env} task={task} goal={list(goal)[:3]} K={K_global} ({K_local}/GPU) T={T} "
-                                   f"{'multi-modal' if multi_modal else 'single-mode'} halton-spline, "
+                                   f"{'multi-modal' if multi_modal else 'single-mode'} "
+                                   f"{'mppi_mode simple, in-kernel noise' if name in SIMPLE_MODE else 'halton-spline'}, "
                                    "initial scene, open loop (fixed world, warm-started plan)",
                        "name": name, "command_hz": args.steps / r["wall"],
                        "command_latency_ms": {"p50": float(np.percentile(r["lat_ms"], 50)),
@@ -408,7 +415,7 @@ def main():
     if world == 1 and rank == 0 and extras:
         line["closed_loop"] = closed_loop(r, min(args.steps, 200), device)
         others = {}
-        for oname, key in (("northstar", "northstar"), ("hybrid", "hybrid"), ("panda", "panda"), ("c5", "c5shard")):
+        for oname, key in (("northstar", "northstar"), ("hybrid", "hybrid"), ("panda", "panda"), ("c5", "c5shard"), ("c1", "c1")):
             if oname == name:
                 continue
             try:

@@ -60,6 +60,6 @@ def test_bench_single_gpu_line_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["reference_shaped"]["value"] > 0
-    assert set(d["other_configs"]) == {"northstar", "hybrid", "panda", "c5shard"}
+    assert set(d["other_configs"]) == {"northstar", "hybrid", "panda", "c5shard", "c1"}
     assert all(v["value"] > 0 for v in d["other_configs"].values()), d["other_configs"]
     assert d["closed_loop"]["ms_per_step"] > d["ms_per_step"] and d["closed_loop"]["final_pos_error_m"] < 0.5
