@@ -2178,7 +2178,8 @@ bool update_small_applies(const UpdateArgs& a) {
     // (with two controls: up to 64 register rows in single mode, K <= 16384, the north-star size; 32 in
     // multi-modal mode, K <= 8192, a C5 shard's size)
     const int kmax = (a.nu != 2) ? 4096 : a.multi_modal ? 8192 : 16384;
-    return !a.mode_simple && a.Kl == a.Kg && a.Kg <= kmax && a.n_cand == topk_workgroups(a.Kg) && (a.nu == 2 || a.nu == 9);
+    // (mppi_mode 'simple' takes the single-mode path with beta = lambda_: mppi.py:226, skill_utils.py:3)
+    return a.Kl == a.Kg && a.Kg <= kmax && a.n_cand == topk_workgroups(a.Kg) && (a.nu == 2 || a.nu == 9);
 }
 
 // ---------------------------------------------------------------------------------------
