@@ -182,3 +182,32 @@ print("RESULT" + json.dumps(out))
         np.testing.assert_allclose(a["eta"], b["eta"], rtol=1e-6)
         np.testing.assert_allclose(a["w"], b["w"], rtol=1e-5, atol=1e-12)
         np.testing.assert_allclose(a["action"], b["action"], atol=1e-6)
+
+
+@pytest.mark.parametrize("dt,substeps,iters", [(0.04, 3, 4), (0.05, 1, 6), (0.05, 2, 8), (0.02, 2, 1)])
+def test_rollout_bit_exact_with_other_solver_settings(oracle, dt, substeps, iters):
+    """isaacgym/point.yaml dt, isaacgym_wrapper.py:10 substeps and :28 solver iterations are run-time settings of the
+    library (m3_config.dt / substeps / solver_iters): the kernels specialise the reference's values (six passes,
+    unrolled) and keep generic loops for everything else -- both against the oracle, bit for bit."""
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    K, T = 512, 20
+    rng = np.random.default_rng(int(dt * 1000) + 10 * substeps + iters)
+    delta = (rng.standard_normal((K, T, 2)) * 1.2).astype(np.float32)
+    sc = oracle.default_scene()
+    sc.dt, sc.substeps, sc.iters = dt, substeps, iters
+    w = oracle.init_world(1)[0]
+    w[0:2] = (0.1, 1.45)                         # next to the box: contacts from the first step
+    for task, goal, mm in (("push", (-1.0, 3.0), False), ("push_pull", (-3.75, -3.75), True)):
+        opl = oracle.OraclePointPlanner(oracle.make_cfg(K, T, 2, task=task, goal=goal, multi_modal=mm), delta, scene=sc)
+        opl.command(w)
+        eng = HipEngine(make_config(K=K, T=T, nu=2, multi_modal=mm, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3],
+                                    dt=dt, substeps=substeps, solver_iters=iters))
+        eng.set_objective(task, goal)
+        eng.set_noise(delta)
+        eng.set_world_point_raw(np.concatenate([w[[0, 1, 4, 5]], w[7:14], w[14:21]]))
+        eng.command()
+        np.testing.assert_array_equal(eng.states.cpu().numpy(), opl.last["states"])
+        np.testing.assert_array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+        np.testing.assert_array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
+        eng.close()
