@@ -639,6 +639,8 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
                 if (s_rd.on) solve<ROBOT, BOXD>(sc, v, s_rd, sc.mu_rd);
             }
         };
+        // (a version runs to the end of the substep: the integration of a body whose rows it does not have is skipped
+        // with them -- x + h * 0 == x -- without a branch of its own)
         auto passes = [&](auto with_b, auto with_d, auto with_rd) {
             if (sc.iters == 6) {
                 pass(with_b, with_d, with_rd); pass(with_b, with_d, with_rd); pass(with_b, with_d, with_rd);
@@ -646,6 +648,21 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
             } else {
                 for (int it = 0; it < sc.iters; ++it) pass(with_b, with_d, with_rd);
             }
+            w.rvx = v.rvx; w.rvy = v.rvy;
+            w.B.vx = v.bvx; w.B.vy = v.bvy; w.B.w = v.bw;
+            w.D.vx = v.dvx; w.D.vy = v.dvy; w.D.w = v.dw;
+            M3_PH(3);
+            if (form_dyn_force) {   // (see below: the navigation cost's input)
+                float fx = 0.0f, fy = 0.0f;
+                if constexpr (RD) { M3_ACC(fx, fy, s_rd, +1) }
+                fx += fD.lx; fy += fD.ly;
+                w.fcDx = fx * sc.inv_h; w.fcDy = fy * sc.inv_h;
+            }
+            w.rx = w.rx + h * w.rvx;
+            w.ry = w.ry + h * w.rvy;
+            if constexpr (decltype(with_b)::value) integrate_box(w.B, h);
+            if constexpr (decltype(with_d)::value) integrate_box(w.D, h);
+            M3_PH(4);
         };
         if constexpr (RD) {
             // (the dyn-obs is in reach of the robot: usually no lane touches it, and then a dyn-obs that rests in
@@ -659,7 +676,8 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
             if (skipB) { if (skipD) passes(RowOff{}, RowOff{}, RowOff{}); else passes(RowOff{}, RowOn{}, RowOff{}); }
             else { if (skipD) passes(RowOn{}, RowOff{}, RowOff{}); else passes(RowOn{}, RowOn{}, RowOff{}); }
         }
-    } else
+        return;
+    }
     for (int it = 0; it < sc.iters; ++it) {
         {
             float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
