@@ -273,16 +273,22 @@ struct PandaObs {
 // REGION + trav + 1 mm skips the kinematics and the grasp test of that substep: nothing they could
 // have changed.  Identical results (the oracle evaluates them every substep); reach rollout -13 %.
 constexpr float PANDA_LEVER = 1.2f;
+struct HeldYes { static constexpr bool value = true; };
+struct HeldNo { static constexpr bool value = false; };
 template <bool FORCES = true, bool LAZY_FK = false>
 __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, const float* u,
                                            PandaObs& obs, float* hp = nullptr, float* trav = nullptr) {
     const float h = sc.h;
-    for (int sub = 0; sub < sc.substeps; ++sub) {
+    // One substep in two versions: `may_hold` false is chosen (rollouts) when no lane of the wavefront holds a cube --
+    // the reach task throughout: the held-cube blocks are not in that version at all, instead of five exec-mask regions
+    // that every lane skips (a TAKEN branch each: ~30 cycles for the lone wavefront).  Same operations otherwise.
+    auto substep = [&](int sub, auto may_hold) {
+        auto holds = [&]() { return decltype(may_hold)::value && w.held != 0.0f; };
         // 1. velocity servo
         float dq_sum = 0.0f;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            if (w.held != 0.0f && i >= 7) { w.qd[i] = 0.0f; continue; }
+            if (holds() && i >= 7) { w.qd[i] = 0.0f; continue; }
             float qd1 = (w.qd[i] + sc.a[i] * u[i]) * sc.rden[i];
             const float tau = sc.drive_damping * (u[i] - qd1);
             if (tau > sc.effort[i]) qd1 = w.qd[i] + sc.dv[i];
@@ -301,7 +307,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         bool have_fk = true;
         if constexpr (LAZY_FK) {
             *trav = *trav + PANDA_LEVER * dq_sum;
-            if (sub != sc.substeps - 1 && __builtin_amdgcn_ballot_w64(w.held != 0.0f) == 0ull) have_fk = false;
+            if (sub != sc.substeps - 1 && !decltype(may_hold)::value) have_fk = false;   // (no lane holds a cube)
         }
         if (have_fk) {
             panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
@@ -311,11 +317,11 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         const float cubeB_box[6] = {w.cubeB[0], w.cubeB[1], w.cubeB[2], sc.cube_half, sc.cube_half, sc.cube_half};
 
         // 3. cubeA
-        if (w.held != 0.0f && (u[7] >= 0.0f || u[8] >= 0.0f)) {
+        if (holds() && (u[7] >= 0.0f || u[8] >= 0.0f)) {
             w.held = 0.0f;
             w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
         }
-        if (w.held != 0.0f) {
+        if (holds()) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 w.cube[i] = hand.p[i] + ((w.rel_p[0] * hand.x[i] + w.rel_p[1] * hand.y[i]) + w.rel_p[2] * hand.z[i]);
@@ -440,6 +446,10 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
             mat2quat(hand, obs.left_q);
         }
+    };
+    for (int sub = 0; sub < sc.substeps; ++sub) {
+        if (LAZY_FK && __builtin_amdgcn_ballot_w64(w.held != 0.0f) == 0ull) substep(sub, HeldNo{});
+        else substep(sub, HeldYes{});
     }
 }
 
