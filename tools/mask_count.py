@@ -1,4 +1,6 @@
-"""GPU experiment (needs a -DM3_ABL_COUNT build loaded through M3P2I_HIP_LIB): histogram of the
+"""GPU experiment (needs a -DM3_ABL_COUNT build loaded through M3P2I_HIP_LIB; the per-instance timings
+additionally -DM3_ABL_COUNT_CYCLES, which since the pass versions of point_substep no longer gives correct
+rollouts -- see planar_dyn.hpp -- so only the histogram part is trustworthy today): histogram of the
 wave-uniform pair-group masks the substep dispatcher sees, over commands 5..60 of a bench config."""
 import ctypes, os, sys
 import numpy as np, torch
