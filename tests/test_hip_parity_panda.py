@@ -70,7 +70,7 @@ def test_panda_command_matches_oracle(oracle, task, mm, grip, held):
     eng.close()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(24))
 def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed):
     """Fuzz: random joint configuration inside the limits, random joint velocities, cubeA anywhere on
     the table / shelf / in the air (falls), random gripper command and task; strong random controls.

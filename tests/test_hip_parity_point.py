@@ -300,7 +300,7 @@ def test_shard_mix_multi_modal_is_refused_without_a_noise_table():
                 u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(48))
 def test_rollout_bit_exact_on_random_worlds(oracle, seed):
     """Fuzz: robot, box and dyn-obs anywhere in the arena -- overlapping each other, the obstacle or a
     wall, rotated, moving and spinning -- with a random task; strong random controls.  Exercises the
