@@ -201,6 +201,11 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
         delete h;
         return M3_ERR_HIP;
     }
+    if (!c->sim_only && init_ladder_table() != 0) {
+        g_create_err = "m3_create: could not initialise the beta ladder table";
+        delete h;
+        return M3_ERR_HIP;
+    }
     build_point_scene(*c, h->scene);
     default_world(h->world0);
     build_panda_scene(*c, h->pscene);

@@ -177,6 +177,7 @@ void launch_cov_update(const float* actions, const float* w, const float* mean, 
                        int nu, hipStream_t s);
 void launch_local_topk(const UpdateArgs& a, hipStream_t s);
 void launch_regen_fast(const UpdateArgs& a, hipStream_t s);
+int init_ladder_table();   // update.hip: the beta ladder into constant memory (per device context)
 int regen_chunks(int Kg);   // workgroups per time step of k_regen_part
 int rollout_lanes_for(int Kl);
 int mins_workgroups(int Kg);

@@ -576,11 +576,18 @@ void launch_mins(const UpdateArgs& a, hipStream_t s) {
 // the three searches (all / first half / second half).  Thread = (ladder index j, element
 // parity g): it loops over its half of the workgroup's costs (LDS broadcast reads) -- no
 // reductions inside the loop, one LDS combine at the end.  lad[b][j][s].
-__device__ __forceinline__ float ladder_beta(int j) {
-    float b = 1.0f;  // same repeated multiplication as the iterative search => identical bits
-    if (j < LAD_S) { for (int i = 0; i < j; ++i) b = b * 0.9f; }
-    else { for (int i = 0; i < j - LAD_S + 1; ++i) b = b * 1.2f; }
-    return b;
+// beta of ladder point j: 0.9^j (j < LAD_S), 1.2^(j - LAD_S + 1) -- formed by the same repeated f32 multiplication
+// as the iterative search (=> identical bits), once, on the host (m3_create -> init_ladder_table): as a loop per
+// use its back-edge was taken up to 63 times, ~1 us for the workgroups that need one value
+__constant__ float c_ladder_beta[LAD_N];
+__device__ __forceinline__ float ladder_beta(int j) { return c_ladder_beta[j]; }
+int init_ladder_table() {
+    float t[LAD_N];
+    float b = 1.0f;
+    for (int j = 0; j < LAD_S; ++j) { t[j] = b; b = b * 0.9f; }
+    b = 1.0f;
+    for (int j = 0; j < LAD_G; ++j) { b = b * 1.2f; t[LAD_S + j] = b; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_ladder_beta), t, sizeof(t)) == hipSuccess ? 0 : 1;
 }
 __global__ __launch_bounds__(256) void k_ladder(const UpdateArgs a) {
     __shared__ float2 sd[LAD_EL];  // (J - min_all, J - min_of_its_half); +inf past the end => exp = 0
@@ -1867,9 +1874,7 @@ __global__ __launch_bounds__(WT) void k_update_small(const UpdateArgs a) {
             __shared__ float s_walk[3][4];
             int nbuf = 0;
             for (int p = t; p < NPT; p += T, ++nbuf) {
-                float bp = 1.0f;
-                if (p < LS) { for (int i = 0; i < p; ++i) bp = bp * 0.9f; }
-                else { for (int i = 0; i < p - LS + 1; ++i) bp = bp * 1.2f; }
+                const float bp = ladder_beta(p < LS ? p : LAD_S + (p - LS));   // 0.9^p / 1.2^(p - LS + 1)
                 const float np_ = uniform_f(-1.0f / bp);
                 float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
 #pragma unroll
