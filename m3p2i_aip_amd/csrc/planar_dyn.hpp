@@ -680,8 +680,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     }
     // (generic pass; the corner instance -- the whole closed loop once the box is pushed along the walls -- picks a
     // version without the dyn-obs friction row / the robot-wall rows when no lane needs them: rows every lane would
-    // skip cost a taken branch each, see LEAN above; not unrolled: six copies of these passes fall out of the
-    // instruction cache, measured +7 %)
+    // skip cost a taken branch each, see LEAN above; not unrolled: six copies of these passes measured +7 %)
     auto gen_pass = [&](auto with_d, auto with_rw) {
         {
             float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
