@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- the MPPI/M3P2I command() hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config push|hybrid|northstar|panda|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config push|hybrid|northstar|panda|c5|...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full MPPI iteration (M3P2I.command(): rollout of every sample over the
@@ -12,15 +12,27 @@ Workload
   N = 1   BASELINE.json configs[1], the config the metric is quoted on: task=push goal=[-1,-1],
           K=2000 samples, T=30 horizon, single-mode, halton-spline noise.  After the headline loop
           the same process also times the other BASELINE configs that fit one GPU and the north-star
-          operating point (`other_configs`: hybrid C3, panda C4, northstar K=10000, c5shard = one
-          rank's share of C5 run unsharded) and the headline config in CLOSED loop (`closed_loop`:
-          a 1-env world stepped between commands, reference flow of scripts/sim.py).
-  N > 1   BASELINE.json configs[4] (C5): task=push_pull multi_modal, 8000 samples per GPU (K = 8000 N:
-          64000 at N = 8), T=30, samples sharded over the ranks, collectives over RCCL.  Weak scaling:
-          the per-GPU sample count is fixed as N grows.  `scaling_reference` is the SAME per-GPU
-          workload on one GPU (unsharded handle on rank 0, same process), so that the line carries
-          its own 1-GPU point; `collective_ms` is the time per command spent in the collectives.
-          (--config overrides the workload for any N.)
+          operating point (`other_configs`: hybrid C3, panda C4 in its reach phase AND in its pick phase
+          (`panda_pick`: the scene the product's own closed-loop reach ends in, cube held, FORCES kernel
+          instance), northstar K=10000, c5shard = one rank's share of C5 run unsharded, c5_unsharded = ALL
+          of C5 (K=64000 multi-modal) on this ONE GPU -- the honest denominator of any sharding claim --,
+          worst_case_scene = the headline workload with robot, box and dyn-obs packed into the wall corner
+          (every substep in the all-contact-slots instance), c1) and the headline config in CLOSED loop
+          (`closed_loop`: a 1-env world stepped between commands, reference flow of scripts/sim.py).
+  N > 1   the SAME per-GPU workload as N = 1 -- push, 2000 samples per GPU (K = 2000 N), single-mode --
+          sharded over the ranks with ONE collective per command, so that value(N) / (N value(1)) is a
+          like-for-like weak-scaling efficiency (`scaling`: "weak").  `other_configs` carries, each row with
+          its own `scaling` and 1-GPU references measured in the same run on rank 0:
+            c5               BASELINE configs[4]: push_pull multi-modal, 8000 samples per GPU (64000 at N = 8),
+                             weak; `scaling_reference` = the same 8000 samples unsharded on one GPU,
+                             `strong_scaling_reference` = ALL K_global samples unsharded on one GPU (at every
+                             BASELINE size one MI355X is latency-bound: it runs the whole of C5 in ~0.2 ms, so
+                             sharding C5 cannot be faster than not sharding it -- DESIGN.md section 7)
+            push_saturating  single-mode push with 131072 samples per GPU (K = 2^17 N): the smallest per-GPU
+                             size at which the rollout kernel is throughput-bound (2 waves per SIMD), i.e.
+                             where adding GPUs can pay; weak, with its own 1-GPU reference
+          `collective_ms` is the time per command spent in the collectives.
+          (--config overrides the headline workload for any N.)
 
 Prints ONE JSON line (rank 0).  `value` = K_global*T*steps / wall time (state-steps/s) with
 inputs resident in HBM.  `roofline` is for the dominant kernel (the fused rollout kernel):
@@ -54,7 +66,15 @@ CONFIGS = {
     # BASELINE configs[0], the reference's own CPU-runnable case: navigation, K = 100, T = 10 -- too short for the
     # Halton spline (T >= 12), so mppi_mode 'simple' with in-kernel random noise
     "c1": ("point_env", "navigation", (-3.0, 3.0), False, 100, 10),
+    # C4 as BASELINE names it, reactive PICK: same planner, task=pick (gripper override close, pick + motion cost on
+    # the penalty forces: the <FORCES=true> kernel instance); scene + goal come from panda_pick_scene()
+    "panda_pick": ("panda_env", "pick", (0.0,) * 7, False, 4000, 20),
+    "c5_unsharded": ("point_env", "push_pull", (-3.75, -3.75), True, 64000, 30),   # ALL of C5 on one GPU
+    "worst_case": ("point_env", "push", (-1.0, -1.0), False, 2000, 30),            # C2 in the corner scene below
+    "push_sat": ("point_env", "push", (-1.0, -1.0), False, 131072, 30),            # saturating per-GPU size
 }
+# per-GPU sample count fixed as N grows for every workload of this file (K_global = K_local * N)
+SCALING = "weak"
 SIMPLE_MODE = {"c1"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # rollout kernel, per state-step: delta read (4*nu) + state 16 + action 4*nu + cost 4 written
@@ -92,6 +112,49 @@ def build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device, s
     pl = M3P2I(cfg).attach(sim, obj)
     pl.update_gripper_command(task)
     return pl, sim, obj, cfg
+
+
+def corner_scene(pl, sim, obj, cfg):
+    """Worst case of the point_env rollout: box in the wall corner (touching both walls), dyn-obs beside it against
+    the wall and the box, the robot on top of the box against the other wall -- robot-box, robot-dyn-obs, robot-walls, box-walls, dyn-obs-walls
+    and box-dyn-obs pairs are all inside their broad-phase ranges, so every substep of every wavefront runs the
+    instance with all 19 contact slots."""
+    from m3p2i_aip_amd import scenes
+    ib, idn = scenes.actor_index("point_env", "box"), scenes.actor_index("point_env", "dyn-obs")
+    # walls' inner faces at +-3.95, boxes 0.4 x 0.4, robot radius 0.2; 5 mm gaps (contact_offset is 10 mm)
+    sim._root_state[:, ib, 0] = -3.745
+    sim._root_state[:, ib, 1] = -3.745
+    sim._root_state[:, idn, 0] = -3.34
+    sim._root_state[:, idn, 1] = -3.745
+    sim._dof_state[:] = torch.tensor([-3.745, 0.0, -3.34, 0.0], device=sim._dof_state.device)
+    sim.set_dof_state_tensor(sim._dof_state)
+    sim.set_actor_root_state_tensor(sim._root_state)
+
+
+def panda_pick_scene(device):
+    """The scene C4's pick phase starts in, produced by the PRODUCT: the closed loop of tools/closed_loop.py
+    (1-env world + planner K=4000, T=20 + the active-inference task planner) is run through its reach phase
+    and 12 ticks into `pick` -- gripper closed on the cube, cube held and on its way to the goal."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import closed_loop
+    res = closed_loop.run("config_panda", ["mppi.num_samples=4000", "mppi.horizon=20", f"mppi.device={device}"],
+                          ticks=400, until_task="pick", extra_ticks=12)
+    cap = res.get("captured")
+    if cap is None:
+        raise RuntimeError(f"the closed loop never reached the pick phase: {res.get('timeline')}")
+    return cap
+
+
+def make_pick_scene(cap):
+    def scene(pl, sim, obj, cfg):
+        dev = sim._dof_state.device
+        sim._dof_state[:] = torch.tensor(cap["dof_state"], device=dev)
+        sim._root_state[:] = torch.tensor(cap["root_state"], device=dev)
+        sim.set_dof_state_tensor(sim._dof_state)
+        sim.set_actor_root_state_tensor(sim._root_state)
+        obj.update_objective("pick", torch.tensor(cap["goal"], device=dev))
+        pl.update_gripper_command("pick")
+    return scene
 
 
 def usable_cores():
@@ -151,7 +214,8 @@ def cpu_baseline(env, task, goal, multi_modal, K, T, delta):
     return res
 
 
-def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=None, latency=True, time_collectives=False):
+def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=None, latency=True, time_collectives=False,
+               scene=None):
     """Builds the planner for CONFIGS[name] and measures it: `warmup` untimed commands, an event loop
     for the kernel durations, then EXACTLY `steps` commands between barrier + synchronize pairs."""
     env, task, goal, multi_modal, K_cfg, T = CONFIGS[name]
@@ -159,6 +223,8 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
     K_global = K_local * world
     pl, sim, obj, cfg = build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device,
                                    simple=name in SIMPLE_MODE)
+    if scene is not None:
+        scene(pl, sim, obj, cfg)     # a world other than the reference's initial scene (and its objective)
     # synthetic noise: the reference's Halton-spline sampler for this rank's rows of the global
     # sample set, generated by the planner on its first command() (device sampler; init only, not
     # the hot path).  NOT tiled -- duplicated samples would make the reference's beta search
@@ -238,7 +304,7 @@ def brief(r):
     out = {"workload": f"{r['env']} task={r['task']} K={r['K_global']} T={r['T']} "
                        f"{'multi-modal' if r['multi_modal'] else 'single-mode'}" + (" simple mode, in-kernel noise" if r.get("simple") else ""),
            "steps": r["steps"], "ms_per_step": r["ms_per_step"], "command_hz": 1e3 / r["ms_per_step"],
-           "value": r["value"], "unit": "state-steps/s",
+           "value": r["value"], "unit": "state-steps/s", "scaling": SCALING,
            "kernel_ms": {"rollout": r["rollout_ms"], "update": r["update_ms"], "finalize": r["finalize_ms"]},
            "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": r["achieved"] / HBM_PEAK_GBS, "bytes_per_launch": r["alg_bytes"]}}
@@ -303,7 +369,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default=None, choices=list(CONFIGS),
-                    help="default: push (BASELINE configs[1]) on 1 GPU, c5 (configs[4]) on N > 1")
+                    help="default: push (BASELINE configs[1]), 2000 samples per GPU, for every N")
     ap.add_argument("--samples-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (profiling runs)")
@@ -334,7 +400,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(device))
 
-    name = args.config or ("c5" if world > 1 else "push")
+    name = args.config or "push"
     r = run_config(name, args, world, rank, device, dist, args.steps, args.warmup, K_local=args.samples_per_gpu,
                    time_collectives=True)
     env, task, goal, multi_modal, K_local, K_global, T = (r[k] for k in ("env", "task", "goal", "multi_modal", "K_local",
@@ -363,8 +429,9 @@ def main():
             "value": r["value"], "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True,
-            # the per-GPU sample count is fixed as N grows (K_global = K_local * N)
-            "scaling": "weak", "vs_baseline": None,   # BASELINE.md holds no published number for this metric
+            # the per-GPU sample count is fixed as N grows (K_global = K_local * N); the default headline of an
+            # N > 1 run is the N = 1 headline's own per-GPU workload, so the driver's value(N) / (N value(1)) compares like with like
+            "scaling": SCALING, "vs_baseline": None,   # BASELINE.md holds no published number for this metric
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{env} task={task} goal={list(goal)[:3]} K={K_global} ({K_local}/GPU) T={T} "
                                    f"{'multi-modal' if multi_modal else 'single-mode'} "
@@ -390,39 +457,82 @@ def main():
             line["collective_ms"] = r["collective_ms"]
     delta_np = pl.delta.contiguous().cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
-    if world > 1 and extras and name != "push":
-        # the N = 1 headline's workload (C2: push, 2000 samples per GPU, single-mode) weak-scaled over the same
-        # ranks (one collective per command): value(N) / (N x the N = 1 line's value) is a like-for-like efficiency
-        rw = run_config("push", args, world, rank, device, dist, args.steps, args.warmup, latency=False,
-                        time_collectives=True)
+    def one_gpu_reference(cname, K, what):
+        """The named workload with K samples on ONE GPU (unsharded handle, rank 0's GPU, the other ranks wait at
+        the caller's barrier): the denominator of a scaling claim, measured in the same run."""
+        r1 = run_config(cname, args, 1, 0, device, None, min(args.steps, 200), args.warmup, K_local=K, latency=False)
+        out = {"n_gpus": 1, "K": K, "value": r1["value"], "ms_per_step": r1["ms_per_step"],
+               "kernel_ms": {"rollout": r1["rollout_ms"], "update": r1["update_ms"], "finalize": r1["finalize_ms"]},
+               "what": what}
+        r1["pl"]._engine.close()
+        return out
+
+    if world > 1 and extras:
+        small = args.samples_per_gpu if share else None      # (test mode: every row at the test's size)
+        others = {}
+        rows = [("c5", "c5", "BASELINE configs[4]: 8000 samples per GPU, push_pull multi-modal"),
+                ("push_sat", "push_saturating", "131072 samples per GPU: the rollout kernel's throughput-bound regime")]
+        if name != "push":
+            rows.insert(0, ("push", "push_weak", "BASELINE configs[1] weak-scaled"))
+        for cname, key, what in rows:
+            if cname == name:
+                continue
+            rw = run_config(cname, args, world, rank, device, dist, args.steps, args.warmup, K_local=small,
+                            latency=False, time_collectives=True)
+            if rank == 0:
+                bq = brief(rw)
+                bq["n_gpus"], bq["collective_ms"] = world, rw["collective_ms"]
+                bq["workload"] += f" ({rw['K_local']}/GPU, sharded x{world}: {what})"
+                others[key] = bq
+            rw["pl"]._engine.close()
+            if not share:
+                # 1-GPU references of this row, measured now on rank 0
+                if rank == 0:
+                    others[key]["scaling_reference"] = one_gpu_reference(
+                        cname, rw["K_local"], f"weak-scaling denominator: the same per-GPU workload ({rw['K_local']} samples) unsharded on one GPU")
+                    if cname == "c5":
+                        others[key]["strong_scaling_reference"] = one_gpu_reference(
+                            "c5", rw["K_global"], f"strong-scaling denominator: ALL {rw['K_global']} samples unsharded on ONE GPU "
+                            "(below ~65536 samples per GPU the rollout is latency-bound: one MI355X runs this in about the "
+                            "time a rank needs for its 1/N share, DESIGN.md section 7)")
+                        others[key]["speedup_vs_one_gpu_same_K"] = others[key]["strong_scaling_reference"]["ms_per_step"] / bq["ms_per_step"]
+                torch.cuda.synchronize()
+                dist.barrier()
         if rank == 0:
-            b = brief(rw)
-            b["n_gpus"], b["collective_ms"] = world, rw["collective_ms"]
-            b["workload"] += f" ({rw['K_local']}/GPU, sharded x{world}: BASELINE configs[1] weak-scaled)"
-            line["other_configs"] = {"push_weak": b}
-        rw["pl"]._engine.close()
+            line["other_configs"] = others
     if world > 1 and extras and not share:
-        # the same per-GPU workload on ONE GPU, unsharded (rank 0, after the distributed run; the other
-        # ranks wait at the barrier below)
         if rank == 0:
-            r1 = run_config(name, args, 1, 0, device, None, min(args.steps, 200), args.warmup, K_local=K_local, latency=False)
-            line["scaling_reference"] = {"n_gpus": 1, "value": r1["value"], "ms_per_step": r1["ms_per_step"],
-                                         "kernel_ms": {"rollout": r1["rollout_ms"], "update": r1["update_ms"],
-                                                       "finalize": r1["finalize_ms"]},
-                                         "what": f"same per-GPU workload ({K_local} samples, unsharded handle) on rank 0's GPU"}
+            line["scaling_reference"] = one_gpu_reference(
+                name, K_local, f"same per-GPU workload ({K_local} samples, unsharded handle) on rank 0's GPU")
         torch.cuda.synchronize()
         dist.barrier()
     if world == 1 and rank == 0 and extras:
         line["closed_loop"] = closed_loop(r, min(args.steps, 200), device)
         others = {}
-        for oname, key in (("northstar", "northstar"), ("hybrid", "hybrid"), ("panda", "panda"), ("c5", "c5shard"), ("c1", "c1")):
-            if oname == name:
+        pick_scene = None
+        try:
+            pick_scene = make_pick_scene(panda_pick_scene(device))
+        except Exception as e:
+            others["panda_pick"] = {"error": repr(e)}
+        for oname, key, scene in (("northstar", "northstar", None), ("hybrid", "hybrid", None), ("panda", "panda", None),
+                                  ("panda_pick", "panda_pick", pick_scene), ("c5", "c5shard", None),
+                                  ("c5_unsharded", "c5_unsharded", None), ("worst_case", "worst_case_scene", corner_scene),
+                                  ("c1", "c1", None)):
+            if oname == name or (oname == "panda_pick" and pick_scene is None):
                 continue
             try:
-                ro = run_config(oname, args, 1, 0, device, None, max(200, min(args.steps, 400)), args.warmup)
+                ro = run_config(oname, args, 1, 0, device, None, max(200, min(args.steps, 400)), args.warmup, scene=scene)
                 others[key] = brief(ro)
                 if oname == "hybrid":
                     others[key]["closed_loop"] = closed_loop(ro, 200, device)
+                if oname == "panda_pick":
+                    others[key]["workload"] += (" -- C4's pick phase: scene = 12 ticks into `pick` of the product's own closed "
+                                                "loop (cube held), gripper override close, k_rollout_panda<FORCES=true>")
+                if oname == "worst_case":
+                    others[key]["workload"] += (" -- robot, box and dyn-obs packed into the wall corner (open loop from that "
+                                                "scene): the all-contact-slots substep instance")
+                if oname == "c5_unsharded":
+                    others[key]["workload"] += " -- ALL of BASELINE configs[4] on ONE GPU (the denominator of any sharding claim)"
                 ro["pl"]._engine.close()
             except Exception as e:
                 others[key] = {"error": repr(e)}

@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("config,mode", [("push", "single-mode"), (None, "multi-modal")])
+@pytest.mark.parametrize("config,mode", [(None, "single-mode"), ("c5", "multi-modal")])
 def test_bench_with_two_ranks(config, mode):
-    """config None: the default of an N > 1 run, BASELINE configs[4] (c5: push_pull, multi-modal)."""
+    """config None: the default of an N > 1 run = the N = 1 headline's own per-GPU workload (push, single-mode),
+    weak-scaled; c5 = BASELINE configs[4] (push_pull, multi-modal) as the headline."""
     env = dict(os.environ, M3_BENCH_SHARE_GPU="1")
     port = 29800 + os.getpid() % 150
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -28,15 +29,16 @@ def test_bench_with_two_ranks(config, mode):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 3 and d["scaling"] == "weak"
     assert "K=1024 (512/GPU)" in d["config"]["workload"] and mode in d["config"]["workload"]
-    assert d["config"]["name"] == (config or "c5") and "ONE collective per command" in d["config"]["parallelism"]
+    assert d["config"]["name"] == (config or "push") and "ONE collective per command" in d["config"]["parallelism"]
     assert d["collective_ms"]["per_command"] == 1.0 and d["collective_ms"]["total"] > 0
     assert d["value"] > 0 and abs(d["value"] - 1024 * 30 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
-    if config is None:   # the N = 1 headline's workload weak-scaled over the same ranks rides along
-        w = d["other_configs"]["push_weak"]
-        assert w["n_gpus"] == 2 and w["collective_ms"]["per_command"] == 1.0 and "K=4000" in w["workload"] and w["value"] > 0
-    else:
-        assert "other_configs" not in d
+    # the other sharded workloads ride along, every row with its own `scaling`
+    want = {"c5", "push_saturating"} if config is None else {"push_weak", "push_saturating"}
+    assert set(d["other_configs"]) == want
+    for w in d["other_configs"].values():
+        assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["collective_ms"]["per_command"] == 1.0 and w["value"] > 0
+        assert "K=1024" in w["workload"]          # (test mode: every row at the test's size)
 
 
 def test_bench_single_gpu_line_contract():
@@ -60,6 +62,13 @@ def test_bench_single_gpu_line_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["reference_shaped"]["value"] > 0
-    assert set(d["other_configs"]) == {"northstar", "hybrid", "panda", "c5shard", "c1"}
-    assert all(v["value"] > 0 for v in d["other_configs"].values()), d["other_configs"]
+    assert set(d["other_configs"]) == {"northstar", "hybrid", "panda", "panda_pick", "c5shard", "c5_unsharded",
+                                       "worst_case_scene", "c1"}
+    assert all(v["value"] > 0 and v["scaling"] == "weak" and 0 < v["roofline"]["frac"] < 1
+               for v in d["other_configs"].values()), d["other_configs"]
+    oc = d["other_configs"]
+    assert "K=64000" in oc["c5_unsharded"]["workload"] and "multi-modal" in oc["c5_unsharded"]["workload"]
+    assert "task=pick" in oc["panda_pick"]["workload"] and oc["panda_pick"]["roofline"]["bytes_per_launch"] == 92 * 4000 * 20
+    # the corner scene is the slow end of the same kernel: >= the initial scene's time
+    assert oc["worst_case_scene"]["kernel_ms"]["rollout"] > d["kernel_ms"]["rollout"]
     assert d["closed_loop"]["ms_per_step"] > d["ms_per_step"] and d["closed_loop"]["final_pos_error_m"] < 0.5

@@ -11,6 +11,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
+# weights: relative, not absolute -- with eta in [3, 10] all but a handful of the K weights are below 1e-3, so an
+# absolute bar of 1e-3 asserts nothing about the tail; the form of test_hip_parity_point.py:152
+W_TOL = dict(rtol=2e-3, atol=1e-6)
+
 POINT = {
     "C2_push_K2000": dict(K=2000, task="push", goal=(-1.0, -1.0), mm=False),
     "C3_hybrid_K4000": dict(K=4000, task="push_pull", goal=(-3.75, -3.75), mm=True),
@@ -51,11 +55,11 @@ def test_point_env_full_size_vs_oracle(oracle, name):
             assert np.array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
             assert np.array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
         np.testing.assert_allclose(a, b, atol=1e-3, err_msg=f"{name} call {call}")
-        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), opl.last["w"], atol=1e-3)
+        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), opl.last["w"], **W_TOL)
         i, oi = eng.info(), opl.last["info"]
         if c["mm"]:
-            np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS_1).cpu().numpy(), opl.last["w1"], atol=1e-3)
-            np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS_2).cpu().numpy(), opl.last["w2"], atol=1e-3)
+            np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS_1).cpu().numpy(), opl.last["w1"], **W_TOL)
+            np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS_2).cpu().numpy(), opl.last["w2"], **W_TOL)
             assert (i.iters, i.iters_1, i.iters_2) == (oi.iters, oi.iters_1, oi.iters_2), f"{name} call {call}"
             assert (i.best_idx_1, i.best_idx_2) == (oi.best_idx_1, K // 2 + oi.best_idx_2)
             assert i.pull_preference == opl.pull_preference()
@@ -70,20 +74,35 @@ def test_point_env_full_size_vs_oracle(oracle, name):
     eng.close()
 
 
-def test_panda_full_size_vs_oracle(oracle):
-    """C4: panda_env reach, K=4000, T=20 -- k_update_small<9,false,16> and the panda rollout at full size."""
+@pytest.mark.parametrize("task,grip,start", [("reach", 1, "init"), ("pick", 2, "held"), ("place", 1, "held"),
+                                             ("pick", 2, "open3")])
+def test_panda_full_size_vs_oracle(oracle, task, grip, start):
+    """C4: panda_env K=4000, T=20 at full size -- k_update_small<9,false,16> and both panda rollout instances:
+    reach (k_rollout_panda<false,..>, the first commands of the reactive pick) and the config BASELINE names,
+    reactive PICK: start from a grasp (cube held), gripper override close (mppi.py:412-416), pick cost + motion
+    cost on the penalty forces (cost_functions.py:116-125, :158-169) = the <FORCES=true> instance; place from the
+    same grasp (gripper override open: the cube is released inside the horizon); and pick with the OPEN gripper
+    3 cm above the grasp pose (rollouts grasp, or just miss, on their own).  Three calls each: persistent beta
+    (mppi.py:446-454) and the warm start are part of the trace."""
     import oracle.panda as P
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
+    from tests.panda_worlds import grasp_world
     K, T = 4000, 20
     delta = _smooth_noise(K, T, 9, 22)
     goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
-    w0 = P.init_world(1)[0]
-    opl = P.OraclePandaPlanner(P.make_cfg(K, T, task="reach", goal=goal, gripper_cmd=1), delta)
+    sc = P.default_scene()
+    if start == "init":
+        w0 = P.init_world(1)[0]
+    elif start == "held":
+        w0 = grasp_world(P, sc)
+    else:
+        w0 = grasp_world(P, sc, close_gripper=False, lift=0.03)
+    opl = P.OraclePandaPlanner(P.make_cfg(K, T, task=task, goal=goal, gripper_cmd=grip), delta)
     eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", u_min=[-2.0] * 7 + [-1.5] * 2,
                                 u_max=[2.0] * 7 + [1.5] * 2, noise_sigma_diag=[10.0] * 7 + [0.8] * 2, lambda_=0.05,
                                 pre_height_diff=0.05, dt=0.01))
-    eng.set_objective("reach", goal, gripper_cmd=1)
+    eng.set_objective(task, goal, gripper_cmd=grip)
     eng.set_noise(delta)
     eng.set_world_panda_raw(np.concatenate([w0[P.W_Q:P.W_Q + 18], w0[P.W_CUBEA:P.W_CUBEA + 10], w0[P.W_CUBEB:P.W_CUBEB + 3]]))
     for call in range(3):
@@ -91,8 +110,14 @@ def test_panda_full_size_vs_oracle(oracle):
         b = opl.command(w0)
         if call == 0:
             assert np.array_equal(eng.states.cpu().numpy(), opl.last["states"])
+            assert np.array_equal(eng.actions.cpu().numpy(), opl.last["actions"])
             assert np.array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+            assert np.array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
         np.testing.assert_allclose(a, b, atol=1e-3, err_msg=f"call {call}")
-        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), opl.last["w"], atol=1e-3)
+        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), opl.last["w"], **W_TOL)
         assert eng.info().beta == pytest.approx(opl.beta, rel=1e-5)
+        assert eng.info().best_idx == opl.last["info"].best_idx
+    if task == "pick" and start == "held":
+        ch = eng.cost_horizon.cpu().numpy()
+        assert np.ptp(ch) > 0.05          # the held cube really travels with the hand in these rollouts
     eng.close()

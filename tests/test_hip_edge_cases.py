@@ -59,7 +59,7 @@ def test_hip_equals_oracle_on_edge_configs(oracle, case):
             np.testing.assert_array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
         np.testing.assert_allclose(a, b, atol=1e-3)
         w = eng.buffer(L.BUF_WEIGHTS).cpu().numpy()
-        np.testing.assert_allclose(w, opl.last["w"], atol=1e-3)
+        np.testing.assert_allclose(w, opl.last["w"], rtol=2e-3, atol=1e-6)
         assert abs(w.sum() - 1.0) < 1e-4
         # top-20 by weight: when fewer than 20 weights are non-zero, torch.topk may return ANY of
         # the zero-weight samples (the library orders those by cost), so compare the weights

@@ -80,7 +80,7 @@ def test_command_traces_vs_reference_and_oracle(golden, oracle, tag):
         np.testing.assert_allclose(a_hip[:rows], a_ref, atol=1e-3, err_msg=f"{tag} call {call} vs reference")
         np.testing.assert_allclose(a_hip[:rows], a_orc, atol=1e-3, err_msg=f"{tag} call {call} vs oracle")
         w_hip = eng.buffer(L.BUF_WEIGHTS).cpu().numpy()
-        np.testing.assert_allclose(w_hip, golden[f"g9_{tag}_weights"][call], atol=1e-3)
+        np.testing.assert_allclose(w_hip, golden[f"g9_{tag}_weights"][call], rtol=2e-3, atol=1e-6)
         if call == 0:
             # identical inputs on the first call: rollout must be bit-identical to the oracle
             st = eng.states.cpu().numpy()

@@ -122,9 +122,14 @@ def serve(cn, overrides, endpoint):
     server.run()
 
 
-def run(cn="config_point", overrides=(), ticks=2000, connect=None):
+def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=None, extra_ticks=0, jitter=None):
     """One closed-loop episode; returns the report dict (what main() prints).  connect = endpoint of a
-    planner served by `--serve` in another process (otherwise the planner lives in this process)."""
+    planner served by `--serve` in another process (otherwise the planner lives in this process).
+    until_task: stop `extra_ticks` ticks after the task planner first hands out that task and return the
+    world at that moment (`captured`: dof_state, root_state, task, goal as lists) -- bench.py's panda_pick row
+    starts from the scene the product's own reach phase ends in.
+    jitter (point_env): dict(dyn_phase=int, box=(dx, dy), robot=(dx, dy)) -- the episode starts with the dyn-obs
+    `dyn_phase` ticks into its walk and box / robot displaced (tools/band_stats.py: N episodes per scenario)."""
     overrides = list(overrides)
     compat.install(force_standins=True)
     import m3p2i_aip.utils.isaacgym_utils.isaacgym_wrapper as wrapper
@@ -134,11 +139,24 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None):
     real = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=1, viewer=False, device=cfg.mppi.device,
                                    cube_on_shelf=cfg.cube_on_shelf)
     nu = real.dofs_per_robot
+    phase = 0
+    if jitter and cfg.env_type == "point_env":
+        phase = int(jitter.get("dyn_phase", 0))
+        ib = int(real._get_actor_index_by_name("box"))
+        real._root_state[0, ib, 0] += float(jitter.get("box", (0, 0))[0])
+        real._root_state[0, ib, 1] += float(jitter.get("box", (0, 0))[1])
+        real._dof_state[0, 0] += float(jitter.get("robot", (0, 0))[0])
+        real._dof_state[0, 2] += float(jitter.get("robot", (0, 0))[1])
+        real.set_dof_state_tensor(real._dof_state)
+        real.set_actor_root_state_tensor(real._root_state)
+    coll_ticks = 0          # ticks with a contact force on the dyn-obs: |Fx| + |Fy| > 0.1, the test of
+                            # get_motion_cost (cost_functions.py:158-169) applied to the REAL world (plot_point.py col 17)
     timeline, lat = [], []
     success_tick = None
+    stop_at, captured = None, None
     for i in range(ticks):
         if cfg.env_type == "point_env":
-            real.update_dyn_obs(i)
+            real.update_dyn_obs(i + phase)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         action = tamp.run_tamp(real._dof_state, real._root_state)
@@ -150,11 +168,21 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None):
         if tamp.task_success:
             success_tick = i
             break
+        if until_task is not None and stop_at is None and task == until_task:
+            stop_at = i + extra_ticks
+        if stop_at is not None and i >= stop_at:
+            goal = tamp.goal if connect else tamp.task_planner.curr_goal.float().cpu().reshape(-1).tolist()
+            captured = dict(tick=i, task=task, goal=[float(x) for x in goal],
+                            dof_state=real._dof_state[0].cpu().tolist(), root_state=real._root_state[0].cpu().tolist())
+            break
         real.set_dof_velocity_target_tensor(action.view(1, nu))
         if cfg.env_type == "point_env":
             cfg.suction_active = tamp.suction_active
             check_and_apply_suction(cfg, real, action.view(1, nu))
         real.step()
+        if cfg.env_type == "point_env":
+            f = real.get_actor_contact_forces_by_name("dyn-obs", "box")[0]
+            coll_ticks += int(float(f[0].abs() + f[1].abs()) > 0.1)
     res = dict(config=cn, overrides=overrides, K=cfg.mppi.num_samples, T=cfg.mppi.horizon,
                ticks=i + 1, success=success_tick is not None, transport="rpc " + connect if connect else "in-process",
                sim_time_s=(i + 1) * cfg.isaacgym.dt, timeline=timeline,
@@ -164,11 +192,14 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None):
         goal = torch.tensor(tamp.goal) if connect else tamp.task_planner.curr_goal.float().cpu()
         who = real.robot_pos[0].cpu() if cfg.task == "navigation" else real.get_actor_position_by_name("box")[0, :2].cpu()
         res["final_pos_error"] = float(torch.norm(who - goal))
+        res["dyn_obs_collision_ticks"] = coll_ticks
     else:
         cube = real.get_actor_link_by_name("cubeA", "box")[0, :3].cpu()
         goal = real.get_actor_link_by_name("cubeB", "box")[0, :3].cpu()
         res["cube_to_goal_xy"] = float(torch.norm(cube[:2] - goal[:2]))
         res["cube_height_above_goal"] = float(cube[2] - goal[2])
+    if captured is not None:
+        res["captured"] = captured
     real.stop_sim()
     tamp.close()
     return res

@@ -27,8 +27,29 @@ if kt:
     if r:
         x = r[-1]
         print("rollout dispatch: grid", x.get("Grid_Size_X"), "wg", x.get("Workgroup_Size_X"),
-              "VGPR", x.get("VGPR_Count"), "accum", x.get("Accum_VGPR_Count"), "SGPR", x.get("SGPR_Count"),
               "LDS", x.get("LDS_Block_Size"), "scratch", x.get("Scratch_Size"))
+        # registers: from the code object's metadata, not from the trace CSV (its VGPR_Count column is half the
+        # combined arch + acc allocation of this gfx950 kernel and its Accum_VGPR_Count reads 0 -- r02's summaries
+        # printed "VGPR 172 accum 0" for a kernel whose descriptor says 340 = 256 + 84)
+        try:
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            import codeobj_info as CI
+            lib = os.environ.get("M3P2I_HIP_LIB") or os.path.join(CI.ROOT, "m3p2i_aip_amd", "lib", "libm3p2i_hip.so")
+            tmp, cos = CI.extract(lib)
+            short = x["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            for co in cos:
+                ks = CI.kernels(co)
+                for k, d in zip(ks, CI.demangle([k["name"] for k in ks])):
+                    if d.split("(")[0].replace("void ", "").strip() == short:
+                        print("rollout code object:", short, "vgpr_count", k.get("vgpr_count"), "(arch",
+                              k.get("vgpr_count", 0) - k.get("agpr_count", 0), "+ acc", k.get("agpr_count"), ")",
+                              "sgpr", k.get("sgpr_count"), "sgpr_spill", k.get("sgpr_spill_count"),
+                              "vgpr_spill", k.get("vgpr_spill_count"), "lds", k.get("group_segment_fixed_size"),
+                              "scratch", k.get("private_segment_fixed_size"))
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+        except Exception as e:
+            print("rollout code object: unavailable:", repr(e))
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
     f = find(sub, "*counter_collection.csv")
     if not f:
