@@ -268,6 +268,18 @@ int m3_set_noise_knots_global(m3_handle* h, const float* knots_all, int n_knots,
  * differ from the host's libm in the last ulp) -- so the planner's default stays m3_set_noise_knots with host
  * knots, pinned bit for bit by golden G8; this entry (MPPIConfig.device_knots) removes the last host values. */
 int m3_set_noise_halton(m3_handle* h, int n_knots, int degree, float smoothing);
+/* The same with a GENERALIZED (digit-permuted) Halton sequence -- the structure of the branch the reference's
+ * planner actually executes: mppi.py:465-471 calls generate_gaussian_halton_samples(..., use_ghalton=True) ->
+ * ghalton.GeneralizedHalton(EA_PERMS[:ndims]) (mppi_utils.py:89-95).  `ghalton` is a third-party package that is
+ * absent here and unpinned in the reference (pyproject.toml:15), so its EA_PERMS table cannot be restated; what can
+ * be is the construction with a published, formula-defined permutation set:
+ *   M3_HALTON_FAURE   H. Faure, "Good permutations for extreme discrepancy", J. Number Theory 42 (1992) 47-56.
+ * The plain sequence's high dimensions are strongly correlated (the panda_env knots are 45-dimensional: primes up to
+ * 197, |corr| up to 0.45 between neighbouring dimensions at K = 4000; 0.08 with Faure's permutations).
+ * M3_HALTON_PLAIN == m3_set_noise_halton (the default: pinned by golden G8). */
+#define M3_HALTON_PLAIN 0
+#define M3_HALTON_FAURE 1
+int m3_set_noise_halton_scrambled(m3_handle* h, int n_knots, int degree, float smoothing, int scramble);
 /* sampling_random / simple mode: the draws of N(noise_mu, noise_sigma) that the NEXT m3_rollout generates in
  * registers (MultivariateNormal(...).sample((K, T)), mppi.py:340 / :481), written to M3_BUF_NOISE for a caller
  * that runs the rollout itself (the planner's STEP mode: user dynamics / running_cost callables) */

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M3P2I_HIP_LIB") or os.path.join(_HERE, "lib", "libm3p2i_hip.so")
 
 ENV_POINT, ENV_PANDA = 0, 1
+HALTON_PLAIN, HALTON_FAURE = 0, 1
 TASKS = {"navigation": 0, "push": 1, "pull": 2, "push_pull": 3, "reach": 4, "pick": 5,
          "place": 6, "idle": 7}
 
@@ -83,6 +84,7 @@ SYMBOLS = [
     ("m3_set_noise_global", C.c_int, [_H, _FP, C.c_int]),
     ("m3_set_noise_knots_global", C.c_int, [_H, _FP, C.c_int, C.c_int, C.c_float, C.c_int]),
     ("m3_set_noise_halton", C.c_int, [_H, C.c_int, C.c_int, C.c_float]),
+    ("m3_set_noise_halton_scrambled", C.c_int, [_H, C.c_int, C.c_int, C.c_float, C.c_int]),
     ("m3_sample_noise", C.c_int, [_H]),
     ("m3_set_call_count", C.c_int, [_H, C.c_uint]),
     ("m3_set_objective", C.c_int, [_H, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int]),

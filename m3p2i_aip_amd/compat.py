@@ -41,7 +41,9 @@ def torch_to_bytes(t) -> bytes:
 
 
 def bytes_to_torch(b: bytes):
-    return torch.load(io.BytesIO(b))
+    """data_transfer.py:9-12.  The blob comes off a network socket: weights_only=True restricts the unpickler to
+    tensors and plain containers (bool / int / float / str / list / dict), which is all the scripts exchange."""
+    return torch.load(io.BytesIO(b), weights_only=True)
 
 
 # ------------------------------------------------------------------ task_planner.py (module)
@@ -209,13 +211,15 @@ def install(force_standins: bool = False):
                             Objective=cost_functions.Objective)
     tp = mod("m3p2i_aip.planners.task_planner")
     tp.task_planner = mod("m3p2i_aip.planners.task_planner.task_planner", set_task_planner=set_task_planner,
-                          PLANNER_SIMPLE=PLANNER_SIMPLE, PLANNER_AIF_PANDA=PLANNER_AIF_PANDA)
+                          PLANNER_SIMPLE=PLANNER_SIMPLE, PLANNER_AIF_PANDA=PLANNER_AIF_PANDA,
+                          PLANNER_PATROLLING=task_planner.PLANNER_PATROLLING)
     tp.ai_agent = mod("m3p2i_aip.planners.task_planner.ai_agent", AiAgent=task_planner.AiAgent)
     tp.adaptive_action_selection = mod("m3p2i_aip.planners.task_planner.adaptive_action_selection",
                                        adapt_act_sel=task_planner.adapt_act_sel)
     tp.isaac_state_action_templates = mod(
         "m3p2i_aip.planners.task_planner.isaac_state_action_templates",
-        MDPIsCubeAtReal=task_planner.MDPIsCubeAtReal)
+        MDPIsCubeAtReal=task_planner.MDPIsCubeAtReal,
+        **{n: getattr(task_planner, n) for n in task_planner.TEMPLATE_TABLE})
     cfgm = mod("m3p2i_aip.config")
     cfgm.config_store = mod("m3p2i_aip.config.config_store", ExampleConfig=ExampleConfig)
     ut = mod("m3p2i_aip.utils")

@@ -6,6 +6,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 #include <new>
 
 #include "m3_internal.hpp"
@@ -141,6 +142,13 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
         if (c->K_global % c->K_local != 0 || c->k_offset % c->K_local != 0 || c->K_global / c->K_local > MIX_MAX_RANKS)
             return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs equal shards (K_global = n * K_local, n <= 32)");
         if (c->K_local < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs K_local >= 20");
+        if (c->multi_modal && !c->mode_simple) {
+            // the record of a one-collective multi-modal shard holds its top trajectories as float2 rows at
+            // rec + K_local + 40 (regen_off_trajs): 8-byte aligned only for even K_local; shard_of() forms k / K_local
+            // through a binary32 product that is exact only below 2^24
+            if (c->K_local % 2) return fail(nullptr, M3_ERR_SHAPE, "m3_create: one-collective multi-modal sharding needs an even K_local");
+            if (c->K_global >= (1 << 24)) return fail(nullptr, M3_ERR_SHAPE, "m3_create: one-collective multi-modal sharding needs K_global < 2^24");
+        }
     }
     for (int j = 0; j < c->nu; ++j)
         if (!(c->noise_sigma_diag[j] > 0.0f) || !(c->u_max[j] >= c->u_min[j]))
@@ -532,10 +540,31 @@ extern "C" int m3_set_noise_knots_global(m3_handle* h, const float* knots_all, i
 }
 
 // the whole reference sampler on the device: Halton -> erfinv -> smoothing spline (no host values at all)
-extern "C" int m3_set_noise_halton(m3_handle* h, int n_knots, int degree, float smoothing) {
+// Faure's permutations (H. Faure, "Good permutations for extreme discrepancy", J. Number Theory 42 (1992) 47-56),
+// defined recursively: pi_2 = (0 1); for even b = 2k, pi_b = (2 pi_k, 2 pi_k + 1); for odd b = 2k + 1, pi_b is
+// pi_2k with every value >= k increased by one and the value k inserted in the middle.  pi_b(0) = 0 for every b.
+static std::vector<int> faure_permutation(int b) {
+    if (b == 2) return {0, 1};
+    std::vector<int> r;
+    if (b % 2 == 0) {
+        const std::vector<int> hlf = faure_permutation(b / 2);
+        for (int x : hlf) r.push_back(2 * x);
+        for (int x : hlf) r.push_back(2 * x + 1);
+    } else {
+        const int k = (b - 1) / 2;
+        r = faure_permutation(b - 1);
+        for (int& x : r) if (x >= k) x += 1;
+        r.insert(r.begin() + k, k);
+    }
+    return r;
+}
+
+extern "C" int m3_set_noise_halton_scrambled(m3_handle* h, int n_knots, int degree, float smoothing, int scramble) {
     if (!h) return M3_ERR_BAD_ARG;
     const m3_config& c = h->cfg;
     if (c.sim_only) return fail(h, M3_ERR_STATE, "m3_set_noise_halton: handle was created sim_only");
+    if (scramble != M3_HALTON_PLAIN && scramble != M3_HALTON_FAURE)
+        return fail(h, M3_ERR_BAD_ARG, "m3_set_noise_halton_scrambled: scramble must be M3_HALTON_PLAIN or M3_HALTON_FAURE");
     const int ncol = c.nu * n_knots;
     if (n_knots < 1 || ncol > 100) return fail(h, M3_ERR_SHAPE, "m3_set_noise_halton: nu * n_knots must be <= 100 (mppi_utils.py:81)");
     int primes[100], np_ = 0;
@@ -545,24 +574,40 @@ extern "C" int m3_set_noise_halton(m3_handle* h, int n_knots, int degree, float 
             if (cand % primes[q] == 0) { is_p = false; break; }
         if (is_p) primes[np_++] = cand;
     }
+    std::vector<int> perm, perm_off;
+    if (scramble == M3_HALTON_FAURE)
+        for (int j = 0; j < ncol; ++j) {
+            perm_off.push_back((int)perm.size());
+            const std::vector<int> pj = faure_permutation(primes[j]);
+            perm.insert(perm.end(), pj.begin(), pj.end());
+        }
     const long long rows = h->regen ? c.K_global : c.K_local;
     const int k0 = h->regen ? 0 : c.k_offset;
     float* knots = nullptr;
-    int* primes_dev = nullptr;
+    int* tab = nullptr;           // primes | perm offsets | permutations
+    const size_t ntab = (size_t)ncol + perm_off.size() + perm.size();
     HIPCHK(h, hipMalloc((void**)&knots, (size_t)rows * ncol * sizeof(float)));
-    if (hipMalloc((void**)&primes_dev, ncol * sizeof(int)) != hipSuccess) { (void)hipFree(knots); return fail(h, M3_ERR_HIP, "m3_set_noise_halton: hipMalloc"); }
+    if (hipMalloc((void**)&tab, ntab * sizeof(int)) != hipSuccess) { (void)hipFree(knots); return fail(h, M3_ERR_HIP, "m3_set_noise_halton: hipMalloc"); }
+    std::vector<int> host(primes, primes + ncol);
+    host.insert(host.end(), perm_off.begin(), perm_off.end());
+    host.insert(host.end(), perm.begin(), perm.end());
     int rc = M3_OK;
-    if (hipMemcpyAsync(primes_dev, primes, ncol * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = M3_ERR_HIP;
+    if (hipMemcpyAsync(tab, host.data(), ntab * sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK) {
-        launch_halton_knots(knots, k0, (int)rows, ncol, primes_dev, h->stream);
+        const bool sc = scramble != M3_HALTON_PLAIN;
+        launch_halton_knots(knots, k0, (int)rows, ncol, tab, sc ? tab + 2 * ncol : nullptr, sc ? tab + ncol : nullptr, h->stream);
         // knots [rows][nu][n_knots] == [rows][ncol]: column j * n_knots + q is knot q of control dimension j
         rc = upload_knots(h, knots, rows, h->regen ? h->noise_all : (float*)h->buf[M3_BUF_NOISE], n_knots, degree, smoothing, 1);
     }
-    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);     // (also keeps `host` alive until the copy is done)
     (void)hipFree(knots);
-    (void)hipFree(primes_dev);
+    (void)hipFree(tab);
     if (rc != M3_OK && h->err.empty()) h->err = "m3_set_noise_halton failed";
     return rc;
+}
+
+extern "C" int m3_set_noise_halton(m3_handle* h, int n_knots, int degree, float smoothing) {
+    return m3_set_noise_halton_scrambled(h, n_knots, degree, smoothing, M3_HALTON_PLAIN);
 }
 
 extern "C" int m3_sample_noise(m3_handle* h) {
@@ -648,6 +693,12 @@ extern "C" int m3_reset(m3_handle* h) {
     std::memset(&init, 0, sizeof(init));
     init.beta = init.beta_1 = init.beta_2 = 1.0f;
     HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_INFO], &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    // update_cov adapts cov_action / scale_tril (mppi.py:508-516): a reset planner starts from the configured
+    // diag(noise_sigma) again, like a freshly built one (mppi.py:175-176)
+    float cv[2 * M3_MAX_NU];
+    const int nu = h->cfg.nu;
+    for (int j = 0; j < nu; ++j) { cv[j] = h->cfg.noise_sigma_diag[j]; cv[nu + j] = std::sqrt(h->cfg.noise_sigma_diag[j]); }
+    HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_COV], cv, (size_t)(2 * nu) * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->calls = 0;
     return M3_OK;

@@ -155,7 +155,8 @@ void launch_transpose_noise(const float* src_ktn, float* dst_tkn, int K, int T, 
 void launch_spline_noise(const float* knots, float* noise, int Kl, int nu, int n_knots, int T, int degree,
                          double smoothing, hipStream_t s);
 void launch_sample_noise(const RolloutArgs& a, float* out, hipStream_t s);
-void launch_halton_knots(float* knots, int k0, int n, int ncol, const int* primes_dev, hipStream_t s);
+void launch_halton_knots(float* knots, int k0, int n, int ncol, const int* primes_dev, const int* perm_dev,
+                         const int* perm_off_dev, hipStream_t s);
 struct OrderScene {   // where the scene's objects are when the wavefront order is computed
     const float* sim_root;  // != null: box / dyn-obs positions are read from the bound root_state tensor
     int sim_box, sim_dyn;

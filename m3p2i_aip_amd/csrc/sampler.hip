@@ -69,26 +69,36 @@ __device__ __forceinline__ float dev_erfinv(float y) {
     return x;
 }
 
-__global__ void k_halton_knots(float* __restrict__ knots /*[n][ncol]*/, int k0, int n, int ncol, const int* __restrict__ primes) {
+// perm == nullptr: the plain van der Corput radical inverse (the reference's in-tree branch, mppi_utils.py:69-87).
+// Otherwise the GENERALIZED Halton sequence: digit d of base primes[c] is replaced by perm[perm_off[c] + d]
+// (pi_b(0) = 0, so the infinitely many leading zero digits still contribute nothing) -- the structure of the
+// branch the reference's planner actually takes (ghalton.GeneralizedHalton, mppi_utils.py:89-95) with a published,
+// formula-defined permutation set (m3_api.hip: Faure 1992) in place of ghalton's unpinnable EA_PERMS table.
+__global__ void k_halton_knots(float* __restrict__ knots /*[n][ncol]*/, int k0, int n, int ncol, const int* __restrict__ primes,
+                               const int* __restrict__ perm, const int* __restrict__ perm_off) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n * ncol) return;
     const int c = o % ncol;
     unsigned rem = (unsigned)(k0 + o / ncol) + 1u;      // Halton indices start at 1
     const unsigned base = (unsigned)primes[c];
+    const int* pc = perm ? perm + perm_off[c] : nullptr;
     float acc = 0.0f;
     double scale = 1.0;
     while (rem > 0u) {
         scale /= (double)base;
-        acc += (float)scale * (float)(rem % base);
+        const unsigned d = rem % base;
+        acc += (float)scale * (float)(pc ? (unsigned)pc[d] : d);
         rem /= base;
     }
     const float u = 2.0f * acc - 1.0f;
     knots[o] = 1.41421356237309515f * dev_erfinv(u);
 }
 
-void launch_halton_knots(float* knots, int k0, int n, int ncol, const int* primes_dev, hipStream_t s) {
+void launch_halton_knots(float* knots, int k0, int n, int ncol, const int* primes_dev, const int* perm_dev,
+                         const int* perm_off_dev, hipStream_t s) {
     const int total = n * ncol;
-    hipLaunchKernelGGL(k_halton_knots, dim3((total + 255) / 256), dim3(256), 0, s, knots, k0, n, ncol, primes_dev);
+    hipLaunchKernelGGL(k_halton_knots, dim3((total + 255) / 256), dim3(256), 0, s, knots, k0, n, ncol, primes_dev, perm_dev,
+                       perm_off_dev);
 }
 
 // ---- wavefront order of the samples (point_env rollout) ---------------------------------

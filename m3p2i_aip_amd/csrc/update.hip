@@ -385,7 +385,7 @@ __device__ __forceinline__ void topk_finish(const UpdateArgs& a, const VI* top /
             if (gi >= 0 && gi < a.Kg) {
                 const float* rec = a.records_all + (size_t)(gi / a.Kls) * a.rec_len;
                 for (int q = 0; q < M3_TOPK; ++q)
-                    if (__float_as_int(rec[regen_off_topi(a.Kls) + q]) == gi) off = (gi / a.Kls) * a.rec_len + regen_off_trajs(a.Kls) + q * T * 2;
+                    if (__float_as_int(rec[regen_off_topi(a.Kls) + q]) == gi) off = (int)((size_t)(gi / a.Kls) * a.rec_len + regen_off_trajs(a.Kls) + q * T * 2);   // < 2^25: K_global < 2^24 (m3_create)
             }
             s_src[tid] = off;
         }

@@ -174,9 +174,11 @@ class HipEngine:
         self._ck(self.lib.m3_sample_noise(self._h))
         return self.buffer(L.BUF_NOISE)
 
-    def set_noise_halton(self, n_knots, degree=2, smoothing=0.5):
-        """The whole Halton-spline sampler on the device (knots included): include/m3p2i_hip.h."""
-        self._ck(self.lib.m3_set_noise_halton(self._h, int(n_knots), int(degree), float(smoothing)))
+    def set_noise_halton(self, n_knots, degree=2, smoothing=0.5, scramble="none"):
+        """The whole Halton-spline sampler on the device (knots included): include/m3p2i_hip.h.
+        scramble: "none" (plain van der Corput, pinned by golden G8) or "faure" (generalized Halton)."""
+        code = {"none": L.HALTON_PLAIN, "faure": L.HALTON_FAURE}[scramble]
+        self._ck(self.lib.m3_set_noise_halton_scrambled(self._h, int(n_knots), int(degree), float(smoothing), code))
 
     def set_objective(self, task, goal, gripper_cmd=0):
         t = L.TASKS[task] if isinstance(task, str) else int(task)

@@ -79,6 +79,9 @@ class MPPIConfig(object):
     shard_mix: Optional[int] = None   # None: one-collective protocol whenever it applies (multi-modal: 2); 1 / 2 / False
     relabel_samples: bool = True      # generated noise rows into wavefront-coherent order (same sample set)
     device_knots: bool = False        # Halton + erfinv knots on the device too (~1e-6 from the host sampler's)
+    halton_scramble: str = "none"     # "none": plain Halton (mppi_utils.py:81-87, pinned by golden G8); "faure": the
+                                      # generalized Halton structure of the ghalton branch the reference's planner
+                                      # takes (mppi.py:465-471, mppi_utils.py:89-95) with Faure's (1992) permutations
 
 
 def _get(cfg, name, default=None):
@@ -306,15 +309,18 @@ class MPPI():
         e = self._engine
         # (a one-collective multi-modal shard holds the rows of ALL samples: engine.needs_global_noise)
         k0, k1 = (0, self.K) if e.needs_global_noise else (self.k_offset, self.k_offset + self.K_local)
+        scramble = str(_get(self._top_cfg.mppi, "halton_scramble", "none") or "none")
+        if scramble not in sampling.SCRAMBLES:
+            raise ValueError(f"unknown halton_scramble {scramble!r} (one of {sampling.SCRAMBLES})")
         # device sampler: Halton knots on the host (K*nu*n_knots values, vectorised), the K*nu
         # spline fits -- where the reference's ~1 s init goes -- one GPU thread each
         if bool(_get(self._top_cfg.mppi, "device_knots", False)):
             if self.n_knots <= self.degree:
                 raise ValueError(f"horizon T={self.T} gives n_knots={self.n_knots}: the spline needs T >= {self.knot_scale * (self.degree + 1)}")
-            e.set_noise_halton(self.n_knots, self.degree, 0.5)     # ... and the knots on the device as well
+            e.set_noise_halton(self.n_knots, self.degree, 0.5, scramble)     # ... and the knots on the device as well
         else:
-            e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree, k0, k1),
-                              self.degree, 0.5)
+            e.set_noise_knots(sampling.halton_knots(self.K, self.T, self.nu, self.knot_scale, self.degree, k0, k1,
+                                                    scramble=scramble), self.degree, 0.5)
         if self.relabel_samples:
             e.relabel_samples()   # the sampler's row labels are arbitrary: wavefront-coherent ones
         self._have_noise = True

@@ -10,10 +10,22 @@ connection per client, length-prefixed msgpack frames -- request [method, args],
 `bytes` payloads (the scripts ship `torch.save` blobs, utils/data_transfer.py:4-12) travel as msgpack
 bin.  Like zerorpc's server on gevent, calls are served one at a time in the order they arrive
 (reactive_tamp.py's command() is never re-entered).  Only public methods of the served object are
-callable; there is no pickle on the wire.
+callable.
+
+Security posture (this is a lab transport, like the zerorpc it stands in for -- no authentication):
+  * the transport itself never unpickles: frames are msgpack.  The `bytes` payloads the scripts exchange ARE
+    `torch.save` blobs, i.e. pickles; `compat.bytes_to_torch` loads them with `weights_only=True` (tensors and
+    plain containers only -- no arbitrary object construction);
+  * "tcp://0.0.0.0:port" / "tcp://*:port" (what the reference's scripts bind) listens on 127.0.0.1 ONLY unless
+    M3P2I_RPC_BIND_ALL=1 is set: planner and world run on one machine in every documented use;
+  * a frame must be a 2-element list [str, list]; anything else closes that client, never the server;
+  * a client that stalls in the middle of a frame is dropped after CLIENT_TIMEOUT seconds;
+  * frames above MAX_FRAME (64 MiB; the largest real payload is a [K, nA, 13] root-state blob: 2.3 MB at K = 4000)
+    are refused before any allocation.
 """
 from __future__ import annotations
 
+import os
 import select
 import socket
 import struct
@@ -21,7 +33,8 @@ import struct
 import msgpack
 
 _HDR = struct.Struct("!I")
-MAX_FRAME = 1 << 30
+MAX_FRAME = 64 << 20
+CLIENT_TIMEOUT = 10.0      # seconds a half-sent frame may stall before the client is dropped
 
 
 class RemoteError(RuntimeError):
@@ -37,6 +50,13 @@ def _endpoint(ep: str):
         raise ValueError(f"only tcp:// endpoints are supported, got {ep!r}")
     host, _, port = ep[len("tcp://"):].rpartition(":")
     return ("" if host in ("*", "0.0.0.0") else host), int(port)
+
+
+def _bind_host(host: str) -> str:
+    """Wildcard endpoints listen on the loopback interface unless the operator opts in to all interfaces."""
+    if host == "":
+        return "" if os.environ.get("M3P2I_RPC_BIND_ALL") == "1" else "127.0.0.1"
+    return host
 
 
 def _recv_exact(sock, n):
@@ -72,7 +92,7 @@ class Server:
         host, port = _endpoint(endpoint)
         s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        s.bind((host, port))
+        s.bind((_bind_host(host), port))
         s.listen(8)
         self._listen.append(s)
         return s.getsockname()[1]
@@ -85,21 +105,37 @@ class Server:
             raise AttributeError(f"{name!r} is not callable")
         return fn(*args)
 
+    def _drop(self, s):
+        if s in self._clients:
+            self._clients.remove(s)
+        try:
+            s.close()
+        except OSError:
+            pass
+
     def serve_once(self, timeout=None):
         """Wait for activity (up to `timeout` seconds) and serve what arrived; returns the number of calls."""
-        ready, _, _ = select.select(self._listen + self._clients, [], [], timeout)
+        try:
+            ready, _, _ = select.select(self._listen + self._clients, [], [], timeout)
+        except (OSError, ValueError):      # close() from another thread while waiting
+            return 0
         served = 0
         for s in ready:
             if s in self._listen:
                 c, _ = s.accept()
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(CLIENT_TIMEOUT)        # a stalled half-frame must not block the (single-threaded) server
                 self._clients.append(c)
                 continue
             try:
-                name, args = _recv(s)
-            except (LostRemote, ConnectionError, ValueError):
-                self._clients.remove(s)
-                s.close()
+                frame = _recv(s)
+                if not (isinstance(frame, (list, tuple)) and len(frame) == 2 and isinstance(frame[0], str)
+                        and isinstance(frame[1], (list, tuple))):
+                    raise ValueError("malformed request frame (want [method: str, args: list])")
+                name, args = frame
+            except (LostRemote, OSError, ValueError, TypeError, msgpack.exceptions.UnpackException,
+                    msgpack.exceptions.ExtraData):   # (socket.timeout and ConnectionError are OSErrors)
+                self._drop(s)
                 continue
             try:
                 reply = [None, self._call(name, args)]
@@ -108,8 +144,7 @@ class Server:
             try:
                 _send(s, reply)
             except (ConnectionError, OSError):
-                self._clients.remove(s)
-                s.close()
+                self._drop(s)
             served += 1
         return served
 

@@ -9,9 +9,11 @@ Mirrors what the reference does ONCE at the first command() and then caches
 
 The reference takes its Halton points from the third-party ``ghalton`` package
 (GeneralizedHalton with EA_PERMS, unpinned in pyproject.toml:15), which is not available
-here: PARITY UNPINNED for the sample VALUES.  This build uses the reference's own in-tree
+here: PARITY UNPINNED for the sample VALUES.  This build's default is the reference's own in-tree
 alternative branch (van der Corput radical inverse on the first primes, mppi_utils.py:81-87)
-which is restatable and pinned by golden group G8.  The spline is SciPy FITPACK
+which is restatable and pinned by golden group G8; `scramble="faure"` (MPPIConfig.halton_scramble)
+gives the generalized -- digit-permuted -- sequence the planner's ghalton branch has the structure of,
+with Faure's published permutations in place of the unobtainable EA_PERMS table.  The spline is SciPy FITPACK
 (splrep k=2 s=0.5 / splev ext=3), the same library call the reference makes.
 
 Not on the hot path (runs once; the result is uploaded with m3_set_noise).
@@ -32,27 +34,50 @@ def first_primes(n: int):
     return out
 
 
-def radical_inverse(idx: torch.Tensor, base: int) -> torch.Tensor:
+def faure_permutation(base: int):
+    """Faure's digit permutation pi_b (H. Faure, "Good permutations for extreme discrepancy", J. Number Theory 42
+    (1992) 47-56): pi_2 = (0 1); even b = 2k: pi_b = (2 pi_k, 2 pi_k + 1); odd b = 2k + 1: pi_2k with every value
+    >= k increased by one and k inserted in the middle.  pi_b(0) = 0.  E.g. pi_5 = (0 3 2 1 4), pi_7 = (0 2 5 3 1 4 6)."""
+    if base == 2:
+        return [0, 1]
+    if base % 2 == 0:
+        h = faure_permutation(base // 2)
+        return [2 * x for x in h] + [2 * x + 1 for x in h]
+    k = (base - 1) // 2
+    r = [x + 1 if x >= k else x for x in faure_permutation(base - 1)]
+    return r[:k] + [k] + r[k:]
+
+
+SCRAMBLES = ("none", "faure")
+
+
+def radical_inverse(idx: torch.Tensor, base: int, perm=None) -> torch.Tensor:
     """van der Corput radical inverse of the integers `idx` in `base`, accumulated in f32
-    digit by digit from the least significant one (same arithmetic as mppi_utils.py:69-78)."""
+    digit by digit from the least significant one (same arithmetic as mppi_utils.py:69-78).  With `perm`
+    (a permutation of 0..base-1 with perm[0] = 0) every digit d is replaced by perm[d]: the generalized
+    Halton sequence, the structure of ghalton.GeneralizedHalton (mppi_utils.py:89-95)."""
     acc = torch.zeros(idx.shape[0], dtype=torch.float32)
     rem = idx.clone()
     scale = 1.0
+    table = None if perm is None else torch.tensor(perm, dtype=torch.int64)
     while bool((rem > 0).any()):
         scale /= float(base)
-        acc += scale * (rem % base)
+        d = rem % base
+        acc += scale * (d if table is None else table[d])
         rem = rem // base
     return acc
 
 
-def halton_uniform(num_samples: int, ndims: int) -> torch.Tensor:
+def halton_uniform(num_samples: int, ndims: int, scramble: str = "none") -> torch.Tensor:
+    if scramble not in SCRAMBLES:
+        raise ValueError(f"unknown halton_scramble {scramble!r} (one of {SCRAMBLES})")
     idx = torch.arange(1, num_samples + 1)
-    cols = [radical_inverse(idx, b) for b in first_primes(ndims)]
+    cols = [radical_inverse(idx, b, faure_permutation(b) if scramble == "faure" else None) for b in first_primes(ndims)]
     return torch.stack(cols, dim=1)
 
 
-def halton_gaussian(num_samples: int, ndims: int) -> torch.Tensor:
-    u = halton_uniform(num_samples, ndims)
+def halton_gaussian(num_samples: int, ndims: int, scramble: str = "none") -> torch.Tensor:
+    u = halton_uniform(num_samples, ndims, scramble)
     return torch.sqrt(torch.tensor([2.0], dtype=torch.float32)) * torch.erfinv(2 * u - 1)
 
 
@@ -67,7 +92,7 @@ def smoothing_spline(knots: np.ndarray, n_out: int, degree: int = 2) -> np.ndarr
 
 
 def halton_knots(K: int, T: int, nu: int, knot_scale: int = 4, degree: int = 2, k0: int = 0,
-                 k1: int | None = None) -> torch.Tensor:
+                 k1: int | None = None, scramble: str = "none") -> torch.Tensor:
     """The spline knots of samples k0..k1: [k1-k0, nu, n_knots] float32 (Gaussian Halton values,
     mppi_utils.py:81-104).  Input of the device sampler (engine.set_noise_knots)."""
     n_knots = T // knot_scale
@@ -76,12 +101,13 @@ def halton_knots(K: int, T: int, nu: int, knot_scale: int = 4, degree: int = 2, 
                          f"needs T >= {knot_scale * (degree + 1)} (reference: splrep raises "
                          "'m > k must hold'); use sampling_method='random' or mppi_mode='simple'")
     k1 = K if k1 is None else k1
-    g = halton_gaussian(K, n_knots * nu).view(K, nu, n_knots)
+    g = halton_gaussian(K, n_knots * nu, scramble).view(K, nu, n_knots)
     return g[k0:k1].to(torch.float32).contiguous()
 
 
 def halton_spline_delta(K: int, T: int, nu: int, knot_scale: int = 4, degree: int = 2,
-                        k0: int = 0, k1: int | None = None, workers: int | None = None) -> torch.Tensor:
+                        k0: int = 0, k1: int | None = None, workers: int | None = None,
+                        scramble: str = "none") -> torch.Tensor:
     """delta[K, T, nu] (rows k0..k1 only if given).  n_knots = T // knot_scale must be >= 3
     for a degree-2 spline ("At least 12 for Halton Sampling", mppi/point.yaml:7)."""
     n_knots = T // knot_scale
@@ -90,7 +116,7 @@ def halton_spline_delta(K: int, T: int, nu: int, knot_scale: int = 4, degree: in
                          f"needs T >= {knot_scale * (degree + 1)} (reference: splrep raises "
                          "'m > k must hold'); use sampling_method='random' or mppi_mode='simple'")
     k1 = K if k1 is None else k1
-    g = halton_gaussian(K, n_knots * nu).view(K, nu, n_knots).numpy()
+    g = halton_gaussian(K, n_knots * nu, scramble).view(K, nu, n_knots).numpy()
     rows = g[k0:k1].astype(np.float32)
     if workers is None:
         workers = min(_usable_cores(), 32) if (k1 - k0) * nu >= 100000 else 1  # ~30 us per fit;

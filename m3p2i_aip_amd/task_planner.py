@@ -8,9 +8,10 @@ Mirrors the reference's interface for the caller of the hot path (`reactive_tamp
 * `adapt_act_sel`             -- adaptive_action_selection.py:11-84 (action selection with
                                  precondition push-back)
 * `MDP`, `MDPIsCubeAtReal`    -- isaac_state_action_templates.py:192-232 (the one template the
-                                 planner path uses; the others -- dead code in the reference,
-                                 SURVEY.md section 2 -- live on only as test data,
-                                 tests/aif_templates.py)
+                                 planner path uses)
+* `MDPIsAt` ... `MDPIsCubeAt` -- isaac_state_action_templates.py:6-190, table-driven (`TEMPLATE_TABLE`): not on
+                                 the planner path, built by examples/example_aip_parallel.py
+* `PLANNER_PATROLLING`        -- task_planner.py:109-125 (waypoint tour for the navigation task)
 
 This is a restatement, not a transcription: the agent's per-policy loops are evaluated as array
 operations over the policy axis and the templates are table-driven.  What is kept exactly is the
@@ -74,6 +75,35 @@ def MDPIsCubeAtReal():    # :192-232
                ["idle", "reach", "pick", "place"],
                [["cube_at_goal"], ["cube_at_table"], ["cube_close_to_gripper"], ["cube_at_pre_place"]],
                [1.0, 1.01, 1.0, 1.0], kappa_d=0.8)
+
+
+# The templates of the multi-factor examples (isaac_state_action_templates.py:6-190; the planner path itself
+# only uses MDPIsCubeAtReal; examples/example_aip_parallel.py builds the first four) as a table:
+#   name: (factor, states, actions, preconditions per action, habits E, kappa_d)
+TEMPLATE_TABLE = {
+    "MDPIsAt": ("isAt", ("at_goal", "not_at_goal"), ("idle", "move_to"), (("none",), ("battery_ok",)), (1.01, 1), 1.0),
+    "MDPIsCloseTo": ("isCloseTo", ("close_to", "not_close_to"), ("idle", "approach_obj"), (("none",), ("none",)),
+                     (1.01, 1), 1.0),
+    "MDPIsLocFree": ("isLocFree", ("loc_free", "not_loc_free"), ("idle", "push_to_non_goal", "pull_to_non_goal"),
+                     (("none",), ("close_to",), ("close_to",)), (1.01, 1, 1), 1.0),
+    "MDPIsBlockAt": ("isBlockAt", ("block_at_loc", "not_block_at_loc"), ("idle", "push_to_goal", "pull_to_goal"),
+                     (("none",), ("loc_free", "close_to"), ("loc_free", "close_to")), (1.01, 1, 1), 1.0),
+    "MDPIsCubeAt": ("isCubeAt", ("cube_at_table", "cube_at_hand", "cube_at_goal"), ("idle", "pick", "place"),
+                    (("cube_at_goal",), ("cube_at_table",), ("cube_at_hand",)), (1.0, 1.01, 1.0), 0.8),
+}
+
+
+def _template(name):
+    def make():
+        factor, states, actions, pre, habits, kappa = TEMPLATE_TABLE[name]
+        return MDP(factor, states, actions, pre, habits, kappa_d=kappa)
+    make.__name__ = make.__qualname__ = name
+    make.__doc__ = f"{name}() -> MDP (TEMPLATE_TABLE[{name!r}])"
+    return make
+
+
+MDPIsAt, MDPIsCloseTo, MDPIsLocFree = _template("MDPIsAt"), _template("MDPIsCloseTo"), _template("MDPIsLocFree")
+MDPIsBlockAt, MDPIsCubeAt = _template("MDPIsBlockAt"), _template("MDPIsCubeAt")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -366,6 +396,35 @@ class PLANNER_AIF_PANDA(PLANNER_SIMPLE):
             return False
         offset = self.curr_goal[:2] - self._pose(sim, "cubeA", "box")[:2]
         return bool((offset * offset).sum() < self.SUCCESS_RADIUS ** 2)
+
+
+class PLANNER_PATROLLING(PLANNER_SIMPLE):
+    """Navigation through a closed tour of waypoints (behaves like task_planner.py:109-125): `curr_goal` is the
+    waypoint being approached; reaching it (within SUCCESS_RADIUS) selects the next, the last wraps to the first.
+    Never "done": check_task_success of a patrol is False."""
+
+    def __init__(self, goals, device="cuda:0") -> None:
+        import torch
+        self.task = "navigation"
+        self.device = device
+        self.goals = torch.as_tensor(goals, dtype=torch.float32, device=device).reshape(-1, 2)
+        self.dist_threshold = self.SUCCESS_RADIUS
+        self.reset_plan()
+
+    def reset_plan(self):
+        self.goal_id = 0
+
+    @property
+    def curr_goal(self):
+        return self.goals[self.goal_id]
+
+    def update_plan(self, robot_pos, stay_still=False):
+        import torch
+        if bool(torch.norm(robot_pos.reshape(-1)[:2].to(self.goals) - self.curr_goal) < self.dist_threshold):
+            self.goal_id = (self.goal_id + 1) % self.goals.shape[0]
+
+    def check_task_success(self, sim):
+        return False
 
 
 def set_task_planner(cfg):

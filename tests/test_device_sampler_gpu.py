@@ -62,8 +62,9 @@ def test_bad_knot_shapes_are_refused():
     eng.close()
 
 
+@pytest.mark.parametrize("scramble", ["none", "faure"])
 @pytest.mark.parametrize("K,T,nu,k0,k1", [(2000, 30, 2, 0, 2000), (4000, 20, 9, 0, 4000), (4096, 30, 2, 1024, 2048)])
-def test_whole_sampler_on_the_device_agrees_with_the_host_sampler(K, T, nu, k0, k1):
+def test_whole_sampler_on_the_device_agrees_with_the_host_sampler(K, T, nu, k0, k1, scramble):
     """m3_set_noise_halton: Halton radical inverses + erfinv on the device as well (MPPIConfig.device_knots).
     The Halton uniforms are the host's bit for bit (the knot signs and magnitudes below would scatter
     otherwise); the Gaussian values go through the device's erff / expf / logf, so the final noise agrees with
@@ -74,10 +75,10 @@ def test_whole_sampler_on_the_device_agrees_with_the_host_sampler(K, T, nu, k0, 
     env = "point_env" if nu == 2 else "panda_env"
     kw = dict(u_min=[-1.0] * nu, u_max=[1.0] * nu, noise_sigma_diag=[1.0] * nu)
     eng = HipEngine(make_config(K=K, K_local=k1 - k0, k_offset=k0, T=T, nu=nu, env_type=env, **kw))
-    eng.set_noise_halton(T // 4)
+    eng.set_noise_halton(T // 4, scramble=scramble)      # "faure": generalized Halton, m3_set_noise_halton_scrambled
     torch.cuda.synchronize()
     dev = eng.buffer(L.BUF_NOISE).permute(1, 0, 2).cpu().numpy()
-    ref = sampling.halton_spline_delta(K, T, nu, k0=k0, k1=k1, workers=1).numpy()
+    ref = sampling.halton_spline_delta(K, T, nu, k0=k0, k1=k1, workers=1, scramble=scramble).numpy()
     assert np.isfinite(dev).all()
     np.testing.assert_allclose(dev, ref, atol=3e-5, rtol=1e-5)
     eng.close()
@@ -93,3 +94,22 @@ def test_planner_with_device_knots_plans_like_the_default_sampler():
         outs.append(a.cpu().numpy())
         pl._engine.close()
     np.testing.assert_allclose(outs[1], outs[0], atol=2e-3)
+
+
+@pytest.mark.parametrize("device_knots", [False, True])
+def test_planner_with_scrambled_halton(device_knots):
+    """MPPIConfig.halton_scramble='faure' (host knots and device knots): a different -- better spread -- sample set of
+    the same distribution: the planner runs on it, the noise has the default's moments, the plan is of the same kind."""
+    import bench
+    stats = {}
+    for sc in ("none", "faure"):
+        pl, sim, obj, cfg = bench.build_tamp("panda_env", "reach", (0.0,) * 7, False, 4000, 0, 1, 20, "cuda:0")
+        cfg.mppi.halton_scramble, cfg.mppi.device_knots = sc, device_knots
+        a = [pl.command(sim._dof_state[0]).clone() for _ in range(3)][-1]
+        d = pl.delta.contiguous().cpu().numpy()
+        stats[sc] = (d.mean(), d.std(), a.cpu().numpy(), float(pl.cost_total.min()))
+        assert np.isfinite(a.cpu().numpy()).all()
+        pl._engine.close()
+    assert abs(stats["faure"][0]) < 0.02 and abs(stats["faure"][1] - stats["none"][1]) < 0.05 * stats["none"][1]
+    assert not np.array_equal(stats["faure"][2], stats["none"][2])
+    assert stats["faure"][3] < 1.5 * stats["none"][3] + 1.0          # best rollout cost of the same order

@@ -131,3 +131,53 @@ def test_non_diagonal_noise_sigma_uses_its_diagonal_in_halton_spline_mode():
         assert [round(v, 6) for v in list(c.noise_sigma_full)[:4]] == [3.0, 0.7, 0.7, 2.0]
     finally:
         P.ENGINE_CLS = old
+
+
+def test_faure_permutations_known_answers_and_shape():
+    """MPPIConfig.halton_scramble='faure': Faure's (1992) recursive digit permutations.  Known answers from the
+    construction (pi_2 = (0 1); even b: (2 pi_{b/2}, 2 pi_{b/2} + 1); odd b = 2k + 1: pi_{2k} with values >= k
+    raised by one and k inserted in the middle)."""
+    from m3p2i_aip_amd import sampling as S
+    assert S.faure_permutation(2) == [0, 1]
+    assert S.faure_permutation(3) == [0, 1, 2]
+    assert S.faure_permutation(4) == [0, 2, 1, 3]
+    assert S.faure_permutation(5) == [0, 3, 2, 1, 4]
+    assert S.faure_permutation(6) == [0, 2, 4, 1, 3, 5]
+    assert S.faure_permutation(7) == [0, 2, 5, 3, 1, 4, 6]
+    assert S.faure_permutation(8) == [0, 4, 2, 6, 1, 5, 3, 7]
+    for b in S.first_primes(100):
+        p = S.faure_permutation(b)
+        assert sorted(p) == list(range(b)) and p[0] == 0      # a permutation that keeps digit 0 (trailing zeros stay zeros)
+
+
+def test_generalized_halton_keeps_the_one_dimensional_stratification():
+    """Permuting digits permutes the points of every complete block: the first b^m values of the base-b coordinate
+    are exactly {j / b^m} -- with index 0 (value 0) replaced by index b^m, whose only non-zero digit maps to pi(1)/b^(m+1)."""
+    from m3p2i_aip_amd import sampling as S
+    for j, b in enumerate(S.first_primes(6)):
+        m = 2
+        n = b ** m
+        u = S.halton_uniform(n - 1, j + 1, "faure")[:, j].double().numpy()     # indices 1 .. b^m - 1
+        got = np.sort(np.round(u * n).astype(int))
+        assert np.array_equal(got, np.arange(1, n)), (b, got)
+    # default stays the reference's in-tree plain sequence (golden G8 pins it elsewhere): Appendix A row 1
+    np.testing.assert_allclose(S.halton_gaussian(8, 4)[0].numpy(), [0.0, -0.4307, -0.8416, -1.0676], atol=1e-4)
+
+
+def test_scrambled_halton_decorrelates_the_high_dimensions():
+    """The panda_env knots are 45-dimensional (nu 9 x T//4 = 5 knots: primes up to 197).  At K = 4000 the plain
+    sequence's neighbouring high dimensions are strongly correlated; Faure's permutations remove that
+    (the bound a set of 4000 independent uniforms meets is ~4.5 / sqrt(K) = 0.07)."""
+    from m3p2i_aip_amd import sampling as S
+    K, nd = 4000, 45
+    worst = {}
+    for sc in ("none", "faure"):
+        u = S.halton_uniform(K, nd, sc).double().numpy()
+        c = np.corrcoef(u[:, 29:].T)                      # dimensions 30 .. 45
+        np.fill_diagonal(c, 0.0)
+        worst[sc] = float(np.abs(c).max())
+        assert abs(u.mean() - 0.5) < 5e-3 and u.min() > 0 and u.max() < 1
+    assert worst["none"] > 0.4, worst            # what the plain set does
+    assert worst["faure"] < 0.1, worst           # the bound the scrambled set passes and the plain one fails
+    with pytest.raises(ValueError):
+        S.halton_uniform(8, 2, "sobol")

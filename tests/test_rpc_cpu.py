@@ -70,3 +70,56 @@ def test_bad_endpoint_and_lost_remote():
     c = rpc.Client()
     with pytest.raises(rpc.LostRemote):
         c.anything()
+
+
+def test_server_survives_malformed_frames_stalled_clients_and_hostile_blobs():
+    """a well-formed msgpack frame of the wrong shape, a client that stalls inside a frame and an
+    oversized frame each cost that CLIENT its connection, never the server; torch blobs are loaded with
+    weights_only=True (a pickle that constructs an arbitrary object is refused)."""
+    import pickle
+    import socket
+    import struct
+    import time
+    import msgpack
+    from m3p2i_aip_amd import compat, rpc
+    obj = _Planner()
+    server = rpc.Server(obj)
+    port = server.bind("tcp://0.0.0.0:0")                # wildcard endpoint of the reference's scripts ...
+    assert server._listen[0].getsockname()[0] == "127.0.0.1"   # ... listens on the loopback interface only
+    old = rpc.CLIENT_TIMEOUT
+    rpc.CLIENT_TIMEOUT = 0.3
+    th = threading.Thread(target=server.run, daemon=True)
+    th.start()
+    try:
+        def raw():
+            return socket.create_connection(("127.0.0.1", port), timeout=5)
+        for payload in (msgpack.packb(7), msgpack.packb(["run_tamp"]), msgpack.packb([3, []]), msgpack.packb(["x", 5]),
+                        b"\xc1\xc1\xc1"):
+            s = raw()
+            s.sendall(struct.pack("!I", len(payload)) + payload)
+            assert s.recv(16) == b""                     # the server closed THIS connection
+            s.close()
+        s = raw()                                        # header promising 100 bytes, then silence
+        s.sendall(struct.pack("!I", 100) + b"abc")
+        t0 = time.time()
+        assert s.recv(16) == b"" and time.time() - t0 < 5
+        s.close()
+        s = raw()                                        # oversized frame: refused before any allocation
+        s.sendall(struct.pack("!I", rpc.MAX_FRAME + 1))
+        assert s.recv(16) == b""
+        s.close()
+        good = rpc.Client(f"tcp://127.0.0.1:{port}")     # the server is still serving
+        assert compat.bytes_to_torch(good.get_suction()) in (True, False)
+        good.close()
+    finally:
+        rpc.CLIENT_TIMEOUT = old
+        server.close()
+        th.join(timeout=5)
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("code execution",))
+    with pytest.raises(Exception):
+        compat.bytes_to_torch(pickle.dumps(Evil()))
+    assert torch.equal(compat.bytes_to_torch(compat.torch_to_bytes(torch.arange(3.0))), torch.arange(3.0))
+    assert compat.bytes_to_torch(compat.torch_to_bytes(True)) is True

@@ -127,3 +127,26 @@ def test_planner_simple_success_thresholds():
     assert bool(pl.check_task_success(sim))
     sim.get_actor_position_by_name = lambda n: torch.tensor([[-1.0, -0.85, 0.0]])
     assert not bool(pl.check_task_success(sim))
+
+
+def test_patrolling_planner_and_template_exports():
+    """The drop-in surface of m3p2i_aip.planners.task_planner.* (ADVICE r2): the five table-driven templates and
+    PLANNER_PATROLLING (task_planner.py:109-125: next waypoint within 0.1 m, wrapping) are exported by compat."""
+    import torch
+    from m3p2i_aip_amd import compat
+    compat.install(force_standins=True)
+    from m3p2i_aip.planners.task_planner import isaac_state_action_templates as T
+    from m3p2i_aip.planners.task_planner.task_planner import PLANNER_PATROLLING
+    for name in ("MDPIsAt", "MDPIsCloseTo", "MDPIsLocFree", "MDPIsBlockAt", "MDPIsCubeAt", "MDPIsCubeAtReal"):
+        m = getattr(T, name)()
+        assert m.B.shape == (len(m.state_names), len(m.state_names), len(m.action_names)) and m.action_names[0] == "idle"
+    p = PLANNER_PATROLLING([[1.0, 0.0], [1.0, 1.0], [0.0, 1.0]], device="cpu")
+    assert p.task == "navigation" and p.curr_goal.tolist() == [1.0, 0.0]
+    p.update_plan(torch.tensor([0.5, 0.0]), False)
+    assert p.goal_id == 0
+    for want, pos in ((1, [0.95, 0.0]), (2, [1.0, 0.92]), (0, [0.05, 1.0])):
+        p.update_plan(torch.tensor(pos), False)
+        assert p.goal_id == want and p.curr_goal.tolist() == p.goals[want].tolist()
+    p.goal_id = 2
+    p.reset_plan()
+    assert p.goal_id == 0 and p.check_task_success(None) is False

@@ -2,7 +2,10 @@
 (deterministic seeds): statistics of what the reference logged per run (plot/plot_point.py:26-34) -- final
 block-to-goal error, task time, dyn-obs collisions -- next to the logged statistics (tests/golden/behaviour_band.json).
 
-    python tools/band_stats.py [--n 20] [--json out.json] [scenario ...]
+    python tools/band_stats.py [--n 20] [--json out.json] [--size baseline|default] [scenario ...]
+
+--size default: the reference's shipped planner size, K=200 samples, T=15 (config/mppi/point.yaml) -- the size the
+logged runs were most plausibly made with (it is not recorded); baseline (default here): K, T of the BASELINE configs.
 
 The reference's runs differ from each other through PhysX's own non-determinism, its unseeded per-shape torsion
 friction (isaacgym_wrapper.py:318) and the asynchronous RPC loop; this build is deterministic, so the spread is
@@ -44,17 +47,25 @@ def stats(x):
     return {"mean": float(x.mean()), "std": float(x.std()), "min": float(x.min()), "max": float(x.max()), "n": int(x.size)}
 
 
-def episodes(scenario, n=20, max_sim_time_s=40.0):
+def overrides(scenario, size="baseline"):
+    ov = list(SCENARIOS[scenario])
+    if size == "default":      # config/mppi/point.yaml: 200 samples, horizon 15 (400 / 15 multi-modal: 200 per mode)
+        mm = "multi_modal=True" in ov
+        ov = [o for o in ov if not o.startswith("mppi.")] + [f"mppi.num_samples={400 if mm else 200}", "mppi.horizon=15"]
+    return ov
+
+
+def episodes(scenario, n=20, max_sim_time_s=40.0, size="baseline"):
     import closed_loop
     runs = []
     for e in range(n):
         j = jitter_of(scenario, e)
-        r = closed_loop.run("config_point", SCENARIOS[scenario], ticks=int(max_sim_time_s / 0.05), jitter=j)
+        r = closed_loop.run("config_point", overrides(scenario, size), ticks=int(max_sim_time_s / 0.05), jitter=j)
         runs.append(dict(episode=e, jitter=j, success=r["success"], final_pos_error_m=r["final_pos_error"],
                          task_time_s=r["sim_time_s"], dyn_obs_collision_ticks=r["dyn_obs_collision_ticks"],
                          command_ms_p50=r["command_ms_p50"]))
     ok = [r for r in runs if r["success"]]
-    return dict(scenario=scenario, n=n, successes=len(ok),
+    return dict(scenario=scenario, n=n, size=size, overrides=overrides(scenario, size), successes=len(ok),
                 final_pos_error_m=stats([r["final_pos_error_m"] for r in ok]) if ok else None,
                 task_time_s=stats([r["task_time_s"] for r in ok]) if ok else None,
                 dyn_obs_collided_episodes=int(sum(r["dyn_obs_collision_ticks"] > 0 for r in runs)),
@@ -62,26 +73,62 @@ def episodes(scenario, n=20, max_sim_time_s=40.0):
                 command_ms_p50=stats([r["command_ms_p50"] for r in runs]), runs=runs)
 
 
+def panda_episodes(n=20, overrides=("mppi.num_samples=4000", "mppi.horizon=20"), ticks=600):
+    """Panda reactive pick-and-place (config_panda), cubeA's start jittered by +-2 cm (episode 0: the reference scene)."""
+    import closed_loop
+    runs = []
+    for e in range(n):
+        rng = np.random.default_rng([77, e])
+        j = dict(cube=(0.0, 0.0) if e == 0 else tuple(rng.uniform(-0.02, 0.02, 2).tolist()))
+        r = closed_loop.run("config_panda", list(overrides), ticks=ticks, jitter=j)
+        runs.append(dict(episode=e, jitter=j, success=r["success"], ticks=r["ticks"], timeline=r["timeline"],
+                         cube_to_goal_xy=r["cube_to_goal_xy"], cube_height_above_goal=r["cube_height_above_goal"]))
+    ok = [r for r in runs if r["success"]]
+    return dict(n=n, overrides=list(overrides), successes=len(ok),
+                final_xy_error_m=stats([r["cube_to_goal_xy"] for r in ok]) if ok else None,
+                ticks_to_success=stats([r["ticks"] for r in ok]) if ok else None, runs=runs)
+
+
 def main(argv):
-    n, out, names = 20, None, []
+    n, out, names, size = 20, None, [], "baseline"
     it = iter(argv)
     for a in it:
         if a == "--n":
             n = int(next(it))
         elif a == "--json":
             out = next(it)
+        elif a == "--size":
+            size = next(it)
         else:
             names.append(a)
-    band = json.load(open(os.path.join(ROOT, "tests", "golden", "behaviour_band.json")))["point"]
+    allband = json.load(open(os.path.join(ROOT, "tests", "golden", "behaviour_band.json")))
+    band = allband["point"]
     res = {}
+    if "panda" in names:
+        names.remove("panda")
+        for tag, ov in (("panda_pick", ["mppi.num_samples=4000", "mppi.horizon=20"]),
+                        ("panda_pick_faure", ["mppi.num_samples=4000", "mppi.horizon=20", "mppi.halton_scramble=faure"]),
+                        ("panda_pick_default_size", ["mppi.num_samples=200", "mppi.horizon=12"]),
+                        ("panda_pick_default_size_faure", ["mppi.num_samples=200", "mppi.horizon=12", "mppi.halton_scramble=faure"])):
+            r = panda_episodes(n, ov)
+            r["logged"] = allband["panda"]["reactive_pick"]["final_xy_error_m"]
+            res[tag] = r
+            e = r["final_xy_error_m"]
+            print(f"{tag}: {r['successes']}/{n} ok; xy err " + (f"{e['mean']:.4f}+-{e['std']:.4f}" if e else "-") +
+                  f" (logged {r['logged']['mean']:.4f}+-{r['logged']['std']:.4f}); ticks " +
+                  (f"{r['ticks_to_success']['mean']:.0f}+-{r['ticks_to_success']['std']:.0f}" if e else "-"), flush=True)
+        if not names:
+            if out:
+                json.dump(res, open(out, "w"), indent=1)
+            return
     for sc in names or list(SCENARIOS):
-        r = episodes(sc, n)
+        r = episodes(sc, n, size=size)
         r["logged"] = {k: band[sc][k] for k in ("final_pos_error_m", "task_time_s", "dyn_obs_collisions")}
         res[sc] = r
         lg = r["logged"]
-        print(f"{sc}: {r['successes']}/{n} ok; err {r['final_pos_error_m']['mean']:.3f}+-{r['final_pos_error_m']['std']:.3f} "
+        print(f"{sc} [{size}]: {r['successes']}/{n} ok; err {r['final_pos_error_m']['mean']:.3f}+-{r['final_pos_error_m']['std']:.3f} "
               f"(logged {lg['final_pos_error_m']['mean']:.3f}+-{lg['final_pos_error_m']['std']:.3f}); "
-              f"time {r['task_time_s']['mean']:.2f}+-{r['task_time_s']['std']:.2f} s "
+              f"time {r['task_time_s']['mean']:.2f}+-{r['task_time_s']['std']:.2f} s (median {np.median([q['task_time_s'] for q in r['runs']]):.2f}) "
               f"(logged {lg['task_time_s']['mean']:.2f}+-{lg['task_time_s']['std']:.2f}); "
               f"dyn-obs collided in {r['dyn_obs_collided_episodes']}/{n} episodes "
               f"(logged {lg['dyn_obs_collisions']['mean'] * lg['dyn_obs_collisions']['n']:.0f}/{lg['dyn_obs_collisions']['n']})", flush=True)

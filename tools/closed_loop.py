@@ -122,7 +122,7 @@ def serve(cn, overrides, endpoint):
     server.run()
 
 
-def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=None, extra_ticks=0, jitter=None):
+def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=None, extra_ticks=0, jitter=None, trace=False):
     """One closed-loop episode; returns the report dict (what main() prints).  connect = endpoint of a
     planner served by `--serve` in another process (otherwise the planner lives in this process).
     until_task: stop `extra_ticks` ticks after the task planner first hands out that task and return the
@@ -145,15 +145,27 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
         ib = int(real._get_actor_index_by_name("box"))
         real._root_state[0, ib, 0] += float(jitter.get("box", (0, 0))[0])
         real._root_state[0, ib, 1] += float(jitter.get("box", (0, 0))[1])
+        # the dyn-obs where its walk (update_dyn_obs: 1 cm per tick along the diagonal, back for ticks 0-25 and
+        # 75-99 of each 100, forth in between) has taken it after `phase` ticks: same track as an unjittered run
+        off = sum(0.01 if 25 < (i % 100) < 75 else -0.01 for i in range(phase))
+        idn = int(real._get_actor_index_by_name("dyn-obs"))
+        real._root_state[0, idn, 0] += off
+        real._root_state[0, idn, 1] += off
         real._dof_state[0, 0] += float(jitter.get("robot", (0, 0))[0])
         real._dof_state[0, 2] += float(jitter.get("robot", (0, 0))[1])
         real.set_dof_state_tensor(real._dof_state)
+        real.set_actor_root_state_tensor(real._root_state)
+    if jitter and cfg.env_type == "panda_env" and "cube" in jitter:
+        ia = int(real._get_actor_index_by_name("cubeA"))
+        real._root_state[0, ia, 0] += float(jitter["cube"][0])
+        real._root_state[0, ia, 1] += float(jitter["cube"][1])
         real.set_actor_root_state_tensor(real._root_state)
     coll_ticks = 0          # ticks with a contact force on the dyn-obs: |Fx| + |Fy| > 0.1, the test of
                             # get_motion_cost (cost_functions.py:158-169) applied to the REAL world (plot_point.py col 17)
     timeline, lat = [], []
     success_tick = None
     stop_at, captured = None, None
+    path = []               # trace=True: per tick [robot x, y, box x, y, box quat z, w, dyn-obs x, y, action x, y] (point_env)
     for i in range(ticks):
         if cfg.env_type == "point_env":
             real.update_dyn_obs(i + phase)
@@ -175,6 +187,12 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
             captured = dict(tick=i, task=task, goal=[float(x) for x in goal],
                             dof_state=real._dof_state[0].cpu().tolist(), root_state=real._root_state[0].cpu().tolist())
             break
+        if trace and cfg.env_type == "point_env":
+            b = real.get_actor_link_by_name("box", "box")[0].cpu()
+            dyn = real.get_actor_position_by_name("dyn-obs")[0].cpu()
+            rp = real.robot_pos[0].cpu()
+            path.append([float(rp[0]), float(rp[1]), float(b[0]), float(b[1]), float(b[5]), float(b[6]), float(dyn[0]),
+                         float(dyn[1]), float(action_host[0]), float(action_host[1])])
         real.set_dof_velocity_target_tensor(action.view(1, nu))
         if cfg.env_type == "point_env":
             cfg.suction_active = tamp.suction_active
@@ -200,13 +218,15 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
         res["cube_height_above_goal"] = float(cube[2] - goal[2])
     if captured is not None:
         res["captured"] = captured
+    if trace:
+        res["trace"] = path
     real.stop_sim()
     tamp.close()
     return res
 
 
 def main(argv):
-    cn, ticks, out, overrides, serve_ep, connect_ep = "config_point", 2000, None, [], None, None
+    cn, ticks, out, overrides, serve_ep, connect_ep, trace = "config_point", 2000, None, [], None, None, False
     it = iter(argv)
     for a in it:
         if a in ("-cn", "--config-name"):
@@ -219,12 +239,14 @@ def main(argv):
             serve_ep = next(it)
         elif a == "--connect":
             connect_ep = next(it)
+        elif a == "--trace":
+            trace = True
         else:
             overrides.append(a)
     if serve_ep:
         return serve(cn, overrides, serve_ep)
-    res = run(cn, overrides, ticks, connect=connect_ep)
-    print(json.dumps(res))
+    res = run(cn, overrides, ticks, connect=connect_ep, trace=trace)
+    print(json.dumps({k: v for k, v in res.items() if k != 'trace'}))
     if out:
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
         json.dump(res, open(out, "w"), indent=1)
