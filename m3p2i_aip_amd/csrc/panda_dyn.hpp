@@ -37,7 +37,8 @@ struct PandaScene {
     static constexpr float table[6] = {0.0f, 0.0f, 1.0f, 0.6f, 0.6f, 0.025f};    // 1_table.yaml
     static constexpr float shelf[6] = {0.5f, 0.0f, 1.175f, 0.1f, 0.1f, 0.15f};   // 3_shelf_stand.yaml
     static constexpr float cube_half = 0.025f, cube_m = 0.125f, cube_mu = 1.0f;  // 5_cubeA.yaml
-    static constexpr float grasp_z = 0.1034f, grasp_dx = 0.02f, grasp_dz = 0.02f;
+    static constexpr float grasp_z = 0.1034f, grasp_dx = 0.025f, grasp_dz = 0.025f;   // spec v1.1: pad centre on the cube's face
+    static constexpr float finger_max = 0.04f;                                          // franka_panda.urdf:226-242
     static constexpr float grasp_align = 0.95f, grasp_tol = 0.002f;
     static constexpr float k_contact = 5000.0f;
     static constexpr float tip_z = 0.045f, tip_r = 0.012f, hand_z = 0.03f, hand_r = 0.04f;
@@ -224,8 +225,10 @@ __device__ __forceinline__ void grasp_geom(const PandaScene& sc, const PandaWorl
         ay = fmaxf(ay, fabsf(dot3(hand.y, col)));
         az = fmaxf(az, fabsf(dot3(hand.z, col)));
     }
+    // spec v1.1: footprint of the pads along the hand's x and z + alignment; the callers add their y condition
+    // (step: centre between the two pad faces; infer_held: centred between closed pads)
     g.in_region = fabsf(g.cx) <= sc.grasp_dx && fabsf(g.cz - sc.grasp_z) <= sc.grasp_dz &&
-                  fabsf(g.cy) <= sc.cube_half && ay >= sc.grasp_align && az >= sc.grasp_align;
+                  ay >= sc.grasp_align && az >= sc.grasp_align;
 }
 __device__ __forceinline__ void set_rel_rot(PandaWorld& w, const Frame& hand, const float* Rc) {
     Frame r;
@@ -246,8 +249,9 @@ __device__ __forceinline__ void panda_infer_held(const PandaScene& sc, PandaWorl
     GraspGeom g;
     grasp_geom(sc, w, hand, g);
     const float gap = w.q[7] + w.q[8];
+    const float mid = 0.5f * (w.q[7] - w.q[8]);
     w.held = 0.0f;
-    if (g.in_region && gap <= 2.0f * sc.cube_half + sc.grasp_tol) {
+    if (g.in_region && fabsf(g.cy - mid) <= sc.grasp_tol && gap <= 2.0f * sc.cube_half + sc.grasp_tol) {
         w.held = 1.0f;
         w.rel_p[0] = g.cx; w.rel_p[1] = g.cy; w.rel_p[2] = g.cz;
         set_rel_rot(w, hand, g.Rc);
@@ -267,7 +271,7 @@ struct PandaObs {
 // (cube centre inside the pad region of the hand frame) -- unless a cube is held.  The hand origin
 // cannot move farther than LEVER * sum_i |dq_i| (every joint is a revolute with at most LEVER =
 // 1.2 m between its axis and the hand origin: the arm's reach is 0.855 m + flange/hand 0.21 m), and
-// the test can only succeed within REGION = |(grasp_dx, cube_half, |grasp_z| + grasp_dz)| of the
+// the test can only succeed within REGION = |(grasp_dx, finger_max, |grasp_z| + grasp_dz)| of the
 // hand origin.  So with the hand origin of the last evaluated kinematics (`hp`) and the joint travel
 // since (`trav`), a wave in which no lane holds a cube and every lane's cube is farther from hp than
 // REGION + trav + 1 mm skips the kinematics and the grasp test of that substep: nothing they could
@@ -376,7 +380,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             if constexpr (LAZY_FK) {
                 if (!have_fk) {   // (wave-uniform: no lane holds a cube, so every lane is in this branch)
                     const float gz = fabsf(sc.grasp_z) + sc.grasp_dz;
-                    const float lim = sqrtf((sc.grasp_dx * sc.grasp_dx + sc.cube_half * sc.cube_half) + gz * gz) +
+                    const float lim = sqrtf((sc.grasp_dx * sc.grasp_dx + sc.finger_max * sc.finger_max) + gz * gz) +
                                       *trav + 1.0e-3f;
                     const float dx = w.cube[0] - hp[0], dy = w.cube[1] - hp[1], dz = w.cube[2] - hp[2];
                     const bool far = (dx * dx + dy * dy) + dz * dz > lim * lim;
@@ -390,13 +394,28 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             GraspGeom g;
             g.in_region = false;
             if (have_fk) grasp_geom(sc, w, hand, g);
-            if (g.in_region) {
+            // spec v1.1, the pad channel: the cube's centre lies between the two pad faces
+            if (g.in_region && g.cy < w.q[7] && g.cy > -w.q[8]) {
                 float gap = w.q[7] + w.q[8];
                 const float wdt = 2.0f * sc.cube_half;
                 if (gap < wdt) {
                     const float mid = 0.5f * (w.q[7] - w.q[8]);
                     w.q[7] = 0.5f * wdt + mid; w.q[8] = 0.5f * wdt - mid;
                     gap = wdt;
+                }
+                if (u[7] < 0.0f && u[8] < 0.0f) {
+                    // closing pads sweep the cube along the hand's y so that it stays between them; it slides on its
+                    // support: the horizontal part of the displacement, horizontal velocity lost
+                    const float lo = sc.cube_half - w.q[8], hi = w.q[7] - sc.cube_half;
+                    const float cyn = fminf(fmaxf(g.cy, lo), hi);
+                    if (cyn != g.cy) {
+                        const float sh = cyn - g.cy;
+                        w.cube[0] = w.cube[0] + sh * hand.y[0];
+                        w.cube[1] = w.cube[1] + sh * hand.y[1];
+                        w.cube_v[0] = 0.0f; w.cube_v[1] = 0.0f;
+                        const float d[3] = {w.cube[0] - hand.p[0], w.cube[1] - hand.p[1], w.cube[2] - hand.p[2]};
+                        g.cx = dot3(d, hand.x); g.cz = dot3(d, hand.z);
+                    }
                 }
                 if (gap <= wdt + sc.grasp_tol && u[7] < 0.0f && u[8] < 0.0f) {
                     w.held = 1.0f;

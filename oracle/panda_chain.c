@@ -63,7 +63,7 @@ void m3o_panda_scene_default(m3o_panda_scene* sc) {
     sc->cube_half = 0.025f;                                             /* 5_cubeA.yaml */
     sc->cube_m = 0.125f;           /* 0.05^3 at the default density 1000 */
     sc->cube_mu = 1.0f;
-    sc->grasp_z = 0.1034f; sc->grasp_dx = 0.02f; sc->grasp_dz = 0.02f;
+    sc->grasp_z = 0.1034f; sc->grasp_dx = 0.025f; sc->grasp_dz = 0.025f;
     sc->grasp_align = 0.95f; sc->grasp_tol = 0.002f;
     sc->k_contact = 5000.0f;
     sc->tip_z = 0.045f; sc->tip_r = 0.012f; sc->hand_z = 0.03f; sc->hand_r = 0.04f;
@@ -279,8 +279,11 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
                 ay = fmaxf(ay, fabsf(dot3(hy, col)));
                 az = fmaxf(az, fabsf(dot3(hz, col)));
             }
+            /* spec v1.1, the pad channel: the cube is "between the pads" when its centre lies inside the pads' footprint
+             * along the hand's x and z (|cx| <= grasp_dx, |cz - grasp_z| <= grasp_dz: the pad's centre is on the cube's
+             * face), it is aligned with the pads, and its centre lies between the two pad faces (-q8 < cy < q7). */
             int in_region = fabsf(cx) <= sc->grasp_dx && fabsf(cz - sc->grasp_z) <= sc->grasp_dz &&
-                            fabsf(cy) <= sc->cube_half && ay >= sc->grasp_align && az >= sc->grasp_align;
+                            cy < w->q[7] && cy > -w->q[8] && ay >= sc->grasp_align && az >= sc->grasp_align;
             if (in_region) {
                 float gap = w->q[7] + w->q[8];
                 float wdt = 2.0f * sc->cube_half;
@@ -288,6 +291,21 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
                     float mid = 0.5f * (w->q[7] - w->q[8]);
                     w->q[7] = 0.5f * wdt + mid; w->q[8] = 0.5f * wdt - mid;
                     gap = wdt;
+                }
+                if (u[7] < 0.0f && u[8] < 0.0f) {
+                    /* closing pads sweep the cube along the hand's y so that it stays between them (what the
+                     * physical fingers do to a cube that is off their centre line); it slides on its support:
+                     * only the horizontal part of the displacement is applied, the horizontal velocity is lost */
+                    float lo = sc->cube_half - w->q[8], hi = w->q[7] - sc->cube_half;
+                    float cyn = fminf(fmaxf(cy, lo), hi);
+                    if (cyn != cy) {
+                        float sh = cyn - cy;
+                        w->cubeA[0] = w->cubeA[0] + sh * hy[0];
+                        w->cubeA[1] = w->cubeA[1] + sh * hy[1];
+                        w->cubeA[7] = 0.0f; w->cubeA[8] = 0.0f;
+                        d[0] = w->cubeA[0] - ph[0]; d[1] = w->cubeA[1] - ph[1];
+                        cx = dot3(d, hx); cz = dot3(d, hz);
+                    }
                 }
                 if (gap <= wdt + sc->grasp_tol && u[7] < 0.0f && u[8] < 0.0f) {
                     w->held = 1.0f;
@@ -346,9 +364,11 @@ void m3o_panda_infer_held(const m3o_panda_scene* sc, m3o_panda_world* w) {
         ay = fmaxf(ay, fabsf(dot3(hy, col)));
         az = fmaxf(az, fabsf(dot3(hz, col)));
     }
-    int in_region = fabsf(cx) <= sc->grasp_dx && fabsf(cz - sc->grasp_z) <= sc->grasp_dz &&
-                    fabsf(cy) <= sc->cube_half && ay >= sc->grasp_align && az >= sc->grasp_align;
+    /* held = in the pad channel (spec v1.1), pads closed on the cube and the cube centred between them */
     float gap = w->q[7] + w->q[8];
+    float mid = 0.5f * (w->q[7] - w->q[8]);
+    int in_region = fabsf(cx) <= sc->grasp_dx && fabsf(cz - sc->grasp_z) <= sc->grasp_dz &&
+                    fabsf(cy - mid) <= sc->grasp_tol && ay >= sc->grasp_align && az >= sc->grasp_align;
     w->held = 0.0f;
     if (in_region && gap <= 2.0f * sc->cube_half + sc->grasp_tol) {
         w->held = 1.0f;

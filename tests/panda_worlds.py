@@ -3,14 +3,15 @@ tests/golden/make_golden.py, so that the golden traces and the tests start from 
 import numpy as np
 
 
-def grasp_world(P, sc, close_gripper=True, lift=0.0):
+def grasp_world(P, sc, close_gripper=True, lift=0.0, offset=(0.0, 0.0)):
     """A world in which the gripper holds cubeA (built with the oracle: IK + closing); with
     close_gripper=False the open gripper is left around the cube (`lift` metres above the grasp
-    pose), so that rollouts grasp -- or just miss -- it on their own."""
+    pose, displaced by `offset` = (dx, dy) in world coordinates: the hand's y axis is world y, its x axis
+    world -x), so that rollouts grasp -- or just miss -- it on their own."""
     w = P.init_world(1)
     for _ in range(30):
         P.step_batch(sc, w, np.zeros((1, 9), np.float32))
-    target = w[0, P.W_CUBEA:P.W_CUBEA + 3] + np.array([0, 0, sc.grasp_z + lift])
+    target = w[0, P.W_CUBEA:P.W_CUBEA + 3] + np.array([offset[0], offset[1], sc.grasp_z + lift])
     q = np.array([0, 0.3, 0, -2.2, 0, 2.5, 0.785, 0.04, 0.04], np.float32)
 
     def feat(L):

@@ -27,7 +27,11 @@ from tests.panda_worlds import grasp_world  # noqa: E402
                                                # rollouts grasp during the horizon, or pass the bound of
                                                # the lazy kinematics (panda_step LAZY_FK) closely
                                                ("pick", False, 2, "open0"), ("pick", False, 2, "open3"),
-                                               ("pick", False, 2, "open8"), ("reach", False, 2, "open15")])
+                                               ("pick", False, 2, "open8"), ("reach", False, 2, "open15"),
+                                               # spec v1.1 (pad channel): open gripper at the grasp height, displaced
+                                               # along the pads' closing direction (swept + held) / their width
+                                               ("pick", False, 2, "offy12"), ("pick", False, 2, "offy30"),
+                                               ("pick", False, 2, "offx20"), ("pick", False, 2, "offx30")])
 def test_panda_command_matches_oracle(oracle, task, mm, grip, held):
     import oracle.panda as P
     from m3p2i_aip_amd import _lib as L
@@ -37,7 +41,11 @@ def test_panda_command_matches_oracle(oracle, task, mm, grip, held):
     rng = np.random.default_rng(5)
     delta = rng.standard_normal((K, T, 9)).astype(np.float32)
     goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
-    if isinstance(held, str):
+    if isinstance(held, str) and held.startswith("off"):
+        d = 0.001 * int(held[4:])
+        w0 = grasp_world(P, sc, close_gripper=False, offset=(d, 0.0) if held[3] == "x" else (0.0, d))
+        held = False
+    elif isinstance(held, str):
         w0 = grasp_world(P, sc, close_gripper=False, lift=0.01 * int(held[4:]))
         held = False
     else:

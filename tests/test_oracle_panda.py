@@ -114,6 +114,49 @@ def test_cube_settles_on_table_and_can_be_grasped_and_lifted(P):
     assert w[0, P.W_HELD] == 0.0 and w[0, P.W_CUBEA + 2] == pytest.approx(1.05, abs=1e-5)  # fell back
 
 
+def test_pad_channel_spec_v11(P):
+    """Chain spec v1.1 -- the pad channel: a cube whose centre lies between the two pad faces, inside the pads'
+    footprint (|x| <= 2.5 cm, |z - 0.1034| <= 2.5 cm in the hand frame) and aligned with them is SWEPT to the pads'
+    centre line by closing fingers (it slides on the table) and held when they meet it; open fingers do not move it;
+    a cube outside the footprint, or beyond a pad face, is not captured."""
+    from tests.panda_worlds import grasp_world
+    sc = P.default_scene()
+    close = np.zeros((1, 9), np.float32); close[0, 7:] = -1.5
+    opened = np.zeros((1, 9), np.float32); opened[0, 7:] = 1.5
+
+    def run(offset, u, steps=40):
+        w = grasp_world(P, sc, close_gripper=False, offset=offset).reshape(1, -1).copy()
+        c0 = w[0, P.W_CUBEA:P.W_CUBEA + 3].copy()
+        for _ in range(steps):
+            P.step_batch(sc, w, u)
+        return w[0], c0
+
+    # hand 1.2 cm off the cube along the pads' closing direction: swept to the centre line, then held
+    w, c0 = run((0.0, 0.012), close)
+    hand_y = c0[1] + 0.012
+    assert w[P.W_HELD] == 1.0
+    assert w[P.W_CUBEA + 1] == pytest.approx(hand_y, abs=2e-4) and w[P.W_CUBEA] == pytest.approx(c0[0], abs=1e-4)
+    assert w[P.W_Q + 7] + w[P.W_Q + 8] == pytest.approx(0.05, abs=2.1e-3)
+    assert abs(w[P.W_RELP + 1]) < 1e-6 and w[P.W_CUBEA + 2] == pytest.approx(c0[2], abs=1e-6)   # slid on the table
+    # the same pose with the fingers commanded open: nothing touches the cube
+    w, c0 = run((0.0, 0.012), opened)
+    assert w[P.W_HELD] == 0.0 and np.array_equal(w[P.W_CUBEA:P.W_CUBEA + 3], c0)
+    # 2 cm off along the pads' width (inside the footprint): held off-centre, not moved
+    w, c0 = run((0.02, 0.0), close)
+    assert w[P.W_HELD] == 1.0 and abs(abs(w[P.W_RELP]) - 0.02) < 1e-3 and np.allclose(w[P.W_CUBEA:P.W_CUBEA + 2], c0[:2], atol=1e-4)
+    # 3 cm off along the width: outside the footprint -- the fingers close on nothing
+    w, c0 = run((0.03, 0.0), close)
+    assert w[P.W_HELD] == 0.0 and np.array_equal(w[P.W_CUBEA:P.W_CUBEA + 3], c0) and w[P.W_Q + 7] + w[P.W_Q + 8] < 1e-3
+    # 4.5 cm off along the closing direction: the cube's centre is beyond a pad face -- not captured
+    w, c0 = run((0.0, 0.045), close)
+    assert w[P.W_HELD] == 0.0 and np.array_equal(w[P.W_CUBEA:P.W_CUBEA + 3], c0)
+    # 3 cm above the grasp height: out of reach of the pads
+    w = grasp_world(P, sc, close_gripper=False, lift=0.03).reshape(1, -1).copy()
+    for _ in range(40):
+        P.step_batch(sc, w, close)
+    assert w[0, P.W_HELD] == 0.0
+
+
 PANDA_TRACES = {"panda_reach": ("reach", False, 1), "panda_reachmm": ("reach", True, 1), "panda_pick": ("pick", False, 2)}
 
 

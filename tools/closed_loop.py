@@ -193,6 +193,10 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
             rp = real.robot_pos[0].cpu()
             path.append([float(rp[0]), float(rp[1]), float(b[0]), float(b[1]), float(b[5]), float(b[6]), float(dyn[0]),
                          float(dyn[1]), float(action_host[0]), float(action_host[1])])
+        if trace and cfg.env_type == "panda_env":
+            hand = real.get_actor_link_by_name("panda", "panda_hand")[0, :7].cpu().tolist()
+            cube = real.get_actor_link_by_name("cubeA", "box")[0, :7].cpu().tolist()
+            path.append([task] + hand + cube + real._dof_state[0, [14, 16]].cpu().tolist() + action_host[7:9].tolist())
         real.set_dof_velocity_target_tensor(action.view(1, nu))
         if cfg.env_type == "point_env":
             cfg.suction_active = tamp.suction_active
