@@ -122,12 +122,16 @@ def serve(cn, overrides, endpoint):
     server.run()
 
 
-def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=None, extra_ticks=0, jitter=None, trace=False):
+def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=None, extra_ticks=0, jitter=None, trace=False,
+        settle_ticks=0):
     """One closed-loop episode; returns the report dict (what main() prints).  connect = endpoint of a
     planner served by `--serve` in another process (otherwise the planner lives in this process).
     until_task: stop `extra_ticks` ticks after the task planner first hands out that task and return the
     world at that moment (`captured`: dof_state, root_state, task, goal as lists) -- bench.py's panda_pick row
     starts from the scene the product's own reach phase ends in.
+    settle_ticks: after the success tick the world is stepped that many more ticks with the zero action the planner
+    side returns once the task is done (reactive_tamp.py:52-54) before the final error is taken -- the reference's logs
+    were written after the run, not at the success tick.
     jitter (point_env): dict(dyn_phase=int, box=(dx, dy), robot=(dx, dy)) -- the episode starts with the dyn-obs
     `dyn_phase` ticks into its walk and box / robot displaced (tools/band_stats.py: N episodes per scenario)."""
     overrides = list(overrides)
@@ -205,6 +209,11 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
         if cfg.env_type == "point_env":
             f = real.get_actor_contact_forces_by_name("dyn-obs", "box")[0]
             coll_ticks += int(float(f[0].abs() + f[1].abs()) > 0.1)
+    for k in range(settle_ticks if success_tick is not None else 0):
+        if cfg.env_type == "point_env":
+            real.update_dyn_obs(i + 1 + k + phase)
+        real.set_dof_velocity_target_tensor(torch.zeros(1, nu, device=cfg.mppi.device))
+        real.step()
     res = dict(config=cn, overrides=overrides, K=cfg.mppi.num_samples, T=cfg.mppi.horizon,
                ticks=i + 1, success=success_tick is not None, transport="rpc " + connect if connect else "in-process",
                sim_time_s=(i + 1) * cfg.isaacgym.dt, timeline=timeline,
