@@ -401,8 +401,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(device))
 
     name = args.config or "push"
+    # (--config panda_pick / worst_case as the headline of a profiling run: their scenes)
+    head_scene = make_pick_scene(panda_pick_scene(device)) if name == "panda_pick" else (corner_scene if name == "worst_case" else None)
     r = run_config(name, args, world, rank, device, dist, args.steps, args.warmup, K_local=args.samples_per_gpu,
-                   time_collectives=True)
+                   time_collectives=True, scene=head_scene)
     env, task, goal, multi_modal, K_local, K_global, T = (r[k] for k in ("env", "task", "goal", "multi_modal", "K_local",
                                                                           "K_global", "T"))
     pl = r["pl"]

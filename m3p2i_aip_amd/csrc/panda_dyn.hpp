@@ -267,15 +267,22 @@ struct PandaObs {
 // instantiated twice and the host launches the one the task needs (only the pick cost reads them):
 // merely carrying the 12 sphere-box tests in the kernel cost 7 % of the reach / place rollouts.
 //
-// LAZY_FK (rollout): the kinematics of a substep that is not a step's last feed only the grasp test
-// (cube centre inside the pad region of the hand frame) -- unless a cube is held.  The hand origin
+// LAZY_FK (rollout): the kinematics of a substep that is not a step's last feed only the grasp test of a FREE
+// cube (cube centre inside the pad channel of the hand frame).  A HELD cube does not need them: it is
+// re-attached to the hand in every substep, so its pose after the step is the last substep's; it cannot be
+// released later in the step (the command is constant over a step's substeps: a release happens in the first,
+// and leaves the cube where it was), its fingers are locked and nothing reads its pose in between.  And the
+// grasp test changes something only under a closing command (sweep / hold) or when the fingers have entered
+// the cube's width (push-back): a lane with neither -- the null-action sample after it has let go -- is idle.
+// The hand origin
 // cannot move farther than LEVER * sum_i |dq_i| (every joint is a revolute with at most LEVER =
 // 1.2 m between its axis and the hand origin: the arm's reach is 0.855 m + flange/hand 0.21 m), and
 // the test can only succeed within REGION = |(grasp_dx, finger_max, |grasp_z| + grasp_dz)| of the
 // hand origin.  So with the hand origin of the last evaluated kinematics (`hp`) and the joint travel
 // since (`trav`), a wave in which no lane holds a cube and every lane's cube is farther from hp than
 // REGION + trav + 1 mm skips the kinematics and the grasp test of that substep: nothing they could
-// have changed.  Identical results (the oracle evaluates them every substep); reach rollout -13 %.
+// have changed.  Identical results (the oracle evaluates them every substep); reach rollout -13 %; pick rollout
+// (every lane carrying its cube, the null sample dropping it) 131 -> see DESIGN.md section 6.
 constexpr float PANDA_LEVER = 1.2f;
 struct HeldYes { static constexpr bool value = true; };
 struct HeldNo { static constexpr bool value = false; };
@@ -311,7 +318,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         bool have_fk = true;
         if constexpr (LAZY_FK) {
             *trav = *trav + PANDA_LEVER * dq_sum;
-            if (sub != sc.substeps - 1 && !decltype(may_hold)::value) have_fk = false;   // (no lane holds a cube)
+            if (sub != sc.substeps - 1) have_fk = false;   // a step's earlier substeps: only if a grasp test needs them
         }
         if (have_fk) {
             panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
@@ -326,6 +333,11 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
         }
         if (holds()) {
+          // (LAZY_FK, a step's earlier substeps: a held cube is re-attached to the hand in EVERY substep, so its pose
+          // after the step is the last substep's; it cannot be released later in the step -- the command is constant
+          // over the substeps and a release happens in the first --, its fingers are locked and nothing reads its pose
+          // in between: nothing to do.  The oracle re-attaches it every substep; identical results.)
+          if (!LAZY_FK || sub == sc.substeps - 1) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 w.cube[i] = hand.p[i] + ((w.rel_p[0] * hand.x[i] + w.rel_p[1] * hand.y[i]) + w.rel_p[2] * hand.z[i]);
@@ -340,6 +352,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
             mat2quat(c, w.cube_q);
             w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
+          }
         } else {
             w.cube_v[2] = w.cube_v[2] - sc.g * h;
 #pragma unroll
@@ -378,12 +391,15 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 }
             }
             if constexpr (LAZY_FK) {
-                if (!have_fk) {   // (wave-uniform: no lane holds a cube, so every lane is in this branch)
+                if (!have_fk) {   // (the lanes with a free cube)
                     const float gz = fabsf(sc.grasp_z) + sc.grasp_dz;
                     const float lim = sqrtf((sc.grasp_dx * sc.grasp_dx + sc.finger_max * sc.finger_max) + gz * gz) +
                                       *trav + 1.0e-3f;
                     const float dx = w.cube[0] - hp[0], dy = w.cube[1] - hp[1], dz = w.cube[2] - hp[2];
-                    const bool far = (dx * dx + dy * dy) + dz * dz > lim * lim;
+                    // the grasp test below changes something only for a cube in the pad channel AND (fingers that
+                    // have entered the cube's width: pushed back -- or a closing command: swept / held)
+                    const bool idle = !(u[7] < 0.0f && u[8] < 0.0f) && !(w.q[7] + w.q[8] < 2.0f * sc.cube_half);
+                    const bool far = idle || (dx * dx + dy * dy) + dz * dz > lim * lim;
                     if (__builtin_amdgcn_ballot_w64(!far) != 0ull) {
                         panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
                         hp[0] = hand.p[0]; hp[1] = hand.p[1]; hp[2] = hand.p[2]; *trav = 0.0f;
