@@ -333,6 +333,32 @@ int m3_command(m3_handle* h, float* action_host);
 int m3_rollout(m3_handle* h);
 int m3_update(m3_handle* h);
 int m3_finalize(m3_handle* h);
+
+/* ---- device-side exchange of the per-rank records (csrc/p2p.hip) -------------------------------------------------
+ * The ONE collective of a sharded command (the all-gather of the records between m3_update and m3_finalize;
+ * SURVEY.md section 8(e), replaces nothing in the reference: it has no multi-GPU path) without a
+ * communication library: every rank owns an exchange block in device memory, maps every peer's block (hipIpc between
+ * processes, direct pointers inside one), and an exchange is two small kernels on the handle's stream -- put: this
+ * rank's record into its slot of every peer's block (one hop over xGMI) + a release flag; wait: acquire every
+ * peer's flag of this exchange (bounded: a missing peer sets an error word after ~0.5 s instead of hanging the
+ * GPU).  The m3_finalize that follows reads the records from the block.  Selectable beside RCCL
+ * (m3p2i_aip_amd.distributed.attach_p2p / attach_collectives); the records phase of cfg.shard_mix 1 and 2 and
+ * of single-mode sharding.
+ *   m3_p2p_export         this rank's block as an IPC handle (allocates it: uncached device memory)
+ *   m3_p2p_connect        all ranks' handles, in rank order (the own entry is ignored)
+ *   m3_p2p_connect_local  the same for handles that live in THIS process (peers[p] = handle of rank p)
+ *   m3_p2p_put / _wait    the two halves (a process that drives several handles enqueues every put before any wait)
+ *   m3_p2p_exchange       put + wait
+ *   m3_p2p_status         synchronises; missing_rank = -1 or the rank a wait gave up on; memory_kind 1 uncached,
+ *                         2 fine-grained, 3 plain device memory */
+typedef struct { unsigned char bytes[64]; } m3_ipc_handle;
+int m3_p2p_export(m3_handle* h, m3_ipc_handle* out);
+int m3_p2p_connect(m3_handle* h, const m3_ipc_handle* all, int n_ranks);
+int m3_p2p_connect_local(m3_handle* h, m3_handle* const* peers, int n_ranks);
+int m3_p2p_put(m3_handle* h);
+int m3_p2p_wait(m3_handle* h);
+int m3_p2p_exchange(m3_handle* h);
+int m3_p2p_status(m3_handle* h, int* missing_rank, int* memory_kind);
 /* m3_update + m3_finalize for an UNSHARDED handle in as few launches as the sizes allow (what
  * m3_command does after its rollout): for a caller that fills TRAJ_COST / ACTIONS itself (step mode,
  * planner._command_step).  M3_ERR_STATE on a sharded handle (the collectives go in between). */

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("M3P2I_HIP_LIB") or os.path.join(_HERE, "lib", "libm3p
 
 ENV_POINT, ENV_PANDA = 0, 1
 HALTON_PLAIN, HALTON_FAURE = 0, 1
+IPC_HANDLE_BYTES = 64
 TASKS = {"navigation": 0, "push": 1, "pull": 2, "push_pull": 3, "reach": 4, "pick": 5,
          "place": 6, "idle": 7}
 
@@ -103,6 +104,13 @@ SYMBOLS = [
     ("m3_update", C.c_int, [_H]),
     ("m3_finalize", C.c_int, [_H]),
     ("m3_update_finalize", C.c_int, [_H]),
+    ("m3_p2p_export", C.c_int, [_H, C.c_void_p]),
+    ("m3_p2p_connect", C.c_int, [_H, C.c_void_p, C.c_int]),
+    ("m3_p2p_connect_local", C.c_int, [_H, C.POINTER(_H), C.c_int]),
+    ("m3_p2p_put", C.c_int, [_H]),
+    ("m3_p2p_wait", C.c_int, [_H]),
+    ("m3_p2p_exchange", C.c_int, [_H]),
+    ("m3_p2p_status", C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("m3_get_buffer", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     ("m3_reduce_len", C.c_int, [_H]),
     ("m3_record_len", C.c_int, [_H]),

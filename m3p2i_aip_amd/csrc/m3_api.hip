@@ -317,6 +317,9 @@ extern "C" void m3_destroy(m3_handle* h) {
     if (h->order) (void)hipFree(h->order);
     if (h->order_scratch) (void)hipFree(h->order_scratch);
     if (h->noise_sorted) (void)hipFree(h->noise_sorted);
+    for (int p = 0; p < MIX_MAX_RANKS; ++p)
+        if (h->peer_ipc[p] && h->peer_base[p]) (void)hipIpcCloseMemHandle(h->peer_base[p]);
+    if (h->xb) (void)hipFree(h->xb);
     for (auto& ev : h->ev)
         if (ev) (void)hipEventDestroy(ev);
     delete h;
@@ -883,7 +886,7 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.half_g = c.K_global / 2;
     a.n_ranks = c.K_global / c.K_local;
     a.rank = c.k_offset / c.K_local;
-    a.records_all = (const float*)h->buf[M3_BUF_RECORDS_ALL];
+    a.records_all = h->records_src ? h->records_src : (const float*)h->buf[M3_BUF_RECORDS_ALL];
     a.rec_topj = a.rec_topi = nullptr;
     a.rec_mins = a.rec_table = nullptr;
     a.fast = 0;
@@ -1032,8 +1035,150 @@ static int after_finalize(m3_handle* h) {
     return M3_OK;
 }
 
+// ---- device-side exchange of the records (p2p.hip) -------------------------------------------------------------
+static int p2p_ranks(const m3_handle* h) { return h->cfg.K_global / h->cfg.K_local; }
+static int p2p_rank(const m3_handle* h) { return h->cfg.k_offset / h->cfg.K_local; }
+static int p2p_alloc(m3_handle* h) {
+    if (h->xb) return M3_OK;
+    const m3_config& c = h->cfg;
+    if (!(c.shard_mix && c.K_local != c.K_global) || !h->buf[M3_BUF_RECORD])
+        return fail(h, M3_ERR_STATE, "m3_p2p: the handle has no record to exchange (needs cfg.shard_mix on a sharded handle)");
+    const size_t rl = (size_t)m3_record_len(h);
+    h->xb_bytes = P2P_HDR_BYTES + 2 * (size_t)p2p_ranks(h) * rl * sizeof(float);
+    // uncached: neither the peers' stores nor the owner's loads may be served from a stale L2 line
+    if (hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocUncached) == hipSuccess) h->xb_kind = 1;
+    else if ((void)hipGetLastError(), hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocFinegrained) == hipSuccess) h->xb_kind = 2;
+    else if ((void)hipGetLastError(), hipMalloc(&h->xb, h->xb_bytes) == hipSuccess) h->xb_kind = 3;
+    else { h->xb = nullptr; return fail(h, M3_ERR_HIP, "m3_p2p: allocation of the exchange block failed"); }
+    HIPCHK(h, hipMemset(h->xb, 0, h->xb_bytes));
+    HIPCHK(h, hipDeviceSynchronize());
+    return M3_OK;
+}
+
+extern "C" int m3_p2p_export(m3_handle* h, m3_ipc_handle* out) {
+    if (!h || !out) return M3_ERR_BAD_ARG;
+    const int rc = p2p_alloc(h);
+    if (rc != M3_OK) return rc;
+    static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(m3_ipc_handle), "m3_ipc_handle too small");
+    hipIpcMemHandle_t ih;
+    HIPCHK(h, hipIpcGetMemHandle(&ih, h->xb));
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->bytes, &ih, sizeof(ih));
+    return M3_OK;
+}
+
+static int p2p_finish_connect(m3_handle* h) {
+    for (int p = 0; p < p2p_ranks(h); ++p)
+        if (!h->peer_base[p]) return fail(h, M3_ERR_STATE, "m3_p2p_connect: a peer's block is missing");
+    h->p2p_ready = true;
+    h->p2p_seq = 0;
+    return M3_OK;
+}
+
+extern "C" int m3_p2p_connect(m3_handle* h, const m3_ipc_handle* all, int n) {
+    if (!h || !all) return M3_ERR_BAD_ARG;
+    int rc = p2p_alloc(h);
+    if (rc != M3_OK) return rc;
+    if (n != p2p_ranks(h)) return fail(h, M3_ERR_SHAPE, "m3_p2p_connect: need one handle per rank");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    for (int p = 0; p < n; ++p) {
+        if (p == p2p_rank(h)) { h->peer_base[p] = h->xb; continue; }
+        if (h->peer_ipc[p] && h->peer_base[p]) continue;
+        hipIpcMemHandle_t ih;
+        std::memcpy(&ih, all[p].bytes, sizeof(ih));
+        void* ptr = nullptr;
+        if (hipIpcOpenMemHandle(&ptr, ih, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, M3_ERR_HIP, "m3_p2p_connect: hipIpcOpenMemHandle failed (peer block of another process)");
+        }
+        h->peer_base[p] = ptr;
+        h->peer_ipc[p] = true;
+    }
+    return p2p_finish_connect(h);
+}
+
+extern "C" int m3_p2p_connect_local(m3_handle* h, m3_handle* const* peers, int n) {
+    if (!h || !peers) return M3_ERR_BAD_ARG;
+    int rc = p2p_alloc(h);
+    if (rc != M3_OK) return rc;
+    if (n != p2p_ranks(h)) return fail(h, M3_ERR_SHAPE, "m3_p2p_connect_local: need one handle per rank");
+    for (int p = 0; p < n; ++p) {
+        m3_handle* q = peers[p];
+        if (!q || p2p_rank(q) != p || m3_record_len(q) != m3_record_len(h) || p2p_ranks(q) != n)
+            return fail(h, M3_ERR_SHAPE, "m3_p2p_connect_local: peers[p] must be the handle of rank p of the same sharding");
+        rc = p2p_alloc(q);
+        if (rc != M3_OK) return fail(h, rc, "m3_p2p_connect_local: a peer could not allocate its block");
+        if (q->cfg.device != h->cfg.device) {
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, h->cfg.device, q->cfg.device);
+            if (!can) return fail(h, M3_ERR_UNSUPPORTED, "m3_p2p_connect_local: no peer access between the two devices");
+            (void)hipSetDevice(h->cfg.device);
+            const hipError_t e = hipDeviceEnablePeerAccess(q->cfg.device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return fail(h, M3_ERR_HIP, "m3_p2p_connect_local: hipDeviceEnablePeerAccess"); }
+            (void)hipGetLastError();
+        }
+        h->peer_base[p] = q->xb;
+    }
+    return p2p_finish_connect(h);
+}
+
+static void p2p_args(m3_handle* h, P2PArgs& a) {
+    std::memset(&a, 0, sizeof(a));
+    a.rec = (const float*)h->buf[M3_BUF_RECORD];
+    a.rec_len = m3_record_len(h);
+    a.n_ranks = p2p_ranks(h);
+    a.rank = p2p_rank(h);
+    a.seq = h->p2p_seq;
+    a.slot = h->p2p_seq & 1;
+    a.timeout_ticks = 50000000ull;   // 0.5 s of the 100 MHz wall clock
+    a.err = (int*)((char*)h->xb + 2 * MIX_MAX_RANKS * sizeof(int));
+    for (int p = 0; p < a.n_ranks; ++p) {
+        a.peer_flags[p] = (int*)h->peer_base[p];
+        a.peer_data[p] = (float*)((char*)h->peer_base[p] + P2P_HDR_BYTES);
+    }
+}
+
+extern "C" int m3_p2p_put(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->p2p_ready) return fail(h, M3_ERR_STATE, "m3_p2p_put: m3_p2p_connect first");
+    h->p2p_seq += 1;
+    P2PArgs a;
+    p2p_args(h, a);
+    launch_p2p_put(a, h->stream);
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
+extern "C" int m3_p2p_wait(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->p2p_ready || h->p2p_seq == 0) return fail(h, M3_ERR_STATE, "m3_p2p_wait: no exchange in flight (m3_p2p_put first)");
+    P2PArgs a;
+    p2p_args(h, a);
+    launch_p2p_wait(a, h->stream);
+    HIPCHK(h, hipGetLastError());
+    h->records_src = a.peer_data[a.rank] + (size_t)a.slot * a.n_ranks * a.rec_len;
+    return M3_OK;
+}
+
+extern "C" int m3_p2p_exchange(m3_handle* h) {
+    const int rc = m3_p2p_put(h);
+    return rc != M3_OK ? rc : m3_p2p_wait(h);
+}
+
+extern "C" int m3_p2p_status(m3_handle* h, int* missing_rank, int* memory_kind) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->xb) return fail(h, M3_ERR_STATE, "m3_p2p_status: no exchange block");
+    int e = 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(&e, (char*)h->xb + 2 * MIX_MAX_RANKS * sizeof(int), sizeof(int), hipMemcpyDeviceToHost));
+    if (missing_rank) *missing_rank = e - 1;      // -1: every exchange so far was complete
+    if (memory_kind) *memory_kind = h->xb_kind;
+    return M3_OK;
+}
+
 extern "C" int m3_finalize(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
+    struct Consume { m3_handle* h; ~Consume() { h->records_src = nullptr; } } consume{h};   // one exchange, one finalize
     if (h->regen) {
         const int rc = regen_finalize(h);
         if (rc != M3_OK) return rc;

@@ -189,6 +189,19 @@ int apply_workgroups(int Kg);
 void launch_mins(const UpdateArgs& a, hipStream_t s);
 void launch_ladder(const UpdateArgs& a, hipStream_t s);
 
+// p2p.hip: device-side exchange of the records over peer-mapped memory
+struct P2PArgs {
+    const float* rec;                      // this rank's record
+    int rec_len, n_ranks, rank, slot, seq;
+    unsigned long long timeout_ticks;      // of the 100 MHz wall clock
+    int* err;                              // device word in the own block: 0, or 1 + the rank that never arrived
+    float* peer_data[MIX_MAX_RANKS];       // data part of every rank's exchange block: [2][n_ranks][rec_len]
+    int* peer_flags[MIX_MAX_RANKS];        // flag part: [2][MIX_MAX_RANKS]
+};
+constexpr size_t P2P_HDR_BYTES = 1024;    // flags [2][32] ints + error word, then the data part
+void launch_p2p_put(const P2PArgs& a, hipStream_t s);
+void launch_p2p_wait(const P2PArgs& a, hipStream_t s);
+
 // step mode
 struct SimViews {
     float* dof_state;          // [Kl][2*ndof]
@@ -285,6 +298,15 @@ struct m3_handle {
     float* noise_stage = nullptr;
     m3::SimViews views{};
     bool views_bound = false;
+    // device-side exchange (p2p.hip)
+    void* xb = nullptr;                 // own exchange block: header (flags, error word) + [2][n_ranks][rec_len]
+    size_t xb_bytes = 0;
+    int xb_kind = 0;                    // 1 uncached, 2 fine-grained, 3 plain device memory
+    void* peer_base[m3::MIX_MAX_RANKS] = {};   // every rank's block as mapped here (own: xb)
+    bool peer_ipc[m3::MIX_MAX_RANKS] = {};     // opened with hipIpcOpenMemHandle (closed in m3_destroy)
+    bool p2p_ready = false;
+    int p2p_seq = 0;
+    const float* records_src = nullptr; // != null: the records of the exchange just enqueued (consumed by m3_finalize)
     // timing
     bool timing = false;
     hipEvent_t ev[4] = {};

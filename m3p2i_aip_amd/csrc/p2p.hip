@@ -1,0 +1,61 @@
+// p2p.hip -- device-side exchange of the per-rank records over peer-mapped memory (xGMI between the GPUs of
+// one node; gfx950).  SURVEY.md section 5 / 8(e): "every rank writes its slot into every peer's buffer ... 1 hop".
+//
+// The sharded update needs ONE all-gather of small records per command (m3_internal.hpp: record_length /
+// regen_record_length; at most ~33 KB per rank at K = 64000).  As an RCCL collective that is a host-issued call
+// (8-14 us of host time, 15-17 us on the stream at world_size 1 -- profiles/r02/collective_overhead_c5.json).  Here
+// it is two tiny kernels on the handle's own stream, no library call in between:
+//
+//   k_p2p_put   workgroup p copies this rank's record into slot [parity][rank] of PEER p's exchange block (plain
+//               stores through the peer mapping: one hop over xGMI, or a local copy for p == rank), makes them
+//               visible at system scope and then releases flag [parity][rank] of that peer with the exchange's
+//               sequence number;
+//   k_p2p_wait  lane p of one wavefront acquires flag [parity][p] of the OWN block until it shows the sequence
+//               number (bounded: ~0.5 s of the 100 MHz wall clock, then the error word is set and the stream moves
+//               on -- a peer that died must not hang the GPU).
+//
+// The kernels that follow on the stream (k_mix / k_regen_part / ...) read the records from the own block.  The block
+// is allocated uncached (hipDeviceMallocUncached; fine-grained or plain device memory as fallbacks), so neither the
+// peers' stores nor the owner's loads can be served from a stale L2 line.  Two parities: a rank can run at most one
+// exchange ahead of the slowest one (it needs every peer's flag of exchange n before it can finish it, and a peer
+// raises that flag only after its own finalize of exchange n - 1), so slot n & 1 is never overwritten while read.
+#include <hip/hip_runtime.h>
+
+#include "m3_internal.hpp"
+
+namespace m3 {
+
+__global__ __launch_bounds__(256) void k_p2p_put(const P2PArgs a) {
+    const int p = blockIdx.x;
+    float* dst = a.peer_data[p] + ((size_t)a.slot * a.n_ranks + a.rank) * a.rec_len;
+    for (int o = threadIdx.x; o < a.rec_len; o += blockDim.x) dst[o] = a.rec[o];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(a.peer_flags[p] + a.slot * MIX_MAX_RANKS + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(64) void k_p2p_wait(const P2PArgs a) {
+    const int p = threadIdx.x;
+    if (p < a.n_ranks) {
+        const int* f = a.peer_flags[a.rank] + a.slot * MIX_MAX_RANKS + p;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+            if (wall_clock64() - t0 > a.timeout_ticks) {   // the peer never arrived: report, do not hang
+                atomicExch(a.err, 1 + p);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __threadfence_system();
+}
+
+void launch_p2p_put(const P2PArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_p2p_put, dim3(a.n_ranks), dim3(256), 0, s, a);
+}
+void launch_p2p_wait(const P2PArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, s, a);
+}
+
+}  // namespace m3

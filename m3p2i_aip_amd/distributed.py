@@ -31,6 +31,11 @@ in-kernel noise has no table): two collectives,
     rollout -> all_gather J[K] -> update (weights for all K, weighted sums over the local shard)
       -> all_reduce(sum) packed buffer (6*T*nu + 40*T floats) -> finalize.
 
+Transport of the records phase: RCCL (`attach_collectives`, a host-issued all_gather on the stream) or the library's
+own device-side exchange over peer-mapped memory (`attach_p2p`: every rank stores its record straight into every
+peer's block -- one hop over xGMI -- and acquires the peers' flags; two small kernels on the handle's stream, no
+library call, csrc/p2p.hip).
+
 All messages are latency-bound (<= 300 KB at K = 64000): bucket size and ring bandwidth over the 7
 xGMI links are irrelevant here; the number of dependent collectives per command is what counts.
 """
@@ -66,4 +71,29 @@ def attach_collectives(planner, group=None):
             raise ValueError(phase)
 
     planner.collective = exchange
+    return planner
+
+
+def attach_p2p(planner, group=None):
+    """The records exchange of a shard_mix planner through peer-mapped device memory instead of RCCL (one process
+    per GPU; the IPC handles of the exchange blocks travel once, at set-up, through the process group's object
+    gather).  Planners without the one-collective protocol (shard_mix=False) keep their two RCCL collectives."""
+    if planner.world_size != dist.get_world_size(group):
+        raise ValueError("planner.world_size does not match the process group")
+    if not planner.shard_mix:
+        return attach_collectives(planner, group)
+    e = planner._engine
+    mine = e.p2p_export()
+    handles = [None] * planner.world_size
+    dist.all_gather_object(handles, mine, group=group)
+    e.p2p_connect(handles)
+    dist.barrier(group=group)      # nobody starts exchanging before every rank has mapped every block
+
+    def exchange(pl, phase):
+        if phase != "records":
+            raise ValueError(phase)
+        pl._engine.p2p_exchange()
+
+    planner.collective = exchange
+    planner.transport = "p2p"
     return planner

@@ -259,6 +259,41 @@ class HipEngine:
     def finalize(self):
         self._ck(self.lib.m3_finalize(self._h))
 
+    # ---- device-side exchange of the records (include/m3p2i_hip.h: m3_p2p_*) ----
+    def p2p_export(self) -> bytes:
+        """This rank's exchange block as an IPC handle (64 bytes) for the other ranks' p2p_connect."""
+        buf = C.create_string_buffer(L.IPC_HANDLE_BYTES)
+        self._ck(self.lib.m3_p2p_export(self._h, C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def p2p_connect(self, handles):
+        """handles: the p2p_export() of every rank, in rank order (other processes)."""
+        blob = b"".join(bytes(x) for x in handles)
+        assert len(blob) == L.IPC_HANDLE_BYTES * len(handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        self._ck(self.lib.m3_p2p_connect(self._h, C.cast(buf, C.c_void_p), len(handles)))
+
+    def p2p_connect_local(self, engines):
+        """engines: the HipEngine of every rank, in rank order, all living in this process."""
+        arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        self._p2p_peers = list(engines)     # keep the peers' blocks alive as long as this handle writes into them
+        self._ck(self.lib.m3_p2p_connect_local(self._h, arr, len(engines)))
+
+    def p2p_put(self):
+        self._ck(self.lib.m3_p2p_put(self._h))
+
+    def p2p_wait(self):
+        self._ck(self.lib.m3_p2p_wait(self._h))
+
+    def p2p_exchange(self):
+        self._ck(self.lib.m3_p2p_exchange(self._h))
+
+    def p2p_status(self):
+        """(missing_rank or -1, memory kind: 1 uncached / 2 fine-grained / 3 plain); synchronises the stream."""
+        miss, kind = C.c_int(), C.c_int()
+        self._ck(self.lib.m3_p2p_status(self._h, C.byref(miss), C.byref(kind)))
+        return miss.value, kind.value
+
     def update_finalize(self):
         """update + finalize of an unsharded handle in as few launches as possible."""
         self._ck(self.lib.m3_update_finalize(self._h))

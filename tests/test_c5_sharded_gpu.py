@@ -113,8 +113,10 @@ def test_c5_gather_reduce_protocol_8x8000_equals_unsharded():
         e.close()
 
 
-@pytest.mark.parametrize("Kt,Nt,level", [(K, N, 1), (512, 2, 1), (6000, 4, 1), (K, N, 2), (512, 2, 2), (6000, 4, 2), (32000, 2, 2)])
-def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level):
+@pytest.mark.parametrize("Kt,Nt,level,transport", [(K, N, 1, "copy"), (512, 2, 1, "copy"), (6000, 4, 1, "copy"), (K, N, 2, "copy"),
+                                                   (512, 2, 2, "copy"), (6000, 4, 2, "copy"), (32000, 2, 2, "copy"),
+                                                   (K, N, 2, "p2p"), (6000, 4, 1, "p2p"), (6000, 4, 2, "p2p-streams")])
+def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
     """cfg.shard_mix for the multi-modal search: ONE all-gather of per-rank records {costs of the shard |
     its top-k}; every rank then runs the unsharded update on all K costs and RE-GENERATES the other
     ranks' actions from the replicated noise table instead of receiving them.  Same kernels, same
@@ -125,7 +127,11 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level):
     level 2 (cfg.shard_mix = 2, the planner's default): the records also carry each shard's minima and ladder
     sums; the searches walk the MIXTURE of the shards' tables and one kernel forms weights, sums, best rows
     and the plan.  Bar: ranks bit-identical to each other; vs the unsharded handle the same beta-search
-    iteration counts and best samples, plan within 3e-5, weights within 2e-3 relative."""
+    iteration counts and best samples, plan within 3e-5, weights within 2e-3 relative.
+    transport: "copy" -- the all-gather done by hand into M3_BUF_RECORDS_ALL (what RCCL does); "p2p" -- the library's
+    device-side exchange (csrc/p2p.hip): every handle stores its record into every peer's block and acquires the
+    peers' flags, all handles on one stream; "p2p-streams" -- the same with every handle on a stream of its own, so
+    that the puts and the spinning waits of different ranks really run side by side."""
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
     kl = Kt // Nt
@@ -139,6 +145,15 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level):
         e.set_noise(delta)                                   # every rank holds the whole table
     for e in [full] + shards:
         e.set_objective("push_pull", (-3.75, -3.75))
+    streams = None
+    if transport != "copy":
+        if transport == "p2p-streams":
+            torch.cuda.synchronize()
+            streams = [torch.cuda.Stream() for _ in shards]
+            for e, st in zip(shards, streams):
+                e.use_torch_stream(st)
+        for e in shards:
+            e.p2p_connect_local(shards)
     for call in range(5):
         for e in [full] + shards:
             e.set_world_point_raw(_world(call))
@@ -146,10 +161,19 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level):
         for e in shards:
             e.rollout()
             e.update()                                       # the shard's own top-k into its record
-        allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])   # the ONE collective: all_gather
-        for e in shards:
-            e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
-            e.finalize()
+        if transport == "copy":
+            allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])   # the ONE collective: all_gather
+            for e in shards:
+                e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
+                e.finalize()
+        else:
+            # one process drives every handle: all puts are enqueued before any wait (a wait in front of another
+            # handle's put on the same hardware queue would spin until its time-out)
+            for e in shards:
+                e.p2p_put()
+            for e in shards:
+                e.p2p_wait()
+                e.finalize()
         torch.cuda.synchronize()
         fi = full.info()
         exact = Kt > 8192 and level == 1
@@ -178,7 +202,30 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level):
                 assert torch.equal(e.states, full.states[r * kl:(r + 1) * kl])
                 assert torch.equal(e.actions, full.actions[r * kl:(r + 1) * kl])
         assert min(fi.iters, fi.iters_1, fi.iters_2) > 1      # the searches really searched
+    if transport != "copy":
+        for e in shards:
+            assert e.p2p_status()[0] == -1                    # no wait ever gave up on a peer
     for e in shards + [full]:
+        e.close()
+
+
+def test_p2p_wait_gives_up_on_a_missing_peer_instead_of_hanging():
+    """A peer that never puts its record: the wait kernel sets the error word after ~0.5 s and the stream moves on."""
+    import time
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    kw = dict(T=T, nu=2, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+    shards = [HipEngine(make_config(K=512, K_local=256, k_offset=r * 256, shard_mix=1, **kw)) for r in range(2)]
+    with pytest.raises(L.M3Error):
+        shards[0].p2p_put()                                   # not connected yet
+    for e in shards:
+        e.p2p_connect_local(shards)
+    t0 = time.time()
+    shards[0].p2p_put()
+    shards[0].p2p_wait()                                      # rank 1 never arrives
+    missing, kind = shards[0].p2p_status()
+    assert missing == 1 and kind in (1, 2, 3) and 0.3 < time.time() - t0 < 5.0
+    for e in shards:
         e.close()
 
 

@@ -46,27 +46,38 @@ def run(pl, sim, delta, n=4):
     return out
 
 
-def worker(rank, world, port, multi_modal, task, goal, ret):
+def worker(rank, world, port, multi_modal, task, goal, ret, transport="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
-    from m3p2i_aip_amd.distributed import attach_collectives
+    from m3p2i_aip_amd.distributed import attach_collectives, attach_p2p
     delta = np.load(os.path.join(ROOT, "tests", "golden", "ref_golden.npz"))["g9_push_delta"]
     delta = np.concatenate([delta, delta[::-1] * 0.7]).astype(np.float32)   # 512 distinct rows
     pl, sim = build(rank, world, multi_modal, task, goal)
-    attach_collectives(pl)
+    if transport == "p2p":
+        # the records exchange through peer-mapped device memory: the other process's block is opened with
+        # hipIpcOpenMemHandle (here both processes sit on the same GPU; on a node: one hop over xGMI)
+        attach_p2p(pl)
+        assert pl.transport == "p2p"
+    else:
+        attach_collectives(pl)
     out = run(pl, sim, delta)
+    if transport == "p2p":
+        missing, kind = pl._engine.p2p_status()
+        assert missing == -1, f"rank {rank}: the wait for rank {missing} timed out"
+        out[0]["p2p_memory_kind"] = kind
     if rank == 0:
         ret.put(out)
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["gloo", "p2p"])
 @pytest.mark.parametrize("multi_modal,task,goal", [(False, "push", (-1.0, -1.0)),
                                                    (True, "push_pull", (-3.75, -3.75))])
-def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal):
+def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal, transport):
     import torch.multiprocessing as mp
     delta = golden["g9_push_delta"]
     delta = np.concatenate([delta, delta[::-1] * 0.7]).astype(np.float32)
@@ -74,8 +85,8 @@ def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal):
     ref = run(pl, sim, delta)
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 29700 + (os.getpid() % 1500)
-    procs = [ctx.Process(target=worker, args=(r, 2, port, multi_modal, task, goal, ret)) for r in range(2)]
+    port = 29700 + (os.getpid() % 1500) + (7 if transport == "p2p" else 0)
+    procs = [ctx.Process(target=worker, args=(r, 2, port, multi_modal, task, goal, ret, transport)) for r in range(2)]
     for p in procs:
         p.start()
     got = ret.get(timeout=300)
