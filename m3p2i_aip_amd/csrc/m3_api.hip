@@ -894,6 +894,7 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.Jout = nullptr;
     a.Kls = c.K_local;
     a.rec_len = h->regen ? regen_record_length(c.K_local, c.T) : record_length(c.T, c.nu);
+    if (h->records_src) a.rec_len = h->records_stride;   // (the p2p block's slots are padded to 16 bytes; rec_len is only ever a stride)
     a.noise_all = h->noise_all;
     for (int j = 0; j < c.nu; ++j) {
         a.u_min[j] = c.u_min[j]; a.u_max[j] = c.u_max[j];
@@ -1044,7 +1045,7 @@ static int p2p_alloc(m3_handle* h) {
     if (!(c.shard_mix && c.K_local != c.K_global) || !h->buf[M3_BUF_RECORD])
         return fail(h, M3_ERR_STATE, "m3_p2p: the handle has no record to exchange (needs cfg.shard_mix on a sharded handle)");
     const size_t rl = (size_t)m3_record_len(h);
-    h->xb_bytes = P2P_HDR_BYTES + 2 * (size_t)p2p_ranks(h) * rl * sizeof(float);
+    h->xb_bytes = P2P_HDR_BYTES + 2 * (size_t)p2p_ranks(h) * ((rl + 3) & ~(size_t)3) * sizeof(float);
     // uncached: neither the peers' stores nor the owner's loads may be served from a stale L2 line
     if (hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocUncached) == hipSuccess) h->xb_kind = 1;
     else if ((void)hipGetLastError(), hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocFinegrained) == hipSuccess) h->xb_kind = 2;
@@ -1126,11 +1127,13 @@ static void p2p_args(m3_handle* h, P2PArgs& a) {
     std::memset(&a, 0, sizeof(a));
     a.rec = (const float*)h->buf[M3_BUF_RECORD];
     a.rec_len = m3_record_len(h);
+    a.rec_stride = (a.rec_len + 3) & ~3;
     a.n_ranks = p2p_ranks(h);
     a.rank = p2p_rank(h);
     a.seq = h->p2p_seq;
     a.slot = h->p2p_seq & 1;
     a.timeout_ticks = 50000000ull;   // 0.5 s of the 100 MHz wall clock
+    a.plain_memory = h->xb_kind == 3;
     a.err = (int*)((char*)h->xb + 2 * MIX_MAX_RANKS * sizeof(int));
     for (int p = 0; p < a.n_ranks; ++p) {
         a.peer_flags[p] = (int*)h->peer_base[p];
@@ -1156,7 +1159,8 @@ extern "C" int m3_p2p_wait(m3_handle* h) {
     p2p_args(h, a);
     launch_p2p_wait(a, h->stream);
     HIPCHK(h, hipGetLastError());
-    h->records_src = a.peer_data[a.rank] + (size_t)a.slot * a.n_ranks * a.rec_len;
+    h->records_src = a.peer_data[a.rank] + (size_t)a.slot * a.n_ranks * a.rec_stride;
+    h->records_stride = a.rec_stride;
     return M3_OK;
 }
 

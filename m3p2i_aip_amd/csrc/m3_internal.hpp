@@ -192,10 +192,11 @@ void launch_ladder(const UpdateArgs& a, hipStream_t s);
 // p2p.hip: device-side exchange of the records over peer-mapped memory
 struct P2PArgs {
     const float* rec;                      // this rank's record
-    int rec_len, n_ranks, rank, slot, seq;
+    int rec_len, rec_stride, n_ranks, rank, slot, seq;   // rec_stride: floats between two slots of a block (rec_len rounded up to 4)
+    int plain_memory;                      // the block is ordinary (cached) device memory: system-scope fences needed
     unsigned long long timeout_ticks;      // of the 100 MHz wall clock
     int* err;                              // device word in the own block: 0, or 1 + the rank that never arrived
-    float* peer_data[MIX_MAX_RANKS];       // data part of every rank's exchange block: [2][n_ranks][rec_len]
+    float* peer_data[MIX_MAX_RANKS];       // data part of every rank's exchange block: [2][n_ranks][rec_stride]
     int* peer_flags[MIX_MAX_RANKS];        // flag part: [2][MIX_MAX_RANKS]
 };
 constexpr size_t P2P_HDR_BYTES = 1024;    // flags [2][32] ints + error word, then the data part
@@ -306,6 +307,7 @@ struct m3_handle {
     bool peer_ipc[m3::MIX_MAX_RANKS] = {};     // opened with hipIpcOpenMemHandle (closed in m3_destroy)
     bool p2p_ready = false;
     int p2p_seq = 0;
+    int records_stride = 0;             // floats between two records of records_src
     const float* records_src = nullptr; // != null: the records of the exchange just enqueued (consumed by m3_finalize)
     // timing
     bool timing = false;

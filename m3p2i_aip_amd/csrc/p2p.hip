@@ -25,14 +25,25 @@
 
 namespace m3 {
 
-__global__ __launch_bounds__(256) void k_p2p_put(const P2PArgs a) {
+__global__ __launch_bounds__(1024) void k_p2p_put(const P2PArgs a) {
     const int p = blockIdx.x;
-    float* dst = a.peer_data[p] + ((size_t)a.slot * a.n_ranks + a.rank) * a.rec_len;
-    for (int o = threadIdx.x; o < a.rec_len; o += blockDim.x) dst[o] = a.rec[o];
-    __threadfence_system();
+    // (slots are rec_stride = rec_len rounded up to 4 floats apart: 16-byte stores -- uncached stores are not
+    // combined, a dword per lane was 41 us per put of 38 KB records to 8 peers)
+    float* dst = a.peer_data[p] + ((size_t)a.slot * a.n_ranks + a.rank) * a.rec_stride;
+    const int n4 = a.rec_len >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(a.rec);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int o = threadIdx.x; o < n4; o += blockDim.x) d4[o] = s4[o];
+    for (int o = (n4 << 2) + threadIdx.x; o < a.rec_len; o += blockDim.x) dst[o] = a.rec[o];
+    // Order: every data store of the workgroup acknowledged, THEN the flag.  The block is uncached (fine-grained)
+    // memory, so the stores are not held in this GPU's L2 and `s_waitcnt vmcnt(0)` is all the release needs; a
+    // system-scope fence would also write back the WHOLE L2 (`buffer_wbl2 sc0 sc1`: the rollout's outputs are in
+    // there -- measured 110 us per exchange).  Only a block in plain device memory (the last fallback) needs it.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.plain_memory) __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0)
-        __hip_atomic_store(a.peer_flags[p] + a.slot * MIX_MAX_RANKS + a.rank, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.peer_flags[p] + a.slot * MIX_MAX_RANKS + a.rank, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(64) void k_p2p_wait(const P2PArgs a) {
@@ -40,19 +51,21 @@ __global__ __launch_bounds__(64) void k_p2p_wait(const P2PArgs a) {
     if (p < a.n_ranks) {
         const int* f = a.peer_flags[a.rank] + a.slot * MIX_MAX_RANKS + p;
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+        // (relaxed system-scope loads: they bypass the caches; the acquire is the end of this kernel -- the readers
+        // of the records are the NEXT kernels on the stream)
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
             if (wall_clock64() - t0 > a.timeout_ticks) {   // the peer never arrived: report, do not hang
                 atomicExch(a.err, 1 + p);
                 break;
             }
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(2);
         }
     }
-    __threadfence_system();
+    if (a.plain_memory) __threadfence_system();
 }
 
 void launch_p2p_put(const P2PArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_p2p_put, dim3(a.n_ranks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_p2p_put, dim3(a.n_ranks), dim3(1024), 0, s, a);
 }
 void launch_p2p_wait(const P2PArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, s, a);

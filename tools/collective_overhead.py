@@ -51,9 +51,10 @@ def emulate_rank(name, N, steps):
     env, task, goal, mm, K, T = bench.CONFIGS[name]
     res = {}
     only = os.environ.get("M3P2I_EMUL_PROTOCOLS")      # (profiling runs: one protocol at a time)
-    for label, mix in (("one_collective", None), ("one_collective_exact", 1), ("gather_reduce", False)):
+    for label, mix in (("one_collective", None), ("one_collective_p2p", None), ("one_collective_exact", 1), ("gather_reduce", False)):
         if only and label not in only.split(","):
             continue
+        p2p = label.endswith("_p2p")
         from m3p2i_aip_amd import isaacgym_wrapper as wrapper
         from m3p2i_aip_amd.cost_functions import Objective
         from m3p2i_aip_amd.planner import M3P2I, MPPIConfig
@@ -80,9 +81,45 @@ def emulate_rank(name, N, steps):
         state = sim._dof_state[0]
         pl.command(state)
         torch.cuda.synchronize()
+        peers = []
+        if p2p:
+            # the library's device-side exchange (csrc/p2p.hip) instead of RCCL: rank 0 puts its record into the
+            # blocks of seven peer handles and acquires their flags; the peers (bare handles of ranks 1..N-1 on a side
+            # stream, records filled once below) only put, every command -- what is missing vs a node is the xGMI hop
+            from m3p2i_aip_amd.engine import HipEngine
+            import copy
+            side = torch.cuda.Stream()
+            for r in range(1, N):
+                c = copy.copy(e.cfg)
+                c.k_offset = r * K
+                q = HipEngine(c)
+                q.use_torch_stream(side)
+                peers.append(q)
+            ranks = [e] + peers
+            for q in ranks:
+                q.p2p_connect_local(ranks)
+
+            def exchange_p2p(p, phase, e=e, peers=peers):
+                # the peers run one exchange AHEAD of rank 0 (their puts for exchange n + 1 are enqueued on the side
+                # stream right after rank 0's exchange n and overlap with its next rollout, as the peers of a real node
+                # work concurrently): rank 0's stream then carries exactly its own share -- its put into the eight
+                # blocks and a wait that finds the flags raised
+                assert phase == "records"
+                if not primed:
+                    for q in peers:
+                        q.p2p_put()
+                    primed.append(1)
+                    torch.cuda.synchronize()
+                e.p2p_exchange()
+                for q in peers:
+                    q.p2p_put()
+            primed = []
+            switch_to_p2p = exchange_p2p      # (installed below, once the peers' records are in place)
         # the other ranks' contributions: shifted copies of rank 0's (filled once; only slot 0 is live)
         if pl.shard_mix:
             R = e.buffer(L.BUF_RECORDS_ALL)
+            if p2p:   # (the same shifted copies, staged here and then installed as the peers' own records)
+                R[0].copy_(e.buffer(L.BUF_RECORD))
             for r in range(1, N):
                 R[r].copy_(R[0])
                 R[r, :K] += 0.37 * r
@@ -96,6 +133,11 @@ def emulate_rank(name, N, steps):
                     tab[:, 1] = 0.0
                     R[r, om + 2] = R[r, om + 1]
                     R[r, om + 1] = float("inf")
+            for r, q in enumerate(peers, start=1):
+                q.buffer(L.BUF_RECORD).copy_(R[r])
+            torch.cuda.synchronize()
+            if p2p:
+                pl.collective = switch_to_p2p
         else:
             J = e.buffer(L.BUF_TRAJ_COST_ALL)
             for r in range(1, N):
@@ -121,6 +163,11 @@ def emulate_rank(name, N, steps):
                       "collective_stream_ms": {ph: float(np.mean(v)) for ph, v in per.items()},
                       "collectives_per_command": len(per), "eta": [info.eta, info.eta_1, info.eta_2],
                       "iters": [info.iters, info.iters_1, info.iters_2]}
+        if p2p:
+            missing, kind = e.p2p_status()
+            res[label]["p2p"] = {"missing_rank": missing, "memory_kind": {1: "uncached", 2: "fine-grained", 3: "device"}[kind]}
+            for q in peers:
+                q.close()
         e.close()
     return res
 
