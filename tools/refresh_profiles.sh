@@ -1,20 +1,25 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): regenerates everything under profiles/<round>/ into gpurun_out/.
-# usage: tools/refresh_profiles.sh     (then, in the build container: python tools/collect_profiles.py profiles/r02)
+# usage: tools/refresh_profiles.sh     (then, in the build container: python tools/collect_profiles.py profiles/r03)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 O=$ROOT/gpurun_out
 mkdir -p $O
 cd $ROOT
-python bench.py > $O/bench_default.json 2> $O/bench_default.err            # the driver's line: headline + other_configs + closed loop + cpu baselines
-for c in push hybrid panda northstar c5; do
+# the driver's own command, verbatim (BENCH_rNN.json: `python3 bench.py --gpus 1 --steps 20 --warmup 5`)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+python bench.py > $O/bench_default.json 2> $O/bench_default.err            # 200 steps / 20 warm-ups: headline + other_configs + closed loop + cpu baselines
+for c in push hybrid panda panda_pick northstar c5 c5_unsharded worst_case; do
   python bench.py --config $c --no-extras --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err
 done
 # profiling passes run the headline loop only (--no-extras): kernel-trace stats, then separate PMC passes
 TRAFFIC_KEY=push:K2000:T30 tools/profile_gpu.sh push --config push --no-extras > $O/prof_push.log 2>&1
 TRAFFIC_KEY=hybrid:K4000:T30 tools/profile_gpu.sh hybrid --config hybrid --no-extras > $O/prof_hybrid.log 2>&1
 TRAFFIC_KEY=panda:K4000:T20 tools/profile_gpu.sh panda --config panda --no-extras > $O/prof_panda.log 2>&1
+TRAFFIC_KEY=panda_pick:K4000:T20 tools/profile_gpu.sh panda_pick --config panda_pick --no-extras > $O/prof_panda_pick.log 2>&1
 TRAFFIC_KEY=northstar:K10000:T30 tools/profile_gpu.sh northstar --config northstar --no-extras > $O/prof_northstar.log 2>&1
 TRAFFIC_KEY=c5:K8000:T30 tools/profile_gpu.sh c5 --config c5 --no-extras > $O/prof_c5.log 2>&1
+TRAFFIC_KEY=c5_unsharded:K64000:T30 tools/profile_gpu.sh c5_unsharded --config c5_unsharded --no-extras > $O/prof_c5_unsharded.log 2>&1
+TRAFFIC_KEY=worst_case:K2000:T30 tools/profile_gpu.sh worst_case --config worst_case --no-extras > $O/prof_worst_case.log 2>&1
 cd $ROOT
 python tools/k_sweep.py > $O/k_sweep.log 2>&1
 python tools/host_overhead.py > $O/host_overhead.txt 2>&1
@@ -24,12 +29,19 @@ python tools/closed_loop.py -cn config_panda mppi.num_samples=4000 mppi.horizon=
 python tools/closed_loop_perf.py > $O/closed_loop_perf.log 2>&1
 tools/pmc_rollout.sh final 2000 0 push > $O/pmc_final.txt 2>&1
 tools/pmc_rollout.sh pandaf 4000 0 reach > $O/pmc_panda.txt 2>&1
-# sharding: what the collectives cost on one rank, rank 0 of 8 emulated on this GPU (both protocols)
+# dynamic instruction mix of the rollout kernels (the thread-trace decoder is not in this image: tools/att_rollout.sh)
+tools/pmc_mix.sh push_K2000 2000 push > $O/pmc_mix_push.log 2>&1
+tools/pmc_mix_bench.sh panda_pick > $O/pmc_mix_panda_pick.log 2>&1
+tools/pmc_mix_bench.sh panda > $O/pmc_mix_panda.log 2>&1
+tools/pmc_mix_bench.sh worst_case > $O/pmc_mix_worst_case.log 2>&1
+python tools/codeobj_info.py --isa "k_rollout_point<false, 1>" --json $O/codeobj_info.json > $O/codeobj_info.txt 2>&1
+# behaviour: N = 20 jittered episodes per scenario (tests/test_behaviour_band_gpu.py asserts on the first and the last)
+python tools/band_stats.py --n 20 --json $O/behaviour_stats_baseline.json > $O/behaviour_stats_baseline.log 2>&1
+python tools/band_stats.py --n 20 --size default --json $O/behaviour_stats_default_size.json > $O/behaviour_stats_default_size.log 2>&1
+python tools/band_stats.py --n 20 --json $O/behaviour_stats_panda.json panda > $O/behaviour_stats_panda.log 2>&1
+python tools/scramble_compare.py --json $O/halton_scramble.json > $O/halton_scramble.log 2>&1
+# sharding: what the collectives cost on one rank, rank 0 of 8 emulated on this GPU (RCCL and the p2p exchange)
 python tools/collective_overhead.py --config c5 --emulate-rank-of 8 --json $O/collective_overhead_c5.json > $O/collective_overhead_c5.log 2>&1
 python tools/collective_overhead.py --config push --json $O/collective_overhead_push.json > $O/collective_overhead_push.log 2>&1
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_emul -o emul -- python $ROOT/tools/collective_overhead.py --config c5 --steps 100 --emulate-rank-of 8 > $O/prof_emul.log 2>&1)
-# evidence for the lane mapping
-[ -x gpurun_variants/coop_rows ] && ./gpurun_variants/coop_rows 2000 > $O/coop_rows_K2000.json 2>&1
-[ -f gpurun_variants/phases.so ] && M3P2I_HIP_LIB=$ROOT/gpurun_variants/phases.so python tools/phase_breakdown.py push northstar hybrid > $O/phase_breakdown.log 2>&1
-[ -f gpurun_variants/count.so ] && M3P2I_HIP_LIB=$ROOT/gpurun_variants/count.so python tools/mask_count_closed_loop.py push pushcorner hybrid 400 > $O/mask_count_closed_loop.log 2>&1
 echo done
