@@ -215,7 +215,10 @@ typedef enum {
                                multi-modal shards only; M3_BUF_NOISE is this rank's block of it) */
     M3_BUF_COV = 25,        /* f32 [2][nu]: cov_action | scale_tril (mppi.py:175-176; rewritten by every command
                                when update_cov is on) */
-    M3_BUF_COUNT = 26
+    M3_BUF_RECORD_B = 26,   /* f32 [recb_len] shard_mix = 3: this rank's SECOND record -- {-w, index} of its best sample per
+                             * weight set, its half sums, its weighted action sums [3][T][nu] and best rows [3][T][nu] */
+    M3_BUF_RECORDS_B_ALL = 27, /* f32 [K_global/K_local][recb_len]: all-gather M3_BUF_RECORD_B into it before m3_finalize */
+    M3_BUF_COUNT = 28
 } m3_buffer_id;
 
 typedef struct m3_handle m3_handle;
@@ -333,6 +336,18 @@ int m3_command(m3_handle* h, float* action_host);
 int m3_rollout(m3_handle* h);
 int m3_update(m3_handle* h);
 int m3_finalize(m3_handle* h);
+/* cfg.shard_mix = 3 (multi-modal, more ranks / samples than the one-collective protocol is meant for): TWO small
+ * exchanges per command and O(K_local) work per rank after the first --
+ *   m3_rollout, m3_update (as shard_mix = 2: costs | top-k | minima + ladder table into M3_BUF_RECORD)
+ *   all-gather M3_BUF_RECORD -> M3_BUF_RECORDS_ALL
+ *   m3_update_b   searches on the mixture of the tables; weights of the rank's OWN samples; their weighted action
+ *                 sums from its own action buffer (nothing re-generated) + its best rows -> M3_BUF_RECORD_B
+ *   all-gather M3_BUF_RECORD_B -> M3_BUF_RECORDS_B_ALL      (~6 T nu floats per rank)
+ *   m3_finalize   sums in rank order, best rows from the rank whose best sample wins, the plan.
+ * Equal to the unsharded run up to f32 rounding, identical on every rank; M3_BUF_WEIGHTS* hold the rank's own
+ * samples' entries.  m3_record_b_len: floats of M3_BUF_RECORD_B. */
+int m3_update_b(m3_handle* h);
+int m3_record_b_len(const m3_handle* h);
 
 /* ---- device-side exchange of the per-rank records (csrc/p2p.hip) -------------------------------------------------
  * The ONE collective of a sharded command (the all-gather of the records between m3_update and m3_finalize;
@@ -358,6 +373,10 @@ int m3_p2p_connect_local(m3_handle* h, m3_handle* const* peers, int n_ranks);
 int m3_p2p_put(m3_handle* h);
 int m3_p2p_wait(m3_handle* h);
 int m3_p2p_exchange(m3_handle* h);
+/* channel 0: M3_BUF_RECORD (== the three above); channel 1: M3_BUF_RECORD_B, the second exchange of shard_mix = 3 */
+int m3_p2p_put_ch(m3_handle* h, int channel);
+int m3_p2p_wait_ch(m3_handle* h, int channel);
+int m3_p2p_exchange_b(m3_handle* h);
 int m3_p2p_status(m3_handle* h, int* missing_rank, int* memory_kind);
 /* m3_update + m3_finalize for an UNSHARDED handle in as few launches as the sizes allow (what
  * m3_command does after its rollout): for a caller that fills TRAJ_COST / ACTIONS itself (step mode,

@@ -25,7 +25,7 @@ TASKS = {"navigation": 0, "push": 1, "pull": 2, "push_pull": 3, "reach": 4, "pic
  BUF_WEIGHTS_1, BUF_WEIGHTS_2, BUF_MEAN, BUF_MEAN_1, BUF_MEAN_2, BUF_BEST, BUF_BEST_1,
  BUF_BEST_2, BUF_ACTION_OUT, BUF_TOP_IDX, BUF_TOP_TRAJS, BUF_REDUCE, BUF_NOISE,
  BUF_PENDING_FORCE, BUF_INFO, BUF_SIM_WORLD, BUF_RECORD, BUF_RECORDS_ALL, BUF_NOISE_ALL, BUF_COV,
- BUF_COUNT) = range(27)
+ BUF_RECORD_B, BUF_RECORDS_B_ALL, BUF_COUNT) = range(29)
 
 
 class Config(C.Structure):
@@ -110,6 +110,11 @@ SYMBOLS = [
     ("m3_p2p_put", C.c_int, [_H]),
     ("m3_p2p_wait", C.c_int, [_H]),
     ("m3_p2p_exchange", C.c_int, [_H]),
+    ("m3_p2p_put_ch", C.c_int, [_H, C.c_int]),
+    ("m3_p2p_wait_ch", C.c_int, [_H, C.c_int]),
+    ("m3_p2p_exchange_b", C.c_int, [_H]),
+    ("m3_update_b", C.c_int, [_H]),
+    ("m3_record_b_len", C.c_int, [_H]),
     ("m3_p2p_status", C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("m3_get_buffer", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     ("m3_reduce_len", C.c_int, [_H]),

@@ -136,9 +136,11 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
         if (c->multi_modal && !c->mode_simple && c->sampling_random)
             return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: one-collective multi-modal sharding re-generates the other ranks' "
                                                      "actions from the noise TABLE: not with sampling_random");
-        if (c->shard_mix == 2 && !(c->multi_modal && !c->mode_simple))
-            return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: shard_mix = 2 (ladder tables in the records) is a multi-modal protocol");
-        if (c->shard_mix < 0 || c->shard_mix > 2) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: shard_mix must be 0, 1 or 2");
+        if (c->shard_mix >= 2 && !(c->multi_modal && !c->mode_simple))
+            return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: shard_mix = 2 / 3 (ladder tables in the records) are multi-modal protocols");
+        if (c->shard_mix < 0 || c->shard_mix > 3) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: shard_mix must be 0, 1, 2 or 3");
+        if (c->shard_mix == 3 && (long long)c->T * c->nu > 2048)
+            return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: shard_mix = 3 needs T * nu <= 2048");
         if (c->K_global % c->K_local != 0 || c->k_offset % c->K_local != 0 || c->K_global / c->K_local > MIX_MAX_RANKS)
             return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs equal shards (K_global = n * K_local, n <= 32)");
         if (c->K_local < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs K_local >= 20");
@@ -202,7 +204,8 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     h->cfg = *c;
     h->cov_active = c->update_cov && single_halton && !c->sim_only;   // (elsewhere the reference ignores the flag)
     h->regen = c->shard_mix && c->K_local != c->K_global && c->multi_modal && !c->mode_simple;
-    h->regen_fast = h->regen && c->shard_mix == 2;
+    h->regen_fast = h->regen && c->shard_mix >= 2;
+    h->p3 = h->regen && c->shard_mix == 3;   // ... and O(K_local) work after the gather + a second small exchange
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) {
         g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
@@ -263,6 +266,10 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
         if (rc == M3_OK && hipMalloc((void**)&h->noise_all, (size_t)(T * Kg * nu * f)) != hipSuccess) rc = M3_ERR_HIP;
         if (rc == M3_OK && hipMemsetAsync(h->noise_all, 0, (size_t)(T * Kg * nu * f), h->stream) != hipSuccess) rc = M3_ERR_HIP;
         if (rc == M3_OK && hipMalloc((void**)&h->local_top_idx, M3_TOPK * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
+        if (h->p3) {
+            A(M3_BUF_RECORD_B, (long long)recb_length((int)T, (int)nu) * f);
+            A(M3_BUF_RECORDS_B_ALL, (Kg / Kl) * (long long)recb_length((int)T, (int)nu) * f);
+        }
         if (rc == M3_OK) {   // non-owning aliases (m3_destroy skips them)
             h->buf[M3_BUF_TRAJ_COST] = h->buf[M3_BUF_RECORD]; h->nbytes[M3_BUF_TRAJ_COST] = Kl * f;
             h->buf[M3_BUF_NOISE] = h->noise_all + (size_t)(c->k_offset / Kl) * T * Kl * nu; h->nbytes[M3_BUF_NOISE] = T * Kl * nu * f;
@@ -889,6 +896,9 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.records_all = h->records_src ? h->records_src : (const float*)h->buf[M3_BUF_RECORDS_ALL];
     a.rec_topj = a.rec_topi = nullptr;
     a.rec_mins = a.rec_table = nullptr;
+    a.rec_b = nullptr;
+    a.recb_all = h->recb_src ? h->recb_src : (const float*)h->buf[M3_BUF_RECORDS_B_ALL];
+    a.recb_len = h->recb_src ? h->recb_stride : recb_length(c.T, c.nu);
     a.fast = 0;
     a.regen = 0;
     a.Jout = nullptr;
@@ -1025,6 +1035,46 @@ static int regen_finalize(m3_handle* h) {
     return M3_OK;
 }
 
+// shard_mix = 3, between the two exchanges (update.hip: k_p3_done's comment): searches on the mixed tables, then
+// weights and weighted sums of this rank's OWN samples into its second record
+extern "C" int m3_update_b(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->p3) return fail(h, M3_ERR_STATE, "m3_update_b: only for cfg.shard_mix = 3 handles");
+    const m3_config& c = h->cfg;
+    float* rec = (float*)h->buf[M3_BUF_RECORD];
+    float* recb = (float*)h->buf[M3_BUF_RECORD_B];
+    {   // searches (all ranks' tables; the gathered costs only if one leaves its ladder) + the global top-k
+        UpdateArgs a;
+        fill_update_args(h, a);
+        a.regen = 1; a.fast = 1;
+        a.Kl = c.K_global; a.k0 = 0;
+        a.top_dst = a.top_trajs;
+        launch_p3_search(a, h->stream);
+    }
+    {   // weights of the local samples (global minima / eta / beta from the search)
+        UpdateArgs a;
+        fill_update_args(h, a);
+        a.Kg = c.K_local;
+        a.Jall = rec;
+        a.kbase = c.k_offset;
+        a.w = (float*)h->buf[M3_BUF_WEIGHTS] + c.k_offset;
+        a.w1 = (float*)h->buf[M3_BUF_WEIGHTS_1] + c.k_offset;
+        a.rec_b = recb;
+        if (apply_workgroups(c.K_local) > 256) return fail(h, M3_ERR_UNSUPPORTED, "m3_update_b: K_local too large");
+        launch_p3_local_weights(a, h->stream);
+    }
+    {   // their weighted action sums + the rows of the local best samples
+        UpdateArgs a;
+        fill_update_args(h, a);
+        a.reduce = recb + RECB_HDR;
+        a.n_cand = 0;
+        a.fuse_finalize = 0;
+        launch_wsum(a, h->stream);
+    }
+    HIPCHK(h, hipGetLastError());
+    return M3_OK;
+}
+
 // MPPIConfig.update_cov: the covariance update that follows the mean update (mppi.py:508-516)
 static int after_finalize(m3_handle* h) {
     if (!h->cov_active) return M3_OK;
@@ -1044,8 +1094,8 @@ static int p2p_alloc(m3_handle* h) {
     const m3_config& c = h->cfg;
     if (!(c.shard_mix && c.K_local != c.K_global) || !h->buf[M3_BUF_RECORD])
         return fail(h, M3_ERR_STATE, "m3_p2p: the handle has no record to exchange (needs cfg.shard_mix on a sharded handle)");
-    const size_t rl = (size_t)m3_record_len(h);
-    h->xb_bytes = P2P_HDR_BYTES + 2 * (size_t)p2p_ranks(h) * ((rl + 3) & ~(size_t)3) * sizeof(float);
+    const size_t rl = (size_t)m3_record_len(h), rlb = (size_t)m3_record_b_len(h);
+    h->xb_bytes = P2P_HDR_BYTES + 2 * (size_t)p2p_ranks(h) * (((rl + 3) & ~(size_t)3) + ((rlb + 3) & ~(size_t)3)) * sizeof(float);
     // uncached: neither the peers' stores nor the owner's loads may be served from a stale L2 line
     if (hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocUncached) == hipSuccess) h->xb_kind = 1;
     else if ((void)hipGetLastError(), hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocFinegrained) == hipSuccess) h->xb_kind = 2;
@@ -1072,7 +1122,7 @@ static int p2p_finish_connect(m3_handle* h) {
     for (int p = 0; p < p2p_ranks(h); ++p)
         if (!h->peer_base[p]) return fail(h, M3_ERR_STATE, "m3_p2p_connect: a peer's block is missing");
     h->p2p_ready = true;
-    h->p2p_seq = 0;
+    h->p2p_seq[0] = h->p2p_seq[1] = 0;
     return M3_OK;
 }
 
@@ -1123,50 +1173,61 @@ extern "C" int m3_p2p_connect_local(m3_handle* h, m3_handle* const* peers, int n
     return p2p_finish_connect(h);
 }
 
-static void p2p_args(m3_handle* h, P2PArgs& a) {
+// channel 0: the records (M3_BUF_RECORD); channel 1: the second records of shard_mix = 3 (M3_BUF_RECORD_B)
+static void p2p_args(m3_handle* h, P2PArgs& a, int ch) {
     std::memset(&a, 0, sizeof(a));
-    a.rec = (const float*)h->buf[M3_BUF_RECORD];
-    a.rec_len = m3_record_len(h);
+    const int lenA = m3_record_len(h), strideA = (lenA + 3) & ~3;
+    a.rec = (const float*)h->buf[ch == 0 ? M3_BUF_RECORD : M3_BUF_RECORD_B];
+    a.rec_len = ch == 0 ? lenA : m3_record_b_len(h);
     a.rec_stride = (a.rec_len + 3) & ~3;
     a.n_ranks = p2p_ranks(h);
     a.rank = p2p_rank(h);
-    a.seq = h->p2p_seq;
-    a.slot = h->p2p_seq & 1;
+    a.seq = h->p2p_seq[ch];
+    a.slot = a.seq & 1;
     a.timeout_ticks = 50000000ull;   // 0.5 s of the 100 MHz wall clock
     a.plain_memory = h->xb_kind == 3;
     a.err = (int*)((char*)h->xb + 2 * MIX_MAX_RANKS * sizeof(int));
     for (int p = 0; p < a.n_ranks; ++p) {
-        a.peer_flags[p] = (int*)h->peer_base[p];
-        a.peer_data[p] = (float*)((char*)h->peer_base[p] + P2P_HDR_BYTES);
+        a.peer_flags[p] = (int*)((char*)h->peer_base[p] + (ch == 0 ? 0 : 512));
+        a.peer_data[p] = (float*)((char*)h->peer_base[p] + P2P_HDR_BYTES) + (ch == 0 ? 0 : 2 * (size_t)a.n_ranks * strideA);
     }
 }
 
-extern "C" int m3_p2p_put(m3_handle* h) {
+extern "C" int m3_p2p_put_ch(m3_handle* h, int ch) {
     if (!h) return M3_ERR_BAD_ARG;
+    if (ch != 0 && !(ch == 1 && h->p3)) return fail(h, M3_ERR_BAD_ARG, "m3_p2p_put: channel 1 exists on shard_mix = 3 handles only");
     if (!h->p2p_ready) return fail(h, M3_ERR_STATE, "m3_p2p_put: m3_p2p_connect first");
-    h->p2p_seq += 1;
+    h->p2p_seq[ch] += 1;
     P2PArgs a;
-    p2p_args(h, a);
+    p2p_args(h, a, ch);
     launch_p2p_put(a, h->stream);
     HIPCHK(h, hipGetLastError());
     return M3_OK;
 }
 
-extern "C" int m3_p2p_wait(m3_handle* h) {
+extern "C" int m3_p2p_wait_ch(m3_handle* h, int ch) {
     if (!h) return M3_ERR_BAD_ARG;
-    if (!h->p2p_ready || h->p2p_seq == 0) return fail(h, M3_ERR_STATE, "m3_p2p_wait: no exchange in flight (m3_p2p_put first)");
+    if (ch != 0 && !(ch == 1 && h->p3)) return fail(h, M3_ERR_BAD_ARG, "m3_p2p_wait: channel 1 exists on shard_mix = 3 handles only");
+    if (!h->p2p_ready || h->p2p_seq[ch] == 0) return fail(h, M3_ERR_STATE, "m3_p2p_wait: no exchange in flight (m3_p2p_put first)");
     P2PArgs a;
-    p2p_args(h, a);
+    p2p_args(h, a, ch);
     launch_p2p_wait(a, h->stream);
     HIPCHK(h, hipGetLastError());
-    h->records_src = a.peer_data[a.rank] + (size_t)a.slot * a.n_ranks * a.rec_stride;
-    h->records_stride = a.rec_stride;
+    const float* src = a.peer_data[a.rank] + (size_t)a.slot * a.n_ranks * a.rec_stride;
+    if (ch == 0) { h->records_src = src; h->records_stride = a.rec_stride; }
+    else { h->recb_src = src; h->recb_stride = a.rec_stride; }
     return M3_OK;
 }
 
+extern "C" int m3_p2p_put(m3_handle* h) { return m3_p2p_put_ch(h, 0); }
+extern "C" int m3_p2p_wait(m3_handle* h) { return m3_p2p_wait_ch(h, 0); }
 extern "C" int m3_p2p_exchange(m3_handle* h) {
-    const int rc = m3_p2p_put(h);
-    return rc != M3_OK ? rc : m3_p2p_wait(h);
+    const int rc = m3_p2p_put_ch(h, 0);
+    return rc != M3_OK ? rc : m3_p2p_wait_ch(h, 0);
+}
+extern "C" int m3_p2p_exchange_b(m3_handle* h) {
+    const int rc = m3_p2p_put_ch(h, 1);
+    return rc != M3_OK ? rc : m3_p2p_wait_ch(h, 1);
 }
 
 extern "C" int m3_p2p_status(m3_handle* h, int* missing_rank, int* memory_kind) {
@@ -1182,7 +1243,18 @@ extern "C" int m3_p2p_status(m3_handle* h, int* missing_rank, int* memory_kind) 
 
 extern "C" int m3_finalize(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
-    struct Consume { m3_handle* h; ~Consume() { h->records_src = nullptr; } } consume{h};   // one exchange, one finalize
+    struct Consume { m3_handle* h; ~Consume() { h->records_src = nullptr; h->recb_src = nullptr; } } consume{h};   // one exchange, one finalize
+    if (h->p3) {
+        UpdateArgs a;
+        fill_update_args(h, a);
+        a.Kl = h->cfg.K_global; a.k0 = 0;      // (finalize_body: the top trajectories are already in place)
+        launch_p3_done(a, h->stream);
+        HIPCHK(h, hipGetLastError());
+        h->recb_src = nullptr;
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+        h->calls += 1;
+        return M3_OK;
+    }
     if (h->regen) {
         const int rc = regen_finalize(h);
         if (rc != M3_OK) return rc;
@@ -1239,6 +1311,11 @@ extern "C" int m3_command(m3_handle* h, float* action_host) {
 }
 
 static int ensure_sim(m3_handle* h);
+extern "C" int m3_record_b_len(const m3_handle* h) {
+    if (!h || !h->p3) return 0;
+    return recb_length(h->cfg.T, h->cfg.nu);
+}
+
 extern "C" int m3_record_len(const m3_handle* h) {
     if (!h) return 0;
     return h->regen ? regen_record_length(h->cfg.K_local, h->cfg.T) : record_length(h->cfg.T, h->cfg.nu);

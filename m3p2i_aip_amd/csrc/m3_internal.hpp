@@ -117,7 +117,16 @@ struct UpdateArgs {
     float u_min[M3_MAX_NU], u_max[M3_MAX_NU], scale_tril[M3_MAX_NU];
     float u_scale;
     int sample_null_action, gripper_cmd;
+    // ---- shard_mix = 3 (two small exchanges, O(K_local) work after the first): the second record of this rank,
+    // {-w, index of its best sample per weight set (3 pairs) | its half sums (2)} + its weighted sums and best rows
+    float* rec_b;              // k_apply_weights' combine leaves the 8-float header here (null: not this protocol)
+    const float* recb_all;     // [n_ranks][recb_len] after the second exchange
+    int recb_len;
 };
+// record B (shard_mix = 3): header | [3][T][nu] weighted sums of the LOCAL shard (globally normalised weights) |
+// [3][T][nu] action rows of the local best samples
+constexpr int RECB_HDR = 8;
+__host__ __device__ inline int recb_length(int T, int nu) { return (RECB_HDR + 6 * T * nu + 3) / 4 * 4; }
 
 // REDUCE buffer: [3][T][nu] weighted sums (all, mode 1, mode 2) | [3][T][nu] best rows
 // (best, best_1, best_2; zero unless this rank owns the row) | [TOPK][T][2] top trajectories
@@ -178,6 +187,9 @@ void launch_cov_update(const float* actions, const float* w, const float* mean, 
                        int nu, hipStream_t s);
 void launch_local_topk(const UpdateArgs& a, hipStream_t s);
 void launch_regen_fast(const UpdateArgs& a, hipStream_t s);
+void launch_p3_search(const UpdateArgs& a, hipStream_t s);          // mixed-table search (+ top-k merge) of shard_mix = 3
+void launch_p3_local_weights(const UpdateArgs& a, hipStream_t s);   // k_apply_weights<true> over the local costs
+void launch_p3_done(const UpdateArgs& a, hipStream_t s);            // after the second exchange: sums, best rows, plan
 int init_ladder_table();   // update.hip: the beta ladder into constant memory (per device context)
 int regen_chunks(int Kg);   // workgroups per time step of k_regen_part
 int rollout_lanes_for(int Kl);
@@ -278,7 +290,10 @@ struct m3_handle {
     bool cov_active = false;       // cfg.update_cov on a single-mode halton-spline planner (mppi.py:508-516)
     float* noise_mats = nullptr;   // device [2][nu][nu]: chol(noise_sigma) | noise_sigma^-1 (cfg.full_sigma)
     bool regen = false;            // one-collective multi-modal sharding (UpdateArgs::regen)
-    bool regen_fast = false;       // ... with per-rank ladder tables in the records (cfg.shard_mix == 2)
+    bool regen_fast = false;       // ... with per-rank ladder tables in the records (cfg.shard_mix >= 2)
+    bool p3 = false;               // cfg.shard_mix == 3: O(K_local) work after the gather, second small exchange
+    const float* recb_src = nullptr;   // second records as exchanged by m3_p2p_exchange(h, 1) (else M3_BUF_RECORDS_B_ALL)
+    int recb_stride = 0;
     float* noise_all = nullptr;    // regen: [n_ranks][T][Kl][nu]; buf[M3_BUF_NOISE] aliases this rank's block
     int* local_top_idx = nullptr;  // regen: top_idx of the local pre-gather selection (scratch)
     unsigned calls = 0;
@@ -306,7 +321,7 @@ struct m3_handle {
     void* peer_base[m3::MIX_MAX_RANKS] = {};   // every rank's block as mapped here (own: xb)
     bool peer_ipc[m3::MIX_MAX_RANKS] = {};     // opened with hipIpcOpenMemHandle (closed in m3_destroy)
     bool p2p_ready = false;
-    int p2p_seq = 0;
+    int p2p_seq[2] = {0, 0};           // per channel (0: records, 1: second records of shard_mix = 3)
     int records_stride = 0;             // floats between two records of records_src
     const float* records_src = nullptr; // != null: the records of the exchange just enqueued (consumed by m3_finalize)
     // timing

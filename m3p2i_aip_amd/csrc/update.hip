@@ -1104,11 +1104,21 @@ __global__ __launch_bounds__(AP_T) void k_apply_weights(const UpdateArgs a) {
             if (vi_less(x[6], __float_as_int(x[7]), c2.v, c2.i)) { c2.v = x[6]; c2.i = __float_as_int(x[7]); }
         }
         m3_info* f = a.info;
-        f->best_idx = a.kbase + c0.i;
-        f->best_idx_1 = MULTI ? c1.i : -1;
-        f->best_idx_2 = MULTI ? c2.i : -1;
+        // (global indices; a shard without a sample of a subset -- the ranks of the other mode -- has none: -1)
+        const int g0 = c0.i == 0x7fffffff ? -1 : a.kbase + c0.i;
+        const int g1 = (!MULTI || c1.i == 0x7fffffff) ? -1 : a.kbase + c1.i;
+        const int g2 = (!MULTI || c2.i == 0x7fffffff) ? -1 : a.kbase + c2.i;
+        f->best_idx = g0;
+        f->best_idx_1 = g1;
+        f->best_idx_2 = g2;
         f->wsum_push = h0; f->wsum_pull = h1;
         f->pull_preference = h1 > h0;
+        if (a.rec_b) {   // shard_mix = 3: the header of this rank's second record (indices < 2^24: exact as floats)
+            a.rec_b[0] = c0.v; a.rec_b[1] = (float)g0;
+            a.rec_b[2] = c1.v; a.rec_b[3] = (float)g1;
+            a.rec_b[4] = c2.v; a.rec_b[5] = (float)g2;
+            a.rec_b[6] = h0; a.rec_b[7] = h1;
+        }
         if constexpr (!MULTI) {   // what k_weights' single-softmin branch reports
             f->eta = so.eta[0]; f->eta_1 = 0.0f; f->eta_2 = 0.0f;
             f->iters = 1; f->iters_1 = 1; f->iters_2 = 1;
@@ -1640,6 +1650,66 @@ void launch_regen_fast(const UpdateArgs& a_, hipStream_t s) {
         hipLaunchKernelGGL(k_regen_part<9>, grid, dim3(ST), 0, s, a, clen);
         hipLaunchKernelGGL(k_regen_done<9>, dim3(1), dim3(ST), lds, s, a);
     }
+}
+
+// ---- shard_mix = 3: two small exchanges, O(K_local) work per rank after the first --------------------------------
+//   Before exchange A: the shard_mix = 2 record (k_local_topk: the shard's costs, top-k,
+// minima and ladder table).  After it: the searches on the MIXTURE of the tables (k_search with a.fast; passes over
+// the gathered costs only if a search leaves its ladder), then the weights of the rank's OWN samples with the global
+// minima / eta (k_apply_weights<true> over the local costs) and their weighted action sums from the rank's own action
+// buffer (k_wsum) -- nothing is re-generated, nothing of size K_global is touched.  Exchange B gathers the ranks'
+// sums, best rows and (-w, index) pairs; k_p3_done adds the sums in rank order, takes the best rows from the rank
+// whose best sample wins (the unsharded argmax: largest weight, lowest index), and writes the plan.
+template <int NU>
+__global__ __launch_bounds__(ST) void k_p3_done(const UpdateArgs a) {
+    extern __shared__ float sm_fin[];
+    __shared__ int s_win[3];
+    const int tid = threadIdx.x, N = a.n_ranks, T = a.T, L = a.recb_len;
+    if (tid == 0) {
+        const float INF = __builtin_inff();
+        float h0 = 0.0f, h1 = 0.0f;
+        VI best[3] = {{INF, 0x7fffffff}, {INF, 0x7fffffff}, {INF, 0x7fffffff}};
+        int win[3] = {0, 0, 0};
+        for (int r = 0; r < N; ++r) {   // rank order
+            const float* x = a.recb_all + (size_t)r * L;
+            h0 += x[6]; h1 += x[7];
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                const int gi = (int)x[2 * sx + 1];
+                if (gi >= 0 && vi_less(x[2 * sx], gi, best[sx].v, best[sx].i)) { best[sx].v = x[2 * sx]; best[sx].i = gi; win[sx] = r; }
+            }
+        }
+        m3_info* f = a.info;
+        f->best_idx = best[0].i == 0x7fffffff ? -1 : best[0].i;
+        f->best_idx_1 = best[1].i == 0x7fffffff ? -1 : best[1].i;
+        f->best_idx_2 = best[2].i == 0x7fffffff ? -1 : best[2].i;
+        f->wsum_push = h0; f->wsum_pull = h1;
+        f->pull_preference = h1 > h0;
+        s_win[0] = win[0]; s_win[1] = win[1]; s_win[2] = win[2];
+    }
+    __syncthreads();
+    const int n = T * NU;
+    for (int o = tid; o < 3 * n; o += ST) {
+        const int which = o / n, rem = o - which * n;
+        float sum = 0.0f;
+        for (int r = 0; r < N; ++r) sum += a.recb_all[(size_t)r * L + RECB_HDR + which * n + rem];
+        a.reduce[reduce_off_psum(which, T, NU) + rem] = sum;
+        a.reduce[reduce_off_best(which, T, NU) + rem] = a.recb_all[(size_t)s_win[which] * L + RECB_HDR + (3 + which) * n + rem];
+    }
+    __threadfence_block();
+    __syncthreads();
+    finalize_body<false>(a, sm_fin);
+}
+void launch_p3_search(const UpdateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_search, dim3(2), dim3(WT_MAX), 0, s, a);     // workgroup 1: the global top-k from the shards' lists
+}
+void launch_p3_local_weights(const UpdateArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_apply_weights<true>, dim3(apply_workgroups(a.Kg)), dim3(AP_T), 0, s, a);
+}
+void launch_p3_done(const UpdateArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)a.T * a.nu * sizeof(float);
+    if (a.nu == 2) hipLaunchKernelGGL(k_p3_done<2>, dim3(1), dim3(ST), lds, s, a);
+    else hipLaunchKernelGGL(k_p3_done<9>, dim3(1), dim3(ST), lds, s, a);
 }
 
 // the shard's own top-k before the collective ("regen" sharding): stage A per 4096 costs, the last

@@ -26,6 +26,12 @@ only the importance-weight update couples them.  Defaul
     rank; MPPIConfig.shard_mix = 1 selects the variant that re-evaluates all K costs with the unsharded kernels
     and is bit-identical to the single-GPU run (tests/test_c5_sharded_gpu.py).
 
+shard_mix = 3 (multi-modal, opt-in: more ranks / samples per GPU than BASELINE's): TWO small exchanges,
+    rollout -> update (as above: costs | top-20 | minima, ladder table) -> all_gather record
+      -> update_b (searches on the mixed tables; weights of the rank's OWN samples; their weighted action sums from
+                   its own action buffer -- nothing re-generated, nothing of size K_global touched)
+      -> all_gather record_b (~6 T nu floats) -> finalize (sums in rank order, best rows of the winning rank, plan).
+
 Fallback protocol (shard_mix=False; also the multi-modal path with sampling_method='random', whose
 in-kernel noise has no table): two collectives,
     rollout -> all_gather J[K] -> update (weights for all K, weighted sums over the local shard)
@@ -67,6 +73,12 @@ def attach_collectives(planner, group=None):
                 dist.all_gather_into_tensor(out, loc, group=group)
             except (RuntimeError, NotImplementedError):
                 dist.all_gather(list(out.unbind(0)), loc, group=group)
+        elif phase == "records_b":       # shard_mix = 3: the second, small exchange
+            out, loc = e.buffer(L.BUF_RECORDS_B_ALL), e.buffer(L.BUF_RECORD_B)
+            try:
+                dist.all_gather_into_tensor(out, loc, group=group)
+            except (RuntimeError, NotImplementedError):
+                dist.all_gather(list(out.unbind(0)), loc, group=group)
         else:
             raise ValueError(phase)
 
@@ -90,9 +102,9 @@ def attach_p2p(planner, group=None):
     dist.barrier(group=group)      # nobody starts exchanging before every rank has mapped every block
 
     def exchange(pl, phase):
-        if phase != "records":
+        if phase not in ("records", "records_b"):
             raise ValueError(phase)
-        pl._engine.p2p_exchange()
+        pl._engine.p2p_exchange(0 if phase == "records" else 1)
 
     planner.collective = exchange
     planner.transport = "p2p"

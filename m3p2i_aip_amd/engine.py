@@ -72,7 +72,8 @@ def make_config(K, T, nu=2, env_type="point_env", multi_modal=False, mode_simple
         for j in range(nu):
             c.noise_mu[j] = float(noise_mu[j])
     c.noise_abs_cost, c.update_cov = int(bool(noise_abs_cost)), int(bool(update_cov))
-    c.shard_mix = int(shard_mix)   # 0: gather + reduce; 1 (True): one collective; 2: ... with ladder tables (multi-modal)
+    c.shard_mix = int(shard_mix)   # 0: gather + reduce; 1 (True): one collective; 2: ... with ladder tables (multi-modal);
+                                   # 3: two small exchanges, O(K_local) work per rank (multi-modal)
     c.seed = int(seed)
     return c
 
@@ -256,6 +257,10 @@ class HipEngine:
     def update(self):
         self._ck(self.lib.m3_update(self._h))
 
+    def update_b(self):
+        """shard_mix = 3, between the two exchanges: searches on the mixed tables, local weights and sums."""
+        self._ck(self.lib.m3_update_b(self._h))
+
     def finalize(self):
         self._ck(self.lib.m3_finalize(self._h))
 
@@ -279,14 +284,16 @@ class HipEngine:
         self._p2p_peers = list(engines)     # keep the peers' blocks alive as long as this handle writes into them
         self._ck(self.lib.m3_p2p_connect_local(self._h, arr, len(engines)))
 
-    def p2p_put(self):
-        self._ck(self.lib.m3_p2p_put(self._h))
+    def p2p_put(self, channel=0):
+        """channel 0: M3_BUF_RECORD; 1: M3_BUF_RECORD_B (the second exchange of shard_mix = 3)."""
+        self._ck(self.lib.m3_p2p_put_ch(self._h, int(channel)))
 
-    def p2p_wait(self):
-        self._ck(self.lib.m3_p2p_wait(self._h))
+    def p2p_wait(self, channel=0):
+        self._ck(self.lib.m3_p2p_wait_ch(self._h, int(channel)))
 
-    def p2p_exchange(self):
-        self._ck(self.lib.m3_p2p_exchange(self._h))
+    def p2p_exchange(self, channel=0):
+        self.p2p_put(channel)
+        self.p2p_wait(channel)
 
     def p2p_status(self):
         """(missing_rank or -1, memory kind: 1 uncached / 2 fine-grained / 3 plain); synchronises the stream."""
@@ -320,6 +327,8 @@ class HipEngine:
             L.BUF_COV: ((2, nu), "<f4"),
             L.BUF_RECORD: ((self.lib.m3_record_len(self._h),), "<f4"),
             L.BUF_RECORDS_ALL: ((Kg // Kl, self.lib.m3_record_len(self._h)), "<f4"),
+            L.BUF_RECORD_B: ((self.lib.m3_record_b_len(self._h),), "<f4"),
+            L.BUF_RECORDS_B_ALL: ((Kg // Kl, self.lib.m3_record_b_len(self._h)), "<f4"),
         }[which]
 
     def buffer(self, which) -> torch.Tensor:

@@ -184,7 +184,9 @@ class MPPI():
         # multi-modal: shard_mix=2 (default) adds per-shard ladder tables to the records -- half the per-rank work
         # after the collective, equal to the unsharded run up to f32 rounding; shard_mix=True/1 keeps the
         # bit-identical variant (all K costs re-evaluated on every rank)
-        self._shard_mix_level = 0 if not self.shard_mix else (1 if single else (2 if sm in (None, 2) else 1))
+        # shard_mix=3: two small exchanges and O(K_local) work per rank after the first (more ranks / samples than the
+        # one-collective protocols are meant for: their post-gather work grows with K_global)
+        self._shard_mix_level = 0 if not self.shard_mix else (1 if single else (2 if sm in (None, 2) else (3 if sm == 3 else 1)))
         self.relabel_samples = bool(_get(m, "relabel_samples", True))
         self._engine = ENGINE_CLS(make_config(
             K=self.K, K_local=self.K_local, k_offset=self.k_offset, T=self.T, nu=self.nu,
@@ -399,7 +401,13 @@ class MPPI():
             raise RuntimeError("planner built with world_size > 1 but no collectives installed: call "
                                "m3p2i_aip_amd.distributed.attach_collectives(planner) first (without the "
                                "exchange the update would run on zero / stale remote slices)")
-        if self.shard_mix:
+        if self.shard_mix and self._shard_mix_level == 3:
+            e.update()                      # the shard's costs, top-k, minima and ladder table -> its record
+            self._exchange("records")
+            e.update_b()                    # searches on the mixed tables; weights + sums of the OWN samples
+            self._exchange("records_b")     # ~6 T nu floats per rank
+            e.finalize()
+        elif self.shard_mix:
             e.update()                      # softmin over the local shard -> this rank's record
             self._exchange("records")       # the one collective
             e.finalize()                    # mix the ranks' records, then the usual finalize
