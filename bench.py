@@ -82,7 +82,7 @@ BYTES_PER_STATE_STEP_ROLLOUT = {"point_env": 36, "panda_env": 92}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")  # PMC FETCH/WRITE_SIZE per launch
 
 
-def build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device, simple=False):
+def build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device, simple=False, shard_mix=None):
     from m3p2i_aip_amd import isaacgym_wrapper as wrapper
     from m3p2i_aip_amd.cost_functions import Objective
     from m3p2i_aip_amd.planner import M3P2I, MPPIConfig
@@ -90,7 +90,8 @@ def build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device, s
         m = MPPIConfig(num_samples=K_global, horizon=T, nx=4, device=device, lambda_=0.5,
                        u_min=[-3.0, -3.0], u_max=[3.0, 3.0], noise_sigma=[[3.0, 0.0], [0.0, 3.0]],
                        u_per_command=T, sample_null_action=True, filter_u=True, fused=True, rank=rank,
-                       world_size=world, **(dict(mppi_mode="simple", sampling_method="random") if simple else {}))
+                       world_size=world, shard_mix=shard_mix if multi_modal else None,
+                       **(dict(mppi_mode="simple", sampling_method="random") if simple else {}))
         dt = 0.05
     else:
         sig = [[0.0] * 9 for _ in range(9)]
@@ -222,7 +223,7 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
     K_local = K_local or K_cfg
     K_global = K_local * world
     pl, sim, obj, cfg = build_tamp(env, task, goal, multi_modal, K_global, rank, world, T, device,
-                                   simple=name in SIMPLE_MODE)
+                                   simple=name in SIMPLE_MODE, shard_mix=getattr(args, "shard_mix", None))
     if scene is not None:
         scene(pl, sim, obj, cfg)     # a world other than the reference's initial scene (and its objective)
     # synthetic noise: the reference's Halton-spline sampler for this rank's rows of the global
@@ -230,8 +231,9 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
     # the hot path).  NOT tiled -- duplicated samples would make the reference's beta search
     # non-terminating: eta >= number of copies of the best sample.
     if world > 1:
-        from m3p2i_aip_amd.distributed import attach_collectives
-        attach_collectives(pl)
+        from m3p2i_aip_amd.distributed import attach_collectives, attach_p2p
+        # --transport p2p: the records exchange through peer-mapped device memory (csrc/p2p.hip) instead of RCCL
+        (attach_p2p if getattr(args, "transport", "rccl") == "p2p" else attach_collectives)(pl)
     eng = pl._engine
     state = sim._dof_state[0]
 
@@ -372,6 +374,11 @@ def main():
                     help="default: push (BASELINE configs[1]), 2000 samples per GPU, for every N")
     ap.add_argument("--samples-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-mix", type=int, default=None, choices=[1, 2, 3],
+                    help="multi-modal sharding protocol (N > 1): 2 = one collective (default), 1 = its bit-identical variant, "
+                         "3 = two small exchanges with O(K_local) work per rank")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "p2p"],
+                    help="N > 1: the records exchange as an RCCL all-gather (default) or through peer-mapped device memory")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (profiling runs)")
     args = ap.parse_args()
 
@@ -423,9 +430,10 @@ def main():
         if world == 1:
             par = "single GPU"
         else:
-            par = (f"samples sharded x{world}, " + ("ONE collective per command: all-gather of per-rank records"
+            par = (f"samples sharded x{world}, " + (("TWO small exchanges per command (shard_mix 3)" if pl._shard_mix_level == 3 else
+                                                     "ONE collective per command: all-gather of per-rank records")
                                                     if pl.shard_mix else "all-gather J + all-reduce packed sums")
-                   + (" (gloo, shared GPU: test mode)" if share else " (RCCL)"))
+                   + (" (gloo, shared GPU: test mode)" if share else (" (p2p device-side exchange)" if args.transport == "p2p" else " (RCCL)")))
         line = {
             "metric": "mppi_state_steps_per_sec (K x T per command())",
             "value": r["value"], "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,

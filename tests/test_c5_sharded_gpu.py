@@ -115,7 +115,9 @@ def test_c5_gather_reduce_protocol_8x8000_equals_unsharded():
 
 @pytest.mark.parametrize("Kt,Nt,level,transport", [(K, N, 1, "copy"), (512, 2, 1, "copy"), (6000, 4, 1, "copy"), (K, N, 2, "copy"),
                                                    (512, 2, 2, "copy"), (6000, 4, 2, "copy"), (32000, 2, 2, "copy"),
-                                                   (K, N, 2, "p2p"), (6000, 4, 1, "p2p"), (6000, 4, 2, "p2p-streams")])
+                                                   (K, N, 2, "p2p"), (6000, 4, 1, "p2p"), (6000, 4, 2, "p2p-streams"),
+                                                   (K, N, 3, "copy"), (512, 2, 3, "copy"), (6000, 4, 3, "copy"), (32000, 2, 3, "copy"),
+                                                   (K, N, 3, "p2p"), (6000, 4, 3, "p2p-streams")])
 def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
     """cfg.shard_mix for the multi-modal search: ONE all-gather of per-rank records {costs of the shard |
     its top-k}; every rank then runs the unsharded update on all K costs and RE-GENERATES the other
@@ -131,7 +133,10 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
     transport: "copy" -- the all-gather done by hand into M3_BUF_RECORDS_ALL (what RCCL does); "p2p" -- the library's
     device-side exchange (csrc/p2p.hip): every handle stores its record into every peer's block and acquires the
     peers' flags, all handles on one stream; "p2p-streams" -- the same with every handle on a stream of its own, so
-    that the puts and the spinning waits of different ranks really run side by side."""
+    that the puts and the spinning waits of different ranks really run side by side.
+    level 3 (cfg.shard_mix = 3): TWO small exchanges -- the level-2 record, then every rank's weighted sums of its OWN
+    samples (from its own action buffer: nothing re-generated, O(K_local) work) and best rows -- same bars as level 2;
+    a rank materialises the weights of its own samples only."""
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
     kl = Kt // Nt
@@ -165,6 +170,25 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
             allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])   # the ONE collective: all_gather
             for e in shards:
                 e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
+                if level == 3:
+                    e.update_b()
+                else:
+                    e.finalize()
+            if level == 3:
+                allb = torch.stack([e.buffer(L.BUF_RECORD_B) for e in shards])   # the second, small all_gather
+                for e in shards:
+                    e.buffer(L.BUF_RECORDS_B_ALL).copy_(allb)
+                    e.finalize()
+        elif level == 3:
+            for e in shards:
+                e.p2p_put()
+            for e in shards:
+                e.p2p_wait()
+                e.update_b()
+            for e in shards:
+                e.p2p_put(1)
+            for e in shards:
+                e.p2p_wait(1)
                 e.finalize()
         else:
             # one process drives every handle: all puts are enqueued before any wait (a wait in front of another
@@ -187,7 +211,13 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
             else:
                 np.testing.assert_allclose([i.eta, i.eta_1, i.eta_2, i.wsum_push, i.wsum_pull],
                                            [fi.eta, fi.eta_1, fi.eta_2, fi.wsum_push, fi.wsum_pull], rtol=1e-4, atol=1e-6)
-            for name in PLAN_BUFS + ("BUF_WEIGHTS", "BUF_WEIGHTS_1", "BUF_WEIGHTS_2", "BUF_TOP_IDX") + \
+            if level == 3:   # the weights of the rank's own samples (the other entries are not materialised)
+                h = Kt // 2
+                for name, lo, hi in (("BUF_WEIGHTS", r * kl, (r + 1) * kl), ("BUF_WEIGHTS_1", min(r * kl, h), min((r + 1) * kl, h)),
+                                     ("BUF_WEIGHTS_2", max(r * kl - h, 0), max((r + 1) * kl - h, 0))):
+                    b = getattr(L, name)
+                    np.testing.assert_allclose(e.buffer(b)[lo:hi].cpu().numpy(), full.buffer(b)[lo:hi].cpu().numpy(), rtol=2e-3, atol=1e-8)
+            for name in PLAN_BUFS + (("BUF_WEIGHTS", "BUF_WEIGHTS_1", "BUF_WEIGHTS_2") if level != 3 else ()) + ("BUF_TOP_IDX",) + \
                     (("BUF_TRAJ_COST_ALL",) if level == 1 else ()):
                 b = getattr(L, name)
                 assert torch.equal(e.buffer(b), shards[0].buffer(b)), f"call {call}: ranks {r} and 0 disagree on {name}"

@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 K, T = 512, 30
 
 
-def build(rank, world, multi_modal, task, goal):
+def build(rank, world, multi_modal, task, goal, shard_mix=None):
     sys.path.insert(0, ROOT)
     from m3p2i_aip_amd import isaacgym_wrapper as wrapper
     from m3p2i_aip_amd.cost_functions import Objective
     from m3p2i_aip_amd.planner import M3P2I, MPPIConfig
     m = MPPIConfig(num_samples=K, horizon=T, nx=4, device="cuda:0", lambda_=0.5, u_min=[-3.0, -3.0],
                    u_max=[3.0, 3.0], noise_sigma=[[3.0, 0.0], [0.0, 3.0]], u_per_command=T,
-                   sample_null_action=True, filter_u=True, fused=True, rank=rank, world_size=world)
+                   sample_null_action=True, filter_u=True, fused=True, rank=rank, world_size=world, shard_mix=shard_mix)
     cfg = SimpleNamespace(env_type="point_env", multi_modal=multi_modal, suction_active=True, kp_suction=400,
                           pre_height_diff=0.0, task=task, goal=list(goal), cube_on_shelf=False, mppi=m,
                           isaacgym=wrapper.IsaacGymConfig(dt=0.05))
@@ -46,7 +46,7 @@ def run(pl, sim, delta, n=4):
     return out
 
 
-def worker(rank, world, port, multi_modal, task, goal, ret, transport="gloo"):
+def worker(rank, world, port, multi_modal, task, goal, ret, transport="gloo", shard_mix=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -55,7 +55,7 @@ def worker(rank, world, port, multi_modal, task, goal, ret, transport="gloo"):
     from m3p2i_aip_amd.distributed import attach_collectives, attach_p2p
     delta = np.load(os.path.join(ROOT, "tests", "golden", "ref_golden.npz"))["g9_push_delta"]
     delta = np.concatenate([delta, delta[::-1] * 0.7]).astype(np.float32)   # 512 distinct rows
-    pl, sim = build(rank, world, multi_modal, task, goal)
+    pl, sim = build(rank, world, multi_modal, task, goal, shard_mix)
     if transport == "p2p":
         # the records exchange through peer-mapped device memory: the other process's block is opened with
         # hipIpcOpenMemHandle (here both processes sit on the same GPU; on a node: one hop over xGMI)
@@ -75,9 +75,10 @@ def worker(rank, world, port, multi_modal, task, goal, ret, transport="gloo"):
 
 
 @pytest.mark.parametrize("transport", ["gloo", "p2p"])
-@pytest.mark.parametrize("multi_modal,task,goal", [(False, "push", (-1.0, -1.0)),
-                                                   (True, "push_pull", (-3.75, -3.75))])
-def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal, transport):
+@pytest.mark.parametrize("multi_modal,task,goal,shard_mix", [(False, "push", (-1.0, -1.0), None),
+                                                             (True, "push_pull", (-3.75, -3.75), None),
+                                                             (True, "push_pull", (-3.75, -3.75), 3)])
+def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal, shard_mix, transport):
     import torch.multiprocessing as mp
     delta = golden["g9_push_delta"]
     delta = np.concatenate([delta, delta[::-1] * 0.7]).astype(np.float32)
@@ -85,8 +86,8 @@ def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal, t
     ref = run(pl, sim, delta)
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 29700 + (os.getpid() % 1500) + (7 if transport == "p2p" else 0)
-    procs = [ctx.Process(target=worker, args=(r, 2, port, multi_modal, task, goal, ret, transport)) for r in range(2)]
+    port = 29700 + (os.getpid() % 1500) + (7 if transport == "p2p" else 0) + (13 if shard_mix == 3 else 0)
+    procs = [ctx.Process(target=worker, args=(r, 2, port, multi_modal, task, goal, ret, transport, shard_mix)) for r in range(2)]
     for p in procs:
         p.start()
     got = ret.get(timeout=300)
@@ -96,7 +97,7 @@ def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal, t
     for c, (a, b) in enumerate(zip(ref, got)):
         # single-mode runs the one-collective protocol (planner.shard_mix): a rank materialises only
         # its own shard's weights, and the plan equals the unsharded one up to f32 rounding
-        nw = K if multi_modal else K // 2
+        nw = K if (multi_modal and shard_mix != 3) else K // 2     # (shard_mix = 3 too: the rank's own samples' weights)
         np.testing.assert_allclose(a["action"], b["action"], atol=3e-5, err_msg=f"call {c}")
         np.testing.assert_allclose(a["weights"][:nw], b["weights"][:nw], rtol=1e-3, atol=1e-8)
         np.testing.assert_allclose(a["top"], b["top"], atol=1e-4)

@@ -45,13 +45,15 @@ def loop(pl, state, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def emulate_rank(name, N, steps):
+def emulate_rank(name, N, steps, K_override=None):
     """rank 0 of N on one GPU (see module docstring)."""
     from m3p2i_aip_amd import _lib as L
     env, task, goal, mm, K, T = bench.CONFIGS[name]
+    K = K_override or K
     res = {}
     only = os.environ.get("M3P2I_EMUL_PROTOCOLS")      # (profiling runs: one protocol at a time)
-    for label, mix in (("one_collective", None), ("one_collective_p2p", None), ("one_collective_exact", 1), ("gather_reduce", False)):
+    for label, mix in (("one_collective", None), ("one_collective_p2p", None), ("one_collective_exact", 1), ("gather_reduce", False),
+                       ("two_small_exchanges", 3)):
         if only and label not in only.split(","):
             continue
         p2p = label.endswith("_p2p")
@@ -73,6 +75,8 @@ def emulate_rank(name, N, steps):
         def exchange(p, phase, e=e, K=K):
             if phase == "records":
                 dist.all_gather_into_tensor(e.buffer(L.BUF_RECORDS_ALL)[0], e.buffer(L.BUF_RECORD))
+            elif phase == "records_b":
+                dist.all_gather_into_tensor(e.buffer(L.BUF_RECORDS_B_ALL)[0], e.buffer(L.BUF_RECORD_B))
             elif phase == "gather":
                 dist.all_gather_into_tensor(e.buffer(L.BUF_TRAJ_COST_ALL)[:K], e.buffer(L.BUF_TRAJ_COST))
             else:
@@ -133,6 +137,12 @@ def emulate_rank(name, N, steps):
                     tab[:, 1] = 0.0
                     R[r, om + 2] = R[r, om + 1]
                     R[r, om + 1] = float("inf")
+            if mix == 3:   # second records of the other ranks: copies of rank 0's with their own (never winning) best keys
+                RB = e.buffer(L.BUF_RECORDS_B_ALL)
+                for r in range(1, N):
+                    RB[r].copy_(RB[0])
+                    RB[r, 0:6:2] += 0.5          # -w of the best samples: worse than rank 0's
+                    RB[r, 6:] = 0.0              # no weight on the other ranks' samples (the plan follows rank 0's)
             for r, q in enumerate(peers, start=1):
                 q.buffer(L.BUF_RECORD).copy_(R[r])
             torch.cuda.synchronize()
@@ -178,6 +188,8 @@ def main():
     ap.add_argument("--config", default="c5")
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--samples-per-gpu", type=int, default=None, help="K per rank of the emulation (default: the config's)")
+    ap.add_argument("--only-emulation", action="store_true")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29534")
@@ -185,6 +197,15 @@ def main():
     from m3p2i_aip_amd.distributed import attach_collectives
     env, task, goal, mm, K, T = bench.CONFIGS[a.config]
     out = {"config": a.config, "K": K, "T": T, "multi_modal": mm, "steps": a.steps, "backend": "nccl (RCCL), world_size 1"}
+    if a.only_emulation:
+        out["K"] = a.samples_per_gpu or K
+        out[f"rank0_of_{a.emulate_rank_of}"] = emulate_rank(a.config, a.emulate_rank_of, a.steps, a.samples_per_gpu)
+        print(json.dumps(out))
+        if a.json:
+            os.makedirs(os.path.dirname(a.json) or ".", exist_ok=True)
+            json.dump(out, open(a.json, "w"), indent=1)
+        dist.destroy_process_group()
+        return
     pl, sim, obj, cfg = bench.build_tamp(env, task, goal, mm, K, 0, 1, T, "cuda:0")
     state = sim._dof_state[0]
     out["fused_ms"] = loop(pl, state, a.steps)
@@ -221,7 +242,7 @@ def main():
     torch.cuda.synchronize()
     out["host_call_us"] = {"all_gather_into_tensor": (t1 - t0) / 200 * 1e6, "all_reduce": (t3 - t2) / 200 * 1e6}
     if a.emulate_rank_of > 1:
-        out[f"rank0_of_{a.emulate_rank_of}"] = emulate_rank(a.config, a.emulate_rank_of, a.steps)
+        out[f"rank0_of_{a.emulate_rank_of}"] = emulate_rank(a.config, a.emulate_rank_of, a.steps, a.samples_per_gpu)
     print(json.dumps(out))
     if a.json:
         os.makedirs(os.path.dirname(a.json) or ".", exist_ok=True)
