@@ -327,6 +327,7 @@ def closed_loop(r, ticks, device):
     from m3p2i_aip_amd.compat import check_and_apply_suction
     pl, sim, cfg = r["pl"], r["sim"], r["cfg"]
     real = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=1, device=device)
+    real.zero_copy_targets = True     # the action slot handed over below is not touched again before step()
     nu = real.dofs_per_robot
     point = cfg.env_type == "point_env"
     pull = cfg.task in ("pull", "push_pull")

@@ -384,12 +384,20 @@ class HipEngine:
     def sim_push_state(self):
         self._ck(self.lib.m3_sim_push_state(self._h))
 
-    def sim_set_velocity_target(self, u):
-        """The targets are handed to the next sim_step() (one launch instead of a copy + a step); the tensor is
-        kept alive until then, and an in-place change of it in between -- which a copy at this point would not
-        have seen -- is refused there."""
+    def sim_set_velocity_target(self, u, zero_copy=False):
+        """Velocity targets for the next sim_step().  Default: COPIED at this point into an engine-owned tensor (one
+        small device copy on the stream) -- Isaac Gym's set_dof_velocity_target_tensor semantics: what the caller does
+        with `u` afterwards does not matter.  zero_copy=True (the closed-loop tools, which own their tensors): the
+        pointer is handed to the step kernel instead (one launch less per tick); the caller must leave the tensor alone
+        until step() -- an in-place torch op in between is detected and refused there, a write by another library
+        call (e.g. the planner's action ring being rewritten eight commands later) is not."""
         u = u.to(torch.float32).contiguous()
         assert u.is_cuda and tuple(u.shape) == (self.cfg.K_local, self.cfg.nu), u.shape
+        if not zero_copy:
+            if getattr(self, "_u_target", None) is None:
+                self._u_target = torch.empty(self.cfg.K_local, self.cfg.nu, device=self.device, dtype=torch.float32)
+            self._u_target.copy_(u)
+            u = self._u_target
         self._pending_u = (u, u._version)
 
     def sim_apply_body_forces(self, f):
@@ -403,7 +411,7 @@ class HipEngine:
             self._ck(self.lib.m3_sim_step(self._h))      # the targets of the last set call stay in force
             return
         u, version = pending
-        self._pending_u = None
+        self._pending_u = None      # (cleared on every path: a failed step must not leave a stale target behind)
         if u._version != version:
             raise RuntimeError("the velocity-target tensor was modified in place between "
                                "set_dof_velocity_target_tensor() and step(): pass a clone")

@@ -185,8 +185,12 @@ class IsaacGymWrapper:
         self._adopt(self._root_state, u)
         self._engine.sim_pull_state()
 
+    # True: set_dof_velocity_target_tensor hands the caller's tensor to the next step() instead of copying it (the
+    # closed-loop tools, which own their tensors; see HipEngine.sim_set_velocity_target)
+    zero_copy_targets = False
+
     def set_dof_velocity_target_tensor(self, u):
-        self._engine.sim_set_velocity_target(u.reshape(self.num_envs, self.dofs_per_robot))
+        self._engine.sim_set_velocity_target(u.reshape(self.num_envs, self.dofs_per_robot), zero_copy=self.zero_copy_targets)
 
     def set_dof_actuation_force_tensor(self, u):
         raise NotImplementedError("effort mode is not used by the planner path "

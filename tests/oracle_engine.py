@@ -48,6 +48,11 @@ class OracleEngine:
         if self.mix:
             self.np[L.BUF_RECORD] = np.zeros(self.RL, f)
             self.np[L.BUF_RECORDS_ALL] = np.zeros((Kg // Kl, self.RL), f)
+        self.p3 = self.regen and int(c.shard_mix) == 3     # two small exchanges (m3_update_b in between)
+        if self.p3:
+            self.RLB = (8 + 6 * T * nu + 3) // 4 * 4        # record B: m3_internal.hpp recb_length
+            self.np[L.BUF_RECORD_B] = np.zeros(self.RLB, f)
+            self.np[L.BUF_RECORDS_B_ALL] = np.zeros((Kg // Kl, self.RLB), f)
         self.t = {k: _t(v) for k, v in self.np.items()}
         self.sc = O.default_scene()
         self.device = torch.device("cpu")
@@ -247,6 +252,57 @@ class OracleEngine:
             top[slot] = rec[Kl + 2 * L.TOPK:Kl + 2 * L.TOPK + L.TOPK * T * 2].reshape(L.TOPK, T, 2)[q]
         self._info = info
 
+    def update_b(self):
+        """shard_mix = 3 between the two exchanges: the searches on all gathered costs (the library walks the mixture
+        of the shards' ladder tables: the same decisions), then the weights and the weighted action sums of THIS rank's
+        own samples and its best rows into its second record."""
+        assert self.p3
+        cfg = self._ocfg()
+        n, T, nu, Kl, Kg, k0 = self.np, self.T, self.nu, self.Kl, self.Kg, self.k0
+        J = np.ascontiguousarray(n[L.BUF_RECORDS_ALL][:, :Kl].reshape(-1))
+        w, w1, w2, info = O.update_weights(cfg, J, self.beta)
+        n[L.BUF_WEIGHTS][...], n[L.BUF_WEIGHTS_1][...], n[L.BUF_WEIGHTS_2][...] = w, w1, w2
+        actions = np.ascontiguousarray(n[L.BUF_ACTIONS].transpose(1, 0, 2))
+        rb = n[L.BUF_RECORD_B]
+        rb[...] = 0
+        rb[8:8 + 3 * T * nu] = O.partial_sums(cfg, w, w1, w2, actions, k0, k0 + Kl).reshape(-1)
+        h = Kg // 2
+        sets = [(w, 0, Kg, 0), (w1, 0, h, 0), (w2, h, Kg, h)]          # (weights, first / last global index, offset)
+        for i, (ws, lo, hi, off) in enumerate(sets):
+            a, b = max(lo, k0), min(hi, k0 + Kl)
+            rb[2 * i], rb[2 * i + 1] = np.inf, -1.0
+            if a < b:
+                loc = ws[a - off:b - off]
+                g = a + int(np.argmax(loc))                              # first maximum, as the unsharded argmax
+                rb[2 * i], rb[2 * i + 1] = -loc[g - a], float(g)
+                rb[8 + (3 + i) * T * nu:8 + (4 + i) * T * nu] = actions[g - k0].reshape(-1)
+        rb[6], rb[7] = w[max(0, k0):min(h, k0 + Kl)].sum(dtype=np.float32) if k0 < h else 0.0, \
+            w[max(h, k0):k0 + Kl].sum(dtype=np.float32) if k0 + Kl > h else 0.0
+        self._info = info
+
+    def _finalize_p3(self):
+        n, T, nu, Kl, Kg = self.np, self.T, self.nu, self.Kl, self.Kg
+        RB, R = n[L.BUF_RECORDS_B_ALL], n[L.BUF_RECORDS_ALL]
+        red = n[L.BUF_REDUCE]
+        red[...] = 0
+        acc = np.zeros(3 * T * nu, np.float32)
+        for r in range(RB.shape[0]):                                     # rank order
+            acc = (acc + RB[r, 8:8 + 3 * T * nu]).astype(np.float32)
+        red[:3 * T * nu] = acc
+        for i in range(3):
+            keys = [(RB[r, 2 * i], int(RB[r, 2 * i + 1]), r) for r in range(RB.shape[0]) if RB[r, 2 * i + 1] >= 0]
+            win = min(keys)[2]
+            red[(3 + i) * T * nu:(4 + i) * T * nu] = RB[win, 8 + (3 + i) * T * nu:8 + (4 + i) * T * nu]
+        J = np.ascontiguousarray(R[:, :Kl].reshape(-1))
+        order = np.lexsort((np.arange(Kg), J))[:L.TOPK]
+        n[L.BUF_TOP_IDX][...] = order
+        top = red[6 * T * nu:].reshape(L.TOPK, T, 2)
+        for slot, g in enumerate(order):
+            rec = R[g // Kl]
+            ids = rec[Kl + L.TOPK:Kl + 2 * L.TOPK].copy().view(np.int32)
+            q = int(np.nonzero(ids == g)[0][0])
+            top[slot] = rec[Kl + 2 * L.TOPK:Kl + 2 * L.TOPK + L.TOPK * T * 2].reshape(L.TOPK, T, 2)[q]
+
     def update(self):
         if self.regen:
             return self._update_regen()
@@ -280,7 +336,9 @@ class OracleEngine:
         self._info = info
 
     def finalize(self):
-        if self.regen:
+        if self.p3:
+            self._finalize_p3()
+        elif self.regen:
             self._finalize_regen()
         if self.mix:
             self._finalize_mix()

@@ -170,13 +170,24 @@ def test_wrapper_getters_and_step(oracle):
         sim.step()
         oracle.step_batch(sc, worlds, u)
     np.testing.assert_array_equal(sim.robot_pos.cpu().numpy(), worlds[:, 0:2])
-    # ... and the hand-over of the target tensor to step() (one launch for both) refuses a tensor that was changed
-    # in place in between -- a copy at set time would not have seen the change
+    # ... they are COPIED at set time (Isaac Gym's semantics): what happens to the caller's tensor afterwards does not matter
+    t = torch.from_numpy(u).cuda()
+    sim.set_dof_velocity_target_tensor(t)
+    t.mul_(0.0)
+    sim.step()
+    oracle.step_batch(sc, worlds, u)
+    np.testing.assert_array_equal(sim.robot_pos.cpu().numpy(), worlds[:, 0:2])
+    # ... unless the caller opts in to the zero-copy hand-over (the closed-loop tools: one launch less per tick), which
+    # refuses a tensor that was changed in place before step()
+    sim.zero_copy_targets = True
     t = torch.from_numpy(u).cuda()
     sim.set_dof_velocity_target_tensor(t)
     t.mul_(0.5)
     with pytest.raises(RuntimeError, match="modified in place"):
         sim.step()
+    sim.step()       # (the refused target is gone: the last accepted one stays in force, no stale pointer)
+    oracle.step_batch(sc, worlds, u)
+    np.testing.assert_array_equal(sim.robot_pos.cpu().numpy(), worlds[:, 0:2])
 
 
 def test_update_dyn_obs_walks_the_obstacle_like_the_reference(oracle):

@@ -26,6 +26,8 @@ CASES = {
     "hybrid": dict(task="push_pull", goal=(-3.75, -3.75), multi_modal=True, shard_mix=None),
     # multi-modal on the two-collective protocol (all-gather J + all-reduce)
     "hybrid_exact": dict(task="push_pull", goal=(-3.75, -3.75), multi_modal=True, shard_mix=False),
+    # multi-modal, two small exchanges with O(K_local) work per rank in between (shard_mix = 3)
+    "hybrid_p3": dict(task="push_pull", goal=(-3.75, -3.75), multi_modal=True, shard_mix=3),
 }
 
 
@@ -77,7 +79,7 @@ def worker(rank, world, port, case, ret):
     delta = np.load(os.path.join(ROOT, "tests", "golden", "ref_golden.npz"))["g9_push_delta"]
     pl, sim = make_planner(case, rank, world, delta)
     attach_collectives(pl)
-    assert pl.shard_mix == (case in ("push", "hybrid"))
+    assert pl.shard_mix == (case in ("push", "hybrid", "hybrid_p3"))
     pl.collective_calls = 0
     inner = pl.collective
 
@@ -86,7 +88,7 @@ def worker(rank, world, port, case, ret):
         inner(p, phase)
     pl.collective = counting
     outs = run_calls(pl, sim)
-    assert pl.collective_calls == len(outs) * (1 if pl.shard_mix else 2)   # collectives per command()
+    assert pl.collective_calls == len(outs) * (1 if (pl.shard_mix and case != "hybrid_p3") else 2)   # collectives per command()
     if rank == 0:
         ret.put(outs)
     # every rank must hold the same plan
@@ -119,7 +121,7 @@ def test_two_rank_sharded_command_equals_single_process(case, golden):
         # plan, which later calls inherit through the warm start
         # one-collective protocol: only the rank's own weights are materialised, and the mixture
         # exp(-(m_r - m)/beta) * local softmin equals the global softmin up to f32 rounding
-        nw = K // 2 if case == "push" else K
+        nw = K // 2 if case in ("push", "hybrid_p3") else K
         tol = 1e-5 if case == "push" else 2e-6
         np.testing.assert_allclose(a["weights"][:nw], b["weights"][:nw], rtol=1e-4, atol=1e-9, err_msg=f"call {c}")
         np.testing.assert_allclose(a["action"], b["action"], atol=tol, err_msg=f"call {c}")

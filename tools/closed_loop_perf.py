@@ -17,6 +17,7 @@ for name, (base, task_o, goal_o) in CASES.items():
     task, goal = task_o or task, goal_o or goal
     pl, sim, obj, cfg = bench.build_tamp(env, task, goal, mm, K, 0, 1, T, "cuda:0")
     real = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=1, device="cuda:0")
+    real.zero_copy_targets = True
     pl.attach(sim=real)
     pull = task in ("pull", "push_pull")
     goal_t = torch.tensor(goal, device="cuda:0")
