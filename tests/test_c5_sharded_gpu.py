@@ -78,6 +78,22 @@ def _compare(L, full, shards, call, atol, bitwise_ranks=True, exact_rollouts=Fal
     return fi
 
 
+def _exchange_and_finalize(L, shards, level):
+    """the collective(s) of the one-collective protocols (levels 1, 2) / of shard_mix = 3, done by hand"""
+    allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])
+    for e in shards:
+        e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
+        if level == 3:
+            e.update_b()
+        else:
+            e.finalize()
+    if level == 3:
+        allb = torch.stack([e.buffer(L.BUF_RECORD_B) for e in shards])
+        for e in shards:
+            e.buffer(L.BUF_RECORDS_B_ALL).copy_(allb)
+            e.finalize()
+
+
 def test_c5_gather_reduce_protocol_8x8000_equals_unsharded():
     from m3p2i_aip_amd import _lib as L
     delta = _noise()
@@ -273,7 +289,7 @@ def test_one_collective_shard_needs_the_global_noise_table():
     e.close()
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_one_collective_shards_with_the_built_in_sampler_and_relabelling(level):
     """The planner's own path: Halton knots of ALL samples on every rank, spline fits on the device, samples
     relabelled into wavefront order (m3_relabel_samples).  Every rank relabels every shard's block itself --
@@ -302,16 +318,13 @@ def test_one_collective_shards_with_the_built_in_sampler_and_relabelling(level):
         for e in shards:
             e.rollout()
             e.update()
-        allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])
-        for e in shards:
-            e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
-            e.finalize()
+        _exchange_and_finalize(L, shards, level)
         torch.cuda.synchronize()
         tables = [e.buffer(L.BUF_NOISE_ALL) for e in shards]
         for r, e in enumerate(shards):
             assert torch.equal(tables[r], tables[0]), f"call {call}: rank {r} holds another noise table than rank 0"
             assert torch.equal(e.buffer(L.BUF_NOISE), tables[0][r])          # its own block of it
-            for name in PLAN_BUFS + ("BUF_WEIGHTS", "BUF_TOP_IDX"):
+            for name in PLAN_BUFS + (("BUF_WEIGHTS",) if level != 3 else ()) + ("BUF_TOP_IDX",):   # (level 3: own weights only)
                 b = getattr(L, name)
                 assert torch.equal(e.buffer(b), shards[0].buffer(b)), f"call {call}: ranks disagree on {name}"
             np.testing.assert_allclose(e.buffer(L.BUF_ACTION_OUT).cpu().numpy(), full.buffer(L.BUF_ACTION_OUT).cpu().numpy(),
@@ -326,7 +339,7 @@ def test_one_collective_shards_with_the_built_in_sampler_and_relabelling(level):
         e.close()
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_one_collective_protocol_panda_multi_modal(level):
     """The re-generated actions of the panda_env (nine controls, gripper override mppi.py:412-416, best rows at
     k = 0 and K/2): two shard handles of a multi-modal reach vs the unsharded handle."""
@@ -349,10 +362,7 @@ def test_one_collective_protocol_panda_multi_modal(level):
         for e in shards:
             e.rollout()
             e.update()
-        allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])
-        for e in shards:
-            e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
-            e.finalize()
+        _exchange_and_finalize(L, shards, level)      # (level 3: k_p3_done<9>, nine-column sums from the own action buffer)
         torch.cuda.synchronize()
         fi = full.info()
         for r, e in enumerate(shards):
@@ -370,9 +380,10 @@ def test_one_collective_protocol_panda_multi_modal(level):
         e.close()
 
 
+@pytest.mark.parametrize("level", [2, 3])
 @pytest.mark.parametrize("scale", [1e-5, 1.0, 1e8])
 @pytest.mark.parametrize("Kt,Nt", [(16384, 4), (2048, 2)])
-def test_one_collective_fast_protocol_on_synthetic_costs(Kt, Nt, scale):
+def test_one_collective_fast_protocol_on_synthetic_costs(Kt, Nt, scale, level):
     """shard_mix = 2 with cost spreads of 1e-5 and 1e+8, which drive the beta searches (m3p2i.py:24-64) far beyond the
     shards' precomputed ladder tables: every workgroup of k_regen_part then continues with passes over the gathered
     costs (search_body's fallback), and all of them -- and all ranks -- must arrive at the same beta / eta / weights
@@ -382,7 +393,7 @@ def test_one_collective_fast_protocol_on_synthetic_costs(Kt, Nt, scale):
     from tests.test_update_on_synthetic_costs_gpu import search
     kl, Ts = Kt // Nt, 12
     kw = dict(T=Ts, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
-    shards = [HipEngine(make_config(K=Kt, K_local=kl, k_offset=r * kl, shard_mix=2, **kw)) for r in range(Nt)]
+    shards = [HipEngine(make_config(K=Kt, K_local=kl, k_offset=r * kl, shard_mix=level, **kw)) for r in range(Nt)]
     rng = np.random.default_rng(int(Kt + np.log10(scale) * 7))
     J = (scale * np.abs(rng.standard_normal(Kt))).astype(np.float32)
     delta = rng.standard_normal((Kt, Ts, 2)).astype(np.float32)
@@ -392,13 +403,16 @@ def test_one_collective_fast_protocol_on_synthetic_costs(Kt, Nt, scale):
         e.rollout()                                              # (fills states / actions; its costs are replaced)
         e.buffer(L.BUF_TRAJ_COST).copy_(torch.from_numpy(J[r * kl:(r + 1) * kl]))
         e.update()
-    allrec = torch.stack([e.buffer(L.BUF_RECORD) for e in shards])
-    for e in shards:
-        e.buffer(L.BUF_RECORDS_ALL).copy_(allrec)
-        e.finalize()
+    _exchange_and_finalize(L, shards, level)     # (level 3: the search's fallback passes run in k_search, over the gathered costs)
     torch.cuda.synchronize()
     half = Kt // 2
     info = shards[0].info()
+    if level == 3:     # a rank materialises its own samples' weights: assemble the full vectors from the ranks' slices
+        for buf, lo_of in ((L.BUF_WEIGHTS, lambda r: (r * kl, (r + 1) * kl)), (L.BUF_WEIGHTS_1, lambda r: (min(r * kl, half), min((r + 1) * kl, half))),
+                           (L.BUF_WEIGHTS_2, lambda r: (max(r * kl - half, 0), max((r + 1) * kl - half, 0)))):
+            for r, e in enumerate(shards[1:], start=1):
+                lo, hi = lo_of(r)
+                shards[0].buffer(buf)[lo:hi].copy_(e.buffer(buf)[lo:hi])
     for buf, JJ, eta, iters in ((L.BUF_WEIGHTS, J, info.eta, info.iters), (L.BUF_WEIGHTS_1, J[:half], info.eta_1, info.iters_1),
                                 (L.BUF_WEIGHTS_2, J[half:], info.eta_2, info.iters_2)):
         w_ref, eta_ref, beta_ref, it_ref = search(JJ)
@@ -408,7 +422,7 @@ def test_one_collective_fast_protocol_on_synthetic_costs(Kt, Nt, scale):
     if scale != 1.0:     # beyond the 0.9-ladder (64 points) / the 1.2-ladder (32 points): the fallback passes ran
         assert info.iters > (65 if scale < 1.0 else 34), info.iters
     for e in shards[1:]:
-        for name in PLAN_BUFS + ("BUF_WEIGHTS", "BUF_WEIGHTS_1", "BUF_WEIGHTS_2", "BUF_TOP_IDX"):
+        for name in PLAN_BUFS + (("BUF_WEIGHTS", "BUF_WEIGHTS_1", "BUF_WEIGHTS_2") if level != 3 else ()) + ("BUF_TOP_IDX",):
             assert torch.equal(e.buffer(getattr(L, name)), shards[0].buffer(getattr(L, name))), name
     for e in shards:
         e.close()
