@@ -72,6 +72,9 @@ CONFIGS = {
     "c5_unsharded": ("point_env", "push_pull", (-3.75, -3.75), True, 64000, 30),   # ALL of C5 on one GPU
     "worst_case": ("point_env", "push", (-1.0, -1.0), False, 2000, 30),            # C2 in the corner scene below
     "push_sat": ("point_env", "push", (-1.0, -1.0), False, 131072, 30),            # saturating per-GPU size
+    # the reference's SHIPPED planner size (config/mppi/point.yaml: 200 samples, horizon 15) on the scenario of its logged
+    # runs (push to (-3, 3)): the only size its published planner rates (21.2 Hz) can have been taken at
+    "refsize": ("point_env", "push", (-3.0, 3.0), False, 200, 15),
 }
 # per-GPU sample count fixed as N grows for every workload of this file (K_global = K_local * N)
 SCALING = "weak"
@@ -533,7 +536,7 @@ def main():
         for oname, key, scene in (("northstar", "northstar", None), ("hybrid", "hybrid", None), ("panda", "panda", None),
                                   ("panda_pick", "panda_pick", pick_scene), ("c5", "c5shard", None),
                                   ("c5_unsharded", "c5_unsharded", None), ("worst_case", "worst_case_scene", corner_scene),
-                                  ("c1", "c1", None)):
+                                  ("c1", "c1", None), ("refsize", "reference_default_size", None)):
             if oname == name or (oname == "panda_pick" and pick_scene is None):
                 continue
             try:
@@ -548,6 +551,9 @@ def main():
                 if oname == "worst_case":
                     others[key]["workload"] += (" -- robot, box and dyn-obs packed into the wall corner (open loop from that "
                                                 "scene): the all-contact-slots substep instance")
+                if oname == "refsize":
+                    others[key]["workload"] += (" -- the reference's shipped planner size; its own logged planner rate for this "
+                                                "scenario is 21.2 Hz (BASELINE.md: Isaac Gym, hardware / K / T of the runs not recorded)")
                 if oname == "c5_unsharded":
                     others[key]["workload"] += " -- ALL of BASELINE configs[4] on ONE GPU (the denominator of any sharding claim)"
                 ro["pl"]._engine.close()
