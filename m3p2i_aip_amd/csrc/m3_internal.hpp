@@ -193,6 +193,10 @@ void launch_p3_done(const UpdateArgs& a, hipStream_t s);            // after the
 int init_ladder_table();   // update.hip: the beta ladder into constant memory (per device context)
 int regen_chunks(int Kg);   // workgroups per time step of k_regen_part
 int rollout_lanes_for(int Kl);
+// MI355X: 256 CUs x 4 SIMDs.  A rollout launch with more wavefronts than that is throughput-bound: the point_env
+// kernels then run in their two-waves-per-SIMD build (rollout_point_kernel.hpp)
+constexpr int M3_SIMDS = 1024;
+inline bool rollout_two_waves(int wavefronts) { return wavefronts > M3_SIMDS; }
 int mins_workgroups(int Kg);
 int topk_workgroups(int Kg);
 int ladder_workgroups(int Kg);

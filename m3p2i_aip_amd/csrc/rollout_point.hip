@@ -25,7 +25,7 @@ void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_
     const bool general = a.sampling_random || a.mode_simple || a.cp.task < 0 || a.cp.task > 3 ||
                          (a.cp.task == 3 && !a.multi_modal) || a.scale_dev != nullptr /* update_cov */;
 #endif
-    if (general) { hipLaunchKernelGGL((k_rollout_point<true, -1>), dim3(blocks), dim3(64), 0, s, a, sc); return; }
+    if (general) { launch_rollout_point_instance<true, -1>(a, sc, blocks, s); return; }
     switch (a.cp.task) {   // the reference's default sampler: one instance per task (rollout_point_task*.hip)
         case 0: launch_rollout_point_nav(a, sc, blocks, s); break;
         case 1: launch_rollout_point_push(a, sc, blocks, s); break;

@@ -55,7 +55,7 @@ __device__ __forceinline__ void load_world_from_sim(const float* dof, const floa
 // it disappear from the instance.  Measured at C2: one kernel for everything 0.1555 ms per command, sampler
 // mode compiled in 0.1530, task compiled in as well 0.143 (same results bit for bit: only which code exists).
 template <bool GENERAL, int TASK>
-__global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a_, const PointScene sc) {
+__device__ __forceinline__ void rollout_point_body(const RolloutArgs& a_, const PointScene& sc) {
     RolloutArgs a = a_;
     if constexpr (!GENERAL) {
         a.sampling_random = 0; a.mode_simple = 0;
@@ -185,6 +185,28 @@ __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a_, cons
     a.J[i] = a.mode_simple ? (S + pc) : J;
     a.pend[0 * Kl + i] = w.fRx; a.pend[1 * Kl + i] = w.fRy;
     a.pend[2 * Kl + i] = w.fBx; a.pend[3 * Kl + i] = w.fBy;
+}
+
+// Two builds of every instance.  k_rollout_point: no register limit -- 340 VGPRs (256 + 84 AGPR), ONE resident wave
+// per SIMD: the fastest build while the launch has no more wavefronts than the chip has SIMDs (K_local <= 65536:
+// every BASELINE config).  k_rollout_point_occ2: `amdgpu_waves_per_eu(2, 2)` -- 256 VGPRs, ~175 values spilled to
+// scratch, TWO resident waves per SIMD whose instruction streams interleave: 2-3 % slower below 65536 samples, but
+// K = 131072: 0.245 -> 0.181 ms, 1 M: 1.83 -> 1.21 ms (saturation 13.9 -> 19.0 G state-steps/s; three or four waves
+// per SIMD: 0.197 / 0.205 ms at 131072, another +4 % only at 1 M).  The host picks by the number of wavefronts
+// (rollout_two_waves).  Same arithmetic, same bits.
+template <bool GENERAL, int TASK>
+__global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const PointScene sc) {
+    rollout_point_body<GENERAL, TASK>(a, sc);
+}
+template <bool GENERAL, int TASK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rollout_point_occ2(const RolloutArgs a,
+                                                                                                      const PointScene sc) {
+    rollout_point_body<GENERAL, TASK>(a, sc);
+}
+template <bool GENERAL, int TASK>
+inline void launch_rollout_point_instance(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s) {
+    if (rollout_two_waves(blocks)) hipLaunchKernelGGL((k_rollout_point_occ2<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a, sc);
+    else hipLaunchKernelGGL((k_rollout_point<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a, sc);
 }
 
 

@@ -5,7 +5,7 @@
 namespace m3 {
 
 void launch_rollout_point_pushpull(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s) {
-    hipLaunchKernelGGL((k_rollout_point<false, 3>), dim3(blocks), dim3(64), 0, s, a, sc);
+    launch_rollout_point_instance<false, 3>(a, sc, blocks, s);
 }
 
 }  // namespace m3
