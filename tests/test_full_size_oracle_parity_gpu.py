@@ -21,6 +21,10 @@ POINT = {
     "northstar_push_K10000": dict(K=10000, task="push", goal=(-1.0, -1.0), mm=False),
     "C5shard_hybrid_K8000": dict(K=8000, task="push_pull", goal=(-3.75, -3.75), mm=True),
     "C5_hybrid_K64000": dict(K=64000, task="push_pull", goal=(-3.75, -3.75), mm=True),
+    # more wavefronts (1094) than the chip has SIMDs (1024): the two-waves-per-SIMD build of the rollout kernel
+    # (k_rollout_point_occ2: 256 VGPRs, ~175 values in scratch) -- same bits as the oracle
+    "occ2_push_K70016": dict(K=70016, task="push", goal=(-1.0, -1.0), mm=False),
+    "occ2_hybrid_K70016": dict(K=70016, task="push_pull", goal=(-3.75, -3.75), mm=True),
 }
 
 
