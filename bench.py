@@ -273,14 +273,18 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
         coll_ms["total"] = float(sum(coll_ms.values()))
         coll_ms["per_command"] = len(pl.collective_times) / n_cmd
     pl.collective_times = None
+    import gc
     walls = []
     for _ in range(repeats):     # (the headline: exactly once; `other_configs` rows: the better of two timed regions,
-        sync()                   #  both reported -- a one-off host hiccup has been seen to quadruple a 40 ms region)
+        gc.collect()             #  both reported -- a one-off host hiccup of ~65 ms has been seen inside a 40 ms region;
+        gc.disable()             #  the collector is kept out of the region)
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             pl.command(state)
         sync()
         walls.append(time.perf_counter() - t0)
+        gc.enable()
     wall = min(walls)
     if dist is not None:
         tw = torch.tensor([wall], device=device, dtype=torch.float64)

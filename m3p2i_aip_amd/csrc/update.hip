@@ -1264,7 +1264,11 @@ __device__ __forceinline__ void regen_action(const UpdateArgs& a, const RegenRow
         e[j] = uj;   // mppi.py:313
     }
 }
-template <int NU, bool REGEN>
+// MULTI (compile time: the three weight sets of the multi-modal update): as a run-time flag the wave-uniform
+// `if (multi)` around the two extra weight loads made every sample of the unrolled batch its own basic block ending in
+// `s_waitcnt vmcnt(0)` -- EIGHT serialised memory round trips per batch instead of one (round 3, found in the ISA:
+// k_wsum 19.8 us at K = 64000 multi-modal, 361 us at K = 1 M single-mode).
+template <int NU, bool REGEN, bool MULTI>
 __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
     __shared__ float red[3 * 16];
     const int tid = threadIdx.x, C = a.n_chunk;
@@ -1274,7 +1278,6 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         return;
     }
     const int t = blockIdx.x / C, c = blockIdx.x % C;
-    const bool multi = a.multi_modal && !a.mode_simple;
     const float* act = a.actions + (size_t)t * Kl * NU;
     float acc[3][NU];
 #pragma unroll
@@ -1317,7 +1320,7 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
         }
         float w = a.w[k];
         float wa = 0.0f, wb = 0.0f;
-        if (multi) {  // wave-uniform
+        if constexpr (MULTI) {
             const float x1 = a.w1[min(k, max(half - 1, 0))];
             const float x2 = a.w2[min(max(k - half, 0), nh2 - 1)];
             wa = (k < half) ? x1 : 0.0f;
@@ -1430,13 +1433,19 @@ __global__ __launch_bounds__(ST) void k_wsum(const UpdateArgs a) {
 void launch_wsum(const UpdateArgs& a, hipStream_t s) {
     const dim3 grid(a.T * a.n_chunk + (a.n_cand > 1 ? 1 : 0));
     const size_t lds = a.fuse_finalize ? (size_t)a.T * a.nu * sizeof(float) : 0;
+    const bool multi = a.multi_modal && !a.mode_simple;
     if (a.regen) {
-        if (a.nu == 2) hipLaunchKernelGGL((k_wsum<2, true>), grid, dim3(ST), lds, s, a);
-        else hipLaunchKernelGGL((k_wsum<9, true>), grid, dim3(ST), lds, s, a);
+        if (a.nu == 2) hipLaunchKernelGGL((k_wsum<2, true, true>), grid, dim3(ST), lds, s, a);     // (regen is a multi-modal protocol)
+        else hipLaunchKernelGGL((k_wsum<9, true, true>), grid, dim3(ST), lds, s, a);
         return;
     }
-    if (a.nu == 2) hipLaunchKernelGGL((k_wsum<2, false>), grid, dim3(ST), lds, s, a);
-    else hipLaunchKernelGGL((k_wsum<9, false>), grid, dim3(ST), lds, s, a);
+    if (a.nu == 2) {
+        if (multi) hipLaunchKernelGGL((k_wsum<2, false, true>), grid, dim3(ST), lds, s, a);
+        else hipLaunchKernelGGL((k_wsum<2, false, false>), grid, dim3(ST), lds, s, a);
+    } else {
+        if (multi) hipLaunchKernelGGL((k_wsum<9, false, true>), grid, dim3(ST), lds, s, a);
+        else hipLaunchKernelGGL((k_wsum<9, false, false>), grid, dim3(ST), lds, s, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
