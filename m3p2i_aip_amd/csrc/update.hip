@@ -1210,7 +1210,10 @@ constexpr int WS_BATCH = 8;     // loads in flight per thread and array
 // arrival tickets share one address per time step and serialise (~0.3 us each)
 __host__ __device__ inline int wsum_chunk_len(int Kl) {
     const int unit = 2048;   // WS_BATCH * ST
-    const int per32 = (((Kl + 31) / 32) + unit - 1) / unit * unit;
+#ifndef M3_WSUM_MAX_CHUNKS
+#define M3_WSUM_MAX_CHUNKS 32
+#endif
+    const int per32 = (((Kl + M3_WSUM_MAX_CHUNKS - 1) / M3_WSUM_MAX_CHUNKS) + unit - 1) / unit * unit;
 #ifndef M3_WSUM_MIN_CHUNK
 #define M3_WSUM_MIN_CHUNK 8192
 #endif
