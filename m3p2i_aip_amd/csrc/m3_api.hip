@@ -1221,14 +1221,22 @@ extern "C" int m3_p2p_wait_ch(m3_handle* h, int ch) {
 
 extern "C" int m3_p2p_put(m3_handle* h) { return m3_p2p_put_ch(h, 0); }
 extern "C" int m3_p2p_wait(m3_handle* h) { return m3_p2p_wait_ch(h, 0); }
-extern "C" int m3_p2p_exchange(m3_handle* h) {
-    const int rc = m3_p2p_put_ch(h, 0);
-    return rc != M3_OK ? rc : m3_p2p_wait_ch(h, 0);
+static int p2p_exchange_ch(m3_handle* h, int ch) {   // put + wait in one launch
+    if (!h) return M3_ERR_BAD_ARG;
+    if (ch != 0 && !(ch == 1 && h->p3)) return fail(h, M3_ERR_BAD_ARG, "m3_p2p_exchange: channel 1 exists on shard_mix = 3 handles only");
+    if (!h->p2p_ready) return fail(h, M3_ERR_STATE, "m3_p2p_exchange: m3_p2p_connect first");
+    h->p2p_seq[ch] += 1;
+    P2PArgs a;
+    p2p_args(h, a, ch);
+    launch_p2p_exchange(a, h->stream);
+    HIPCHK(h, hipGetLastError());
+    const float* src = a.peer_data[a.rank] + (size_t)a.slot * a.n_ranks * a.rec_stride;
+    if (ch == 0) { h->records_src = src; h->records_stride = a.rec_stride; }
+    else { h->recb_src = src; h->recb_stride = a.rec_stride; }
+    return M3_OK;
 }
-extern "C" int m3_p2p_exchange_b(m3_handle* h) {
-    const int rc = m3_p2p_put_ch(h, 1);
-    return rc != M3_OK ? rc : m3_p2p_wait_ch(h, 1);
-}
+extern "C" int m3_p2p_exchange(m3_handle* h) { return p2p_exchange_ch(h, 0); }
+extern "C" int m3_p2p_exchange_b(m3_handle* h) { return p2p_exchange_ch(h, 1); }
 
 extern "C" int m3_p2p_status(m3_handle* h, int* missing_rank, int* memory_kind) {
     if (!h) return M3_ERR_BAD_ARG;

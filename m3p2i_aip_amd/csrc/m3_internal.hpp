@@ -218,6 +218,7 @@ struct P2PArgs {
 constexpr size_t P2P_HDR_BYTES = 1024;    // flags [2][32] ints + error word, then the data part
 void launch_p2p_put(const P2PArgs& a, hipStream_t s);
 void launch_p2p_wait(const P2PArgs& a, hipStream_t s);
+void launch_p2p_exchange(const P2PArgs& a, hipStream_t s);   // both in one launch
 
 // step mode
 struct SimViews {

@@ -25,8 +25,7 @@
 
 namespace m3 {
 
-__global__ __launch_bounds__(1024) void k_p2p_put(const P2PArgs a) {
-    const int p = blockIdx.x;
+__device__ __forceinline__ void p2p_put_body(const P2PArgs& a, int p) {
     // (slots are rec_stride = rec_len rounded up to 4 floats apart: 16-byte stores -- uncached stores are not
     // combined, a dword per lane was 41 us per put of 38 KB records to 8 peers)
     float* dst = a.peer_data[p] + ((size_t)a.slot * a.n_ranks + a.rank) * a.rec_stride;
@@ -46,7 +45,9 @@ __global__ __launch_bounds__(1024) void k_p2p_put(const P2PArgs a) {
         __hip_atomic_store(a.peer_flags[p] + a.slot * MIX_MAX_RANKS + a.rank, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(64) void k_p2p_wait(const P2PArgs a) {
+__global__ __launch_bounds__(1024) void k_p2p_put(const P2PArgs a) { p2p_put_body(a, blockIdx.x); }
+
+__device__ __forceinline__ void p2p_wait_body(const P2PArgs& a) {
     const int p = threadIdx.x;
     if (p < a.n_ranks) {
         const int* f = a.peer_flags[a.rank] + a.slot * MIX_MAX_RANKS + p;
@@ -63,12 +64,25 @@ __global__ __launch_bounds__(64) void k_p2p_wait(const P2PArgs a) {
     }
     if (a.plain_memory) __threadfence_system();
 }
+__global__ __launch_bounds__(64) void k_p2p_wait(const P2PArgs a) { p2p_wait_body(a); }
+
+// put + wait in ONE launch (m3_p2p_exchange, one process per GPU): workgroups 0 .. n_ranks - 1 put, workgroup n_ranks
+// waits -- the wait concerns the PEERS' stores into the own block, not this rank's puts, so it needs no ordering with
+// them.  (A process that drives several handles on one stream must use the two separate launches, every put before any
+// wait: a wait in front of another handle's put would spin until its time-out.)
+__global__ __launch_bounds__(1024) void k_p2p_exchange(const P2PArgs a) {
+    if ((int)blockIdx.x < a.n_ranks) p2p_put_body(a, blockIdx.x);
+    else if (threadIdx.x < 64) p2p_wait_body(a);
+}
 
 void launch_p2p_put(const P2PArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_p2p_put, dim3(a.n_ranks), dim3(1024), 0, s, a);
 }
 void launch_p2p_wait(const P2PArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, s, a);
+}
+void launch_p2p_exchange(const P2PArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_p2p_exchange, dim3(a.n_ranks + 1), dim3(1024), 0, s, a);
 }
 
 }  // namespace m3

@@ -292,8 +292,9 @@ class HipEngine:
         self._ck(self.lib.m3_p2p_wait_ch(self._h, int(channel)))
 
     def p2p_exchange(self, channel=0):
-        self.p2p_put(channel)
-        self.p2p_wait(channel)
+        """put + wait in one launch (one process per GPU; a process driving several handles on one stream uses
+        p2p_put / p2p_wait, every put before any wait)."""
+        self._ck(self.lib.m3_p2p_exchange(self._h) if channel == 0 else self.lib.m3_p2p_exchange_b(self._h))
 
     def p2p_status(self):
         """(missing_rank or -1, memory kind: 1 uncached / 2 fine-grained / 3 plain); synchronises the stream."""
