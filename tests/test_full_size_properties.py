@@ -28,6 +28,11 @@ CONFIGS = {
     "hybrid_K6000_T30": dict(K=6000, T=30, nu=2, env="point_env", task="push_pull", goal=(-3.75, -3.75), mm=True),
     "push_K40000_T30": dict(K=40000, T=30, nu=2, env="point_env", task="push", goal=(-1.0, -1.0), mm=False),
     "northstar_push_K10000_T30": dict(K=10000, T=30, nu=2, env="point_env", task="push", goal=(-1.0, -1.0), mm=False),
+    # the throughput-bound regime: the two-waves-per-SIMD build of the rollout kernel, the large-K update (local softmins
+    # on many workgroups, 64 / 256 top-k candidate lists merged by stage B)
+    "saturated_push_K262144_T30": dict(K=262144, T=30, nu=2, env="point_env", task="push", goal=(-1.0, -1.0), mm=False),
+    "saturated_hybrid_K262144_T30": dict(K=262144, T=30, nu=2, env="point_env", task="push_pull", goal=(-3.75, -3.75), mm=True),
+    "saturated_push_K1048576_T30": dict(K=1048576, T=30, nu=2, env="point_env", task="push", goal=(-1.0, -1.0), mm=False),
 }
 
 
