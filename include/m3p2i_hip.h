@@ -135,6 +135,9 @@ typedef struct {
                                  plan: per-rank work after the collective halves.  Equal to the unsharded run up to
                                  f32 rounding (plan <= 3e-5, same beta-search iteration counts), bit-identical
                                  across ranks.
+                               3 = (multi-modal only) TWO small exchanges with O(K_local) work per rank in between
+                                 (m3_update_b below): the record of 2, then every rank's weighted sums of its OWN
+                                 samples; pays from K_global ~ 300 k (8 x 131072: 0.402 vs 0.441 ms per command).
                                0 = gather + reduce, two collectives (all-gather TRAJ_COST, all-reduce REDUCE) */
     /* ---- the MPPIConfig switches no shipped config turns on (mppi.py:39-54); zero = the defaults ---- */
     int noise_abs_cost;     /* mppi.py:366-367: |noise| in the action cost (read in simple mode only, as in the reference) */
