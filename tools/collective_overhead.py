@@ -104,19 +104,20 @@ def emulate_rank(name, N, steps, K_override=None):
                 q.p2p_connect_local(ranks)
 
             def exchange_p2p(p, phase, e=e, peers=peers):
-                # the peers run one exchange AHEAD of rank 0 (their puts for exchange n + 1 are enqueued on the side
-                # stream right after rank 0's exchange n and overlap with its next rollout, as the peers of a real node
-                # work concurrently): rank 0's stream then carries exactly its own share -- its put into the eight
-                # blocks and a wait that finds the flags raised
+                # the peers' puts for exchange n are enqueued BEFORE rank 0's rollout of that command (hook below): on this
+                # one GPU every stream ends up in the same hardware queue, and seven 4.6 us put kernels between rank 0's
+                # exchange and its next kernel were 32 of the 33 us first measured here -- on a node they run on the
+                # other GPUs.  Rank 0's stream then carries exactly its own share: its put into the eight blocks and a
+                # wait that finds the flags raised.  (ms_per_command of this row includes the peers' ~32 us.)
                 assert phase == "records"
-                if not primed:
-                    for q in peers:
-                        q.p2p_put()
-                    primed.append(1)
-                    torch.cuda.synchronize()
                 e.p2p_exchange()
+            real_rollout = e.rollout
+
+            def rollout_with_peer_puts(peers=peers):
                 for q in peers:
                     q.p2p_put()
+                real_rollout()
+            e.rollout = rollout_with_peer_puts
             primed = []
             switch_to_p2p = exchange_p2p      # (installed below, once the peers' records are in place)
         # the other ranks' contributions: shifted copies of rank 0's (filled once; only slot 0 is live)
