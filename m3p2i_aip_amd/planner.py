@@ -78,6 +78,8 @@ class MPPIConfig(object):
     world_size: int = 1               #   num_samples/world_size consecutive samples
     shard_mix: Optional[int] = None   # None: one-collective protocol whenever it applies (multi-modal: 2); 1 / 2 / False
     relabel_samples: bool = True      # generated noise rows into wavefront-coherent order (same sample set)
+    action_ring: int = 0              # 0: command() returns a fresh tensor each call (mppi.py:238-246 does); n > 0:
+                                      # slot (call % n) of a ring the planner owns (no allocator call per command)
     device_knots: bool = False        # Halton + erfinv knots on the device too (~1e-6 from the host sampler's)
     halton_scramble: str = "none"     # "none": plain Halton (mppi_utils.py:81-87, pinned by golden G8); "faure": the
                                       # generalized Halton structure of the ghalton branch the reference's planner
@@ -188,6 +190,7 @@ class MPPI():
         # one-collective protocols are meant for: their post-gather work grows with K_global)
         self._shard_mix_level = 0 if not self.shard_mix else (1 if single else (2 if sm in (None, 2) else (3 if sm == 3 else 1)))
         self.relabel_samples = bool(_get(m, "relabel_samples", True))
+        self.action_ring = int(_get(m, "action_ring", 0) or 0)
         self._engine = ENGINE_CLS(make_config(
             K=self.K, K_local=self.K_local, k_offset=self.k_offset, T=self.T, nu=self.nu,
             env_type=self.env_type, multi_modal=self.multi_modal,
@@ -369,17 +372,20 @@ class MPPI():
         e1.record()
         times.append((phase, e0, e1))
 
-    ACTION_RING = 8   # command() returns slot (call % 8) of a ring: a returned plan stays valid
-                      # for the next 7 calls (the reference returns a fresh tensor each time; a
-                      # clone per command costs a ~5 us device copy on the critical path)
-
     def _next_action_slot(self):
+        """The tensor this command's plan is written into by the finalize kernel itself (`m3_set_action_out`): a fresh
+        one per call, as the reference returns (no copy: torch's caching allocator hands out the block, stream-ordered
+        on the stream the kernels run on, ~2 us of host time hidden behind the rollout) -- or, with
+        `MPPIConfig.action_ring = n`, slot (call % n) of a ring."""
         rows = self.u_per_command if self.mppi_mode == "simple" else self.T
-        if getattr(self, "_action_ring", None) is None:
-            self._action_ring = torch.zeros(self.ACTION_RING, rows, self.nu, **self.tensor_args)
-            self._action_slot = 0
-        out = self._action_ring[self._action_slot]
-        self._action_slot = (self._action_slot + 1) % self.ACTION_RING
+        if not self.action_ring:
+            out = torch.empty(rows, self.nu, **self.tensor_args)
+        else:
+            if getattr(self, "_action_ring", None) is None:
+                self._action_ring = torch.zeros(self.action_ring, rows, self.nu, **self.tensor_args)
+                self._action_slot = 0
+            out = self._action_ring[self._action_slot]
+            self._action_slot = (self._action_slot + 1) % self.action_ring
         self._engine.set_action_out(out)
         return out
 

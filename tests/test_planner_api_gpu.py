@@ -256,3 +256,29 @@ def test_simple_mode_planner_matches_reference_traces(golden, tag, mode):
     if mode == "auto":
         assert pl.probe_result["fused"] is True, pl.probe_result
     np.testing.assert_allclose(pl.actions.cpu().numpy(), golden[f"g9_{tag}_actions_last"], atol=5e-4)
+
+
+@pytest.mark.parametrize("ring", [0, 3])
+def test_command_returns_a_fresh_tensor_like_the_reference(ring):
+    """mppi.py:238-246 returns a new tensor per command(): plans a caller keeps must not be overwritten by later
+    calls.  (`action_ring = n` is the opt-in exception: slot call % n of a planner-owned ring.)"""
+    cfg = make_cfg(256, 30, "push", (-1.0, -1.0), fused=True, action_ring=ring)
+    tamp = Tamp(cfg)
+    tamp.objective.update_objective("push", [-1.0, -1.0])
+    pl = tamp.motion_planner.attach(tamp.sim, tamp.objective)
+    kept, copies = [], []
+    for _ in range(6):
+        a = pl.command(tamp.sim._dof_state[0])
+        kept.append(a)
+        copies.append(a.clone())
+    torch.cuda.synchronize()
+    ptrs = {a.data_ptr() for a in kept}
+    if ring == 0:
+        assert len(ptrs) == 6
+        for a, c in zip(kept, copies):
+            assert torch.equal(a, c)
+    else:
+        assert len(ptrs) == 3
+        for a, c in zip(kept[3:], copies[3:]):
+            assert torch.equal(a, c)
+    assert not torch.equal(copies[0], copies[5])   # (warm start: the plan moves from call to call)
