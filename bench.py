@@ -497,9 +497,7 @@ def main():
                 ("push_sat", "push_saturating", "131072 samples per GPU: the rollout kernel's throughput-bound regime")]
         if name != "push":
             rows.insert(0, ("push", "push_weak", "BASELINE configs[1] weak-scaled"))
-        for cname, key, what in rows:
-            if cname == name:
-                continue
+        def sharded_row(cname, key, what):
             rw = run_config(cname, args, world, rank, device, dist, args.steps, args.warmup, K_local=small,
                             latency=False, time_collectives=True)
             if rank == 0:
@@ -519,6 +517,18 @@ def main():
                             "(below ~65536 samples per GPU the rollout is latency-bound: one MI355X runs this in about the "
                             "time a rank needs for its 1/N share, DESIGN.md section 7)")
                         others[key]["speedup_vs_one_gpu_same_K"] = others[key]["strong_scaling_reference"]["ms_per_step"] / bq["ms_per_step"]
+
+        for cname, key, what in rows:
+            if cname == name:
+                continue
+            # (a row that fails -- on every rank alike: a create-time refusal, memory -- must not take the headline
+            # line with it; a failure on one rank only still ends the job through the launcher)
+            try:
+                sharded_row(cname, key, what)
+            except Exception as e:
+                if rank == 0:
+                    others.setdefault(key, {})["error"] = repr(e)
+            if not share:
                 torch.cuda.synchronize()
                 dist.barrier()
         if rank == 0:
