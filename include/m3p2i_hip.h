@@ -358,7 +358,7 @@ int m3_record_b_len(const m3_handle* h);
  * communication library: every rank owns an exchange block in device memory, maps every peer's block (hipIpc between
  * processes, direct pointers inside one), and an exchange is two small kernels on the handle's stream -- put: this
  * rank's record into its slot of every peer's block (one hop over xGMI) + a release flag; wait: acquire every
- * peer's flag of this exchange (bounded: a missing peer sets an error word after ~0.5 s instead of hanging the
+ * peer's flag of this exchange (bounded: a missing peer sets an error word after a time-out instead of hanging the
  * GPU).  The m3_finalize that follows reads the records from the block.  Selectable beside RCCL
  * (m3p2i_aip_amd.distributed.attach_p2p / attach_collectives); the records phase of cfg.shard_mix 1 and 2 and
  * of single-mode sharding.
@@ -368,7 +368,10 @@ int m3_record_b_len(const m3_handle* h);
  *   m3_p2p_put / _wait    the two halves (a process that drives several handles enqueues every put before any wait)
  *   m3_p2p_exchange       put + wait
  *   m3_p2p_status         synchronises; missing_rank = -1 or the rank a wait gave up on; memory_kind 1 uncached,
- *                         2 fine-grained, 3 plain device memory */
+ *                         2 fine-grained, 3 plain device memory
+ *   m3_p2p_set_timeout_ms how long a wait spins before it gives up: `first_ms` for a channel's FIRST exchange (the
+ *                         ranks of a job reach their first command at different times: default 30 000), `ms` for every
+ *                         later one (default 500; peers are then at most one command apart).  1 .. 600 000 each. */
 typedef struct { unsigned char bytes[64]; } m3_ipc_handle;
 int m3_p2p_export(m3_handle* h, m3_ipc_handle* out);
 int m3_p2p_connect(m3_handle* h, const m3_ipc_handle* all, int n_ranks);
@@ -381,6 +384,7 @@ int m3_p2p_put_ch(m3_handle* h, int channel);
 int m3_p2p_wait_ch(m3_handle* h, int channel);
 int m3_p2p_exchange_b(m3_handle* h);
 int m3_p2p_status(m3_handle* h, int* missing_rank, int* memory_kind);
+int m3_p2p_set_timeout_ms(m3_handle* h, int first_ms, int ms);
 /* m3_update + m3_finalize for an UNSHARDED handle in as few launches as the sizes allow (what
  * m3_command does after its rollout): for a caller that fills TRAJ_COST / ACTIONS itself (step mode,
  * planner._command_step).  M3_ERR_STATE on a sharded handle (the collectives go in between). */

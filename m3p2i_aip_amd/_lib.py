@@ -116,6 +116,7 @@ SYMBOLS = [
     ("m3_update_b", C.c_int, [_H]),
     ("m3_record_b_len", C.c_int, [_H]),
     ("m3_p2p_status", C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("m3_p2p_set_timeout_ms", C.c_int, [_H, C.c_int, C.c_int]),
     ("m3_get_buffer", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     ("m3_reduce_len", C.c_int, [_H]),
     ("m3_record_len", C.c_int, [_H]),

@@ -1184,7 +1184,7 @@ static void p2p_args(m3_handle* h, P2PArgs& a, int ch) {
     a.rank = p2p_rank(h);
     a.seq = h->p2p_seq[ch];
     a.slot = a.seq & 1;
-    a.timeout_ticks = 50000000ull;   // 0.5 s of the 100 MHz wall clock
+    a.timeout_ticks = 100000ull * (unsigned long long)(a.seq <= 1 ? h->p2p_first_ms : h->p2p_ms);   // 100 MHz wall clock
     a.plain_memory = h->xb_kind == 3;
     a.err = (int*)((char*)h->xb + 2 * MIX_MAX_RANKS * sizeof(int));
     for (int p = 0; p < a.n_ranks; ++p) {
@@ -1237,6 +1237,15 @@ static int p2p_exchange_ch(m3_handle* h, int ch) {   // put + wait in one launch
 }
 extern "C" int m3_p2p_exchange(m3_handle* h) { return p2p_exchange_ch(h, 0); }
 extern "C" int m3_p2p_exchange_b(m3_handle* h) { return p2p_exchange_ch(h, 1); }
+
+extern "C" int m3_p2p_set_timeout_ms(m3_handle* h, int first_ms, int ms) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (first_ms < 1 || first_ms > 600000 || ms < 1 || ms > 600000)
+        return fail(h, M3_ERR_BAD_ARG, "m3_p2p_set_timeout_ms: 1 .. 600000 ms each");
+    h->p2p_first_ms = first_ms;
+    h->p2p_ms = ms;
+    return M3_OK;
+}
 
 extern "C" int m3_p2p_status(m3_handle* h, int* missing_rank, int* memory_kind) {
     if (!h) return M3_ERR_BAD_ARG;

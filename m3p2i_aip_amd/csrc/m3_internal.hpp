@@ -327,6 +327,7 @@ struct m3_handle {
     bool peer_ipc[m3::MIX_MAX_RANKS] = {};     // opened with hipIpcOpenMemHandle (closed in m3_destroy)
     bool p2p_ready = false;
     int p2p_seq[2] = {0, 0};           // per channel (0: records, 1: second records of shard_mix = 3)
+    int p2p_first_ms = 30000, p2p_ms = 500;   // wait time-outs (m3_p2p_set_timeout_ms)
     int records_stride = 0;             // floats between two records of records_src
     const float* records_src = nullptr; // != null: the records of the exchange just enqueued (consumed by m3_finalize)
     // timing

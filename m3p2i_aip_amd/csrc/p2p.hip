@@ -11,8 +11,9 @@
 //               visible at system scope and then releases flag [parity][rank] of that peer with the exchange's
 //               sequence number;
 //   k_p2p_wait  lane p of one wavefront acquires flag [parity][p] of the OWN block until it shows the sequence
-//               number (bounded: ~0.5 s of the 100 MHz wall clock, then the error word is set and the stream moves
-//               on -- a peer that died must not hang the GPU).
+//               number (bounded: the handle's time-out on the 100 MHz wall clock -- 0.5 s, 30 s for the first
+//               exchange --, then the error word is set and the stream moves on: a peer that died must not hang
+//               the GPU).
 //
 // The kernels that follow on the stream (k_mix / k_regen_part / ...) read the records from the own block.  The block
 // is allocated uncached (hipDeviceMallocUncached; fine-grained or plain device memory as fallbacks), so neither the

@@ -302,6 +302,10 @@ class HipEngine:
         self._ck(self.lib.m3_p2p_status(self._h, C.byref(miss), C.byref(kind)))
         return miss.value, kind.value
 
+    def p2p_set_timeout_ms(self, first_ms=30000, ms=500):
+        """How long a wait spins for a missing peer: a channel's first exchange (start-up skew between the ranks) / later ones."""
+        self._ck(self.lib.m3_p2p_set_timeout_ms(self._h, int(first_ms), int(ms)))
+
     def update_finalize(self):
         """update + finalize of an unsharded handle in as few launches as possible."""
         self._ck(self.lib.m3_update_finalize(self._h))

@@ -266,6 +266,9 @@ def test_p2p_wait_gives_up_on_a_missing_peer_instead_of_hanging():
         shards[0].p2p_put()                                   # not connected yet
     for e in shards:
         e.p2p_connect_local(shards)
+    with pytest.raises(L.M3Error):
+        shards[0].p2p_set_timeout_ms(0, 500)
+    shards[0].p2p_set_timeout_ms(first_ms=500, ms=500)        # (a channel's first exchange waits 30 s by default)
     t0 = time.time()
     shards[0].p2p_put()
     shards[0].p2p_wait()                                      # rank 1 never arrives
