@@ -1,4 +1,4 @@
-"""world_size-2 test of the sample-sharded command() on CPU (gloo).
+"""world_size-2 and -4 tests of the sample-sharded command() on CPU (gloo).
 
 Exercises the product's HOST logic for N > 1 -- planner.py phase sequencing, sample offsets,
 distributed.py's all-gather of trajectory costs and packed all-reduce, owner-only best /
@@ -100,16 +100,18 @@ def worker(rank, world, port, case, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", list(CASES))
-def test_two_rank_sharded_command_equals_single_process(case, golden):
+@pytest.mark.parametrize("case,world", [(c, 2) for c in CASES] + [("push", 4), ("hybrid", 4), ("hybrid_p3", 4)])
+def test_sharded_command_equals_single_process(case, world, golden):
+    """(world 4: the records are mixed / summed in rank order over more than two ranks; the first mode's half spans
+    ranks 0-1 and the second's ranks 2-3)"""
     sys.path.insert(0, ROOT)
     delta = golden["g9_push_delta"]
     ref_pl, ref_sim = make_planner(case, 0, 1, delta)
     ref = run_calls(ref_pl, ref_sim)
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=worker, args=(r, 2, port, case, ret)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + 3 * world
+    procs = [ctx.Process(target=worker, args=(r, world, port, case, ret)) for r in range(world)]
     for p in procs:
         p.start()
     got = ret.get(timeout=180)
@@ -121,8 +123,8 @@ def test_two_rank_sharded_command_equals_single_process(case, golden):
         # plan, which later calls inherit through the warm start
         # one-collective protocol: only the rank's own weights are materialised, and the mixture
         # exp(-(m_r - m)/beta) * local softmin equals the global softmin up to f32 rounding
-        nw = K // 2 if case in ("push", "hybrid_p3") else K
-        tol = 1e-5 if case == "push" else 2e-6
+        nw = K // world if case in ("push", "hybrid_p3") else K
+        tol = 1e-5 if case == "push" else (2e-6 if world == 2 else 5e-6)    # (four partial sums instead of two)
         np.testing.assert_allclose(a["weights"][:nw], b["weights"][:nw], rtol=1e-4, atol=1e-9, err_msg=f"call {c}")
         np.testing.assert_allclose(a["action"], b["action"], atol=tol, err_msg=f"call {c}")
         np.testing.assert_allclose(a["mean"], b["mean"], atol=tol)
