@@ -291,6 +291,12 @@ int m3_set_noise_halton_scrambled(m3_handle* h, int n_knots, int degree, float s
  * that runs the rollout itself (the planner's STEP mode: user dynamics / running_cost callables) */
 int m3_sample_noise(m3_handle* h);
 int m3_set_objective(m3_handle* h, int task, const float* goal, int goal_len, int gripper_cmd);
+/* EXTENSION, off by default (= the reference): push / pull / push_pull add get_motion_cost -- 1000 while the dyn-obs
+ * feels a contact force > 0.1 (cost_functions.py:158-169) -- the way navigation does.  The shipped compute_cost
+ * returns before that term for these tasks (cost_functions.py:23-29 vs :36), so the reference's push / pull rollouts are
+ * blind to the dyn-obs; its logged experiments `plot/point/case2_halton_{push,pull}_coll.npy` show 3 / 60 and 1 / 60
+ * collisions, i.e. were made with the term active.  point_env only.  The rollout then runs its general instance. */
+int m3_set_avoid_dyn_obs(m3_handle* h, int on);
 /* Objective.multi_modal (cost_functions.py:9) for a sim_only handle, whose config does not
  * come from an MPPI object; refused on planner handles (fixed at m3_create) */
 int m3_set_multi_modal(m3_handle* h, int multi_modal);

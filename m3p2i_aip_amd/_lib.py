@@ -89,6 +89,7 @@ SYMBOLS = [
     ("m3_sample_noise", C.c_int, [_H]),
     ("m3_set_call_count", C.c_int, [_H, C.c_uint]),
     ("m3_set_objective", C.c_int, [_H, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int]),
+    ("m3_set_avoid_dyn_obs", C.c_int, [_H, C.c_int]),
     ("m3_set_multi_modal", C.c_int, [_H, C.c_int]),
     ("m3_set_plan", C.c_int, [_H, C.c_int, _FP]),
     ("m3_set_action_out", C.c_int, [_H, C.c_void_p]),

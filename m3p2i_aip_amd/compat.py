@@ -115,6 +115,7 @@ class ExampleConfig:
     render: bool = False
     n_steps: int = 0
     nx: int = 4
+    avoid_dyn_obs: bool = False     # EXTENSION (not a key of the reference's config_store.py): cost_functions.Objective
 
 
 def make_config(config_name="config_point", overrides=()):

@@ -39,6 +39,9 @@ class Objective(object):
         goal = getattr(cfg, "goal", None)
         self.goal = None if goal is None else torch.tensor(list(goal), dtype=torch.float32)
         self.gripper_cmd = 0
+        # EXTENSION, off by default: `avoid_dyn_obs: True` in the config makes push / pull / push_pull add
+        # get_motion_cost (:158-169) as navigation does; the shipped compute_cost returns before it (:23-29 vs :36)
+        self.avoid_dyn_obs = bool(getattr(cfg, "avoid_dyn_obs", False)) and getattr(cfg, "env_type", "point_env") == "point_env"
         _LIVE.add(self)
 
     def update_objective(self, task, goal):
@@ -72,6 +75,9 @@ class Objective(object):
             raise L.M3Error("task 'push_pull' needs multi_modal=True (cost_functions.py:27-29)")
         eng.set_multi_modal(self.multi_modal)  # the wrapper's handle learns it here (:9)
         eng.set_objective(self.task, self.goal_list(), self.gripper_cmd)
+        if self.avoid_dyn_obs or getattr(eng, "_avoid_dyn_obs", False):
+            eng.set_avoid_dyn_obs(self.avoid_dyn_obs)
+            eng._avoid_dyn_obs = self.avoid_dyn_obs
         return eng.cost()
 
 

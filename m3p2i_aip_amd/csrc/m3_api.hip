@@ -656,6 +656,13 @@ extern "C" int m3_set_objective(m3_handle* h, int task, const float* goal, int g
     return M3_OK;
 }
 
+extern "C" int m3_set_avoid_dyn_obs(m3_handle* h, int on) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (h->cfg.env_type != M3_ENV_POINT) return fail(h, M3_ERR_UNSUPPORTED, "m3_set_avoid_dyn_obs: point_env only");
+    h->avoid_dyn_obs = on != 0;
+    return M3_OK;
+}
+
 extern "C" int m3_set_multi_modal(m3_handle* h, int mm) {
     if (!h) return M3_ERR_BAD_ARG;
     if (!h->cfg.sim_only && (mm != 0) != (h->cfg.multi_modal != 0))
@@ -757,6 +764,7 @@ static void fill_cost_params(const m3_handle* h, CostParams& cp) {
     for (int i = 0; i < 7; ++i) cp.goal[i] = h->goal[i];
     cp.kp_suction = h->cfg.kp_suction;
     cp.suction_thresh = (h->cfg.K_global == 1) ? 1.5f : 1.8f;  // skill_utils.py:75-82
+    cp.avoid_dyn_obs = h->avoid_dyn_obs;
 }
 
 static void fill_panda_cost_params(const m3_handle* h, PandaCostParams& cp) {

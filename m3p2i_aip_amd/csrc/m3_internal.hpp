@@ -285,6 +285,7 @@ struct m3_handle {
     int task = M3_TASK_PUSH;
     float goal[7] = {0, 0, 0, 0, 0, 0, 1};
     int gripper_cmd = 0;
+    int avoid_dyn_obs = 0;             // m3_set_avoid_dyn_obs (extension; 0 = the reference's compute_cost)
     // world
     float world0[18];
     const float* world0_bound = nullptr;  // device, 18 floats (filled by world_from_sim)

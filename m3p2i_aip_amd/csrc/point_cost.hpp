@@ -20,6 +20,7 @@ struct CostParams {
     float goal[7];
     float kp_suction;
     float suction_thresh;  // 1.8 (K > 1) or 1.5 (K == 1), skill_utils.py:75-82
+    int avoid_dyn_obs;     // EXTENSION (m3_set_avoid_dyn_obs, default 0 = the reference): push / pull add get_motion_cost
 };
 
 __device__ __forceinline__ float clamp500(float v) { return fminf(fmaxf(v, -500.0f), 500.0f); }
@@ -65,10 +66,15 @@ __device__ __forceinline__ float point_cost(const CostParams& cp, PointWorld& w,
         const float vel_cost = (toward && rdist <= 0.5f) ? 0.6f : 0.0f;
         pull = 3.0f * dist_cost + 3.0f * vel_cost + 7.0f * align;
     }
-    if (task == 1) return push;
-    if (task == 2) return pull;
-    if (task == 3) return (k < cp.half_K) ? push : pull;
-    return 0.0f;
+    float c = 0.0f;
+    if (task == 1) c = push;
+    else if (task == 2) c = pull;
+    else if (task == 3) c = (k < cp.half_K) ? push : pull;
+    if (cp.avoid_dyn_obs) {   // (general rollout instance / step mode only: the per-task instances compile it away)
+        const float coll = fabsf(w.fcDx) + fabsf(w.fcDy);
+        c = c + ((coll > 0.1f) ? 1000.0f : 0.0f);
+    }
+    return c;
 }
 
 }  // namespace m3

@@ -23,7 +23,8 @@ void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_
 #else
     // push_pull without multi_modal is refused upstream (m3_rollout); a task outside 0..3 cannot reach here
     const bool general = a.sampling_random || a.mode_simple || a.cp.task < 0 || a.cp.task > 3 ||
-                         (a.cp.task == 3 && !a.multi_modal) || a.scale_dev != nullptr /* update_cov */;
+                         (a.cp.task == 3 && !a.multi_modal) || a.scale_dev != nullptr /* update_cov */ ||
+                         a.cp.avoid_dyn_obs != 0 /* the extension: the dyn-obs contact force must be formed */;
 #endif
     if (general) { launch_rollout_point_instance<true, -1>(a, sc, blocks, s); return; }
     switch (a.cp.task) {   // the reference's default sampler: one instance per task (rollout_point_task*.hip)

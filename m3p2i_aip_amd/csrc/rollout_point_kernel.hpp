@@ -60,6 +60,7 @@ __device__ __forceinline__ void rollout_point_body(const RolloutArgs& a_, const 
     if constexpr (!GENERAL) {
         a.sampling_random = 0; a.mode_simple = 0;
         a.noise_abs_cost = 0; a.full_sigma = 0; a.scale_dev = nullptr;   // (the host routes those to the general instance)
+        a.cp.avoid_dyn_obs = 0;
     }
     if constexpr (TASK >= 0) {
         a.cp.task = TASK;
@@ -150,7 +151,7 @@ __device__ __forceinline__ void rollout_point_body(const RolloutArgs& a_, const 
 
         M3_PH(0);
         // ---- A6: one sim.step() ----
-        point_step<false>(sc, w, u0, u1, /*need_dyn_force=*/a.cp.task == 0, pc_);
+        point_step<false>(sc, w, u0, u1, /*need_dyn_force=*/a.cp.task == 0 || a.cp.avoid_dyn_obs != 0, pc_);
 
         // ---- A7/A8: running cost on the post-step state ----
         const float c = point_cost(a.cp, w, k);

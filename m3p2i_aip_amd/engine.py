@@ -188,6 +188,10 @@ class HipEngine:
         arr = (C.c_float * len(g))(*g)
         self._ck(self.lib.m3_set_objective(self._h, t, arr, len(g), int(gripper_cmd)))
 
+    def set_avoid_dyn_obs(self, on):
+        """Extension (off = the reference): push / pull / push_pull add get_motion_cost like navigation does."""
+        self._ck(self.lib.m3_set_avoid_dyn_obs(self._h, int(bool(on))))
+
     def set_multi_modal(self, mm):
         self._ck(self.lib.m3_set_multi_modal(self._h, int(bool(mm))))
 

@@ -342,6 +342,10 @@ class MPPI():
                                "use planner.attach(sim, objective)")
         grip = {"open": 1, "close": 2}.get(self.gripper_command, 0)
         self._engine.set_objective(o.task, o.goal_list(), grip)
+        avoid = bool(getattr(o, "avoid_dyn_obs", False))
+        if avoid != getattr(self, "_avoid_dyn_obs", False):     # (extension, off by default: cost_functions.Objective)
+            self._engine.set_avoid_dyn_obs(avoid)
+            self._avoid_dyn_obs = avoid
 
     def _bind_world(self):
         s = self._sim

@@ -60,7 +60,7 @@ class Cfg(C.Structure):
                 ("gripper_cmd", C.c_int), ("pre_height_diff", C.c_float),
                 ("tilt_cos_theta", C.c_float), ("noise_abs_cost", C.c_int), ("full_sigma", C.c_int),
                 ("noise_mu", C.c_float * MAX_NU), ("chol", C.c_float * (MAX_NU * MAX_NU)),
-                ("sigma_inv_full", C.c_float * (MAX_NU * MAX_NU))]
+                ("sigma_inv_full", C.c_float * (MAX_NU * MAX_NU)), ("avoid_dyn_obs", C.c_int)]
 
 
 class UpdateInfo(C.Structure):

@@ -117,6 +117,10 @@ typedef struct {
     float noise_mu[M3O_MAX_NU];                        /* mppi.py:127 */
     float chol[M3O_MAX_NU * M3O_MAX_NU];               /* row-major lower Cholesky factor of noise_sigma */
     float sigma_inv_full[M3O_MAX_NU * M3O_MAX_NU];     /* mppi.py:128 */
+    /* an EXTENSION of this repository (off in every reference configuration): push / pull / push_pull add
+       get_motion_cost (the dyn-obs contact penalty) as navigation does -- the shipped compute_cost returns before it for
+       these tasks (cost_functions.py:23-29 vs :36), while the reference's logged `case2_*_coll` runs avoid the dyn-obs */
+    int avoid_dyn_obs;
 } m3o_cfg;
 
 /* A4: delta[K,T,nu] (global) -> act[(k1-k0),T,nu] for global samples k0..k1-1.

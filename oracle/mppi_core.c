@@ -144,9 +144,13 @@ float m3o_point_cost(const m3o_cfg* cfg, m3o_point_world* w, int k) {
         float vel_cost = (toward && rdist <= 0.5f) ? 0.6f : 0.0f;
         pull = 3.0f * d.dist_cost + 3.0f * vel_cost + 7.0f * align;
     }
-    if (task == M3O_TASK_PUSH) return push;
-    if (task == M3O_TASK_PULL) return pull;
-    if (task == M3O_TASK_PUSH_PULL) return (k < half) ? push : pull; /* :28-29 */
+    const float mc = cfg->avoid_dyn_obs ? motion_cost_point(w) : 0.0f;   /* (extension, m3_oracle.h) */
+    if (task == M3O_TASK_PUSH) return cfg->avoid_dyn_obs ? push + mc : push;
+    if (task == M3O_TASK_PULL) return cfg->avoid_dyn_obs ? pull + mc : pull;
+    if (task == M3O_TASK_PUSH_PULL) {   /* :28-29 */
+        const float c = (k < half) ? push : pull;
+        return cfg->avoid_dyn_obs ? c + mc : c;
+    }
     return 0.0f;
 }
 

@@ -110,12 +110,16 @@ def test_command_traces_vs_reference_and_oracle(golden, oracle, tag):
     eng.close()
 
 
-@pytest.mark.parametrize("task,goal,mm", [("push", (-1, -1), False), ("pull", (0, 0), False),
-                                           ("push_pull", (-3.75, -3.75), True),
-                                           ("navigation", (-3, 3), False)])
-def test_rollout_bit_exact_with_contacts(oracle, task, goal, mm):
+@pytest.mark.parametrize("task,goal,mm,avoid", [("push", (-1, -1), False, False), ("pull", (0, 0), False, False),
+                                                 ("push_pull", (-3.75, -3.75), True, False),
+                                                 ("navigation", (-3, 3), False, False),
+                                                 ("push", (-1, -1), False, True), ("pull", (0, 0), False, True),
+                                                 ("push_pull", (-3.75, -3.75), True, True)])
+def test_rollout_bit_exact_with_contacts(oracle, task, goal, mm, avoid):
     """Dense-contact stress: robot starts between box, dyn-obs, obstacle and a wall corner;
-    large random controls.  Every state / action / cost must equal the oracle's bit-for-bit."""
+    large random controls.  Every state / action / cost must equal the oracle's bit-for-bit.
+    avoid: the extension m3_set_avoid_dyn_obs (push / pull with get_motion_cost, as the reference's logged
+    `case2_*_coll` experiments evidently ran): states identical to the plain task, costs + 1000 per step in contact."""
     from m3p2i_aip_amd import _lib as L
     K, T = 1024, 30
     rng = np.random.default_rng(11)
@@ -133,10 +137,13 @@ def test_rollout_bit_exact_with_contacts(oracle, task, goal, mm):
     w3[oracle.W_D:oracle.W_D + 4] = (2.6, 3.5, np.cos(-0.9), np.sin(-0.9))
     worlds.append(w3)
     ocfg = oracle.make_cfg(K, T, 2, task=task, goal=goal, multi_modal=mm)
+    ocfg.avoid_dyn_obs = int(avoid)
     eng = _engine(K=K, T=T, nu=2, multi_modal=mm, u_min=[-3, -3], u_max=[3, 3],
                   noise_sigma_diag=[3, 3])
     eng.set_objective(task, goal)
+    eng.set_avoid_dyn_obs(avoid)
     eng.set_noise(delta)
+    penalised = 0
     for w0 in worlds:
         opl = oracle.OraclePointPlanner(ocfg, delta)
         eng.reset()
@@ -154,6 +161,8 @@ def test_rollout_bit_exact_with_contacts(oracle, task, goal, mm):
         np.testing.assert_allclose(eng.buffer(L.BUF_MEAN).cpu().numpy(), opl.mean, atol=1e-4)
         np.testing.assert_allclose(eng.buffer(L.BUF_PENDING_FORCE).cpu().numpy().T,
                                    opl.pend, atol=0)
+        penalised += int((opl.last["cost_h"] >= 1000.0).sum())
+    assert (penalised > 100) == (avoid or task == "navigation")     # (the penalty really fired / is really absent)
     eng.close()
 
 

@@ -120,6 +120,22 @@ def test_g6_point_costs_and_g7_suction(golden, oracle, key):
                                    golden[f"g7_frobot_{key}"], rtol=1e-6, atol=1e-4)
 
 
+@pytest.mark.parametrize("key", ["push_0", "pull_0", "push_pull_1", "pull_1"])
+def test_avoid_dyn_obs_extension_is_the_reference_cost_plus_its_own_motion_cost(golden, oracle, key):
+    """The one cost term that is not the reference's compute_cost (off by default): push / pull + get_motion_cost.  Both
+    summands are the reference's own values (G6): the task cost, and the motion cost as the navigation golden carries it
+    (navigation cost - distance to its goal, cost_functions.py:36,38)."""
+    task, mm = key.rsplit("_", 1)
+    w = _worlds(oracle, golden)
+    cfg = oracle.make_cfg(w.shape[0], 30, multi_modal=bool(int(mm)), task=task, goal=golden[f"g6_goal_{key}"])
+    cfg.avoid_dyn_obs = 1
+    c = oracle.cost_batch(cfg, w)
+    motion = golden["g6_cost_navigation_0"] - np.linalg.norm(golden["g6_robot"] - golden["g6_goal_navigation_0"][:2], axis=1)
+    motion = np.where(motion > 500.0, 1000.0, 0.0)           # (the term is binary: strip the rounding of the subtraction)
+    assert 0 < (motion > 0).sum() < motion.size
+    np.testing.assert_allclose(c, golden[f"g6_cost_{key}"] + motion, rtol=2e-6, atol=1e-4)
+
+
 def test_g7_suction_single_env_threshold(golden, oracle):
     for i in range(2):
         w = oracle.init_world(1)

@@ -2,7 +2,7 @@
 (deterministic seeds): statistics of what the reference logged per run (plot/plot_point.py:26-34) -- final
 block-to-goal error, task time, dyn-obs collisions -- next to the logged statistics (tests/golden/behaviour_band.json).
 
-    python tools/band_stats.py [--n 20] [--json out.json] [--size baseline|default] [scenario ...]
+    python tools/band_stats.py [--n 20] [--json out.json] [--size baseline|default] [--avoid] [scenario ...]
 
 --size default: the reference's shipped planner size, K=200 samples, T=15 (config/mppi/point.yaml) -- the size the
 logged runs were most plausibly made with (it is not recorded); baseline (default here): K, T of the BASELINE configs.
@@ -53,8 +53,11 @@ def stats(x):
     return {"mean": float(x.mean()), "std": float(x.std()), "min": float(x.min()), "max": float(x.max()), "n": int(x.size)}
 
 
+AVOID = False      # --avoid: the extension `avoid_dyn_obs=True` (push / pull with get_motion_cost; cost_functions.Objective)
+
+
 def overrides(scenario, size="baseline"):
-    ov = list(SCENARIOS[scenario])
+    ov = list(SCENARIOS[scenario]) + (["avoid_dyn_obs=True"] if AVOID else [])
     if size == "default":      # config/mppi/point.yaml: 200 samples, horizon 15 (400 / 15 multi-modal: 200 per mode)
         mm = "multi_modal=True" in ov
         ov = [o for o in ov if not o.startswith("mppi.")] + [f"mppi.num_samples={400 if mm else 200}", "mppi.horizon=15"]
@@ -106,6 +109,9 @@ def main(argv):
             out = next(it)
         elif a == "--size":
             size = next(it)
+        elif a == "--avoid":
+            global AVOID
+            AVOID = True
         else:
             names.append(a)
     allband = json.load(open(os.path.join(ROOT, "tests", "golden", "behaviour_band.json")))
