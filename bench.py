@@ -446,7 +446,8 @@ def main():
             par = (f"samples sharded x{world}, " + (("TWO small exchanges per command (shard_mix 3)" if pl._shard_mix_level == 3 else
                                                      "ONE collective per command: all-gather of per-rank records")
                                                     if pl.shard_mix else "all-gather J + all-reduce packed sums")
-                   + (" (gloo, shared GPU: test mode)" if share else (" (p2p device-side exchange)" if args.transport == "p2p" else " (RCCL)")))
+                   + " (" + ("p2p device-side exchange" if (args.transport == "p2p" and pl.shard_mix) else ("gloo" if share else "RCCL"))
+                   + (", shared GPU: test mode)" if share else ")"))
         line = {
             "metric": "mppi_state_steps_per_sec (K x T per command())",
             "value": r["value"], "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,

@@ -13,15 +13,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("config,mode", [(None, "single-mode"), ("c5", "multi-modal")])
-def test_bench_with_two_ranks(config, mode):
+@pytest.mark.parametrize("config,mode,extra", [(None, "single-mode", []), ("c5", "multi-modal", []),
+                                               ("c5", "multi-modal", ["--transport", "p2p", "--shard-mix", "3"])])
+def test_bench_with_two_ranks(config, mode, extra):
     """config None: the default of an N > 1 run = the N = 1 headline's own per-GPU workload (push, single-mode),
-    weak-scaled; c5 = BASELINE configs[4] (push_pull, multi-modal) as the headline."""
+    weak-scaled; c5 = BASELINE configs[4] (push_pull, multi-modal) as the headline; the same through the device-side
+    exchange (hipIpc between the two processes) with the two-exchange protocol."""
     env = dict(os.environ, M3_BENCH_SHARE_GPU="1")
     port = 29800 + os.getpid() % 150
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
-           "--warmup", "3", "--samples-per-gpu", "512"] + (["--config", config] if config else [])
+           "--warmup", "3", "--samples-per-gpu", "512"] + (["--config", config] if config else []) + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -29,15 +31,18 @@ def test_bench_with_two_ranks(config, mode):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 3 and d["scaling"] == "weak"
     assert "K=1024 (512/GPU)" in d["config"]["workload"] and mode in d["config"]["workload"]
-    assert d["config"]["name"] == (config or "push") and "ONE collective per command" in d["config"]["parallelism"]
-    assert d["collective_ms"]["per_command"] == 1.0 and d["collective_ms"]["total"] > 0
+    p3 = "--shard-mix" in extra
+    assert d["config"]["name"] == (config or "push")
+    assert ("TWO small exchanges" if p3 else "ONE collective per command") in d["config"]["parallelism"]
+    assert ("p2p device-side exchange" in d["config"]["parallelism"]) == ("p2p" in extra)
+    assert d["collective_ms"]["per_command"] == (2.0 if p3 else 1.0) and d["collective_ms"]["total"] > 0
     assert d["value"] > 0 and abs(d["value"] - 1024 * 30 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
     # the other sharded workloads ride along, every row with its own `scaling`
     want = {"c5", "push_saturating"} if config is None else {"push_weak", "push_saturating"}
     assert set(d["other_configs"]) == want
     for w in d["other_configs"].values():
-        assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["collective_ms"]["per_command"] == 1.0 and w["value"] > 0
+        assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["collective_ms"]["per_command"] == 1.0 and w["value"] > 0   # (single-mode rows)
         assert "K=1024" in w["workload"]          # (test mode: every row at the test's size)
 
 
