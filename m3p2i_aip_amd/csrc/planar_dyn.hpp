@@ -1,4 +1,4 @@
-// planar_dyn.hpp -- device-side "Planar contact dynamics spec v1" (DESIGN.md).
+// planar_dyn.hpp -- device-side "Planar contact dynamics spec" (currently v1.4).
 //
 // Replaces, for the point_env scene, what the reference delegates to Isaac Gym / PhysX:
 //   IsaacGymWrapper.step()                    isaacgym_wrapper.py:354-360
@@ -10,9 +10,9 @@
 // Mapping: ONE LANE PER SAMPLE, the whole world (robot disc + 2 boxes, 18 floats) and all 19
 // contact slots live in VGPRs.  Slots are STATIC (slot i always means the same body pair), so
 // no dynamic register indexing and every `if (slot.on)` is a plain exec-mask branch that
-// costs nothing when no lane of the wave is in that contact.  Only + - * / sqrt min max and
-// compares are used, in a fixed expression order (compiled with -ffp-contract=off), so the
-// result is bit-identical to the scalar CPU oracle.
+// costs nothing when no lane of the wave is in that contact.  Only + - * / min max, the explicit
+// fused multiply-add mad() and compares are used, in a fixed expression order (compiled with
+// -ffp-contract=off), so the result is bit-identical to the scalar CPU oracle.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -83,12 +83,17 @@ struct Vel {
 // exactly this order (the oracle runs the same sequence).  The correctly rounded sqrtf followed by
 // an IEEE division is a ~32-instruction dependent chain here (3 of them compare->select pairs);
 // this is 15, and it sits in the friction row of every solver pass.
+// spec v1.4: where the spec writes mad(a, b, c) the product and the sum are ONE operation with one rounding (IEEE 754
+// fusedMultiplyAdd: v_fma_f32 here, fmaf in the oracle) -- every a*b + c of the dynamics.  Half the multiplies and
+// adds of the solver pair up; -ffp-contract=off stays, so nothing else is ever fused (the task costs follow torch).
+__device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 __device__ __forceinline__ float spec_rsqrt(float a) {
     float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(a) >> 1));
     const float hlf = 0.5f * a;
-    y = y * (1.5f - hlf * (y * y));
-    y = y * (1.5f - hlf * (y * y));
-    y = y * (1.5f - hlf * (y * y));
+    y = y * mad(-hlf, y * y, 1.5f);
+    y = y * mad(-hlf, y * y, 1.5f);
+    y = y * mad(-hlf, y * y, 1.5f);
     return y;
 }
 
@@ -134,18 +139,15 @@ template <int ID, int SG>
 __device__ __forceinline__ void apply(const PointScene& sc, Vel& v, float dl, float dx, float dy,
                                       float arm) {
     if constexpr (!moves<ID>()) return;
-    const float im = invm<ID>(sc) * dl;
+    const float im = (SG < 0) ? -(invm<ID>(sc) * dl) : invm<ID>(sc) * dl;
     if constexpr (ID == ROBOT) {
-        if (SG < 0) { v.rvx -= im * dx; v.rvy -= im * dy; }
-        else { v.rvx += im * dx; v.rvy += im * dy; }
+        v.rvx = mad(im, dx, v.rvx); v.rvy = mad(im, dy, v.rvy);
     } else if constexpr (ID == BOXB) {
-        const float ia = (invI<ID>(sc) * arm) * dl;
-        if (SG < 0) { v.bvx -= im * dx; v.bvy -= im * dy; v.bw -= ia; }
-        else { v.bvx += im * dx; v.bvy += im * dy; v.bw += ia; }
+        const float ia = (SG < 0) ? -(invI<ID>(sc) * arm) : invI<ID>(sc) * arm;
+        v.bvx = mad(im, dx, v.bvx); v.bvy = mad(im, dy, v.bvy); v.bw = mad(ia, dl, v.bw);
     } else if constexpr (ID == BOXD) {
-        const float ia = (invI<ID>(sc) * arm) * dl;
-        if (SG < 0) { v.dvx -= im * dx; v.dvy -= im * dy; v.dw -= ia; }
-        else { v.dvx += im * dx; v.dvy += im * dy; v.dw += ia; }
+        const float ia = (SG < 0) ? -(invI<ID>(sc) * arm) : invI<ID>(sc) * arm;
+        v.dvx = mad(im, dx, v.dvx); v.dvy = mad(im, dy, v.dvy); v.dw = mad(ia, dl, v.dw);
     }
 }
 
@@ -155,19 +157,19 @@ __device__ __forceinline__ void prepare(const PointScene& sc, Slot& c, float nx,
                                         float rax, float ray, float rbx, float rby, float sep) {
     const float tx = -ny, ty = nx;
     c.nx = nx; c.ny = ny;
-    c.rna = rotates<A>() ? (rax * ny - ray * nx) : 0.0f;
-    c.rnb = rotates<B>() ? (rbx * ny - rby * nx) : 0.0f;
-    c.rta = rotates<A>() ? (rax * ty - ray * tx) : 0.0f;
-    c.rtb = rotates<B>() ? (rbx * ty - rby * tx) : 0.0f;
+    c.rna = rotates<A>() ? mad(rax, ny, -(ray * nx)) : 0.0f;
+    c.rnb = rotates<B>() ? mad(rbx, ny, -(rby * nx)) : 0.0f;
+    c.rta = rotates<A>() ? mad(rax, ty, -(ray * tx)) : 0.0f;
+    c.rtb = rotates<B>() ? mad(rbx, ty, -(rby * tx)) : 0.0f;
     float kn = invm<A>(sc), kt = invm<A>(sc);
     if constexpr (moves<B>()) { kn = kn + invm<B>(sc); kt = kt + invm<B>(sc); }
     if constexpr (rotates<A>()) {
-        kn = kn + invI<A>(sc) * c.rna * c.rna;
-        kt = kt + invI<A>(sc) * c.rta * c.rta;
+        kn = mad(invI<A>(sc) * c.rna, c.rna, kn);
+        kt = mad(invI<A>(sc) * c.rta, c.rta, kt);
     }
     if constexpr (rotates<B>()) {
-        kn = kn + invI<B>(sc) * c.rnb * c.rnb;
-        kt = kt + invI<B>(sc) * c.rtb * c.rtb;
+        kn = mad(invI<B>(sc) * c.rnb, c.rnb, kn);
+        kt = mad(invI<B>(sc) * c.rtb, c.rtb, kt);
     }
     c.mn = 1.0f / kn;
     c.mt = 1.0f / kt;
@@ -188,9 +190,9 @@ template <int A, int B>
 __device__ __forceinline__ void solve(const PointScene& sc, Vel& v, Slot& c, float mu) {
     const float tx = -c.ny, ty = c.nx;
     float dvx = gvx<B>(v) - gvx<A>(v), dvy = gvy<B>(v) - gvy<A>(v);
-    float vn = dvx * c.nx + dvy * c.ny;
-    if constexpr (rotates<B>()) vn = vn + gw<B>(v) * c.rnb;
-    if constexpr (rotates<A>()) vn = vn - gw<A>(v) * c.rna;
+    float vn = mad(dvx, c.nx, dvy * c.ny);
+    if constexpr (rotates<B>()) vn = mad(gw<B>(v), c.rnb, vn);
+    if constexpr (rotates<A>()) vn = mad(-gw<A>(v), c.rna, vn);
     float dl = -c.mn * (vn + c.bias);
     float l0 = c.ln;
     float l1 = l0 + dl;
@@ -200,9 +202,9 @@ __device__ __forceinline__ void solve(const PointScene& sc, Vel& v, Slot& c, flo
     apply<A, -1>(sc, v, dl, c.nx, c.ny, c.rna);
     apply<B, +1>(sc, v, dl, c.nx, c.ny, c.rnb);
     dvx = gvx<B>(v) - gvx<A>(v); dvy = gvy<B>(v) - gvy<A>(v);
-    float vt = dvx * tx + dvy * ty;
-    if constexpr (rotates<B>()) vt = vt + gw<B>(v) * c.rtb;
-    if constexpr (rotates<A>()) vt = vt - gw<A>(v) * c.rta;
+    float vt = mad(dvx, tx, dvy * ty);
+    if constexpr (rotates<B>()) vt = mad(gw<B>(v), c.rtb, vt);
+    if constexpr (rotates<A>()) vt = mad(-gw<A>(v), c.rta, vt);
     dl = -c.mt * vt;
     const float maxf = mu * c.ln;
     l0 = c.lt;
@@ -225,14 +227,14 @@ __device__ __forceinline__ void detect_disc_box(const PointScene& sc, Slot& c, f
     const float dx = px - qx, dy = py - qy;
     {   // conservative broad phase (does not change results)
         const float lim = r + rad + sc.contact_offset + 1e-3f;
-        if (dx * dx + dy * dy > lim * lim) return;
+        if (mad(dx, dx, dy * dy) > lim * lim) return;
     }
-    const float lx = bc * dx + bs * dy;
-    const float ly = bc * dy - bs * dx;
+    const float lx = mad(bc, dx, bs * dy);
+    const float ly = mad(bc, dy, -(bs * dx));
     float cx = fminf(fmaxf(lx, -hx), hx);
     float cy = fminf(fmaxf(ly, -hy), hy);
     const float ex = lx - cx, ey = ly - cy;
-    const float d2 = ex * ex + ey * ey;
+    const float d2 = mad(ex, ex, ey * ey);
     float nlx, nly, sep;
     if (d2 > 0.0f) {
         const float rd = spec_rsqrt(d2);
@@ -250,10 +252,10 @@ __device__ __forceinline__ void detect_disc_box(const PointScene& sc, Slot& c, f
         }
     }
     if (!(sep < sc.contact_offset)) return;
-    const float wx = bc * nlx - bs * nly;
-    const float wy = bs * nlx + bc * nly;
-    const float rbx = bc * cx - bs * cy;
-    const float rby = bs * cx + bc * cy;
+    const float wx = mad(bc, nlx, -(bs * nly));
+    const float wy = mad(bs, nlx, bc * nly);
+    const float rbx = mad(bc, cx, -(bs * cy));
+    const float rby = mad(bs, cx, bc * cy);
     prepare<ROBOT, B>(sc, c, -wx, -wy, 0.0f, 0.0f, rbx, rby, sep);
 }
 
@@ -261,10 +263,10 @@ __device__ __forceinline__ void detect_disc_walls(const PointScene& sc, Slot& cx
                                                   float px, float py) {
     cx_.on = false; cy_.on = false;
     float sg = (px >= 0.0f) ? 1.0f : -1.0f;
-    float sep = (sc.wall - sg * px) - sc.robot_r;
+    float sep = mad(-sg, px, sc.wall) - sc.robot_r;      // (sg = +-1: an exact product)
     if (sep < sc.contact_offset) prepare<ROBOT, STATIC>(sc, cx_, sg, 0.0f, 0.f, 0.f, 0.f, 0.f, sep);
     sg = (py >= 0.0f) ? 1.0f : -1.0f;
-    sep = (sc.wall - sg * py) - sc.robot_r;
+    sep = mad(-sg, py, sc.wall) - sc.robot_r;
     if (sep < sc.contact_offset) prepare<ROBOT, STATIC>(sc, cy_, 0.0f, sg, 0.f, 0.f, 0.f, 0.f, sep);
 }
 
@@ -277,11 +279,11 @@ __device__ __forceinline__ void detect_box_walls(const PointScene& sc, Slot& x1,
     const bool nearx = (sc.wall - fabsf(X.x)) <= lim;
     const bool neary = (sc.wall - fabsf(X.y)) <= lim;
     if (!(nearx || neary)) return;
-    const float r0x = X.c * hx - X.s * hy, r0y = X.s * hx + X.c * hy;
-    const float r1x = -X.c * hx - X.s * hy, r1y = -X.s * hx + X.c * hy;
+    const float r0x = mad(X.c, hx, -(X.s * hy)), r0y = mad(X.s, hx, X.c * hy);
+    const float r1x = mad(-X.c, hx, -(X.s * hy)), r1y = mad(-X.s, hx, X.c * hy);
     if (nearx) {
         const float sg = (X.x >= 0.0f) ? 1.0f : -1.0f;
-        const float base = sc.wall - sg * X.x;
+        const float base = mad(-sg, X.x, sc.wall);
         const float pa = sg * r0x, pb = sg * r1x;
         const float sep1 = base - fabsf(pa), sep2 = base - fabsf(pb);
         if (sep1 < sc.contact_offset) {
@@ -295,7 +297,7 @@ __device__ __forceinline__ void detect_box_walls(const PointScene& sc, Slot& x1,
     }
     if (neary) {
         const float sg = (X.y >= 0.0f) ? 1.0f : -1.0f;
-        const float base = sc.wall - sg * X.y;
+        const float base = mad(-sg, X.y, sc.wall);
         const float pa = sg * r0y, pb = sg * r1y;
         const float sep1 = base - fabsf(pa), sep2 = base - fabsf(pb);
         if (sep1 < sc.contact_offset) {
@@ -319,19 +321,19 @@ __device__ __forceinline__ void detect_box_box(const PointScene& sc, Slot& c1, S
     const float dxw = bx - ax, dyw = by - ay;
     {
         const float lim = rada + radb + sc.contact_offset + 1e-3f;
-        if (dxw * dxw + dyw * dyw > lim * lim) return;
+        if (mad(dxw, dxw, dyw * dyw) > lim * lim) return;
     }
-    const float dx = ca * dxw + sa * dyw;
-    const float dy = ca * dyw - sa * dxw;
-    const float cr = ca * cb + sa * sb;
-    const float sr = ca * sb - sa * cb;
+    const float dx = mad(ca, dxw, sa * dyw);
+    const float dy = mad(ca, dyw, -(sa * dxw));
+    const float cr = mad(ca, cb, sa * sb);
+    const float sr = mad(ca, sb, -(sa * cb));
     const float acr = fabsf(cr), asr = fabsf(sr);
-    const float sAx = fabsf(dx) - (hax + (acr * hbx + asr * hby));
-    const float sAy = fabsf(dy) - (hay + (asr * hbx + acr * hby));
-    const float ex = -(cr * dx + sr * dy);
-    const float ey = -(cr * dy - sr * dx);
-    const float sBx = fabsf(ex) - (hbx + (acr * hax + asr * hay));
-    const float sBy = fabsf(ey) - (hby + (asr * hax + acr * hay));
+    const float sAx = fabsf(dx) - (hax + mad(acr, hbx, asr * hby));
+    const float sAy = fabsf(dy) - (hay + mad(asr, hbx, acr * hby));
+    const float ex = -mad(cr, dx, sr * dy);
+    const float ey = -mad(cr, dy, -(sr * dx));
+    const float sBx = fabsf(ex) - (hbx + mad(acr, hax, asr * hay));
+    const float sBy = fabsf(ey) - (hby + mad(asr, hax, acr * hay));
     float best = sAx;
     int axis = 0;
     if (sAy > best + sc.face_tol) { best = sAy; axis = 1; }
@@ -349,50 +351,50 @@ __device__ __forceinline__ void detect_box_box(const PointScene& sc, Slot& c1, S
     const float sg = (dn >= 0.0f) ? 1.0f : -1.0f;
     const float hn = xface ? hrx : hry;
     const float ht = xface ? hry : hrx;
-    const float r0x = crr * hix - srr * hiy, r0y = srr * hix + crr * hiy;
-    const float r1x = -crr * hix - srr * hiy, r1y = -srr * hix + crr * hiy;
+    const float r0x = mad(crr, hix, -(srr * hiy)), r0y = mad(srr, hix, crr * hiy);
+    const float r1x = mad(-crr, hix, -(srr * hiy)), r1y = mad(-srr, hix, crr * hiy);
     const float pa = sg * (xface ? r0x : r0y);
     const float pb = sg * (xface ? r1x : r1y);
     const float f0 = (pa <= 0.0f) ? 1.0f : -1.0f;
     const float f1 = (pb <= 0.0f) ? 1.0f : -1.0f;
-    const float p1x = drx + f0 * r0x, p1y = dry + f0 * r0y;
-    const float p2x = drx + f1 * r1x, p2y = dry + f1 * r1y;
-    const float s1 = sg * (xface ? p1x : p1y) - hn;
-    const float s2 = sg * (xface ? p2x : p2y) - hn;
+    const float p1x = mad(f0, r0x, drx), p1y = mad(f0, r0y, dry);     // (f, sg = +-1: exact products)
+    const float p2x = mad(f1, r1x, drx), p2y = mad(f1, r1y, dry);
+    const float s1 = mad(sg, xface ? p1x : p1y, -hn);
+    const float s2 = mad(sg, xface ? p2x : p2y, -hn);
     const float t1 = xface ? p1y : p1x;
     const float t2 = xface ? p2y : p2x;
     float cs1 = s1, ct1 = t1, cs2 = s2, ct2 = t2;
     bool ok = true;
     if (t1 > ht) {
         if (t2 > ht) ok = false;
-        else { const float lam = (ht - t2) / (t1 - t2); cs1 = s2 + lam * (s1 - s2); ct1 = ht; }
+        else { const float lam = (ht - t2) / (t1 - t2); cs1 = mad(lam, s1 - s2, s2); ct1 = ht; }
     } else if (t1 < -ht) {
         if (t2 < -ht) ok = false;
-        else { const float lam = (-ht - t2) / (t1 - t2); cs1 = s2 + lam * (s1 - s2); ct1 = -ht; }
+        else { const float lam = (-ht - t2) / (t1 - t2); cs1 = mad(lam, s1 - s2, s2); ct1 = -ht; }
     }
     if (t2 > ht) {
-        if (!(t1 > ht)) { const float lam = (ht - t1) / (t2 - t1); cs2 = s1 + lam * (s2 - s1); ct2 = ht; }
+        if (!(t1 > ht)) { const float lam = (ht - t1) / (t2 - t1); cs2 = mad(lam, s2 - s1, s1); ct2 = ht; }
     } else if (t2 < -ht) {
-        if (!(t1 < -ht)) { const float lam = (-ht - t1) / (t2 - t1); cs2 = s1 + lam * (s2 - s1); ct2 = -ht; }
+        if (!(t1 < -ht)) { const float lam = (-ht - t1) / (t2 - t1); cs2 = mad(lam, s2 - s1, s1); ct2 = -ht; }
     }
     if (!ok) return;
     const float qrx = refA ? ax : bx, qry = refA ? ay : by;
     const float rc = refA ? ca : cb, rs = refA ? sa : sb;
     const float nrx = xface ? sg : 0.0f, nry = xface ? 0.0f : sg;
-    float nwx = rc * nrx - rs * nry, nwy = rs * nrx + rc * nry;
+    float nwx = mad(rc, nrx, -(rs * nry)), nwy = mad(rs, nrx, rc * nry);
     if (!refA) { nwx = -nwx; nwy = -nwy; }
     if (cs1 < sc.contact_offset) {
         const float pn = sg * (hn + cs1);
         const float plx = xface ? pn : ct1, ply = xface ? ct1 : pn;
-        const float pwx = qrx + (rc * plx - rs * ply);
-        const float pwy = qry + (rs * plx + rc * ply);
+        const float pwx = qrx + mad(rc, plx, -(rs * ply));
+        const float pwy = qry + mad(rs, plx, rc * ply);
         prepare<A, B>(sc, c1, nwx, nwy, pwx - ax, pwy - ay, pwx - bx, pwy - by, cs1);
     }
     if (cs2 < sc.contact_offset) {
         const float pn = sg * (hn + cs2);
         const float plx = xface ? pn : ct2, ply = xface ? ct2 : pn;
-        const float pwx = qrx + (rc * plx - rs * ply);
-        const float pwy = qry + (rs * plx + rc * ply);
+        const float pwx = qrx + mad(rc, plx, -(rs * ply));
+        const float pwy = qry + mad(rs, plx, rc * ply);
         prepare<A, B>(sc, c2, nwx, nwy, pwx - ax, pwy - ay, pwx - bx, pwy - by, cs2);
     }
 }
@@ -409,13 +411,15 @@ struct Fric {
 template <int ID>
 __device__ __forceinline__ void solve_ground_friction(const PointScene& sc, Vel& v, Fric& f,
                                                       float m, float I, float Llin, float Lang) {
-    // spec: a body at rest (v = 0 and w = 0) has no friction row in this pass
-    // (one v_or3 + shift + compare on the bit patterns: +-0 are the only values whose bits below
-    // the sign are all zero -- instead of three float compares joined through scalar registers)
-    if (((__float_as_uint(gvx<ID>(v)) | __float_as_uint(gvy<ID>(v)) | __float_as_uint(gw<ID>(v))) << 1) == 0u) return;
-    float nlx = f.lx + (-m * gvx<ID>(v));
-    float nly = f.ly + (-m * gvy<ID>(v));
-    const float mag2 = nlx * nlx + nly * nly;
+    // spec: a body at rest (v = 0 and w = 0) has no friction row in this pass.  v1.4: "zero" = below the smallest normal
+    // number -- 1 / I is a rounded reciprocal, so an angular friction row leaves ~1e-8 of the spin, which the next
+    // passes shrink by that factor each until it is subnormal, where it can stay (-I * 1e-45 rounds to 0): such a
+    // body IS at rest.  (one v_or3 + v_and + compare on the bit patterns: the exponent fields of all three are zero
+    // -- instead of three float compares joined through scalar registers)
+    if (((__float_as_uint(gvx<ID>(v)) | __float_as_uint(gvy<ID>(v)) | __float_as_uint(gw<ID>(v))) & 0x7f800000u) == 0u) return;
+    float nlx = mad(-m, gvx<ID>(v), f.lx);
+    float nly = mad(-m, gvy<ID>(v), f.ly);
+    const float mag2 = mad(nlx, nlx, nly * nly);
     {   // disc clamp as a select: a body that moves is almost always sliding (saturated), so the
         // sqrt + divide chain is on the path anyway and the exec-mask region around it only
         // added its ~40-cycle turnaround; unused lanes' inf / NaN are discarded by the select
@@ -424,34 +428,34 @@ __device__ __forceinline__ void solve_ground_friction(const PointScene& sc, Vel&
         nlx = sat ? nlx * scl : nlx;
         nly = sat ? nly * scl : nly;
     }
-    float nla = f.la + (-I * gw<ID>(v));
+    float nla = mad(-I, gw<ID>(v), f.la);
     if constexpr (ID == BOXB) {
-        v.bvx += sc.invm_b * (nlx - f.lx);
-        v.bvy += sc.invm_b * (nly - f.ly);
+        v.bvx = mad(sc.invm_b, nlx - f.lx, v.bvx);
+        v.bvy = mad(sc.invm_b, nly - f.ly, v.bvy);
     } else {
-        v.dvx += sc.invm_d * (nlx - f.lx);
-        v.dvy += sc.invm_d * (nly - f.ly);
+        v.dvx = mad(sc.invm_d, nlx - f.lx, v.dvx);
+        v.dvy = mad(sc.invm_d, nly - f.ly, v.dvy);
     }
     f.lx = nlx; f.ly = nly;
     nla = clamp_sym(nla, Lang);
-    if constexpr (ID == BOXB) v.bw += sc.invI_b * (nla - f.la);
-    else v.dw += sc.invI_d * (nla - f.la);
+    if constexpr (ID == BOXB) v.bw = mad(sc.invI_b, nla - f.la, v.bw);
+    else v.dw = mad(sc.invI_d, nla - f.la, v.dw);
     f.la = nla;
 }
 
 __device__ __forceinline__ void integrate_box(Box& X, float h) {
-    X.x = X.x + h * X.vx;
-    X.y = X.y + h * X.vy;
-    if (X.w == 0.0f) return;  // spec: orientation is only touched when w != 0
+    X.x = mad(h, X.vx, X.x);
+    X.y = mad(h, X.vy, X.y);
+    if ((__float_as_uint(X.w) & 0x7f800000u) == 0u) return;  // spec: orientation is only touched when w != 0 (v1.4: subnormal = 0)
     const float a = 0.5f * (h * X.w);
     const float a2 = a * a;
     const float den = 1.0f + a2;
     const float rden = 1.0f / den;
     const float cd = (1.0f - a2) * rden;
     const float sd = (2.0f * a) * rden;
-    const float c = X.c * cd - X.s * sd;
-    const float s = X.s * cd + X.c * sd;
-    const float rn = spec_rsqrt(c * c + s * s);
+    const float c = mad(X.c, cd, -(X.s * sd));
+    const float s = mad(X.s, cd, X.c * sd);
+    const float rn = spec_rsqrt(mad(c, c, s * s));
     X.c = c * rn;
     X.s = s * rn;
 }
@@ -459,8 +463,8 @@ __device__ __forceinline__ void integrate_box(Box& X, float h) {
 // impulse of slot c on its body b (+) / a (-), accumulated in slot order like the oracle
 #define M3_ACC(fx, fy, c, sign)                                   \
     if ((c).on) {                                                 \
-        const float ix_ = (c).ln * (c).nx + (c).lt * (-(c).ny);   \
-        const float iy_ = (c).ln * (c).ny + (c).lt * (c).nx;      \
+        const float ix_ = mad((c).ln, (c).nx, (c).lt * (-(c).ny)); \
+        const float iy_ = mad((c).ln, (c).ny, (c).lt * (c).nx);    \
         if ((sign) > 0) { fx += ix_; fy += iy_; }                 \
         else { fx -= ix_; fy -= iy_; }                            \
     }
@@ -471,7 +475,7 @@ __device__ __forceinline__ bool near_centres(const PointScene& sc, float ax, flo
                                              float ra, float rb) {
     const float dx = bx - ax, dy = by - ay;
     const float lim = ra + rb + sc.contact_offset + 1e-3f;
-    return !(dx * dx + dy * dy > lim * lim);
+    return !(mad(dx, dx, dy * dy) > lim * lim);
 }
 __device__ __forceinline__ bool near_walls_disc(const PointScene& sc, float px, float py) {
     return ((sc.wall - fabsf(px)) - sc.robot_r < sc.contact_offset) ||
@@ -548,10 +552,10 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     constexpr bool ANY_RARE = (M & ~G_RB) != 0u, ANY_WALLS = RW || BW || DW, ANY_BOXES = BD || BO || DO;
     const float h = sc.h;
     // 1. external forces
-    w.rvx = w.rvx + (h * w.fRx) * sc.invm_r;
-    w.rvy = w.rvy + (h * w.fRy) * sc.invm_r;
-    w.B.vx = w.B.vx + (h * w.fBx) * sc.invm_b;
-    w.B.vy = w.B.vy + (h * w.fBy) * sc.invm_b;
+    w.rvx = mad(h * w.fRx, sc.invm_r, w.rvx);
+    w.rvy = mad(h * w.fRy, sc.invm_r, w.rvy);
+    w.B.vx = mad(h * w.fBx, sc.invm_b, w.B.vx);
+    w.B.vy = mad(h * w.fBy, sc.invm_b, w.B.vy);
 
     // 2. contacts (static slots; a group that is not in M stays `on = false` and compiles away)
     Slot s_rb, s_rd, s_ro, s_rwx, s_rwy;
@@ -604,9 +608,9 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     constexpr bool B_FREE = (M & (G_RB | G_BW | G_BD | G_BO)) == 0u, D_FREE = (M & (G_RD | G_DW | G_BD | G_DO)) == 0u;
     bool skipB = false, skipD = false;
     if constexpr (B_FREE && !ALL_FORCES)
-        skipB = __builtin_amdgcn_ballot_w64(((__float_as_uint(v.bvx) | __float_as_uint(v.bvy) | __float_as_uint(v.bw)) << 1) != 0u) == 0ull;
+        skipB = __builtin_amdgcn_ballot_w64(((__float_as_uint(v.bvx) | __float_as_uint(v.bvy) | __float_as_uint(v.bw)) & 0x7f800000u) != 0u) == 0ull;
     if constexpr (D_FREE && !ALL_FORCES)
-        skipD = __builtin_amdgcn_ballot_w64(((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u) == 0ull;
+        skipD = __builtin_amdgcn_ballot_w64(((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) & 0x7f800000u) != 0u) == 0ull;
     // The three lean instances (no pair at all / robot-box / + robot-dyn-obs: nearly every substep of the planned
     // rollouts) run their passes in VERSIONS chosen once per substep by wave-uniform flags -- with / without the
     // box's and the dyn-obs' friction rows and the robot-dyn-obs row -- and, for the reference's six iterations,
@@ -619,15 +623,15 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     if constexpr (LEAN) {
         auto pass = [&](auto with_b, auto with_d, auto with_rd) {
             {
-                float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
+                float dl = -(mad(sc.gam, ldx, v.rvx - ux) * sc.md);
                 float l1 = ldx + dl;
                 l1 = clamp_sym(l1, sc.dmax);
-                v.rvx += sc.invm_r * (l1 - ldx);
+                v.rvx = mad(sc.invm_r, l1 - ldx, v.rvx);
                 ldx = l1;
-                dl = -(((v.rvy - uy) + sc.gam * ldy) * sc.md);
+                dl = -(mad(sc.gam, ldy, v.rvy - uy) * sc.md);
                 l1 = ldy + dl;
                 l1 = clamp_sym(l1, sc.dmax);
-                v.rvy += sc.invm_r * (l1 - ldy);
+                v.rvy = mad(sc.invm_r, l1 - ldy, v.rvy);
                 ldy = l1;
             }
             if constexpr (decltype(with_b)::value) solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
@@ -658,8 +662,8 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
                 fx += fD.lx; fy += fD.ly;
                 w.fcDx = fx * sc.inv_h; w.fcDy = fy * sc.inv_h;
             }
-            w.rx = w.rx + h * w.rvx;
-            w.ry = w.ry + h * w.rvy;
+            w.rx = mad(h, w.rvx, w.rx);
+            w.ry = mad(h, w.rvy, w.ry);
             if constexpr (decltype(with_b)::value) integrate_box(w.B, h);
             if constexpr (decltype(with_d)::value) integrate_box(w.D, h);
             M3_PH(4);
@@ -668,7 +672,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
             // (the dyn-obs is in reach of the robot: usually no lane touches it, and then a dyn-obs that rests in
             // every lane stays at rest)
             const bool any_rd = __builtin_amdgcn_ballot_w64(s_rd.on) != 0ull;
-            const bool d_rests = __builtin_amdgcn_ballot_w64(((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u) == 0ull;
+            const bool d_rests = __builtin_amdgcn_ballot_w64(((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) & 0x7f800000u) != 0u) == 0ull;
             if (any_rd) passes(RowOn{}, RowOn{}, RowOn{});
             else if (d_rests) passes(RowOn{}, RowOff{}, RowOff{});
             else passes(RowOn{}, RowOn{}, RowOff{});
@@ -683,15 +687,15 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     // skip cost a taken branch each, see LEAN above; not unrolled: six copies of these passes measured +7 %)
     auto gen_pass = [&](auto with_d, auto with_rw) {
         {
-            float dl = -(((v.rvx - ux) + sc.gam * ldx) * sc.md);
+            float dl = -(mad(sc.gam, ldx, v.rvx - ux) * sc.md);
             float l1 = ldx + dl;
             l1 = clamp_sym(l1, sc.dmax);
-            v.rvx += sc.invm_r * (l1 - ldx);
+            v.rvx = mad(sc.invm_r, l1 - ldx, v.rvx);
             ldx = l1;
-            dl = -(((v.rvy - uy) + sc.gam * ldy) * sc.md);
+            dl = -(mad(sc.gam, ldy, v.rvy - uy) * sc.md);
             l1 = ldy + dl;
             l1 = clamp_sym(l1, sc.dmax);
-            v.rvy += sc.invm_r * (l1 - ldy);
+            v.rvy = mad(sc.invm_r, l1 - ldy, v.rvy);
             ldy = l1;
         }
         if (!skipB) solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
@@ -701,7 +705,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
         if constexpr (RB) {
             if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
         }
-        const bool d_moving = decltype(with_d)::value && ((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) << 1) != 0u;
+        const bool d_moving = decltype(with_d)::value && ((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) & 0x7f800000u) != 0u;
         // (skipD: the dyn-obs rests in every lane and no slot of this instance touches it -- its friction
         // row is a no-op; the rarely-active slots below do not depend on it)
         if ((!skipD && d_moving) | rare) {
@@ -795,8 +799,8 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     }
 
     // 4. integrate
-    w.rx = w.rx + h * w.rvx;
-    w.ry = w.ry + h * w.rvy;
+    w.rx = mad(h, w.rvx, w.rx);
+    w.ry = mad(h, w.rvy, w.ry);
     if (!skipB) integrate_box(w.B, h);   // (a wave whose boxes all rest: x + h * 0 == x)
     if (!skipD) integrate_box(w.D, h);
     M3_PH(4);

@@ -1,7 +1,7 @@
 /*
  * planar_world.c -- CPU ORACLE (test infrastructure, NOT product code).
  *
- * Independent scalar implementation of "Planar contact dynamics spec v1" (DESIGN.md).
+ * Independent scalar implementation of the "Planar contact dynamics spec" (currently v1.4).
  * It stands where the reference calls Isaac Gym / PhysX (closed binary):
  *   IsaacGymWrapper.step()                      isaacgym_wrapper.py:354-360
  *   set_dof_velocity_target_tensor()            isaacgym_wrapper.py:196
@@ -25,6 +25,10 @@
  * in exactly this order (relative error < 1e-9 before the final rounding).  It replaces
  * "sqrtf then divide" where only 1/sqrt or a normalisation is needed: on the GPU the correctly
  * rounded sqrtf + division are ~32 dependent instructions, this is 15. */
+/* spec v1.4: mad(a, b, c) = a*b + c with ONE rounding (IEEE 754 fusedMultiplyAdd; fmaf is exact with or without
+ * hardware FMA) -- every product-plus-sum of the dynamics is written with it, here and in the HIP kernel alike. */
+static inline float mad(float a, float b, float c) { return fmaf(a, b, c); }
+
 static inline float spec_rsqrt(float a) {
     uint32_t i;
     float y;
@@ -32,9 +36,9 @@ static inline float spec_rsqrt(float a) {
     i = 0x5f3759dfu - (i >> 1);
     memcpy(&y, &i, 4);
     const float hlf = 0.5f * a;
-    y = y * (1.5f - hlf * (y * y));
-    y = y * (1.5f - hlf * (y * y));
-    y = y * (1.5f - hlf * (y * y));
+    y = y * mad(-hlf, y * y, 1.5f);
+    y = y * mad(-hlf, y * y, 1.5f);
+    y = y * mad(-hlf, y * y, 1.5f);
     return y;
 }
 
@@ -120,12 +124,12 @@ static void detect_disc_box(const m3o_point_scene* sc, solver_t* s, const m3o_bo
                             float hy, float mu) {
     const float r = sc->robot_r;
     float dx = R->x - qx, dy = R->y - qy;
-    float lx = c * dx + sn * dy;
-    float ly = c * dy - sn * dx;
+    float lx = mad(c, dx, sn * dy);
+    float ly = mad(c, dy, -(sn * dx));
     float cx = fminf(fmaxf(lx, -hx), hx);
     float cy = fminf(fmaxf(ly, -hy), hy);
     float ex = lx - cx, ey = ly - cy;
-    float d2 = ex * ex + ey * ey;
+    float d2 = mad(ex, ex, ey * ey);
     float nlx, nly, sep;
     if (d2 > 0.0f) {
         float rd = spec_rsqrt(d2); /* spec v1.3 */
@@ -143,32 +147,32 @@ static void detect_disc_box(const m3o_point_scene* sc, solver_t* s, const m3o_bo
         }
     }
     if (!(sep < sc->contact_offset)) return;
-    float wx = c * nlx - sn * nly;
-    float wy = sn * nlx + c * nly;
-    float rbx = c * cx - sn * cy;
-    float rby = sn * cx + c * cy;
+    float wx = mad(c, nlx, -(sn * nly));
+    float wy = mad(sn, nlx, c * nly);
+    float rbx = mad(c, cx, -(sn * cy));
+    float rby = mad(sn, cx, c * cy);
     add_contact(s, BR, bid, -wx, -wy, 0.0f, 0.0f, rbx, rby, sep, mu);
 }
 
 static void detect_disc_walls(const m3o_point_scene* sc, solver_t* s, const m3o_body* R) {
     float sg = (R->x >= 0.0f) ? 1.0f : -1.0f;
-    float sep = (sc->wall - sg * R->x) - sc->robot_r;
+    float sep = mad(-sg, R->x, sc->wall) - sc->robot_r;
     if (sep < sc->contact_offset)
         add_contact(s, BR, BS, sg, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, sep, sc->mu_rw);
     sg = (R->y >= 0.0f) ? 1.0f : -1.0f;
-    sep = (sc->wall - sg * R->y) - sc->robot_r;
+    sep = mad(-sg, R->y, sc->wall) - sc->robot_r;
     if (sep < sc->contact_offset)
         add_contact(s, BR, BS, 0.0f, sg, 0.0f, 0.0f, 0.0f, 0.0f, sep, sc->mu_rw);
 }
 
 static void detect_box_walls(const m3o_point_scene* sc, solver_t* s, int bid,
                              const m3o_body* X, float hx, float hy, float mu) {
-    float r0x = X->c * hx - X->s * hy, r0y = X->s * hx + X->c * hy;   /* corner (+,+) */
-    float r1x = -X->c * hx - X->s * hy, r1y = -X->s * hx + X->c * hy; /* corner (-,+) */
+    float r0x = mad(X->c, hx, -(X->s * hy)), r0y = mad(X->s, hx, X->c * hy);   /* corner (+,+) */
+    float r1x = mad(-X->c, hx, -(X->s * hy)), r1y = mad(-X->s, hx, X->c * hy); /* corner (-,+) */
     /* x walls */
     {
         float sg = (X->x >= 0.0f) ? 1.0f : -1.0f;
-        float base = sc->wall - sg * X->x;
+        float base = mad(-sg, X->x, sc->wall);
         float pa = sg * r0x, pb = sg * r1x;
         float sep1 = base - fabsf(pa), sep2 = base - fabsf(pb);
         if (sep1 < sc->contact_offset) {
@@ -183,7 +187,7 @@ static void detect_box_walls(const m3o_point_scene* sc, solver_t* s, int bid,
     /* y walls */
     {
         float sg = (X->y >= 0.0f) ? 1.0f : -1.0f;
-        float base = sc->wall - sg * X->y;
+        float base = mad(-sg, X->y, sc->wall);
         float pa = sg * r0y, pb = sg * r1y;
         float sep1 = base - fabsf(pa), sep2 = base - fabsf(pb);
         if (sep1 < sc->contact_offset) {
@@ -202,17 +206,17 @@ static void detect_box_box(const m3o_point_scene* sc, solver_t* s, int ia, float
                            float ca, float sa, float hax, float hay, int ib, float bx,
                            float by, float cb, float sb, float hbx, float hby, float mu) {
     float dxw = bx - ax, dyw = by - ay;
-    float dx = ca * dxw + sa * dyw;
-    float dy = ca * dyw - sa * dxw;
-    float cr = ca * cb + sa * sb;
-    float sr = ca * sb - sa * cb;
+    float dx = mad(ca, dxw, sa * dyw);
+    float dy = mad(ca, dyw, -(sa * dxw));
+    float cr = mad(ca, cb, sa * sb);
+    float sr = mad(ca, sb, -(sa * cb));
     float acr = fabsf(cr), asr = fabsf(sr);
-    float sAx = fabsf(dx) - (hax + (acr * hbx + asr * hby));
-    float sAy = fabsf(dy) - (hay + (asr * hbx + acr * hby));
-    float ex = -(cr * dx + sr * dy);
-    float ey = -(cr * dy - sr * dx);
-    float sBx = fabsf(ex) - (hbx + (acr * hax + asr * hay));
-    float sBy = fabsf(ey) - (hby + (asr * hax + acr * hay));
+    float sAx = fabsf(dx) - (hax + mad(acr, hbx, asr * hby));
+    float sAy = fabsf(dy) - (hay + mad(asr, hbx, acr * hby));
+    float ex = -mad(cr, dx, sr * dy);
+    float ey = -mad(cr, dy, -(sr * dx));
+    float sBx = fabsf(ex) - (hbx + mad(acr, hax, asr * hay));
+    float sBy = fabsf(ey) - (hby + mad(asr, hax, acr * hay));
     float best = sAx;
     int axis = 0;
     if (sAy > best + sc->face_tol) { best = sAy; axis = 1; }
@@ -232,16 +236,16 @@ static void detect_box_box(const m3o_point_scene* sc, solver_t* s, int ia, float
     float hn = xface ? hrx : hry;
     float ht = xface ? hry : hrx;
     /* incident corners (+,+) and (-,+) in the ref frame */
-    float r0x = crr * hix - srr * hiy, r0y = srr * hix + crr * hiy;
-    float r1x = -crr * hix - srr * hiy, r1y = -srr * hix + crr * hiy;
+    float r0x = mad(crr, hix, -(srr * hiy)), r0y = mad(srr, hix, crr * hiy);
+    float r1x = mad(-crr, hix, -(srr * hiy)), r1y = mad(-srr, hix, crr * hiy);
     float pa = sg * (xface ? r0x : r0y);
     float pb = sg * (xface ? r1x : r1y);
     float f0 = (pa <= 0.0f) ? 1.0f : -1.0f;
     float f1 = (pb <= 0.0f) ? 1.0f : -1.0f;
-    float p1x = drx + f0 * r0x, p1y = dry + f0 * r0y;
-    float p2x = drx + f1 * r1x, p2y = dry + f1 * r1y;
-    float s1 = sg * (xface ? p1x : p1y) - hn;
-    float s2 = sg * (xface ? p2x : p2y) - hn;
+    float p1x = mad(f0, r0x, drx), p1y = mad(f0, r0y, dry);
+    float p2x = mad(f1, r1x, drx), p2y = mad(f1, r1y, dry);
+    float s1 = mad(sg, xface ? p1x : p1y, -hn);
+    float s2 = mad(sg, xface ? p2x : p2y, -hn);
     float t1 = xface ? p1y : p1x;
     float t2 = xface ? p2y : p2x;
     /* clip the incident edge against the side planes |t| <= ht (using the unclipped line) */
@@ -249,15 +253,15 @@ static void detect_box_box(const m3o_point_scene* sc, solver_t* s, int ia, float
     int ok = 1;
     if (t1 > ht) {
         if (t2 > ht) ok = 0;
-        else { float lam = (ht - t2) / (t1 - t2); cs1 = s2 + lam * (s1 - s2); ct1 = ht; }
+        else { float lam = (ht - t2) / (t1 - t2); cs1 = mad(lam, s1 - s2, s2); ct1 = ht; }
     } else if (t1 < -ht) {
         if (t2 < -ht) ok = 0;
-        else { float lam = (-ht - t2) / (t1 - t2); cs1 = s2 + lam * (s1 - s2); ct1 = -ht; }
+        else { float lam = (-ht - t2) / (t1 - t2); cs1 = mad(lam, s1 - s2, s2); ct1 = -ht; }
     }
     if (t2 > ht) {
-        if (!(t1 > ht)) { float lam = (ht - t1) / (t2 - t1); cs2 = s1 + lam * (s2 - s1); ct2 = ht; }
+        if (!(t1 > ht)) { float lam = (ht - t1) / (t2 - t1); cs2 = mad(lam, s2 - s1, s1); ct2 = ht; }
     } else if (t2 < -ht) {
-        if (!(t1 < -ht)) { float lam = (-ht - t1) / (t2 - t1); cs2 = s1 + lam * (s2 - s1); ct2 = -ht; }
+        if (!(t1 < -ht)) { float lam = (-ht - t1) / (t2 - t1); cs2 = mad(lam, s2 - s1, s1); ct2 = -ht; }
     }
     if (!ok) return;
     /* reference box world frame */
@@ -265,7 +269,7 @@ static void detect_box_box(const m3o_point_scene* sc, solver_t* s, int ia, float
     float rc = refA ? ca : cb, rs = refA ? sa : sb;
     /* face normal (ref frame) -> world; n must point from A to B */
     float nrx = xface ? sg : 0.0f, nry = xface ? 0.0f : sg;
-    float nwx = rc * nrx - rs * nry, nwy = rs * nrx + rc * nry;
+    float nwx = mad(rc, nrx, -(rs * nry)), nwy = mad(rs, nrx, rc * nry);
     if (!refA) { nwx = -nwx; nwy = -nwy; }
     float cs[2] = {cs1, cs2}, ct[2] = {ct1, ct2};
     for (int i = 0; i < 2; ++i) {
@@ -273,8 +277,8 @@ static void detect_box_box(const m3o_point_scene* sc, solver_t* s, int ia, float
         float pn = sg * (hn + cs[i]);
         float plx = xface ? pn : ct[i];
         float ply = xface ? ct[i] : pn;
-        float pwx = qrx + (rc * plx - rs * ply);
-        float pwy = qry + (rs * plx + rc * ply);
+        float pwx = qrx + mad(rc, plx, -(rs * ply));
+        float pwy = qry + mad(rs, plx, rc * ply);
         add_contact(s, ia, ib, nwx, nwy, pwx - ax, pwy - ay, pwx - bx, pwy - by, cs[i], mu);
     }
 }
@@ -284,14 +288,14 @@ static void prepare_contacts(const m3o_point_scene* sc, solver_t* s, float h) {
     for (int i = 0; i < s->nc; ++i) {
         contact_t* c = &s->c[i];
         float tx = -c->ny, ty = c->nx;
-        c->rna = c->rax * c->ny - c->ray * c->nx;
-        c->rnb = c->rbx * c->ny - c->rby * c->nx;
-        c->rta = c->rax * ty - c->ray * tx;
-        c->rtb = c->rbx * ty - c->rby * tx;
-        float kn = ((s->invm[c->a] + s->invm[c->b]) + s->invI[c->a] * c->rna * c->rna) +
-                   s->invI[c->b] * c->rnb * c->rnb;
-        float kt = ((s->invm[c->a] + s->invm[c->b]) + s->invI[c->a] * c->rta * c->rta) +
-                   s->invI[c->b] * c->rtb * c->rtb;
+        c->rna = mad(c->rax, c->ny, -(c->ray * c->nx));
+        c->rnb = mad(c->rbx, c->ny, -(c->rby * c->nx));
+        c->rta = mad(c->rax, ty, -(c->ray * tx));
+        c->rtb = mad(c->rbx, ty, -(c->rby * tx));
+        float kn = mad(s->invI[c->b] * c->rnb, c->rnb,
+                       mad(s->invI[c->a] * c->rna, c->rna, s->invm[c->a] + s->invm[c->b]));
+        float kt = mad(s->invI[c->b] * c->rtb, c->rtb,
+                       mad(s->invI[c->a] * c->rta, c->rta, s->invm[c->a] + s->invm[c->b]));
         c->mn = 1.0f / kn;
         c->mt = 1.0f / kt;
         if (c->sep > 0.0f) {
@@ -311,22 +315,22 @@ static void solve_contact(solver_t* s, contact_t* c) {
     const float tx = -c->ny, ty = c->nx;
     /* normal */
     float dvx = s->vx[b] - s->vx[a], dvy = s->vy[b] - s->vy[a];
-    float vn = ((dvx * c->nx + dvy * c->ny) + s->w[b] * c->rnb) - s->w[a] * c->rna;
+    float vn = mad(-s->w[a], c->rna, mad(s->w[b], c->rnb, mad(dvx, c->nx, dvy * c->ny)));
     float dl = -c->mn * (vn + c->bias);
     float l0 = c->ln;
     float l1 = l0 + dl;
     if (l1 < 0.0f) l1 = 0.0f;
     c->ln = l1;
     dl = l1 - l0;
-    s->vx[a] -= (s->invm[a] * dl) * c->nx;
-    s->vy[a] -= (s->invm[a] * dl) * c->ny;
-    s->w[a] -= (s->invI[a] * c->rna) * dl;
-    s->vx[b] += (s->invm[b] * dl) * c->nx;
-    s->vy[b] += (s->invm[b] * dl) * c->ny;
-    s->w[b] += (s->invI[b] * c->rnb) * dl;
+    s->vx[a] = mad(-(s->invm[a] * dl), c->nx, s->vx[a]);
+    s->vy[a] = mad(-(s->invm[a] * dl), c->ny, s->vy[a]);
+    s->w[a] = mad(-(s->invI[a] * c->rna), dl, s->w[a]);
+    s->vx[b] = mad(s->invm[b] * dl, c->nx, s->vx[b]);
+    s->vy[b] = mad(s->invm[b] * dl, c->ny, s->vy[b]);
+    s->w[b] = mad(s->invI[b] * c->rnb, dl, s->w[b]);
     /* friction */
     dvx = s->vx[b] - s->vx[a]; dvy = s->vy[b] - s->vy[a];
-    float vt = ((dvx * tx + dvy * ty) + s->w[b] * c->rtb) - s->w[a] * c->rta;
+    float vt = mad(-s->w[a], c->rta, mad(s->w[b], c->rtb, mad(dvx, tx, dvy * ty)));
     dl = -c->mt * vt;
     float maxf = c->mu * c->ln;
     l0 = c->lt;
@@ -335,12 +339,20 @@ static void solve_contact(solver_t* s, contact_t* c) {
     if (l1 < -maxf) l1 = -maxf;
     c->lt = l1;
     dl = l1 - l0;
-    s->vx[a] -= (s->invm[a] * dl) * tx;
-    s->vy[a] -= (s->invm[a] * dl) * ty;
-    s->w[a] -= (s->invI[a] * c->rta) * dl;
-    s->vx[b] += (s->invm[b] * dl) * tx;
-    s->vy[b] += (s->invm[b] * dl) * ty;
-    s->w[b] += (s->invI[b] * c->rtb) * dl;
+    s->vx[a] = mad(-(s->invm[a] * dl), tx, s->vx[a]);
+    s->vy[a] = mad(-(s->invm[a] * dl), ty, s->vy[a]);
+    s->w[a] = mad(-(s->invI[a] * c->rta), dl, s->w[a]);
+    s->vx[b] = mad(s->invm[b] * dl, tx, s->vx[b]);
+    s->vy[b] = mad(s->invm[b] * dl, ty, s->vy[b]);
+    s->w[b] = mad(s->invI[b] * c->rtb, dl, s->w[b]);
+}
+
+/* spec v1.4: in the rest test and the orientation update "zero" means below the smallest normal binary32 number (a
+ * residual spin decays through the subnormals and can stay there: 1 / I is a rounded reciprocal) */
+static inline int is_zero(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return (u & 0x7f800000u) == 0u;
 }
 
 typedef struct { float lx, ly, la; } fric_acc;
@@ -348,37 +360,37 @@ typedef struct { float lx, ly, la; } fric_acc;
 static void solve_ground_friction(solver_t* s, int b, float m, float I, float Llin, float Lang,
                                   fric_acc* f) {
     /* spec: a body at rest (v = 0 and w = 0) has no friction row in this pass */
-    if (s->vx[b] == 0.0f && s->vy[b] == 0.0f && s->w[b] == 0.0f) return;
-    float nlx = f->lx + (-m * s->vx[b]);
-    float nly = f->ly + (-m * s->vy[b]);
-    float mag2 = nlx * nlx + nly * nly;
+    if (is_zero(s->vx[b]) && is_zero(s->vy[b]) && is_zero(s->w[b])) return;
+    float nlx = mad(-m, s->vx[b], f->lx);
+    float nly = mad(-m, s->vy[b], f->ly);
+    float mag2 = mad(nlx, nlx, nly * nly);
     if (mag2 > Llin * Llin) {
         float sc = Llin * spec_rsqrt(mag2); /* spec v1.3 */
         nlx = nlx * sc; nly = nly * sc;
     }
-    s->vx[b] += s->invm[b] * (nlx - f->lx);
-    s->vy[b] += s->invm[b] * (nly - f->ly);
+    s->vx[b] = mad(s->invm[b], nlx - f->lx, s->vx[b]);
+    s->vy[b] = mad(s->invm[b], nly - f->ly, s->vy[b]);
     f->lx = nlx; f->ly = nly;
-    float nla = f->la + (-I * s->w[b]);
+    float nla = mad(-I, s->w[b], f->la);
     if (nla > Lang) nla = Lang;
     if (nla < -Lang) nla = -Lang;
-    s->w[b] += s->invI[b] * (nla - f->la);
+    s->w[b] = mad(s->invI[b], nla - f->la, s->w[b]);
     f->la = nla;
 }
 
 static void integrate_body(m3o_body* X, float h, int rotate) {
-    X->x = X->x + h * X->vx;
-    X->y = X->y + h * X->vy;
-    if (rotate && X->w != 0.0f) { /* spec: orientation is only touched when w != 0 */
+    X->x = mad(h, X->vx, X->x);
+    X->y = mad(h, X->vy, X->y);
+    if (rotate && !is_zero(X->w)) { /* spec: orientation is only touched when w != 0 */
         float a = 0.5f * (h * X->w);
         float a2 = a * a;
         float den = 1.0f + a2;
         float rden = 1.0f / den;
         float cd = (1.0f - a2) * rden;
         float sd = (2.0f * a) * rden;
-        float c = X->c * cd - X->s * sd;
-        float s = X->s * cd + X->c * sd;
-        float rn = spec_rsqrt(c * c + s * s); /* spec v1.3 */
+        float c = mad(X->c, cd, -(X->s * sd));
+        float s = mad(X->s, cd, X->c * sd);
+        float rn = spec_rsqrt(mad(c, c, s * s)); /* spec v1.3 */
         X->c = c * rn;
         X->s = s * rn;
     }
@@ -402,10 +414,10 @@ void m3o_point_step(const m3o_point_scene* sc, m3o_point_world* w, const float u
 
     for (int sub = 0; sub < sc->substeps; ++sub) {
         /* 1. external forces (suction), constant over the step */
-        w->R.vx = w->R.vx + (h * w->fext_R[0]) * s.invm[BR];
-        w->R.vy = w->R.vy + (h * w->fext_R[1]) * s.invm[BR];
-        w->B.vx = w->B.vx + (h * w->fext_B[0]) * s.invm[BB];
-        w->B.vy = w->B.vy + (h * w->fext_B[1]) * s.invm[BB];
+        w->R.vx = mad(h * w->fext_R[0], s.invm[BR], w->R.vx);
+        w->R.vy = mad(h * w->fext_R[1], s.invm[BR], w->R.vy);
+        w->B.vx = mad(h * w->fext_B[0], s.invm[BB], w->B.vx);
+        w->B.vy = mad(h * w->fext_B[1], s.invm[BB], w->B.vy);
 
         /* 2. contacts, fixed slot order */
         s.nc = 0;
@@ -436,17 +448,17 @@ void m3o_point_step(const m3o_point_scene* sc, m3o_point_world* w, const float u
         for (int it = 0; it < sc->iters; ++it) {
             /* velocity drive (soft constraint, implicit damper) */
             {
-                float dl = -(((s.vx[BR] - u[0]) + gam * ldx) * md);
+                float dl = -(mad(gam, ldx, s.vx[BR] - u[0]) * md);
                 float l1 = ldx + dl;
                 if (l1 > dmax) l1 = dmax;
                 if (l1 < -dmax) l1 = -dmax;
-                s.vx[BR] += s.invm[BR] * (l1 - ldx);
+                s.vx[BR] = mad(s.invm[BR], l1 - ldx, s.vx[BR]);
                 ldx = l1;
-                dl = -(((s.vy[BR] - u[1]) + gam * ldy) * md);
+                dl = -(mad(gam, ldy, s.vy[BR] - u[1]) * md);
                 l1 = ldy + dl;
                 if (l1 > dmax) l1 = dmax;
                 if (l1 < -dmax) l1 = -dmax;
-                s.vy[BR] += s.invm[BR] * (l1 - ldy);
+                s.vy[BR] = mad(s.invm[BR], l1 - ldy, s.vy[BR]);
                 ldy = l1;
             }
             solve_ground_friction(&s, BB, sc->box_m, sc->box_I, LlinB, LangB, &fB);
@@ -461,8 +473,8 @@ void m3o_point_step(const m3o_point_scene* sc, m3o_point_world* w, const float u
         float fx[NBODY] = {0, 0, 0, 0}, fy[NBODY] = {0, 0, 0, 0};
         for (int i = 0; i < s.nc; ++i) {
             const contact_t* c = &s.c[i];
-            float ix = c->ln * c->nx + c->lt * (-c->ny);
-            float iy = c->ln * c->ny + c->lt * c->nx;
+            float ix = mad(c->ln, c->nx, c->lt * (-c->ny));
+            float iy = mad(c->ln, c->ny, c->lt * c->nx);
             fx[c->a] -= ix; fy[c->a] -= iy;
             fx[c->b] += ix; fy[c->b] += iy;
         }

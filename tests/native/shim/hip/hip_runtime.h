@@ -8,7 +8,9 @@
 #define __forceinline__ inline
 static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
-// v_med3_f32(x, -lim, lim), lim >= 0: the clamp
-#define __builtin_amdgcn_fmed3f(x, lo, hi) std::fmin(std::fmax((x), (lo)), (hi))
+// v_med3_f32(x, -lim, lim), lim >= 0: the clamp, written as the spec writes it (compare and assign: the sign of a zero
+// bound is the bound's; fmin / fmax leave that to the implementation)
+static inline float m3_host_med3(float x, float lo, float hi) { return x > hi ? hi : (x < lo ? lo : x); }
+#define __builtin_amdgcn_fmed3f(x, lo, hi) m3_host_med3((x), (lo), (hi))
 // a wavefront of one lane
 #define __builtin_amdgcn_ballot_w64(p) ((p) ? 1ull : 0ull)

@@ -240,7 +240,9 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
                 if exact or name == "BUF_TOP_IDX":
                     assert torch.equal(e.buffer(b), full.buffer(b)), f"call {call} rank {r} {name}"
                 elif "WEIGHTS" in name:
-                    np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), rtol=2e-3, atol=1e-8)
+                    # (the samples that carry the previous command's best trajectories, 0 and K/2: their plans agree to f32
+                    # rounding only, so do their costs, and a cost difference of a few ulp is divided by beta ~ 0.05: 3e-3)
+                    np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), rtol=1e-2, atol=1e-8)
                 else:
                     np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), atol=3e-5,
                                                rtol=1e-4, err_msg=f"call {call} rank {r} {name}")

@@ -124,7 +124,7 @@ def test_sharded_command_equals_single_process(case, world, golden):
         # one-collective protocol: only the rank's own weights are materialised, and the mixture
         # exp(-(m_r - m)/beta) * local softmin equals the global softmin up to f32 rounding
         nw = K // world if case in ("push", "hybrid_p3") else K
-        tol = 1e-5 if case == "push" else (2e-6 if world == 2 else 5e-6)    # (four partial sums instead of two)
+        tol = 1e-5 if (case == "push" or world > 2) else 2e-6    # (four partial sums instead of two: a few ulp more)
         np.testing.assert_allclose(a["weights"][:nw], b["weights"][:nw], rtol=1e-4, atol=1e-9, err_msg=f"call {c}")
         np.testing.assert_allclose(a["action"], b["action"], atol=tol, err_msg=f"call {c}")
         np.testing.assert_allclose(a["mean"], b["mean"], atol=tol)
