@@ -1,4 +1,4 @@
-// panda_dyn.hpp -- device-side "Panda chain spec v1"  and the panda_env task costs.
+// panda_dyn.hpp -- device-side "Panda chain spec" (currently v1.2) and the panda_env task costs.
 //
 // Replaces, for the panda_env scene, what the reference delegates to Isaac Gym / PhysX
 // (IsaacGymWrapper.step(), isaacgym_wrapper.py:354-360) with:
@@ -17,6 +17,8 @@
 // so that the CPU oracle agrees bit-for-bit.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "spec_fma.hpp"
 
 namespace m3 {
 
@@ -59,18 +61,19 @@ struct Frame {
 
 __device__ __forceinline__ void spec_sincos(float x, float& s, float& c) {
     const float k = rintf(x * 0.63661977236758134308f);
-    float r = x - k * 1.5703125f;
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188e-8f;
+    // (spec v1.2: the Cody-Waite steps, the Horner steps and the final sums are fused multiply-adds)
+    float r = mad(-k, 1.5703125f, x);
+    r = mad(-k, 4.837512969970703125e-4f, r);
+    r = mad(-k, 7.54978995489188e-8f, r);
     const float z = r * r;
     float ps = -1.9515295891e-4f;
-    ps = ps * z + 8.3321608736e-3f;
-    ps = ps * z - 1.6666654611e-1f;
-    const float sn = r + r * (z * ps);
+    ps = mad(ps, z, 8.3321608736e-3f);
+    ps = mad(ps, z, -1.6666654611e-1f);
+    const float sn = mad(r, z * ps, r);
     float pc = 2.443315711809948e-5f;
-    pc = pc * z - 1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    const float cs = (1.0f - 0.5f * z) + (z * z) * pc;
+    pc = mad(pc, z, -1.388731625493765e-3f);
+    pc = mad(pc, z, 4.166664568298827e-2f);
+    const float cs = mad(z * z, pc, mad(-0.5f, z, 1.0f));
     // quadrant q = k mod 4: (s, c) = (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn).  One swap select and
     // two sign-bit XORs instead of a chain of compares and selects (same values bit for bit).
     const unsigned q = (unsigned)((int)k) & 3u;
@@ -92,24 +95,23 @@ __device__ __forceinline__ void rot_z(Frame& f, float s, float c) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float x = f.x[i], y = f.y[i];
-        f.x[i] = c * x + s * y;
-        f.y[i] = c * y - s * x;
+        f.x[i] = mad(c, x, s * y);
+        f.y[i] = mad(c, y, -(s * x));
     }
 }
-// p += (tx*x + ty*y) + tz*z.  The offsets are URDF literals, mostly with one or two zero components;
-// under IEEE rules the compiler must keep `0 * x + ...` (NaN / signed-zero semantics), 12 of the
-// 15 operations of a one-component offset.  The zero terms are dropped here by hand (the tests
-// fold at compile time after inlining); the value can differ from the spec's full expression only
-// in the sign of a zero, which no later operation of the chain can observe.
+// p <- mad(tz, z, mad(ty, y, mad(tx, x, p))) (spec v1.2: the offset accumulated into p by fused multiply-adds, x then
+// y then z).  The offsets are URDF literals, mostly with one or two zero components; under IEEE rules the compiler
+// must keep `0 * x + p` (NaN / signed-zero semantics).  The zero terms are dropped here by hand (the tests fold at
+// compile time after inlining); the value can differ from the spec's full expression only in the sign of a zero,
+// which no later operation of the chain can observe.
 __device__ __forceinline__ void trans(Frame& f, float tx, float ty, float tz) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        float acc = 0.0f;
-        bool has = false;
-        if (tx != 0.0f) { acc = tx * f.x[i]; has = true; }
-        if (ty != 0.0f) { acc = has ? acc + ty * f.y[i] : ty * f.y[i]; has = true; }
-        if (tz != 0.0f) { acc = has ? acc + tz * f.z[i] : tz * f.z[i]; has = true; }
-        if (has) f.p[i] = f.p[i] + acc;
+        float p = f.p[i];
+        if (tx != 0.0f) p = mad(tx, f.x[i], p);
+        if (ty != 0.0f) p = mad(ty, f.y[i], p);
+        if (tz != 0.0f) p = mad(tz, f.z[i], p);
+        f.p[i] = p;
     }
 }
 
@@ -175,7 +177,7 @@ __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, F
     hand = f;
     trans(f, 0, 0, 0.0584f);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { pl[i] = f.p[i] + q[7] * f.y[i]; pr[i] = f.p[i] - q[8] * f.y[i]; }
+    for (int i = 0; i < 3; ++i) { pl[i] = mad(q[7], f.y[i], f.p[i]); pr[i] = mad(-q[8], f.y[i], f.p[i]); }
     if constexpr (STORE) {
         Frame g = f;
         g.p[0] = pl[0]; g.p[1] = pl[1]; g.p[2] = pl[2]; store(g);
@@ -193,7 +195,7 @@ __device__ __forceinline__ void sphere_box_force(const PandaScene& sc, const flo
         const float cl = fminf(fmaxf(l, -b[3 + i]), b[3 + i]);
         d[i] = l - cl;
         if (d[i] != 0.0f) inside = false;
-        n2 = n2 + d[i] * d[i];
+        n2 = mad(d[i], d[i], n2);
     }
     // out of range without the correctly rounded sqrtf (~190 cycles for a lone wavefront):
     // n2 > (r + 1e-4)^2 implies sqrt(n2) > r, i.e. pen < 0 below
@@ -203,8 +205,8 @@ __device__ __forceinline__ void sphere_box_force(const PandaScene& sc, const flo
     const float pen = r - dist;
     if (!(pen > 0.0f)) return;
     const float k = sc.k_contact * pen / dist;
-    f[0] = f[0] - k * d[0];
-    f[1] = f[1] - k * d[1];
+    f[0] = mad(-k, d[0], f[0]);
+    f[1] = mad(-k, d[1], f[1]);
 }
 
 // cube pose relative to the hand + alignment test shared by the grasp rule and infer_held
@@ -300,12 +302,12 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             if (holds() && i >= 7) { w.qd[i] = 0.0f; continue; }
-            float qd1 = (w.qd[i] + sc.a[i] * u[i]) * sc.rden[i];
+            float qd1 = mad(sc.a[i], u[i], w.qd[i]) * sc.rden[i];
             const float tau = sc.drive_damping * (u[i] - qd1);
             if (tau > sc.effort[i]) qd1 = w.qd[i] + sc.dv[i];
             if (tau < -sc.effort[i]) qd1 = w.qd[i] - sc.dv[i];
             qd1 = fminf(fmaxf(qd1, -sc.vlim[i]), sc.vlim[i]);
-            float q1 = w.q[i] + h * qd1;
+            float q1 = mad(h, qd1, w.q[i]);
             const float q1c = __builtin_amdgcn_fmed3f(q1, sc.qlo[i], sc.qhi[i]);   // position limits:
             qd1 = (q1c == q1) ? qd1 : 0.0f;                                          // clamp and stop
             q1 = q1c;
@@ -354,9 +356,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
           }
         } else {
-            w.cube_v[2] = w.cube_v[2] - sc.g * h;
+            w.cube_v[2] = mad(-sc.g, h, w.cube_v[2]);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) w.cube[i] = w.cube[i] + h * w.cube_v[i];
+            for (int i = 0; i < 3; ++i) w.cube[i] = mad(h, w.cube_v[i], w.cube[i]);
             const float x = w.cube[0], y = w.cube[1];
             float sup = -1.0e30f;
             int which = 0;
@@ -450,9 +452,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             float tipl[3], tipr[3], hc[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                tipl[i] = pl[i] + sc.tip_z * hand.z[i];
-                tipr[i] = pr[i] + sc.tip_z * hand.z[i];
-                hc[i] = hand.p[i] + sc.hand_z * hand.z[i];
+                tipl[i] = mad(sc.tip_z, hand.z[i], pl[i]);
+                tipr[i] = mad(sc.tip_z, hand.z[i], pr[i]);
+                hc[i] = mad(sc.hand_z, hand.z[i], hand.p[i]);
             }
             sphere_box_force(sc, tipl, sc.tip_r, sc.table, ft);
             sphere_box_force(sc, tipr, sc.tip_r, sc.table, ft);
@@ -475,9 +477,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             // clamp may have moved q7/q8 after this substep's FK)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float fo = hand.p[i] + 0.0584f * hand.z[i];   // (0*x + 0*y) + 0.0584*z, zero terms dropped
-                obs.left[i] = fo + w.q[7] * hand.y[i];
-                obs.right[i] = fo - w.q[8] * hand.y[i];
+                const float fo = mad(0.0584f, hand.z[i], hand.p[i]);   // trans(0, 0, 0.0584), zero terms dropped
+                obs.left[i] = mad(w.q[7], hand.y[i], fo);
+                obs.right[i] = mad(-w.q[8], hand.y[i], fo);
             }
             mat2quat(hand, obs.left_q);
         }

@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "spec_fma.hpp"
+
 namespace m3 {
 
 // Only what depends on dt / substeps / iterations travels as a kernel argument (10 scalars in
@@ -83,11 +85,7 @@ struct Vel {
 // exactly this order (the oracle runs the same sequence).  The correctly rounded sqrtf followed by
 // an IEEE division is a ~32-instruction dependent chain here (3 of them compare->select pairs);
 // this is 15, and it sits in the friction row of every solver pass.
-// spec v1.4: where the spec writes mad(a, b, c) the product and the sum are ONE operation with one rounding (IEEE 754
-// fusedMultiplyAdd: v_fma_f32 here, fmaf in the oracle) -- every a*b + c of the dynamics.  Half the multiplies and
-// adds of the solver pair up; -ffp-contract=off stays, so nothing else is ever fused (the task costs follow torch).
-__device__ __forceinline__ float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
+// spec v1.4: mad(a, b, c) = a*b + c in ONE rounding (spec_fma.hpp) wherever the dynamics form a product plus a sum.
 __device__ __forceinline__ float spec_rsqrt(float a) {
     float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(a) >> 1));
     const float hlf = 0.5f * a;

@@ -19,22 +19,27 @@
 
 #include "m3_oracle.h"
 
+/* chain spec v1.2: mad(a, b, c) = a*b + c with ONE rounding (IEEE 754 fusedMultiplyAdd) where the spec writes it: the
+ * sin/cos reduction and polynomials, the kinematic chain's rotations and offsets, the servo, the free cube's
+ * integration and the penalty forces -- here and in the HIP kernel alike. */
+static inline float mad(float a, float b, float c) { return fmaf(a, b, c); }
+
 /* ---- spec sin/cos: Cody-Waite reduction to [-pi/4, pi/4] + minimax polynomials, plain f32
  * operations only (valid for |x| < 8), so every implementation agrees bit-for-bit ---- */
 void m3o_sincos(float x, float* s, float* c) {
     const float k = rintf(x * 0.63661977236758134308f);
-    float r = x - k * 1.5703125f;
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188e-8f;
+    float r = mad(-k, 1.5703125f, x);
+    r = mad(-k, 4.837512969970703125e-4f, r);
+    r = mad(-k, 7.54978995489188e-8f, r);
     const float z = r * r;
     float ps = -1.9515295891e-4f;
-    ps = ps * z + 8.3321608736e-3f;
-    ps = ps * z - 1.6666654611e-1f;
-    const float sn = r + r * (z * ps);
+    ps = mad(ps, z, 8.3321608736e-3f);
+    ps = mad(ps, z, -1.6666654611e-1f);
+    const float sn = mad(r, z * ps, r);
     float pc = 2.443315711809948e-5f;
-    pc = pc * z - 1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    const float cs = (1.0f - 0.5f * z) + (z * z) * pc;
+    pc = mad(pc, z, -1.388731625493765e-3f);
+    pc = mad(pc, z, 4.166664568298827e-2f);
+    const float cs = mad(z * z, pc, mad(-0.5f, z, 1.0f));
     const int q = ((int)k) & 3;
     if (q == 0) { *s = sn; *c = cs; }
     else if (q == 1) { *s = cs; *c = -sn; }
@@ -91,12 +96,12 @@ static void rot_xm(frame_t* f) { /* R <- R * Rx(-90deg) */
 static void rot_z(frame_t* f, float s, float c) { /* R <- R * Rz */
     for (int i = 0; i < 3; ++i) {
         float x = f->x[i], y = f->y[i];
-        f->x[i] = c * x + s * y;
-        f->y[i] = c * y - s * x;
+        f->x[i] = mad(c, x, s * y);
+        f->y[i] = mad(c, y, -(s * x));
     }
 }
 static void trans(frame_t* f, float tx, float ty, float tz) {
-    for (int i = 0; i < 3; ++i) f->p[i] = f->p[i] + ((tx * f->x[i] + ty * f->y[i]) + tz * f->z[i]);
+    for (int i = 0; i < 3; ++i) f->p[i] = mad(tz, f->z[i], mad(ty, f->y[i], mad(tx, f->x[i], f->p[i])));
 }
 
 /* rotation matrix (columns x,y,z) -> quaternion xyzw (Shepperd) */
@@ -157,7 +162,7 @@ void m3o_panda_fk(const m3o_panda_scene* sc, const float q[9], m3o_panda_links* 
     trans(&f, 0, 0, 0.107f); rot_z(&f, -0.70710678118654752f, 0.70710678118654752f); STORE_LINK(); /* hand */
     trans(&f, 0, 0, 0.0584f);
     frame_t l = f, r = f;
-    for (int i = 0; i < 3; ++i) { l.p[i] = f.p[i] + q[7] * f.y[i]; r.p[i] = f.p[i] - q[8] * f.y[i]; }
+    for (int i = 0; i < 3; ++i) { l.p[i] = mad(q[7], f.y[i], f.p[i]); r.p[i] = mad(-q[8], f.y[i], f.p[i]); }
     f = l; STORE_LINK();
     f = r; STORE_LINK();
 #undef STORE_LINK
@@ -176,15 +181,15 @@ static void sphere_box_force(const m3o_panda_scene* sc, const float c[3], float 
         float cl = fminf(fmaxf(l, -b[3 + i]), b[3 + i]);
         d[i] = l - cl;
         if (d[i] != 0.0f) inside = 0;
-        n2 = n2 + d[i] * d[i];
+        n2 = mad(d[i], d[i], n2);
     }
     if (inside) return; /* centre inside the box: no direction; ignored by the spec */
     float dist = sqrtf(n2);
     float pen = r - dist;
     if (!(pen > 0.0f)) return;
     float k = sc->k_contact * pen / dist;
-    f[0] = f[0] - k * d[0];
-    f[1] = f[1] - k * d[1];
+    f[0] = mad(-k, d[0], f[0]);
+    f[1] = mad(-k, d[1], f[1]);
 }
 
 void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u[9]) {
@@ -197,12 +202,12 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
             float a = (h * sc->drive_damping) / sc->inertia[i];
             float rden = 1.0f / (1.0f + a);
             float dv = (h * sc->effort[i]) / sc->inertia[i];
-            float qd1 = (w->qd[i] + a * u[i]) * rden;
+            float qd1 = mad(a, u[i], w->qd[i]) * rden;
             float tau = sc->drive_damping * (u[i] - qd1);
             if (tau > sc->effort[i]) qd1 = w->qd[i] + dv;
             if (tau < -sc->effort[i]) qd1 = w->qd[i] - dv;
             qd1 = fminf(fmaxf(qd1, -sc->vlim[i]), sc->vlim[i]);
-            float q1 = w->q[i] + h * qd1;
+            float q1 = mad(h, qd1, w->q[i]);
             if (q1 < sc->qlo[i]) { q1 = sc->qlo[i]; qd1 = 0.0f; }
             if (q1 > sc->qhi[i]) { q1 = sc->qhi[i]; qd1 = 0.0f; }
             w->q[i] = q1; w->qd[i] = qd1;
@@ -236,8 +241,8 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
             for (int i = 7; i < 13; ++i) w->cubeA[i] = 0.0f;
         } else {
             /* free body: gravity, support planes, Coulomb friction on the support */
-            w->cubeA[9] = w->cubeA[9] - sc->g * h;
-            for (int i = 0; i < 3; ++i) w->cubeA[i] = w->cubeA[i] + h * w->cubeA[7 + i];
+            w->cubeA[9] = mad(-sc->g, h, w->cubeA[9]);
+            for (int i = 0; i < 3; ++i) w->cubeA[i] = mad(h, w->cubeA[7 + i], w->cubeA[i]);
             const float x = w->cubeA[0], y = w->cubeA[1];
             float sup = -1.0e30f;
             int which = 0; /* 1 table, 2 shelf, 3 cubeB */
@@ -327,9 +332,9 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
         {
             float tipl[3], tipr[3], hc[3];
             for (int i = 0; i < 3; ++i) {
-                tipl[i] = L.pos[9][i] + sc->tip_z * hz[i];
-                tipr[i] = L.pos[10][i] + sc->tip_z * hz[i];
-                hc[i] = ph[i] + sc->hand_z * hz[i];
+                tipl[i] = mad(sc->tip_z, hz[i], L.pos[9][i]);
+                tipr[i] = mad(sc->tip_z, hz[i], L.pos[10][i]);
+                hc[i] = mad(sc->hand_z, hz[i], ph[i]);
             }
             const float* boxes[3] = {sc->table, sc->shelf, cubeB_box};
             float* fo[3] = {ft, fs, fb};

@@ -96,3 +96,83 @@ def test_device_header_on_the_host_equals_the_oracle(oracle, host_lib, seed, mod
 @pytest.mark.parametrize("dt,substeps,iters,mode", [(0.04, 3, 4, 1), (0.05, 1, 6, 0), (0.05, 2, 8, 1), (0.02, 2, 1, 0)])
 def test_device_header_on_the_host_with_other_solver_settings(oracle, host_lib, dt, substeps, iters, mode):
     compare(oracle, host_lib, 100 + substeps + iters, mode, n=600, steps=20, dt=dt, substeps=substeps, iters=iters)
+
+
+# ================================================================ panda_env: csrc/panda_dyn.hpp on the host
+@pytest.fixture(scope="module")
+def panda_host_lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("panda_dyn") / "libpanda_dyn_host.so")
+    subprocess.check_call(["g++"] + HOST_FLAGS + fma_flag() + ["-Wno-unknown-pragmas", "-I" + os.path.join(HERE, "native", "shim"),
+                           os.path.join(HERE, "native", "panda_dyn_host.cpp"), "-o", out])
+    lib = C.CDLL(out)
+    VP = C.c_void_p
+    lib.pnh_step.argtypes = [C.c_float, C.c_int, VP, C.c_int, VP, VP, C.c_int, VP, VP]
+    lib.pnh_infer_held.argtypes = [C.c_float, C.c_int, VP, C.c_int, VP]
+    return lib
+
+
+@pytest.fixture(scope="module")
+def P():
+    import oracle.panda as P
+    P.lib()
+    return P
+
+
+def random_panda_worlds(P, sc, n, rng):
+    """Random joint configurations and velocities; cubeA on the table, near the hand or falling onto the shelf (the
+    generator of the GPU fuzz test); every seventh world holds the cube / has the open gripper around it / just off it."""
+    from tests.panda_worlds import grasp_world
+    w = P.init_world(n)
+    qlo, qhi = np.array(sc.qlo), np.array(sc.qhi)
+    w[:, P.W_Q:P.W_Q + 9] = qlo + rng.uniform(0.05, 0.95, (n, 9)) * (qhi - qlo)
+    w[:, P.W_QD:P.W_QD + 9] = rng.normal(0, 0.3, (n, 9)) * (rng.random((n, 1)) < 0.5)
+    for i in range(n):
+        if i % 3 == 0:
+            w[i, P.W_CUBEA:P.W_CUBEA + 2] = rng.uniform(-0.5, 0.5, 2)
+        elif i % 3 == 1:
+            w[i, P.W_CUBEA:P.W_CUBEA + 3] = P.fk(sc, w[i, P.W_Q:P.W_Q + 9].astype(np.float32))["pos"][8] + rng.uniform(-0.12, 0.12, 3)
+        else:
+            w[i, P.W_CUBEA:P.W_CUBEA + 3] = (0.5 + rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), 1.6)
+    special = [grasp_world(P, sc), grasp_world(P, sc, close_gripper=False), grasp_world(P, sc, close_gripper=False, offset=(0.0, 0.012))]
+    for i in range(0, n, 7):
+        w[i] = special[(i // 7) % 3]
+    return w.astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["step_mode", "pick_rollout_lazy_fk", "reach_rollout_lazy_fk_no_forces"])
+@pytest.mark.parametrize("seed", range(2))
+def test_panda_device_header_on_the_host_equals_the_oracle(P, panda_host_lib, seed, mode):
+    sc = P.default_scene()
+    rng = np.random.default_rng(40 + seed)
+    n, steps = 280, 25
+    a = random_panda_worlds(P, sc, n, rng)
+    b = a.copy()
+    hp, trav, obs = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros((n, 10), np.float32)
+    L = P.lib()
+    L.m3o_panda_infer_held.argtypes = [C.POINTER(P.PandaScene), C.POINTER(C.c_float)]
+    for i in range(n):          # a world is loaded: the grasp state is inferred from the geometry
+        row = np.ascontiguousarray(a[i])
+        L.m3o_panda_infer_held(C.byref(sc), row.ctypes.data_as(C.POINTER(C.c_float)))
+        a[i] = row
+    panda_host_lib.pnh_infer_held(0.01, 2, b.ctypes.data, n, hp.ctypes.data)
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert a[:, P.W_HELD].sum() >= n // 21
+    # (not on the device: cubeA's angular velocity, cubeB beyond its position; the reach rollout forms no contact forces)
+    cols = [c for c in range(58 if mode != 2 else 52) if not (28 <= c < 31) and not (34 <= c < 44)]
+    grip = rng.integers(0, 3, n)
+    for t in range(steps):
+        u = rng.uniform(-2, 2, (n, 9)).astype(np.float32)
+        u[:, 7:] = rng.uniform(-1.5, 1.5, (n, 2))
+        u[grip == 1, 7:] = 1.5          # gripper override open / close (m3p2i.py:10-14) for a third of the worlds each
+        u[grip == 2, 7:] = -1.5
+        P.step_batch(sc, a, u)
+        panda_host_lib.pnh_step(0.01, 2, b.ctypes.data, n, u.ctypes.data, obs.ctypes.data, mode, hp.ctypes.data, trav.ctypes.data)
+        neq = a[:, cols].view(np.uint32) != b[:, cols].view(np.uint32)
+        if neq.any():
+            r, c = np.argwhere(neq)[0]
+            raise AssertionError(f"seed {seed} mode {mode} step {t} world {r} column {cols[c]}: oracle {a[r, cols[c]]!r} "
+                                 f"device-source {b[r, cols[c]]!r} ({int(neq.sum())} values differ)")
+        for i in range(0, n, 13):       # what the costs read: the finger links at the final joint values
+            Lk = P.fk(sc, a[i, :9])
+            want = np.concatenate([Lk["pos"][9], Lk["quat"][9], Lk["pos"][10]]).astype(np.float32)
+            np.testing.assert_array_equal(want.view(np.uint32), obs[i].view(np.uint32))
