@@ -197,6 +197,7 @@ int rollout_lanes_for(int Kl);
 // kernels then run in their two-waves-per-SIMD build (rollout_point_kernel.hpp)
 constexpr int M3_SIMDS = 1024;
 inline bool rollout_two_waves(int wavefronts) { return wavefronts > M3_SIMDS; }
+inline bool rollout_three_waves(int wavefronts) { return wavefronts > 4 * M3_SIMDS; }   // (measured: equal at 4 per SIMD, -11 % at 8)
 int mins_workgroups(int Kg);
 int topk_workgroups(int Kg);
 int ladder_workgroups(int Kg);

@@ -188,13 +188,12 @@ __device__ __forceinline__ void rollout_point_body(const RolloutArgs& a_, const 
     a.pend[2 * Kl + i] = w.fBx; a.pend[3 * Kl + i] = w.fBy;
 }
 
-// Two builds of every instance.  k_rollout_point: no register limit -- 340 VGPRs (256 + 84 AGPR), ONE resident wave
+// Three builds of every instance.  k_rollout_point: no register limit -- 312 VGPRs (256 + 56 AGPR), ONE resident wave
 // per SIMD: the fastest build while the launch has no more wavefronts than the chip has SIMDs (K_local <= 65536:
-// every BASELINE config).  k_rollout_point_occ2: `amdgpu_waves_per_eu(2, 2)` -- 256 VGPRs, ~175 values spilled to
+// every BASELINE config).  k_rollout_point_occ2: `amdgpu_waves_per_eu(2, 2)` -- 256 VGPRs, ~60 values spilled to
 // scratch, TWO resident waves per SIMD whose instruction streams interleave: 2-3 % slower below 65536 samples, but
-// K = 131072: 0.245 -> 0.181 ms, 1 M: 1.83 -> 1.21 ms (saturation 13.9 -> 19.0 G state-steps/s; three or four waves
-// per SIMD: 0.197 / 0.205 ms at 131072, another +4 % only at 1 M).  The host picks by the number of wavefronts
-// (rollout_two_waves).  Same arithmetic, same bits.
+// K = 131072: 0.22 -> 0.162 ms.  k_rollout_point_occ3 (below) from four wavefronts per SIMD on.  The host picks by the
+// number of wavefronts (rollout_two_waves / rollout_three_waves).  Same arithmetic, same bits.
 template <bool GENERAL, int TASK>
 __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const PointScene sc) {
     rollout_point_body<GENERAL, TASK>(a, sc);
@@ -204,9 +203,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                                                                       const PointScene sc) {
     rollout_point_body<GENERAL, TASK>(a, sc);
 }
+// ... and THREE resident waves (170 VGPRs) from four wavefronts per SIMD on: with the fused multiply-adds of spec v1.4 the
+// two-wave build spills only ~60 values, the three-wave build about what the two-wave build used to -- K = 524 288
+// 0.557 -> 0.497 ms, 1 M 1.08 -> 0.95 ms; equal at 262 144, slower below (a third wave that is not there does not help).
+template <bool GENERAL, int TASK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_rollout_point_occ3(const RolloutArgs a,
+                                                                                                      const PointScene sc) {
+    rollout_point_body<GENERAL, TASK>(a, sc);
+}
 template <bool GENERAL, int TASK>
 inline void launch_rollout_point_instance(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s) {
-    if (rollout_two_waves(blocks)) hipLaunchKernelGGL((k_rollout_point_occ2<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a, sc);
+    if (rollout_three_waves(blocks)) hipLaunchKernelGGL((k_rollout_point_occ3<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a, sc);
+    else if (rollout_two_waves(blocks)) hipLaunchKernelGGL((k_rollout_point_occ2<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a, sc);
     else hipLaunchKernelGGL((k_rollout_point<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a, sc);
 }
 
