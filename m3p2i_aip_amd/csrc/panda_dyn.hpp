@@ -456,18 +456,41 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 tipr[i] = mad(sc.tip_z, hand.z[i], pr[i]);
                 hc[i] = mad(sc.hand_z, hand.z[i], hand.p[i]);
             }
-            sphere_box_force(sc, tipl, sc.tip_r, sc.table, ft);
-            sphere_box_force(sc, tipr, sc.tip_r, sc.table, ft);
-            sphere_box_force(sc, hc, sc.hand_r, sc.table, ft);
-            if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, sc.table, ft);
-            sphere_box_force(sc, tipl, sc.tip_r, sc.shelf, fs);
-            sphere_box_force(sc, tipr, sc.tip_r, sc.shelf, fs);
-            sphere_box_force(sc, hc, sc.hand_r, sc.shelf, fs);
-            if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, sc.shelf, fs);
-            sphere_box_force(sc, tipl, sc.tip_r, cubeB_box, fb);
-            sphere_box_force(sc, tipr, sc.tip_r, cubeB_box, fb);
-            sphere_box_force(sc, hc, sc.hand_r, cubeB_box, fb);
-            if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, cubeB_box, fb);
+            // Broad phase per box, once per WAVE (it cannot change a result): all four spheres lie inside the ball of
+            // radius GRIP_R around hc -- the finger tips 0.0734 z + q7 y (q7 <= 0.04) + 0.012 = 0.096 from it, the held
+            // cube's centre at most |(0.025, 0.04, 0.1034 + 0.025 - 0.03)| = 0.109 (the pad channel of the grasp rule
+            // bounds rel_p) + its radius 0.025 = 0.134 -- so a box farther than that from hc in every lane gets no
+            // force from any of them: its four tests (each ~15 instructions up to its own early-out) are skipped.
+            // In the pick phase the shelf and, until the place, cubeB are far: 8 of the 12 tests.
+            constexpr float GRIP_R = 0.15f;
+            auto near_box = [&](const float* b) {
+                float d2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float l = hc[i] - b[i];
+                    const float d = l - fminf(fmaxf(l, -b[3 + i]), b[3 + i]);
+                    d2 = mad(d, d, d2);
+                }
+                return __builtin_amdgcn_ballot_w64(!(d2 > GRIP_R * GRIP_R)) != 0ull;
+            };
+            if (near_box(sc.table)) {
+                sphere_box_force(sc, tipl, sc.tip_r, sc.table, ft);
+                sphere_box_force(sc, tipr, sc.tip_r, sc.table, ft);
+                sphere_box_force(sc, hc, sc.hand_r, sc.table, ft);
+                if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, sc.table, ft);
+            }
+            if (near_box(sc.shelf)) {
+                sphere_box_force(sc, tipl, sc.tip_r, sc.shelf, fs);
+                sphere_box_force(sc, tipr, sc.tip_r, sc.shelf, fs);
+                sphere_box_force(sc, hc, sc.hand_r, sc.shelf, fs);
+                if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, sc.shelf, fs);
+            }
+            if (near_box(cubeB_box)) {
+                sphere_box_force(sc, tipl, sc.tip_r, cubeB_box, fb);
+                sphere_box_force(sc, tipr, sc.tip_r, cubeB_box, fb);
+                sphere_box_force(sc, hc, sc.hand_r, cubeB_box, fb);
+                if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, cubeB_box, fb);
+            }
         }
         w.f_table[0] = ft[0]; w.f_table[1] = ft[1];
         w.f_shelf[0] = fs[0]; w.f_shelf[1] = fs[1];
