@@ -217,6 +217,8 @@ def install(force_standins: bool = False):
     tp.ai_agent = mod("m3p2i_aip.planners.task_planner.ai_agent", AiAgent=task_planner.AiAgent)
     tp.adaptive_action_selection = mod("m3p2i_aip.planners.task_planner.adaptive_action_selection",
                                        adapt_act_sel=task_planner.adapt_act_sel)
+    tp.parallel_action_selection = mod("m3p2i_aip.planners.task_planner.parallel_action_selection",
+                                       par_act_sel=task_planner.par_act_sel)
     tp.isaac_state_action_templates = mod(
         "m3p2i_aip.planners.task_planner.isaac_state_action_templates",
         MDPIsCubeAtReal=task_planner.MDPIsCubeAtReal,

@@ -281,6 +281,76 @@ def adapt_act_sel(agent, obs, verbose=False):
     return "failure", "idle_fail"
 
 
+def par_act_sel(agent, obs, verbose=False):
+    """One tick of the PARALLEL action selection (parallel_action_selection.py:12-106): instead of stopping at the first
+    executable action, every executable action is recorded and inhibited and the selection continues until only idle is
+    left; returns (outcome, plans) -- each plan a list of action names of DIFFERENT state factors that can run side by
+    side.  The reference assembles the plans through Python sets (their order is undefined there); here every plan is
+    sorted and the list of plans is sorted.  Same prologue as adapt_act_sel (habits restored, met pushed preconditions
+    dropped, an observed state with preference exactly 1 is success: ('success', [])), same deliberate difference (the
+    reference does not terminate when a push leaves only idle and nothing was found: ('failure', []) after
+    MAX_SELECTION_ROUNDS rounds)."""
+    agents = agent if isinstance(agent, list) else [agent]
+    obs = obs if isinstance(agent, list) else [obs]
+    n = len(agents)
+    for ag, ob in zip(agents, obs):
+        ag.reset_habits()
+        for idx in range(len(ag._mdp.C)):
+            if ag._mdp.C[idx] > 0 and idx == ob:
+                if verbose:
+                    print("removed preference state", idx)
+                ag.set_preferences(0, idx)
+    if any(ag._mdp.C[idx] == 0 and idx == ob for ag, ob in zip(agents, obs) for idx in range(len(ag._mdp.C))):
+        return "success", []
+
+    found = []                      # (action name, factor) in the order they became executable
+    u = [-1] * n
+    believed = ["null"] * n
+    searching = False
+    outcome = "failure"
+    for _round in range(MAX_SELECTION_ROUNDS):
+        for i, (ag, ob) in enumerate(zip(agents, obs)):
+            if isinstance(ob, str) and ob == "null":
+                continue
+            if not searching:
+                ag.infer_states(ob)
+            _, u[i] = ag.infer_policies()
+            believed[i] = ag._mdp.state_names[int(np.argmax(ag.get_current_state()))]
+        if max(u) == 0:             # only idle left
+            if found:
+                break
+            if not searching:
+                if verbose:
+                    print("No action found for this situation")
+                return "failure", []
+            continue                # (the reference spins here; MAX_SELECTION_ROUNDS ends it)
+        for i, ag in enumerate(agents):
+            if u[i] <= 0:
+                continue
+            missing = [need for need in ag._mdp.preconditions[u[i]] if need != "none" and need not in believed]
+            for need in missing:
+                searching = True
+                for other in agents:
+                    if need in other._mdp.state_names:
+                        other.set_preferences(2, other._mdp.state_names.index(need))
+            ag.reset_habits(u[i])   # inhibited either way: not executable, or taken -- look for alternatives
+            if not missing:
+                found.append((ag._mdp.action_names[u[i]], i))
+                outcome = "running"
+    else:
+        return "failure", []
+    # one plan per found action: that action + every found action of another factor not yet represented in the plan
+    plans = set()
+    for name, factor in found:
+        names, factors = {name}, {factor}
+        for other, f in found:
+            if f not in factors:
+                names.add(other)
+                factors.add(f)
+        plans.add(tuple(sorted(names)))
+    return outcome, sorted(list(p) for p in plans)
+
+
 # ---------------------------------------------------------------------------------------------
 def _rot_cols(q):
     """Columns (x, y, z axes) of the rotation matrix of an (x, y, z, w) quaternion

@@ -20,7 +20,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, "/root/reference/src")
-from m3p2i_aip.planners.task_planner import ai_agent, adaptive_action_selection  # noqa: E402
+from m3p2i_aip.planners.task_planner import ai_agent, adaptive_action_selection, parallel_action_selection  # noqa: E402
 from m3p2i_aip.planners.task_planner import isaac_state_action_templates as T  # noqa: E402
 
 
@@ -56,6 +56,28 @@ def run(templates, schedule):
         finally:
             signal.alarm(0)
         ticks.append(dict(outcome=outcome, action=action, agents=snap(agents)))
+    return ticks
+
+
+def run_parallel(templates, schedule):
+    """parallel_action_selection.par_act_sel: outcome + the set of parallel plans per tick (the reference builds them
+    through Python sets, so their order is not defined: stored sorted)."""
+    agents = [ai_agent.AiAgent(getattr(T, t)()) for t in templates]
+    ticks = []
+    for prefs, obs in schedule:
+        for a, p in zip(agents, prefs):
+            if p is not None:
+                a.set_preferences(np.array(p, dtype=float).reshape(-1, 1))
+        signal.alarm(2)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                outcome, plans = parallel_action_selection.par_act_sel(agents, list(obs))
+        except TimeoutError:
+            ticks.append(dict(outcome="nonterminating", plans=None, agents=[]))
+            break
+        finally:
+            signal.alarm(0)
+        ticks.append(dict(outcome=outcome, plans=sorted(sorted(p) for p in plans), agents=snap(agents)))
     return ticks
 
 
@@ -107,6 +129,18 @@ def main():
         cases.append(dict(name=f"multi_random_{r}", templates=multi, schedule=random_schedule(rng, [2, 2, 2], 16)))
     for c in cases:
         c["ticks"] = run(c["templates"], c["schedule"])
+    # parallel action selection: the reference's own example (examples/example_aip_parallel.py) + random schedules
+    par = ["MDPIsAt", "MDPIsBlockAt", "MDPIsLocFree", "MDPIsCloseTo"]
+    ex = [([None, [1.0, 0.0] if i == 0 else None, None, None], ["null", 1, 0, 1] if i < 5 else ["null", 1, 0, 0]) for i in range(15)]
+    pcases = [dict(name="parallel_example", templates=par, schedule=ex, parallel=True)]
+    for r in range(6):
+        sched = random_schedule(rng, [2, 2, 2, 2], 12)
+        if r % 2 == 0:      # (as in the example: the first factor unobserved)
+            sched = [(p, ["null"] + list(o[1:])) for p, o in sched]
+        pcases.append(dict(name=f"parallel_random_{r}", templates=par, schedule=sched, parallel=True))
+    for c in pcases:
+        c["ticks"] = run_parallel(c["templates"], c["schedule"])
+    cases += pcases
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "aif_golden.json")
     json.dump(cases, open(out, "w"))
     print(out, {c["name"]: len(c["ticks"]) for c in cases})

@@ -66,6 +66,22 @@ def test_unchanged_reference_sim_script_loads_on_the_shims():
     assert ns["zerorpc"] is zerorpc and hasattr(zerorpc.Client(), "connect")
 
 
+@pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="reference checkout not mounted")
+@pytest.mark.parametrize("example", ["example_aip_parallel.py", "example_aip_panda.py"])
+def test_unchanged_reference_task_planner_examples_run_on_the_shims(example, capsys):
+    """examples/example_aip_parallel.py (four state-factor agents, parallel_action_selection.par_act_sel) and
+    examples/example_aip_panda.py (adapt_act_sel) AS THEY ARE, start to end, on this build's task planner."""
+    from m3p2i_aip_amd import compat
+    compat.install(force_standins=True)
+    path = os.path.join(os.path.dirname(os.path.dirname(REF_SCRIPT)), "examples", example)
+    runpy.run_path(path, run_name="__main__")
+    out = capsys.readouterr().out
+    if "parallel" in example:
+        assert out.count("Current plan") == 15 and "approach_obj" in out and "push_to_goal" in out and "pull_to_goal" in out
+    else:
+        assert "reach" in out and "pick" in out and "place" in out and "idle_success" in out
+
+
 @pytest.mark.gpu
 def test_reactive_tamp_wiring_through_compat_names_gpu():
     """reactive_tamp.py:22-61 written against the reference's module names, on the GPU."""

@@ -21,11 +21,18 @@ def test_action_selection_matches_reference_sequences(case):
         for a, p in zip(agents, prefs):
             if p is not None:
                 a.set_preferences(np.array(p, dtype=float).reshape(-1, 1))
-        outcome, action = tp.adapt_act_sel(agents, list(obs))
-        if tick["outcome"] == "nonterminating":   # the reference hangs here; this build gives up
-            assert (outcome, action) == ("failure", "idle_fail")
-            break
-        assert (outcome, action) == (tick["outcome"], tick["action"])
+        if case.get("parallel"):            # parallel_action_selection.par_act_sel: a set of parallel plans per tick
+            outcome, plans = tp.par_act_sel(agents, list(obs))
+            if tick["outcome"] == "nonterminating":
+                assert (outcome, plans) == ("failure", [])
+                break
+            assert outcome == tick["outcome"] and sorted(sorted(p) for p in plans) == tick["plans"], (outcome, plans, tick)
+        else:
+            outcome, action = tp.adapt_act_sel(agents, list(obs))
+            if tick["outcome"] == "nonterminating":   # the reference hangs here; this build gives up
+                assert (outcome, action) == ("failure", "idle_fail")
+                break
+            assert (outcome, action) == (tick["outcome"], tick["action"])
         for a, g in zip(agents, tick["agents"]):
             np.testing.assert_allclose(a._mdp.D.reshape(-1), g["D"], atol=1e-9)
             np.testing.assert_allclose(np.asarray(a._mdp.C, float).reshape(-1), g["C"], atol=1e-9)
