@@ -62,34 +62,12 @@ extern "C" void m3_default_config(m3_config* c, int env_type) {
 
 // "Planar contact dynamics spec v1" constants (sources: config/point_env/*.yaml,
 // pointRobot.urdf, isaacgym_wrapper.py:18-37,341-344,462-469)
-static void build_point_scene(const m3_config& c, PointScene& s) {
-    const float h = c.dt / (float)c.substeps;
-    s.h = h; s.inv_h = 1.0f / h; s.substeps = c.substeps; s.iters = c.solver_iters;
-    const float g = 9.8f;
-    const float invm_r = 1.0f / 10.0f;
-    s.gam = 1.0f / (h * 600.0f);
-    s.md = 1.0f / (invm_r + s.gam);
-    s.dmax = 1000.0f * h;
-    const float req = 0.3825978f * 0.4f;
-    s.LlinB = ((0.75f * 16.0f) * g) * h; s.LangB = s.LlinB * req;
-    s.LlinD = ((1.0f * 16.0f) * g) * h; s.LangD = s.LlinD * req;
-    // everything else of the scene is compile-time constant in PointScene (planar_dyn.hpp)
-}
+static void build_point_scene(const m3_config& c, PointScene& s) { make_point_scene(s, c.dt, c.substeps, c.solver_iters); }
+// everything else of the scene is compile-time constant in PointScene (planar_dyn.hpp)
 
-// "Panda chain spec v1" constants (sources: franka_panda.urdf limits, config/
-// panda_env/*.yaml, isaacgym_wrapper.py:341-344)
-static void build_panda_scene(const m3_config& c, PandaScene& s) {
-    const float h = c.dt / (float)c.substeps;
-    s.h = h; s.substeps = c.substeps;
-    const float inertia[9] = {1.0f, 1.0f, 0.5f, 0.5f, 0.1f, 0.1f, 0.05f, 0.1f, 0.1f};
-    const float effort[9] = {87, 87, 87, 87, 12, 12, 12, 20, 20};
-    for (int i = 0; i < 9; ++i) {  // spec: per-dof servo constants in f32
-        s.a[i] = (h * 600.0f) / inertia[i];
-        s.rden[i] = 1.0f / (1.0f + s.a[i]);
-        s.dv[i] = (h * effort[i]) / inertia[i];
-    }
-    // everything else of the scene is compile-time constant in PandaScene (panda_dyn.hpp)
-}
+// "Panda chain spec" constants (sources: franka_panda.urdf limits, config/panda_env/*.yaml,
+// isaacgym_wrapper.py:341-344)
+static void build_panda_scene(const m3_config& c, PandaScene& s) { make_panda_scene(s, c.dt, c.substeps); }
 
 static void default_panda_world(float* w, int cube_on_shelf) {
     const float q0[9] = {0, 0, 0, -2.0f, 0, 1.8675f, 0, 0.02f, 0.02f};  // panda.yaml:10

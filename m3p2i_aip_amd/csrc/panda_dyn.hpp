@@ -46,6 +46,19 @@ struct PandaScene {
     static constexpr float tip_z = 0.045f, tip_r = 0.012f, hand_z = 0.03f, hand_r = 0.04f;
 };
 
+// the per-dof servo constants from dt / substeps (host side: m3_create, and the host build in tests/native/), in f32
+inline void make_panda_scene(PandaScene& s, float dt, int substeps) {
+    const float h = dt / (float)substeps;
+    s.h = h; s.substeps = substeps;
+    const float inertia[9] = {1.0f, 1.0f, 0.5f, 0.5f, 0.1f, 0.1f, 0.05f, 0.1f, 0.1f};
+    const float effort[9] = {87, 87, 87, 87, 12, 12, 12, 20, 20};
+    for (int i = 0; i < 9; ++i) {
+        s.a[i] = (h * 600.0f) / inertia[i];
+        s.rden[i] = 1.0f / (1.0f + s.a[i]);
+        s.dv[i] = (h * effort[i]) / inertia[i];
+    }
+}
+
 struct PandaWorld {
     float q[9], qd[9];
     float cube[3], cube_q[4], cube_v[3];  // cubeA (angular velocity is always 0 in spec v1)

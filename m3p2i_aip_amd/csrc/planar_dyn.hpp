@@ -49,6 +49,21 @@ struct PointScene {
     static constexpr float rad_b = 0.28285f, rad_d = 0.28285f, rad_o = 0.25f;
 };
 
+// the run-time part of the scene from the reference's solver settings (host side: m3_create, and the host build of this
+// header in tests/native/): every product in binary32, in this order -- the oracle forms the same constants
+inline void make_point_scene(PointScene& s, float dt, int substeps, int iters) {
+    const float h = dt / (float)substeps;
+    s.h = h; s.inv_h = 1.0f / h; s.substeps = substeps; s.iters = iters;
+    const float g = 9.8f;
+    const float invm_r = 1.0f / 10.0f;
+    s.gam = 1.0f / (h * 600.0f);
+    s.md = 1.0f / (invm_r + s.gam);
+    s.dmax = 1000.0f * h;
+    const float req = 0.3825978f * 0.4f;
+    s.LlinB = ((0.75f * 16.0f) * g) * h; s.LangB = s.LlinB * req;
+    s.LlinD = ((1.0f * 16.0f) * g) * h; s.LangD = s.LlinD * req;
+}
+
 struct Box {
     float x, y, c, s, vx, vy, w;
 };

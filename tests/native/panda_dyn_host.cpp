@@ -4,17 +4,7 @@
 #include "../../m3p2i_aip_amd/csrc/panda_dyn.hpp"
 
 namespace {
-void scene(m3::PandaScene& s, float dt, int substeps) {   // == build_panda_scene (csrc/m3_api.hip)
-    const float h = dt / (float)substeps;
-    s.h = h; s.substeps = substeps;
-    const float inertia[9] = {1.0f, 1.0f, 0.5f, 0.5f, 0.1f, 0.1f, 0.05f, 0.1f, 0.1f};
-    const float effort[9] = {87, 87, 87, 87, 12, 12, 12, 20, 20};
-    for (int i = 0; i < 9; ++i) {
-        s.a[i] = (h * 600.0f) / inertia[i];
-        s.rden[i] = 1.0f / (1.0f + s.a[i]);
-        s.dv[i] = (h * effort[i]) / inertia[i];
-    }
-}
+void scene(m3::PandaScene& s, float dt, int substeps) { m3::make_panda_scene(s, dt, substeps); }
 // oracle row (58 floats): q9 qd9 | cubeA pos3 quat4 vel3 angvel3 | cubeB (13) | held | rel_p3 rel_q4 | f_table2 f_shelf2 f_cubeB2
 void load(const float* w, m3::PandaWorld& p) {
     for (int i = 0; i < 9; ++i) { p.q[i] = w[i]; p.qd[i] = w[9 + i]; }

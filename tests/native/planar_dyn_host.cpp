@@ -4,18 +4,7 @@
 #include "../../m3p2i_aip_amd/csrc/planar_dyn.hpp"
 
 namespace {
-void scene(m3::PointScene& s, float dt, int substeps, int iters) {   // == build_point_scene (csrc/m3_api.hip)
-    const float h = dt / (float)substeps;
-    s.h = h; s.inv_h = 1.0f / h; s.substeps = substeps; s.iters = iters;
-    const float g = 9.8f;
-    const float invm_r = 1.0f / 10.0f;
-    s.gam = 1.0f / (h * 600.0f);
-    s.md = 1.0f / (invm_r + s.gam);
-    s.dmax = 1000.0f * h;
-    const float req = 0.3825978f * 0.4f;
-    s.LlinB = ((0.75f * 16.0f) * g) * h; s.LangB = s.LlinB * req;
-    s.LlinD = ((1.0f * 16.0f) * g) * h; s.LangD = s.LlinD * req;
-}
+void scene(m3::PointScene& s, float dt, int substeps, int iters) { m3::make_point_scene(s, dt, substeps, iters); }
 void load(const float* w, m3::PointWorld& p) {   // oracle row (31 floats): 3 bodies x (x y c s vx vy w) | fext R, B | fc R, B, D
     p.rx = w[0]; p.ry = w[1]; p.rvx = w[4]; p.rvy = w[5];
     p.B = {w[7], w[8], w[9], w[10], w[11], w[12], w[13]};
