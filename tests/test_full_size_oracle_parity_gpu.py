@@ -25,6 +25,11 @@ POINT = {
     # (k_rollout_point_occ2: 256 VGPRs, ~175 values in scratch) -- same bits as the oracle
     "occ2_push_K70016": dict(K=70016, task="push", goal=(-1.0, -1.0), mm=False),
     "occ2_hybrid_K70016": dict(K=70016, task="push_pull", goal=(-3.75, -3.75), mm=True),
+    # more than four wavefronts per SIMD (8192 > 4096): the THREE-waves build (k_rollout_point_occ3: 170 VGPRs, the rest
+    # in scratch) and the saturated update (k_mins / k_ladder / k_search / k_apply_weights / k_wsum with the top-k
+    # stage B) against the full oracle command -- every state, action, cost and J of the 524 288 rollouts bit for bit
+    "occ3_push_K524288": dict(K=524288, task="push", goal=(-1.0, -1.0), mm=False, calls=2),
+    "occ3_hybrid_K524288": dict(K=524288, task="push_pull", goal=(-3.75, -3.75), mm=True, calls=2),
 }
 
 
@@ -50,7 +55,7 @@ def test_point_env_full_size_vs_oracle(oracle, name):
     eng.set_noise(delta)
     raw = np.concatenate([w0[[0, 1, 4, 5]], w0[7:14], w0[14:21]]).astype(np.float32)
     eng.set_world_point_raw(raw)
-    for call in range(3):
+    for call in range(c.get("calls", 3)):
         a = eng.command(sync_host=True)
         b = opl.command(w0)
         if call == 0:
@@ -125,3 +130,44 @@ def test_panda_full_size_vs_oracle(oracle, task, grip, start):
         ch = eng.cost_horizon.cpu().numpy()
         assert np.ptp(ch) > 0.05          # the held cube really travels with the hand in these rollouts
     eng.close()
+
+
+@pytest.mark.parametrize("task,mm", [("push", False), ("push_pull", True)])
+def test_the_three_rollout_builds_give_identical_bits(task, mm):
+    """The point_env rollout kernel exists in three builds, chosen by the number of wavefronts of the launch
+    (rollout_point_kernel.hpp: one resident wave per SIMD / `amdgpu_waves_per_eu(2, 2)` above 1024 wavefronts / `(3, 3)`
+    above 4096).  The SAME noise rows through all three -- K = 2000 (occ1), 70 016 (occ2), 524 288 (occ3), the first
+    1999 rows (per mode: 998) shared -- must give the same states, actions, step costs and trajectory costs bit for bit:
+    a sample's rollout depends on nothing but its own noise row, the (zero) mean and the world."""
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    T = 30
+    goal = (-3.75, -3.75) if mm else (-1.0, -1.0)
+    out = {}
+    sizes = (2000, 70016, 524288)
+    base = _smooth_noise(sizes[0], T, 2, 31)
+    n_half = sizes[0] // 2 - 2        # (rows 1..998 of each half: 0 and K/2 carry the best trajectories, K-1 the null action)
+    for K in sizes:
+        delta = _smooth_noise(K, T, 2, 100 + K)
+        if mm:   # the modes are the two halves of the sample range: share rows inside each half
+            delta[1:1 + n_half] = base[1:1 + n_half]
+            delta[K // 2 + 1:K // 2 + 1 + n_half] = base[sizes[0] // 2 + 1:sizes[0] // 2 + 1 + n_half]
+        else:
+            delta[:sizes[0] - 1] = base[:sizes[0] - 1]
+        eng = HipEngine(make_config(K=K, T=T, nu=2, multi_modal=mm, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3]))
+        eng.set_objective(task, goal)
+        eng.set_noise(delta)
+        import oracle as O
+        ow = O.init_world(1)[0]
+        ow[0:2] = (0.05, 1.5)
+        eng.set_world_point_raw(np.concatenate([ow[[0, 1, 4, 5]], ow[7:14], ow[14:21]]).astype(np.float32))
+        eng.command(sync_host=True)
+        rows = (np.r_[1:1 + n_half, K // 2 + 1:K // 2 + 1 + n_half] if mm else np.arange(sizes[0] - 1))
+        idx = torch.as_tensor(rows, device="cuda")
+        out[K] = [eng.states[idx].cpu().numpy(), eng.actions[idx].cpu().numpy(), eng.cost_horizon[idx].cpu().numpy(),
+                  eng.buffer(L.BUF_TRAJ_COST)[idx].cpu().numpy()]
+        eng.close()
+    for K in sizes[1:]:
+        for a, b, what in zip(out[sizes[0]], out[K], ("states", "actions", "cost_h", "J")):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{what}: K={K} build differs from the K={sizes[0]} build"
+    assert np.ptp(out[sizes[0]][2]) > 1.0     # (contacts and costs really vary over these rows)

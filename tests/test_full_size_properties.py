@@ -55,6 +55,36 @@ def build(c, seed=5):
     return eng
 
 
+def _compare_sampled_rows_with_the_oracle(eng, c, st, act, ch, J):
+    """The saturated regime (two / three resident waves per SIMD: the occ2 / occ3 builds of the rollout kernel): 4096
+    rows of the first command -- the first and last 1024 (samples 0 and K-1), 1024 around K/2 (the mode boundary) and 1024
+    at a random place -- recomputed by the CPU oracle from the same noise rows; states, actions, step costs and J must
+    be the kernel's bit for bit.  (First command: the means are zero, so a row's controls are its own noise row.)"""
+    import oracle as O
+    from m3p2i_aip_amd import _lib as L
+    K, T, nu = c["K"], c["T"], c["nu"]
+    cfg = O.make_cfg(K, T, nu, task=c["task"], goal=c["goal"], multi_modal=c["mm"])
+    sc = O.default_scene()
+    w0 = O.init_world(1)[0]
+    z = np.zeros((T, nu), np.float32)
+    noise = eng.buffer(L.BUF_NOISE)                      # [T, K, nu]
+    rnd = int(np.random.default_rng(K).integers(2048, K // 2 - 2048))
+    table = np.zeros((K, T, nu), np.float32)
+    for k0 in (0, K // 2 - 512, rnd, K - 1024):
+        k1 = k0 + 1024
+        delta = noise[:, k0:k1].permute(1, 0, 2).contiguous().cpu().numpy()
+        # controls of rows k0..k1: clamp(mean + delta * scale) with the special rows (best trajectories at 0 and K/2:
+        # zero on the first command; the null action at K-1) -- the oracle's own assembly on a K-row table that
+        # holds these rows at their global places
+        table[k0:k1] = delta
+        act_o = O.assemble_actions(cfg, table, z, z, z, z, z, k0, k1)
+        r = O.point_rollout(cfg, sc, w0, act_o, None, k0, k1)
+        for got, want, what in ((st[k0:k1], r["states"], "states"), (act[k0:k1], r["actions"], "actions"),
+                                (ch[k0:k1], r["cost_h"], "cost_h"), (J[k0:k1], r["J"], "J")):
+            g = got.cpu().numpy()
+            assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), f"rows {k0}..{k1}: {what} differ from the oracle"
+
+
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_command_properties_at_full_size(name):
     import scipy.signal
@@ -73,6 +103,8 @@ def test_command_properties_at_full_size(name):
         ch = eng.cost_horizon                       # [K, T]
         st, act = eng.states, eng.actions           # [K, T, 4], [K, T, nu]
         assert torch.isfinite(st).all() and torch.isfinite(J).all()
+        if K >= 262144 and call == 0:
+            _compare_sampled_rows_with_the_oracle(eng, c, st, act, ch, J)
         # discounted accumulation
         gam = torch.tensor(0.95, dtype=f64, device=J.device) ** torch.arange(T, device=J.device, dtype=f64)
         np.testing.assert_allclose((ch.to(f64) * gam).sum(1).cpu().numpy(), J.to(f64).cpu().numpy(), rtol=2e-5)
