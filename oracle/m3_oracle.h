@@ -190,7 +190,7 @@ void m3o_gauss_fill(unsigned long long seed, unsigned call, int k0, int n, int T
                     float* out);
 void m3o_noise_fill(const m3o_cfg* cfg, unsigned long long seed, unsigned call, int k0, int n, float* out);
 
-/* ---- panda_env: "Panda chain spec v1"  ---- */
+/* ---- panda_env: "Panda world spec v2"  ---- */
 typedef struct {
     float dt; int substeps; float g;
     float base[3];
@@ -199,17 +199,26 @@ typedef struct {
     float table[6], shelf[6];      /* centre xyz + half extents */
     float cube_half, cube_m, cube_mu;
     float grasp_z, grasp_dx, grasp_dz, grasp_align, grasp_tol;
-    float k_contact;
+    float k_contact;               /* (spec v1's penalty stiffness: unused by v2, kept for the struct's layout) */
     float tip_z, tip_r, hand_z, hand_r;
+    /* spec v2: the contact solver (isaacgym_wrapper.py:26-31) and the free bodies */
+    int iters;                     /* velocity passes per substep */
+    float contact_offset, slop, baumgarte, max_bias, act_margin;
+    float mu;                      /* friction of every pair (actor_utils.py:27 default 1.0, averaged) */
+    float obs_half[3], obs_m;      /* 4_obs.yaml */
+    float sleep_v, sleep_w;
+    float rest_gap;                /* a loaded world's cube rests when its facing face is within this of a top face */
 } m3o_panda_scene;
 
-#define M3O_PANDA_WORLD_FLOATS 58
+#define M3O_PANDA_WORLD_FLOATS 84
 typedef struct {
     float q[9], qd[9];
-    float cubeA[13], cubeB[13];    /* pos3 quat4(xyzw) linvel3 angvel3 */
+    float cubeA[13], cubeB[13], obs[13];  /* pos3 quat4(xyzw) linvel3 angvel3 (the plate does not rotate) */
     float held;                    /* 1.0 while cubeA is clamped between the finger pads */
     float rel_p[3], rel_q[4];      /* cubeA pose in the hand frame while held */
-    float f_table[2], f_shelf[2], f_cubeB[2]; /* xy contact force of the last substep */
+    float awake[2];                /* cubeA, cubeB: 0.0 while the cube sleeps on the table / the shelf stand */
+    float f_table[3], f_shelf[3], f_cubeB[3]; /* net contact force of the last substep */
+    float warm_t[4], warm_l[4];    /* per collision sphere: 1 + the target of last substep's contact (0 none), its normal impulse */
 } m3o_panda_world;
 
 typedef struct {                   /* link0..7, hand, leftfinger, rightfinger */
@@ -229,7 +238,9 @@ void m3o_panda_scene_default(m3o_panda_scene* sc);
 void m3o_panda_world_init(m3o_panda_world* w, int cube_on_shelf);
 void m3o_panda_fk(const m3o_panda_scene* sc, const float q[9], m3o_panda_links* L);
 void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u[9]);
-void m3o_panda_infer_held(const m3o_panda_scene* sc, m3o_panda_world* w);
+void m3o_panda_infer_held(const m3o_panda_scene* sc, m3o_panda_world* w);   /* held AND the cubes' sleep state */
+/* diagnostics of the last m3o_panda_step call of this thread: contact rows of its last substep */
+int m3o_panda_last_rows(int* robot_rows, int* body_rows);
 void m3o_panda_observe(const m3o_panda_scene* sc, const m3o_panda_world* w, m3o_panda_obs* o);
 float m3o_panda_cost_obs(const m3o_cfg* cfg, const m3o_panda_obs* o, int k);
 void m3o_panda_rollout(const m3o_cfg* cfg, const m3o_panda_scene* sc, const m3o_panda_world* w0,

@@ -8,9 +8,17 @@ import numpy as np
 
 import oracle as O
 
-WORLD_FLOATS = 58
-# offsets inside one world row
-W_Q, W_QD, W_CUBEA, W_CUBEB, W_HELD, W_RELP, W_RELQ, W_FT, W_FS, W_FB = 0, 9, 18, 31, 44, 45, 48, 52, 54, 56
+WORLD_FLOATS = 84
+# offsets inside one world row (m3o_panda_world): q9 qd9 | cubeA13 cubeB13 obs13 (pos3 quat4 vel3 angvel3) | held |
+# rel_p3 rel_q4 | awake[cubeA, cubeB] | f_table3 f_shelf3 f_cubeB3
+W_Q, W_QD, W_CUBEA, W_CUBEB, W_OBS, W_HELD, W_RELP, W_RELQ, W_AWAKE, W_FT, W_FS, W_FB, W_WARM = 0, 9, 18, 31, 44, 57, 58, 61, 65, 67, 70, 73, 76
+RAW_FLOATS = 57     # what the engine's set_world_panda_raw takes: q9 qd9 cubeA13 cubeB13 obs13
+
+
+def raw57(world):
+    """the first 57 floats of a world row: the state the wrapper's tensors carry (no held / sleep flags, no forces)"""
+    return np.asarray(world, np.float32).reshape(-1)[:RAW_FLOATS].copy()
+
 OBS_FLOATS = 30
 LINK_NAMES = ["panda_link0", "panda_link1", "panda_link2", "panda_link3", "panda_link4", "panda_link5",
               "panda_link6", "panda_link7", "panda_hand", "panda_leftfinger", "panda_rightfinger"]
@@ -24,7 +32,10 @@ class PandaScene(C.Structure):
                 ("cube_m", C.c_float), ("cube_mu", C.c_float), ("grasp_z", C.c_float),
                 ("grasp_dx", C.c_float), ("grasp_dz", C.c_float), ("grasp_align", C.c_float),
                 ("grasp_tol", C.c_float), ("k_contact", C.c_float), ("tip_z", C.c_float),
-                ("tip_r", C.c_float), ("hand_z", C.c_float), ("hand_r", C.c_float)]
+                ("tip_r", C.c_float), ("hand_z", C.c_float), ("hand_r", C.c_float),
+                ("iters", C.c_int), ("contact_offset", C.c_float), ("slop", C.c_float), ("baumgarte", C.c_float),
+                ("max_bias", C.c_float), ("act_margin", C.c_float), ("mu", C.c_float), ("obs_half", C.c_float * 3),
+                ("obs_m", C.c_float), ("sleep_v", C.c_float), ("sleep_w", C.c_float), ("rest_gap", C.c_float)]
 
 
 _bound = False
@@ -42,6 +53,8 @@ def lib():
         l.m3o_panda_step_batch.argtypes = [C.POINTER(PandaScene), FP, C.c_int, FP]
         l.m3o_panda_observe.argtypes = [C.POINTER(PandaScene), FP, FP]
         l.m3o_panda_cost_obs_batch.argtypes = [C.POINTER(O.Cfg), FP, C.c_int, C.c_int, FP]
+        l.m3o_panda_infer_held.argtypes = [C.POINTER(PandaScene), FP]
+        l.m3o_panda_last_rows.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
         l.m3o_panda_rollout.argtypes = [C.POINTER(O.Cfg), C.POINTER(PandaScene), FP, FP, C.c_int, C.c_int,
                                         FP, FP, FP, FP]
         _bound = True
@@ -58,6 +71,20 @@ def init_world(n=1, cube_on_shelf=False) -> np.ndarray:
     w = np.zeros(WORLD_FLOATS, np.float32)
     lib().m3o_panda_world_init(O._fp(w), int(cube_on_shelf))
     return np.tile(w, (n, 1)).astype(np.float32)
+
+
+def infer_state(sc, world):
+    """held + the cubes' sleep flags from the geometry, as a world load does (in place on a float32 row)"""
+    assert world.dtype == np.float32 and world.flags.c_contiguous
+    lib().m3o_panda_infer_held(C.byref(sc), O._fp(world))
+    return world
+
+
+def last_rows():
+    """(gripper contacts, corner contacts) of the last substep of this thread's last single step"""
+    a, b = C.c_int(), C.c_int()
+    lib().m3o_panda_last_rows(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def sincos(x):

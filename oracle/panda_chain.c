@@ -7,14 +7,22 @@
  *       get_panda_place_cost   cost_functions.py:127-136
  *       get_pick_tilt_cost     cost_functions.py:138-156
  *       get_motion_cost        cost_functions.py:158-169 (panda branch)
- * (2) Independent implementation of "Panda chain spec v1" (DESIGN.md): velocity-servoed
- *     9-dof chain, forward kinematics from the URDF constants
- *     (assets/urdf/franka_description/robots/franka_panda.urdf:27-242), cubeA as a free body
- *     with support contact and a position-level grasp model, penalty contact forces.  It
- *     stands where the reference calls Isaac Gym / PhysX (isaacgym_wrapper.py:354-360);
+ * (2) Independent implementation of "Panda world spec v2" (DESIGN.md section 3): velocity-servoed
+ *     9-dof chain with joint-space inertias derived from the collision meshes, forward kinematics from
+ *     the URDF constants (assets/urdf/franka_description/robots/franka_panda.urdf:27-242), cubeA /
+ *     cubeB as free rigid cubes and the dyn-obs plate as a free (non-rotating) body, CONTACT RESPONSE:
+ *     the gripper's collision spheres and a held cube against table / shelf_stand / cubes / plate and
+ *     the cubes' corners against table / shelf_stand / each other as velocity-level unilateral rows
+ *     with Coulomb friction, solved together with the joint drives by projected Gauss-Seidel passes
+ *     (solver settings: isaacgym_wrapper.py:26-31); position-level two-finger grasp (pad channel).
+ *     It stands where the reference calls Isaac Gym / PhysX (isaacgym_wrapper.py:354-360);
  *     PARITY UNPINNED against PhysX.  Scene constants: config/panda_env/ yaml files.
+ *     This file is written as a generic solver over dynamic row lists; the product's device code
+ *     (csrc/panda_dyn.hpp) uses static slots and recomputes the geometry per pass -- same arithmetic.
  */
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "m3_oracle.h"
@@ -52,7 +60,9 @@ void m3o_panda_scene_default(m3o_panda_scene* sc) {
     sc->dt = 0.01f; sc->substeps = 2; sc->g = 9.8f;
     sc->base[0] = -0.45f; sc->base[1] = 0.0f; sc->base[2] = 1.125f; /* panda.yaml:7 */
     sc->drive_damping = 600.0f;                                      /* isaacgym_wrapper.py:344 */
-    const float inertia[9] = {1.0f, 1.0f, 0.5f, 0.5f, 0.1f, 0.1f, 0.05f, 0.1f, 0.1f};
+    /* diagonal of the joint-space mass matrix at the initial pose, from the collision meshes at the default
+     * density (tools/panda_inertia.py) */
+    const float inertia[9] = {1.32f, 2.12f, 1.30f, 0.918f, 0.0271f, 0.0366f, 0.0030f, 0.022f, 0.022f};
     const float effort[9] = {87, 87, 87, 87, 12, 12, 12, 20, 20};   /* urdf :34..240 */
     const float vlim[9] = {2.175f, 2.175f, 2.175f, 2.175f, 2.61f, 2.61f, 2.61f, 0.2f, 0.2f};
     const float lo[9] = {-2.8973f, -1.7628f, -2.8973f, -3.0718f, -2.8973f, -0.0175f, -2.8973f, 0.0f, 0.0f};
@@ -72,6 +82,12 @@ void m3o_panda_scene_default(m3o_panda_scene* sc) {
     sc->grasp_align = 0.95f; sc->grasp_tol = 0.002f;
     sc->k_contact = 5000.0f;
     sc->tip_z = 0.045f; sc->tip_r = 0.012f; sc->hand_z = 0.03f; sc->hand_r = 0.04f;
+    sc->iters = 6;                                                      /* isaacgym_wrapper.py:28 */
+    sc->contact_offset = 0.01f;                                         /* isaacgym_wrapper.py:30 */
+    sc->slop = 0.001f; sc->baumgarte = 0.2f; sc->max_bias = 2.0f; sc->act_margin = 0.002f;
+    sc->mu = 1.0f;
+    sc->obs_half[0] = 0.1f; sc->obs_half[1] = 0.1f; sc->obs_half[2] = 0.01f; sc->obs_m = 0.8f;  /* 4_obs.yaml */
+    sc->sleep_v = 0.02f; sc->sleep_w = 0.4f; sc->rest_gap = 0.002f;
 }
 
 void m3o_panda_world_init(m3o_panda_world* w, int cube_on_shelf) {
@@ -82,7 +98,9 @@ void m3o_panda_world_init(m3o_panda_world* w, int cube_on_shelf) {
     else { w->cubeA[0] = 0.2f; w->cubeA[1] = -0.2f; w->cubeA[2] = 1.06f; }
     w->cubeA[6] = 1.0f;
     w->cubeB[0] = 0.2f; w->cubeB[1] = 0.2f; w->cubeB[2] = 1.06f; w->cubeB[6] = 1.0f;
+    w->obs[0] = 0.35f; w->obs[1] = 0.0f; w->obs[2] = 1.735f; w->obs[6] = 1.0f;   /* 4_obs.yaml */
     w->rel_q[3] = 1.0f;
+    w->awake[0] = 1.0f; w->awake[1] = 1.0f;     /* the cubes start 1 cm above the table (5_cubeA.yaml, 6_cubeB.yaml) */
 }
 
 typedef struct { float x[3], y[3], z[3], p[3]; } frame_t;
@@ -170,61 +188,593 @@ void m3o_panda_fk(const m3o_panda_scene* sc, const float q[9], m3o_panda_links* 
 
 static float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 
-/* sphere (centre c, radius r) against an axis-aligned box (centre/half in b[6]): penalty force
- * ON THE BOX accumulated into f[2] (xy only: get_motion_cost reads [:, :2]) */
-static void sphere_box_force(const m3o_panda_scene* sc, const float c[3], float r, const float b[6],
-                             float f[2]) {
-    float d[3], n2 = 0.0f;
-    int inside = 1;
-    for (int i = 0; i < 3; ++i) {
-        float l = c[i] - b[i];
-        float cl = fminf(fmaxf(l, -b[3 + i]), b[3 + i]);
-        d[i] = l - cl;
-        if (d[i] != 0.0f) inside = 0;
-        n2 = mad(d[i], d[i], n2);
+/* =====================================================================================================
+ * Panda world spec v2: contact response.
+ * ===================================================================================================== */
+/* spec: reciprocal square root = bit-trick seed + three Newton steps in binary32, in this order (as the planar spec) */
+static float spec_rsqrt(float a) {
+    union { float f; unsigned u; } c;
+    c.f = a;
+    c.u = 0x5f3759dfu - (c.u >> 1);
+    float y = c.f;
+    const float hlf = 0.5f * a;
+    y = y * mad(-hlf, y * y, 1.5f);
+    y = y * mad(-hlf, y * y, 1.5f);
+    y = y * mad(-hlf, y * y, 1.5f);
+    return y;
+}
+static void cross3(const float a[3], const float b[3], float c[3]) {
+    c[0] = mad(a[1], b[2], -(a[2] * b[1]));
+    c[1] = mad(a[2], b[0], -(a[0] * b[2]));
+    c[2] = mad(a[0], b[1], -(a[1] * b[0]));
+}
+static float dotm(const float a[3], const float b[3]) { return mad(a[0], b[0], mad(a[1], b[1], a[2] * b[2])); }
+
+/* a free body's rotation matrix (row-major) from its quaternion xyzw */
+static void body_rot(const float q[4], float R[9]) {
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    R[0] = mad(-2.0f, yy + zz, 1.0f); R[1] = 2.0f * (xy - wz);          R[2] = 2.0f * (xz + wy);
+    R[3] = 2.0f * (xy + wz);          R[4] = mad(-2.0f, xx + zz, 1.0f); R[5] = 2.0f * (yz - wx);
+    R[6] = 2.0f * (xz - wy);          R[7] = 2.0f * (yz + wx);          R[8] = mad(-2.0f, xx + yy, 1.0f);
+}
+
+enum { T_TABLE = 0, T_SHELF = 1, T_CUBEA = 2, T_CUBEB = 3, T_OBS = 4 };
+typedef struct { float p[3], e[3], R[9]; int oriented; } box_t;
+
+static void box_static(const float b[6], box_t* o) {
+    for (int i = 0; i < 3; ++i) { o->p[i] = b[i]; o->e[i] = b[3 + i]; }
+    o->oriented = 0;
+}
+static void box_body(const float body[13], const float e[3], int oriented, box_t* o) {
+    for (int i = 0; i < 3; ++i) { o->p[i] = body[i]; o->e[i] = e[i]; }
+    o->oriented = oriented;
+    if (oriented) body_rot(body + 3, o->R);
+}
+static void box_local(const box_t* b, const float c[3], float l[3]) {
+    const float dl[3] = {c[0] - b->p[0], c[1] - b->p[1], c[2] - b->p[2]};
+    for (int i = 0; i < 3; ++i)
+        l[i] = b->oriented ? mad(dl[0], b->R[0 * 3 + i], mad(dl[1], b->R[1 * 3 + i], dl[2] * b->R[2 * 3 + i])) : dl[i];
+}
+static void box_world(const box_t* b, const float v[3], float o[3]) {
+    for (int j = 0; j < 3; ++j)
+        o[j] = b->oriented ? mad(b->R[j * 3 + 0], v[0], mad(b->R[j * 3 + 1], v[1], b->R[j * 3 + 2] * v[2])) : v[j];
+}
+
+/* sphere (centre c, radius r; a cube's corner: r = 0) against a box: the gap, the unit normal from the box to the
+ * sphere (world) and the contact point on the sphere's surface.  Centre outside: along the line to the closest point
+ * of the box; centre inside (or on the surface): the face of least penetration, lowest axis first. */
+static float pt_box(const box_t* b, const float c[3], float r, float n[3], float x[3]) {
+    float l[3], d[3], nl[3], gap;
+    box_local(b, c, l);
+    for (int i = 0; i < 3; ++i) d[i] = l[i] - fminf(fmaxf(l[i], -b->e[i]), b->e[i]);
+    const float d2 = mad(d[0], d[0], mad(d[1], d[1], d[2] * d[2]));
+    if (d2 > 1.0e-12f) {
+        const float rs = spec_rsqrt(d2);
+        for (int i = 0; i < 3; ++i) nl[i] = d[i] * rs;
+        gap = d2 * rs - r;
+    } else {
+        int f = 0;
+        float pen = b->e[0] - fabsf(l[0]);
+        for (int i = 1; i < 3; ++i) {
+            const float pi = b->e[i] - fabsf(l[i]);
+            if (pi < pen) { pen = pi; f = i; }
+        }
+        nl[0] = nl[1] = nl[2] = 0.0f;
+        nl[f] = (l[f] >= 0.0f) ? 1.0f : -1.0f;
+        gap = -pen - r;
     }
-    if (inside) return; /* centre inside the box: no direction; ignored by the spec */
-    float dist = sqrtf(n2);
-    float pen = r - dist;
-    if (!(pen > 0.0f)) return;
-    float k = sc->k_contact * pen / dist;
-    f[0] = mad(-k, d[0], f[0]);
-    f[1] = mad(-k, d[1], f[1]);
+    box_world(b, nl, n);
+    for (int j = 0; j < 3; ++j) x[j] = mad(-r, n[j], c[j]);
+    return gap;
+}
+
+/* unit tangents: the coordinate axis least aligned with n, crossed with n and normalised; t2 = n x t1 */
+static void tangents(const float n[3], float t1[3], float t2[3]) {
+    const float ax = fabsf(n[0]), ay = fabsf(n[1]), az = fabsf(n[2]);
+    float c[3];
+    if (ax <= ay && ax <= az) { c[0] = 0.0f; c[1] = -n[2]; c[2] = n[1]; }
+    else if (ay <= az) { c[0] = n[2]; c[1] = 0.0f; c[2] = -n[0]; }
+    else { c[0] = -n[1]; c[1] = n[0]; c[2] = 0.0f; }
+    const float rs = spec_rsqrt(mad(c[0], c[0], mad(c[1], c[1], c[2] * c[2])));
+    for (int i = 0; i < 3; ++i) t1[i] = c[i] * rs;
+    cross3(n, t1, t2);
+}
+
+/* ---- solver state of one substep ---- */
+typedef struct {
+    int robot;               /* the mover is the gripper (a collision sphere); else body `ma` (a cube's corner) */
+    int ma, tb;              /* mover / target free body: 0 cubeA, 1 cubeB, 2 plate; -1 none (static target) */
+    int target;              /* T_* */
+    float d[3][3];           /* n, t1, t2 */
+    float J[3][9];           /* robot rows */
+    float aa[3][3], ab[3][3];/* (mover arm) x d, (target arm) x d */
+    float meff[3], bias, lam[3];
+    int sphere;
+} contact_t;
+
+#define MAX_CONTACTS 40
+typedef struct {
+    const m3o_panda_scene* sc;
+    float h, inv_h;
+    float qd[9], p[9];       /* joint velocities and drive impulses of a world with robot rows */
+    float* bv[3];            /* the free bodies' linear / angular velocities (into the world) */
+    float* bw[3];
+    float invm[3], invI[3];
+    int rotates[3];
+    float invIj[9];
+    int n;
+    contact_t c[MAX_CONTACTS];
+} solver_t;
+
+static __thread int g_last_robot_rows, g_last_body_rows;
+int m3o_panda_last_rows(int* robot_rows, int* body_rows) {
+    if (robot_rows) *robot_rows = g_last_robot_rows;
+    if (body_rows) *body_rows = g_last_body_rows;
+    return g_last_robot_rows + g_last_body_rows;
+}
+
+/* gripper geometry of one configuration: hand frame, the arm's Jacobian columns at the hand origin, the spheres */
+typedef struct {
+    float ph[3], hx[3], hy[3], hz[3];
+    float Jv[7][3], Jw[7][3];
+    float sc_c[4][3], sc_r[4];    /* tip left, tip right, hand, held cube */
+    int n_spheres;
+} gripper_t;
+
+static void gripper_geometry(const m3o_panda_scene* sc, const m3o_panda_world* w, gripper_t* g) {
+    m3o_panda_links L;
+    m3o_panda_fk(sc, w->q, &L);
+    for (int i = 0; i < 3; ++i) { g->ph[i] = L.pos[8][i]; g->hx[i] = L.ax[8][i]; g->hy[i] = L.ay[8][i]; g->hz[i] = L.az[8][i]; }
+    for (int j = 0; j < 7; ++j) {
+        float lever[3];
+        for (int i = 0; i < 3; ++i) { g->Jw[j][i] = L.az[j + 1][i]; lever[i] = g->ph[i] - L.pos[j + 1][i]; }
+        cross3(g->Jw[j], lever, g->Jv[j]);
+    }
+    for (int i = 0; i < 3; ++i) {
+        g->sc_c[0][i] = mad(sc->tip_z, g->hz[i], L.pos[9][i]);
+        g->sc_c[1][i] = mad(sc->tip_z, g->hz[i], L.pos[10][i]);
+        g->sc_c[2][i] = mad(sc->hand_z, g->hz[i], g->ph[i]);
+        g->sc_c[3][i] = w->cubeA[i];
+    }
+    g->sc_r[0] = sc->tip_r; g->sc_r[1] = sc->tip_r; g->sc_r[2] = sc->hand_r; g->sc_r[3] = sc->cube_half;
+    g->n_spheres = (w->held != 0.0f) ? 4 : 3;
+}
+
+/* the joint-space row of direction d at the point x of the gripper (sphere s: the finger columns) */
+static void robot_row(const gripper_t* g, int s, int held, const float x[3], const float d[3], float J[9]) {
+    float rho[3], m[3];
+    for (int i = 0; i < 3; ++i) rho[i] = x[i] - g->ph[i];
+    cross3(rho, d, m);
+    for (int j = 0; j < 7; ++j) J[j] = dotm(d, g->Jv[j]) + dotm(m, g->Jw[j]);
+    const float dy = dotm(d, g->hy);
+    J[7] = (s == 0 && !held) ? dy : 0.0f;
+    J[8] = (s == 1 && !held) ? -dy : 0.0f;
+}
+
+static float body_k(const solver_t* S, int b, const float a[3]) {
+    return S->rotates[b] ? mad(S->invI[b], dotm(a, a), S->invm[b]) : S->invm[b];
+}
+static float body_vel(const solver_t* S, int b, const float d[3], const float a[3]) {
+    const float lin = dotm(d, S->bv[b]);
+    return S->rotates[b] ? lin + dotm(a, S->bw[b]) : lin;
+}
+static void body_apply(solver_t* S, int b, const float d[3], const float a[3], float dl) {   /* dl signed */
+    const float im = S->invm[b] * dl;
+    for (int i = 0; i < 3; ++i) S->bv[b][i] = mad(im, d[i], S->bv[b][i]);
+    if (S->rotates[b]) {
+        const float ia = S->invI[b] * dl;
+        for (int i = 0; i < 3; ++i) S->bw[b][i] = mad(ia, a[i], S->bw[b][i]);
+    }
+}
+
+/* effective masses and the bias of a contact whose directions, rows and arms are set */
+static void contact_prepare(solver_t* S, contact_t* c, float gap) {
+    const m3o_panda_scene* sc = S->sc;
+    for (int r = 0; r < 3; ++r) {
+        float k;
+        if (c->robot) {
+            k = 0.0f;
+            for (int j = 0; j < 9; ++j) k = mad(c->J[r][j] * S->invIj[j], c->J[r][j], k);
+        } else {
+            k = body_k(S, c->ma, c->aa[r]);
+        }
+        if (c->tb >= 0) k = k + body_k(S, c->tb, c->ab[r]);
+        c->meff[r] = 1.0f / k;
+        c->lam[r] = 0.0f;
+    }
+    if (gap > 0.0f) {
+        c->bias = gap * S->inv_h;
+    } else {
+        float pen = fmaxf(-gap - sc->slop, 0.0f);
+        float push = fminf((sc->baumgarte * pen) * S->inv_h, sc->max_bias);
+        c->bias = -push;
+    }
+}
+
+static float contact_vrel(const solver_t* S, const contact_t* c, int r, const float* qd) {
+    float v;
+    if (c->robot) {
+        v = 0.0f;
+        for (int j = 0; j < 9; ++j) v = mad(c->J[r][j], qd[j], v);
+    } else {
+        v = body_vel(S, c->ma, c->d[r], c->aa[r]);
+    }
+    if (c->tb >= 0) v = v - body_vel(S, c->tb, c->d[r], c->ab[r]);
+    return v;
+}
+
+static void contact_solve(solver_t* S, contact_t* c) {
+    /* the friction rows first (bounded by the normal impulse of the previous pass), the normal row last: what a
+     * pass leaves exactly satisfied is non-penetration */
+    for (int rr = 0; rr < 3; ++rr) {
+        const int r = (rr + 1) % 3;
+        const float v = contact_vrel(S, c, r, S->qd);
+        float dl = -c->meff[r] * (v + ((r == 0) ? c->bias : 0.0f));
+        const float l0 = c->lam[r];
+        float l1 = l0 + dl;
+        if (r == 0) l1 = fmaxf(l1, 0.0f);
+        else { const float mx = S->sc->mu * c->lam[0]; l1 = fminf(fmaxf(l1, -mx), mx); }
+        c->lam[r] = l1;
+        dl = l1 - l0;
+        if (c->robot) { for (int j = 0; j < 9; ++j) S->qd[j] = mad(c->J[r][j] * S->invIj[j], dl, S->qd[j]); }
+        else body_apply(S, c->ma, c->d[r], c->aa[r], dl);
+        if (c->tb >= 0) body_apply(S, c->tb, c->d[r], c->ab[r], -dl);
+    }
+}
+
+/* A cube against a box, face to face: the 4 corners of the cube's face that faces the box against the box's face
+ * that faces the cube (its plane; the normal is that face's).  A corner that lies beyond the face's footprint is
+ * moved onto the footprint's boundary and takes the height of the cube's face there -- for two aligned boxes the four
+ * points are the corners of the overlap rectangle -- as long as the two faces oppose each other within 45 degrees;
+ * otherwise it makes no contact.  x: the contact points (on the box's face plane), r = x - pb, gap: height above the
+ * face.  Returns 0 when the cube is not near the box (or its centre is inside it). */
+typedef struct { float r[4][3], x[4][3], n[3], gap[4]; int centre_over; } manifold_t;
+static int cube_manifold(const m3o_panda_scene* sc, const float pb[3], const float Rb[9], const box_t* tgt, manifold_t* m) {
+    float l[3], dd[3], dw[3], dlc[3];
+    box_local(tgt, pb, l);
+    for (int i = 0; i < 3; ++i) dd[i] = fminf(fmaxf(l[i], -tgt->e[i]), tgt->e[i]) - l[i];
+    const float d2 = mad(dd[0], dd[0], mad(dd[1], dd[1], dd[2] * dd[2]));
+    const float lim = 0.0434f + sc->contact_offset;     /* the cube's bounding radius, sqrt(3) * 0.025 rounded up */
+    if (!(d2 > 1.0e-12f) || d2 > lim * lim) return 0;
+    int pref = 0;
+    if (fabsf(dd[1]) > fabsf(dd[pref])) pref = 1;
+    if (fabsf(dd[2]) > fabsf(dd[pref])) pref = 2;
+    const int a1 = (pref + 1) % 3, a2 = (pref + 2) % 3;
+    const float side = (dd[pref] <= 0.0f) ? 1.0f : -1.0f;    /* the cube's centre lies beyond the box's +face / -face */
+    m->centre_over = (dd[a1] == 0.0f && dd[a2] == 0.0f);       /* ... and projects into that face */
+    box_world(tgt, dd, dw);
+    for (int i = 0; i < 3; ++i) dlc[i] = mad(dw[0], Rb[0 * 3 + i], mad(dw[1], Rb[1 * 3 + i], dw[2] * Rb[2 * 3 + i]));
+    int f = 0;
+    if (fabsf(dlc[1]) > fabsf(dlc[f])) f = 1;
+    if (fabsf(dlc[2]) > fabsf(dlc[f])) f = 2;
+    const float e = sc->cube_half;
+    const float sgn = (dlc[f] >= 0.0f) ? 1.0f : -1.0f;
+    /* the cube's facing face normal in the box's frame; its component along the box's facing normal */
+    float nmw[3], nml[3], nl[3] = {0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < 3; ++k) nmw[k] = sgn * Rb[k * 3 + f];
+    if (tgt->oriented) for (int i = 0; i < 3; ++i) nml[i] = mad(nmw[0], tgt->R[0 * 3 + i], mad(nmw[1], tgt->R[1 * 3 + i], nmw[2] * tgt->R[2 * 3 + i]));
+    else for (int i = 0; i < 3; ++i) nml[i] = nmw[i];
+    const float mz = side * nml[pref];
+    const int clip = (mz <= -0.7f);
+    const float rz = clip ? 1.0f / mz : 0.0f;
+    nl[pref] = side;
+    box_world(tgt, nl, m->n);
+    for (int j = 0; j < 4; ++j) {
+        float cl[3], xw[3], lc[3], lq[3], qw[3];
+        cl[f] = sgn * e;
+        cl[(f + 1) % 3] = (j & 1) ? e : -e;
+        cl[(f + 2) % 3] = (j & 2) ? e : -e;
+        for (int k = 0; k < 3; ++k)
+            xw[k] = pb[k] + mad(Rb[k * 3 + 0], cl[0], mad(Rb[k * 3 + 1], cl[1], Rb[k * 3 + 2] * cl[2]));
+        box_local(tgt, xw, lc);
+        const float hgt = side * lc[pref] - tgt->e[pref];
+        const float q1 = fminf(fmaxf(lc[a1], -tgt->e[a1]), tgt->e[a1]);
+        const float q2 = fminf(fmaxf(lc[a2], -tgt->e[a2]), tgt->e[a2]);
+        const float s1 = q1 - lc[a1], s2 = q2 - lc[a2];
+        const int moved = (s1 != 0.0f) || (s2 != 0.0f);
+        if (moved && !clip) m->gap[j] = 1.0f;
+        else if (moved) m->gap[j] = hgt - mad(nml[a1], s1, nml[a2] * s2) * rz;
+        else m->gap[j] = hgt;
+        lq[a1] = q1; lq[a2] = q2; lq[pref] = side * tgt->e[pref];
+        box_world(tgt, lq, qw);
+        for (int k = 0; k < 3; ++k) { m->x[j][k] = tgt->p[k] + qw[k]; m->r[j][k] = m->x[j][k] - pb[k]; }
+    }
+    return 1;
+}
+
+/* a cube makes contact with ONE of the two static boxes: the nearer to its centre (the table on a tie) */
+static int nearer_static(const m3o_panda_scene* sc, const float pb[3]) {
+    float d2[2];
+    const float* stat[2] = {sc->table, sc->shelf};
+    for (int s = 0; s < 2; ++s) {
+        float dd[3];
+        for (int i = 0; i < 3; ++i) {
+            const float l = pb[i] - stat[s][i];
+            dd[i] = fminf(fmaxf(l, -stat[s][3 + i]), stat[s][3 + i]) - l;
+        }
+        d2[s] = mad(dd[0], dd[0], mad(dd[1], dd[1], dd[2] * dd[2]));
+    }
+    return (d2[0] <= d2[1]) ? T_TABLE : T_SHELF;
+}
+
+/* a cube rests: all four contact points of its facing face within rest_gap of the top of its static box */
+static int cube_on_static(const m3o_panda_scene* sc, const float cube[13]) {
+    float R[9];
+    body_rot(cube + 3, R);
+    box_t b;
+    manifold_t m;
+    box_static(nearer_static(sc, cube) == T_TABLE ? sc->table : sc->shelf, &b);
+    if (!cube_manifold(sc, cube, R, &b, &m)) return 0;
+    for (int j = 0; j < 4; ++j) if (!(m.gap[j] < sc->rest_gap && m.n[2] >= 0.99f)) return 0;
+    return 1;
+}
+
+/* counts[0]: contacts made, [1]: of them carrying the mover (n_z >= 0.99, gap below rest_gap), [2]: carried by it
+ * (n_z <= -0.99), [3]: the mover's centre projects into the facing face */
+static void add_cube_manifold(solver_t* S, int ma, const float* body, const float Rb[9], const box_t* tgt, int target,
+                              int tb, const float* tbody, int counts[4]) {
+    const m3o_panda_scene* sc = S->sc;
+    manifold_t m;
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
+    if (!cube_manifold(sc, body, Rb, tgt, &m)) return;
+    counts[3] = m.centre_over;
+    for (int j = 0; j < 4; ++j) {
+        if (!(m.gap[j] < sc->contact_offset)) continue;
+        ++counts[0];
+        if (m.n[2] >= 0.99f && m.gap[j] < sc->rest_gap) ++counts[1];
+        if (m.n[2] <= -0.99f && m.gap[j] < sc->rest_gap) ++counts[2];
+        contact_t* c = &S->c[S->n++];
+        memset(c, 0, sizeof(*c));
+        c->robot = 0; c->ma = ma; c->tb = tb; c->target = target;
+        for (int i = 0; i < 3; ++i) c->d[0][i] = m.n[i];
+        tangents(c->d[0], c->d[1], c->d[2]);
+        float rt[3] = {0, 0, 0};
+        if (tb >= 0) for (int i = 0; i < 3; ++i) rt[i] = m.x[j][i] - tbody[i];
+        for (int r = 0; r < 3; ++r) {
+            cross3(m.r[j], c->d[r], c->aa[r]);
+            if (tb >= 0) cross3(rt, c->d[r], c->ab[r]);
+        }
+        contact_prepare(S, c, m.gap[j]);
+    }
+}
+
+/* ... or on the other cube: its centre over that cube's top face and at least three of the face-to-face contact
+ * points carrying it */
+static int cube_on_cube(const m3o_panda_scene* sc, const float up[13], const float lo[13]) {
+    const float e[3] = {sc->cube_half, sc->cube_half, sc->cube_half};
+    float Ru[9];
+    box_t bl;
+    manifold_t m;
+    body_rot(up + 3, Ru);
+    box_body(lo, e, 1, &bl);
+    int n = 0;
+    if (!cube_manifold(sc, up, Ru, &bl, &m) || !m.centre_over || !(m.n[2] >= 0.99f)) return 0;
+    for (int j = 0; j < 4; ++j) if (m.gap[j] < sc->rest_gap) ++n;
+    return n >= 3;
+}
+
+static void integrate_quat(float q[4], const float w[3], float h) {
+    if (w[0] == 0.0f && w[1] == 0.0f && w[2] == 0.0f) return;
+    const float hh = 0.5f * h;
+    const float tx = mad(w[0], q[3], mad(w[1], q[2], -(w[2] * q[1])));
+    const float ty = mad(w[1], q[3], mad(w[2], q[0], -(w[0] * q[2])));
+    const float tz = mad(w[2], q[3], mad(w[0], q[1], -(w[1] * q[0])));
+    const float tw = -mad(w[0], q[0], mad(w[1], q[1], w[2] * q[2]));
+    float n[4] = {mad(hh, tx, q[0]), mad(hh, ty, q[1]), mad(hh, tz, q[2]), mad(hh, tw, q[3])};
+    const float rs = spec_rsqrt(mad(n[0], n[0], mad(n[1], n[1], mad(n[2], n[2], n[3] * n[3]))));
+    for (int i = 0; i < 4; ++i) q[i] = n[i] * rs;
 }
 
 void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u[9]) {
     const float h = sc->dt / (float)sc->substeps;
+    const float inv_h = 1.0f / h;
+    const float hD = h * sc->drive_damping;
+    const float cube_e[3] = {sc->cube_half, sc->cube_half, sc->cube_half};
+    float* bodies[3] = {w->cubeA, w->cubeB, w->obs};
     for (int sub = 0; sub < sc->substeps; ++sub) {
-        /* 1. velocity servo per dof (implicit damper, torque + velocity + position limits) */
-        for (int i = 0; i < 9; ++i) {
-            if (w->held != 0.0f && i >= 7) { w->qd[i] = 0.0f; continue; } /* fingers locked on the cube */
-            /* spec: per-dof constants a = hD/I, rden = 1/(1+a), dv = h*effort/I (f32) */
-            float a = (h * sc->drive_damping) / sc->inertia[i];
-            float rden = 1.0f / (1.0f + a);
-            float dv = (h * sc->effort[i]) / sc->inertia[i];
-            float qd1 = mad(a, u[i], w->qd[i]) * rden;
-            float tau = sc->drive_damping * (u[i] - qd1);
-            if (tau > sc->effort[i]) qd1 = w->qd[i] + dv;
-            if (tau < -sc->effort[i]) qd1 = w->qd[i] - dv;
-            qd1 = fminf(fmaxf(qd1, -sc->vlim[i]), sc->vlim[i]);
-            float q1 = mad(h, qd1, w->q[i]);
-            if (q1 < sc->qlo[i]) { q1 = sc->qlo[i]; qd1 = 0.0f; }
-            if (q1 > sc->qhi[i]) { q1 = sc->qhi[i]; qd1 = 0.0f; }
-            w->q[i] = q1; w->qd[i] = qd1;
+        /* 0. release: either finger commanded open lets a held cube go where it is, at rest */
+        if (w->held != 0.0f && (u[7] >= 0.0f || u[8] >= 0.0f)) {
+            w->held = 0.0f;
+            for (int i = 7; i < 13; ++i) w->cubeA[i] = 0.0f;
+            w->awake[0] = 1.0f;
         }
-        /* 2. kinematics */
+        const int held = (w->held != 0.0f);
+        /* 1. the joint servos in closed form (implicit damper, torque + velocity limits): what a substep without
+         * gripper contacts does, and the velocities the contact culling predicts with */
+        float a_[9], rden[9], invI[9], pmax[9], qd1[9];
+        for (int i = 0; i < 9; ++i) {
+            a_[i] = hD / sc->inertia[i];
+            rden[i] = 1.0f / (1.0f + a_[i]);
+            invI[i] = 1.0f / sc->inertia[i];
+            pmax[i] = h * sc->effort[i];
+            if (held && i >= 7) { qd1[i] = 0.0f; continue; }      /* fingers locked on the cube */
+            const float dv = pmax[i] * invI[i];
+            float v = mad(a_[i], u[i], w->qd[i]) * rden[i];
+            const float tau = sc->drive_damping * (u[i] - v);
+            if (tau > sc->effort[i]) v = w->qd[i] + dv;
+            if (tau < -sc->effort[i]) v = w->qd[i] - dv;
+            qd1[i] = fminf(fmaxf(v, -sc->vlim[i]), sc->vlim[i]);
+        }
+        /* 2. the gripper's collision spheres against the boxes: one contact per sphere (the smallest gap, targets in
+         * the order table, shelf_stand, cubeA, cubeB, plate), kept if it is predicted to close */
+        solver_t S;
+        memset(&S, 0, sizeof(S));
+        S.sc = sc; S.h = h; S.inv_h = inv_h; S.n = 0;
+        for (int b = 0; b < 3; ++b) { S.bv[b] = bodies[b] + 7; S.bw[b] = bodies[b] + 10; }
+        S.invm[0] = S.invm[1] = 1.0f / sc->cube_m;
+        S.invI[0] = S.invI[1] = 1.0f / ((sc->cube_m * ((2.0f * sc->cube_half) * (2.0f * sc->cube_half))) / 6.0f);
+        S.invm[2] = 1.0f / sc->obs_m; S.invI[2] = 0.0f;
+        S.rotates[0] = S.rotates[1] = 1; S.rotates[2] = 0;
+        for (int i = 0; i < 9; ++i) S.invIj[i] = invI[i];
+        gripper_t g;
+        gripper_geometry(sc, w, &g);
+        box_t tgt[5];
+        box_static(sc->table, &tgt[T_TABLE]);
+        box_static(sc->shelf, &tgt[T_SHELF]);
+        box_body(w->cubeA, cube_e, 1, &tgt[T_CUBEA]);
+        box_body(w->cubeB, cube_e, 1, &tgt[T_CUBEB]);
+        box_body(w->obs, sc->obs_half, 0, &tgt[T_OBS]);
+        /* the pad channel (the grasp rule's region): there the pads, not the tip spheres, act on cubeA */
+        int in_channel = 0;
+        if (!held) {
+            const float dd[3] = {w->cubeA[0] - g.ph[0], w->cubeA[1] - g.ph[1], w->cubeA[2] - g.ph[2]};
+            const float cx = dot3(dd, g.hx), cy = dot3(dd, g.hy), cz = dot3(dd, g.hz);
+            float Rc[9];
+            quat2mat(&w->cubeA[3], Rc);
+            float ay = 0.0f, az = 0.0f;
+            for (int j = 0; j < 3; ++j) {
+                float col[3] = {Rc[j], Rc[3 + j], Rc[6 + j]};
+                ay = fmaxf(ay, fabsf(dot3(g.hy, col)));
+                az = fmaxf(az, fabsf(dot3(g.hz, col)));
+            }
+            in_channel = fabsf(cx) <= sc->grasp_dx && fabsf(cz - sc->grasp_z) <= sc->grasp_dz && cy < w->q[7] &&
+                         cy > -w->q[8] && ay >= sc->grasp_align && az >= sc->grasp_align;
+        }
+        int robot_rows = 0;
+        int touched[3] = {0, 0, 0};     /* a gripper row acts on this free body */
+        for (int s = 0; s < g.n_spheres; ++s) {
+            float best_gap = sc->contact_offset, bn[3] = {0, 0, 0}, bx[3] = {0, 0, 0};
+            int best = -1;
+            for (int t = 0; t < 5; ++t) {
+                if (t == T_CUBEA && (held || (s < 2 && in_channel))) continue;
+                float n[3], x[3];
+                const float gap = pt_box(&tgt[t], g.sc_c[s], g.sc_r[s], n, x);
+                if (gap < best_gap) { best_gap = gap; best = t; for (int i = 0; i < 3; ++i) { bn[i] = n[i]; bx[i] = x[i]; } }
+            }
+            if (best < 0) continue;
+            contact_t c;
+            memset(&c, 0, sizeof(c));
+            c.robot = 1; c.ma = -1; c.target = best;
+            c.tb = (best >= T_CUBEA) ? best - T_CUBEA : -1;
+            for (int i = 0; i < 3; ++i) c.d[0][i] = bn[i];
+            tangents(c.d[0], c.d[1], c.d[2]);
+            float rt[3] = {0, 0, 0};
+            if (c.tb >= 0) for (int i = 0; i < 3; ++i) rt[i] = bx[i] - bodies[c.tb][i];
+            for (int r = 0; r < 3; ++r) {
+                robot_row(&g, s, held, bx, c.d[r], c.J[r]);
+                if (c.tb >= 0) cross3(rt, c.d[r], c.ab[r]);
+            }
+            /* culling: the gap predicted for the end of the substep from the servo's velocities */
+            const float vn0 = contact_vrel(&S, &c, 0, qd1);
+            if (!(mad(h, vn0, best_gap) < sc->act_margin)) continue;
+            contact_prepare(&S, &c, best_gap);
+            c.sphere = s;
+            if (w->warm_t[s] == (float)(best + 1)) c.lam[0] = w->warm_l[s];     /* warm start: last substep's normal impulse */
+            S.c[S.n++] = c;
+            ++robot_rows;
+            if (c.tb >= 0) { touched[c.tb] = 1; if (c.tb < 2) w->awake[c.tb] = 1.0f; }
+        }
+        /* 3. an awake cube wakes the other one when they are close */
+        const int freeA = !held;
+        if (freeA && (w->awake[0] != 0.0f) != (w->awake[1] != 0.0f)) {
+            const float dx = w->cubeA[0] - w->cubeB[0], dy = w->cubeA[1] - w->cubeB[1], dz = w->cubeA[2] - w->cubeB[2];
+            const float lim = 2.0f * 0.0434f + sc->contact_offset;
+            if (mad(dx, dx, mad(dy, dy, dz * dz)) < lim * lim) { w->awake[0] = 1.0f; w->awake[1] = 1.0f; }
+        }
+        const int act[2] = {freeA && w->awake[0] != 0.0f, w->awake[1] != 0.0f};
+        /* 4. gravity, then the cubes' corner contacts */
+        for (int b = 0; b < 2; ++b) if (act[b]) bodies[b][9] = mad(-sc->g, h, bodies[b][9]);
+        int cAs[4] = {0, 0, 0, 0}, cAB[4] = {0, 0, 0, 0}, cBs[4] = {0, 0, 0, 0};
+        float RA[9], RB[9];
+        body_rot(w->cubeA + 3, RA);
+        body_rot(w->cubeB + 3, RB);
+        if (act[0]) { const int t = nearer_static(sc, w->cubeA); add_cube_manifold(&S, 0, w->cubeA, RA, &tgt[t], t, -1, NULL, cAs); }
+        if (act[0] && act[1]) add_cube_manifold(&S, 0, w->cubeA, RA, &tgt[T_CUBEB], T_CUBEB, 1, w->cubeB, cAB);
+        if (act[1]) { const int t = nearer_static(sc, w->cubeB); add_cube_manifold(&S, 1, w->cubeB, RB, &tgt[t], t, -1, NULL, cBs); }
+        /* 5. velocity passes: the joint drives as rows (only in a world with gripper contacts), then the contacts */
+        if (robot_rows) for (int i = 0; i < 9; ++i) { S.qd[i] = (held && i >= 7) ? 0.0f : w->qd[i]; S.p[i] = 0.0f; }
+        for (int k = 0; k < robot_rows; ++k) {       /* the warm-start impulses act before the first pass */
+            contact_t* c = &S.c[k];
+            const float dl = c->lam[0];
+            if (dl == 0.0f) continue;
+            for (int j = 0; j < 9; ++j) S.qd[j] = mad(c->J[0][j] * S.invIj[j], dl, S.qd[j]);
+            if (c->tb >= 0) body_apply(&S, c->tb, c->d[0], c->ab[0], -dl);
+        }
+        for (int pass = 0; pass < sc->iters; ++pass) {
+            if (robot_rows) {
+                for (int i = 0; i < 9; ++i) {
+                    if (held && i >= 7) continue;
+                    const float e = mad(hD, u[i] - S.qd[i], -S.p[i]);
+                    float dp = e * rden[i];
+                    const float p1 = fminf(fmaxf(S.p[i] + dp, -pmax[i]), pmax[i]);
+                    dp = p1 - S.p[i];
+                    S.p[i] = p1;
+                    S.qd[i] = mad(invI[i], dp, S.qd[i]);
+                }
+            }
+            for (int k = 0; k < S.n; ++k) contact_solve(&S, &S.c[k]);
+        }
+        /* ... and one more sweep over the contacts alone (isaacgym_wrapper.py:29, num_velocity_iterations = 1): the
+         * drives pull against the contacts in every pass; what the substep ends on is the contacts' word */
+        for (int k = 0; k < S.n; ++k) contact_solve(&S, &S.c[k]);
+        for (int i = 0; i < 9; ++i) {
+            float v = robot_rows ? fminf(fmaxf(S.qd[i], -sc->vlim[i]), sc->vlim[i]) : qd1[i];
+            if (held && i >= 7) v = 0.0f;
+            w->qd[i] = v;
+        }
+        /* net contact forces on table / shelf_stand / cubeB: this substep's impulses / h (a step reports its last) */
+        float ft[3] = {0, 0, 0}, fs[3] = {0, 0, 0}, fb[3] = {0, 0, 0};
+        for (int k = 0; k < S.n; ++k) {
+            const contact_t* c = &S.c[k];
+            for (int r = 0; r < 3; ++r) {
+                const float sI = c->lam[r] * inv_h;
+                float* dst = (c->target == T_TABLE) ? ft : (c->target == T_SHELF) ? fs : (c->target == T_CUBEB) ? fb : NULL;
+                if (dst) for (int i = 0; i < 3; ++i) dst[i] = mad(-sI, c->d[r][i], dst[i]);
+                if (!c->robot && c->ma == 1) for (int i = 0; i < 3; ++i) fb[i] = mad(sI, c->d[r][i], fb[i]);
+            }
+        }
+        for (int i = 0; i < 3; ++i) { w->f_table[i] = ft[i]; w->f_shelf[i] = fs[i]; w->f_cubeB[i] = fb[i]; }
+        for (int s4 = 0; s4 < 4; ++s4) { w->warm_t[s4] = 0.0f; w->warm_l[s4] = 0.0f; }
+        for (int k = 0; k < robot_rows; ++k) { w->warm_t[S.c[k].sphere] = (float)(S.c[k].target + 1); w->warm_l[S.c[k].sphere] = S.c[k].lam[0]; }
+        g_last_robot_rows = robot_rows; g_last_body_rows = S.n - robot_rows;
+        if (getenv("M3O_DEBUG")) {
+            for (int k = 0; k < S.n; ++k) {
+                const contact_t* c = &S.c[k];
+                fprintf(stderr, "  sub %d contact %d robot %d ma %d tb %d target %d n (%.3f %.3f %.3f) bias %.4f lam (%.5f %.5f %.5f) meff %.4f\n",
+                        sub, k, c->robot, c->ma, c->tb, c->target, c->d[0][0], c->d[0][1], c->d[0][2], c->bias, c->lam[0], c->lam[1], c->lam[2], c->meff[0]);
+            }
+        }
+        /* 6. sleep: slow cubes that rest -- the whole facing face on the table / shelf_stand, or stacked on the other
+         * cube (centre over its face, three of the face-to-face contacts carrying it) which rests on a static box -- and
+         * that no gripper contact touches; two cubes in contact go to sleep together or not at all */
+        {
+            int slow[2], on_static[2], rests[2];
+            for (int b = 0; b < 2; ++b) {
+                const float* v = bodies[b] + 7;
+                const float* om = bodies[b] + 10;
+                slow[b] = act[b] && !touched[b] && dotm(v, v) < sc->sleep_v * sc->sleep_v && dotm(om, om) < sc->sleep_w * sc->sleep_w;
+            }
+            on_static[0] = cAs[1] == 4;
+            on_static[1] = cBs[1] == 4;
+            rests[0] = on_static[0] || (on_static[1] && cAB[3] && cAB[1] >= 3);     /* A on B: the face pushes A up */
+            rests[1] = on_static[1] || (on_static[0] && cAB[3] && cAB[2] >= 3);     /* B on A: it pushes A down */
+            const int pair = cAB[0] > 0;
+            for (int b = 0; b < 2; ++b) {
+                const int ok = pair ? (slow[0] && slow[1] && rests[0] && rests[1]) : (slow[b] && on_static[b]);
+                if (!ok) continue;
+                for (int i = 7; i < 13; ++i) bodies[b][i] = 0.0f;
+                w->awake[b] = 0.0f;
+            }
+        }
+        /* 7. integration: joints (position limits: clamp and stop), awake cubes, the plate */
+        for (int i = 0; i < 9; ++i) {
+            float q1 = mad(h, w->qd[i], w->q[i]);
+            if (q1 < sc->qlo[i]) { q1 = sc->qlo[i]; w->qd[i] = 0.0f; }
+            if (q1 > sc->qhi[i]) { q1 = sc->qhi[i]; w->qd[i] = 0.0f; }
+            w->q[i] = q1;
+        }
+        for (int b = 0; b < 2; ++b) {
+            if (!(b == 0 ? (freeA && w->awake[0] != 0.0f) : (w->awake[1] != 0.0f))) continue;
+            for (int i = 0; i < 3; ++i) bodies[b][i] = mad(h, bodies[b][7 + i], bodies[b][i]);
+            integrate_quat(bodies[b] + 3, bodies[b] + 10, h);
+        }
+        for (int i = 0; i < 3; ++i) w->obs[i] = mad(h, w->obs[7 + i], w->obs[i]);
+        /* 8. kinematics of the new configuration; the grasp rule (spec v1.1, position level) */
         m3o_panda_links L;
         m3o_panda_fk(sc, w->q, &L);
         const float* ph = L.pos[8];
         const float *hx = L.ax[8], *hy = L.ay[8], *hz = L.az[8];
-        float ft[2] = {0, 0}, fs[2] = {0, 0}, fb[2] = {0, 0};
-        float cubeB_box[6] = {w->cubeB[0], w->cubeB[1], w->cubeB[2], sc->cube_half, sc->cube_half, sc->cube_half};
-
-        /* 3. cubeA */
-        if (w->held != 0.0f && (u[7] >= 0.0f || u[8] >= 0.0f)) { /* release */
-            w->held = 0.0f;
-            for (int i = 7; i < 13; ++i) w->cubeA[i] = 0.0f;
-        }
         if (w->held != 0.0f) {
             for (int i = 0; i < 3; ++i)
                 w->cubeA[i] = ph[i] + ((w->rel_p[0] * hx[i] + w->rel_p[1] * hy[i]) + w->rel_p[2] * hz[i]);
@@ -240,39 +790,6 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
             mat2quat(&c, &w->cubeA[3]);
             for (int i = 7; i < 13; ++i) w->cubeA[i] = 0.0f;
         } else {
-            /* free body: gravity, support planes, Coulomb friction on the support */
-            w->cubeA[9] = mad(-sc->g, h, w->cubeA[9]);
-            for (int i = 0; i < 3; ++i) w->cubeA[i] = mad(h, w->cubeA[7 + i], w->cubeA[i]);
-            const float x = w->cubeA[0], y = w->cubeA[1];
-            float sup = -1.0e30f;
-            int which = 0; /* 1 table, 2 shelf, 3 cubeB */
-            if (fabsf(x - sc->table[0]) <= sc->table[3] && fabsf(y - sc->table[1]) <= sc->table[4]) {
-                sup = sc->table[2] + sc->table[5]; which = 1;
-            }
-            if (fabsf(x - sc->shelf[0]) <= sc->shelf[3] && fabsf(y - sc->shelf[1]) <= sc->shelf[4]) {
-                float t = sc->shelf[2] + sc->shelf[5];
-                if (t > sup) { sup = t; which = 2; }
-            }
-            if (fabsf(x - w->cubeB[0]) <= sc->cube_half && fabsf(y - w->cubeB[1]) <= sc->cube_half) {
-                float t = w->cubeB[2] + sc->cube_half;
-                if (t > sup) { sup = t; which = 3; }
-            }
-            if (which != 0 && w->cubeA[2] - sc->cube_half < sup) {
-                w->cubeA[2] = sup + sc->cube_half;
-                if (w->cubeA[9] < 0.0f) w->cubeA[9] = 0.0f;
-                float vx = w->cubeA[7], vy = w->cubeA[8];
-                float sp = sqrtf(vx * vx + vy * vy);
-                if (sp > 0.0f) {
-                    float dec = (sc->cube_mu * sc->g) * h;
-                    float nvx, nvy;
-                    if (sp <= dec) { nvx = 0.0f; nvy = 0.0f; }
-                    else { float sc_ = 1.0f - dec / sp; nvx = vx * sc_; nvy = vy * sc_; }
-                    float fx = sc->cube_m * (vx - nvx) / h, fy = sc->cube_m * (vy - nvy) / h;
-                    float* dst = (which == 1) ? ft : (which == 2) ? fs : fb;
-                    dst[0] = dst[0] + fx; dst[1] = dst[1] + fy;
-                    w->cubeA[7] = nvx; w->cubeA[8] = nvy;
-                }
-            }
             /* grasp test */
             float d[3] = {w->cubeA[0] - ph[0], w->cubeA[1] - ph[1], w->cubeA[2] - ph[2]};
             float cx = dot3(d, hx), cy = dot3(d, hy), cz = dot3(d, hz);
@@ -328,32 +845,13 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
                 }
             }
         }
-        /* 4. penalty contact forces on table / shelf_stand / cubeB (robot spheres + held cube) */
-        {
-            float tipl[3], tipr[3], hc[3];
-            for (int i = 0; i < 3; ++i) {
-                tipl[i] = mad(sc->tip_z, hz[i], L.pos[9][i]);
-                tipr[i] = mad(sc->tip_z, hz[i], L.pos[10][i]);
-                hc[i] = mad(sc->hand_z, hz[i], ph[i]);
-            }
-            const float* boxes[3] = {sc->table, sc->shelf, cubeB_box};
-            float* fo[3] = {ft, fs, fb};
-            for (int b = 0; b < 3; ++b) {
-                sphere_box_force(sc, tipl, sc->tip_r, boxes[b], fo[b]);
-                sphere_box_force(sc, tipr, sc->tip_r, boxes[b], fo[b]);
-                sphere_box_force(sc, hc, sc->hand_r, boxes[b], fo[b]);
-                if (w->held != 0.0f) sphere_box_force(sc, w->cubeA, sc->cube_half, boxes[b], fo[b]);
-            }
-        }
-        w->f_table[0] = ft[0]; w->f_table[1] = ft[1];
-        w->f_shelf[0] = fs[0]; w->f_shelf[1] = fs[1];
-        w->f_cubeB[0] = fb[0]; w->f_cubeB[1] = fb[1];
     }
 }
 
-/* The wrapper's tensors carry no "held" bit: when a world is loaded from them (rollout start,
- * set_*_state_tensor) it is inferred from geometry -- cube inside the grasp region, aligned
- * with the pads and the pads closed on it. */
+/* The wrapper's tensors carry neither a "held" bit nor the cubes' sleep state: when a world is loaded from them
+ * (rollout start, set_*_state_tensor) both are inferred from geometry -- held: cube inside the grasp region, aligned
+ * with the pads and the pads closed on it; asleep: all six velocities exactly zero and the whole facing face within
+ * the contact offset of the top of the table / the shelf_stand. */
 void m3o_panda_infer_held(const m3o_panda_scene* sc, m3o_panda_world* w) {
     m3o_panda_links L;
     m3o_panda_fk(sc, w->q, &L);
@@ -386,6 +884,19 @@ void m3o_panda_infer_held(const m3o_panda_scene* sc, m3o_panda_world* w) {
         }
         mat2quat(&r, w->rel_q);
     }
+    float* cubes[2] = {w->cubeA, w->cubeB};
+    for (int b = 0; b < 2; ++b) {
+        int still = 1;
+        for (int i = 7; i < 13; ++i) if (cubes[b][i] != 0.0f) still = 0;
+        w->awake[b] = still ? 0.0f : 1.0f;      /* (provisional: the candidates) */
+    }
+    const int stat[2] = {cube_on_static(sc, w->cubeA), cube_on_static(sc, w->cubeB)};
+    const int freeA = (w->held == 0.0f);
+    const int stackA = freeA && !stat[0] && stat[1] && w->awake[0] == 0.0f && w->awake[1] == 0.0f && cube_on_cube(sc, w->cubeA, w->cubeB);
+    const int stackB = freeA && !stat[1] && stat[0] && w->awake[0] == 0.0f && w->awake[1] == 0.0f && cube_on_cube(sc, w->cubeB, w->cubeA);
+    /* (cube_on_cube: cubeA's facing face against cubeB's / cubeB's against cubeA's -- the step itself forms only the first) */
+    if (!(stat[0] || stackA)) w->awake[0] = 1.0f;
+    if (!(stat[1] || stackB)) w->awake[1] = 1.0f;
 }
 
 /* ---- costs on observables (what the reference reads through the wrapper getters) ---- */
