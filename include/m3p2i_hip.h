@@ -326,13 +326,15 @@ int m3_set_world_point_raw(m3_handle* h, const float* w18);
 int m3_bind_sim_point(m3_handle* h, const float* dof_state_dev, const float* root_state_dev,
                       int n_actors, int box_actor, int dyn_obs_actor);
 
-/* panda_env counterparts.  w31 = q[9] qd[9] | cubeA pos3 quat4(xyzw) linvel3 | cubeB pos3;
+/* panda_env counterparts.  w57 = q[9] qd[9] | cubeA | cubeB | dyn-obs, each pos3 quat4(xyzw) linvel3 angvel3 (the
+ * rows of the wrapper's root-state tensor, isaacgym_wrapper.py:102-104; the plate's orientation and angular velocity
+ * are not used: it does not rotate in this world);
  * bind: dof_state f32 [*,18] (pos,vel interleaved), root_state f32 [*,n_actors,13].
- * Whether cubeA starts clamped between the finger pads is inferred from the geometry
- * (DESIGN.md "Panda chain spec v1"): the wrapper's tensors carry no such bit. */
-int m3_set_world_panda_raw(m3_handle* h, const float* w31);
+ * Whether cubeA starts clamped between the finger pads, and whether a cube sleeps on its support, is inferred from the
+ * geometry ("Panda world spec v2"): the wrapper's tensors carry no such bits. */
+int m3_set_world_panda_raw(m3_handle* h, const float* w57);
 int m3_bind_sim_panda(m3_handle* h, const float* dof_state_dev, const float* root_state_dev,
-                      int n_actors, int cubeA_actor, int cubeB_actor);
+                      int n_actors, int cubeA_actor, int cubeB_actor, int obs_actor);
 
 /* one MPPI iteration = rollout + update + finalize of an UNSHARDED handle.  action_host: optional
  * [T][nu] (or [u_per_command][nu] in simple mode) host buffer; if non-NULL the call synchronises.

@@ -99,7 +99,7 @@ SYMBOLS = [
     ("m3_set_world_point_raw", C.c_int, [_H, C.POINTER(C.c_float)]),
     ("m3_bind_sim_point", C.c_int, [_H, _FP, _FP, C.c_int, C.c_int, C.c_int]),
     ("m3_set_world_panda_raw", C.c_int, [_H, C.POINTER(C.c_float)]),
-    ("m3_bind_sim_panda", C.c_int, [_H, _FP, _FP, C.c_int, C.c_int, C.c_int]),
+    ("m3_bind_sim_panda", C.c_int, [_H, _FP, _FP, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("m3_command", C.c_int, [_H, _FP]),
     ("m3_rollout", C.c_int, [_H]),
     ("m3_update", C.c_int, [_H]),

@@ -71,12 +71,13 @@ static void build_panda_scene(const m3_config& c, PandaScene& s) { make_panda_sc
 
 static void default_panda_world(float* w, int cube_on_shelf) {
     const float q0[9] = {0, 0, 0, -2.0f, 0, 1.8675f, 0, 0.02f, 0.02f};  // panda.yaml:10
-    std::memset(w, 0, 31 * sizeof(float));
+    std::memset(w, 0, 57 * sizeof(float));      // q9 qd9 | cubeA13 | cubeB13 | dyn-obs13
     for (int i = 0; i < 9; ++i) w[i] = q0[i];
-    if (cube_on_shelf) { w[18] = 0.425f; w[19] = 0.0f; w[20] = 1.35f; }
+    if (cube_on_shelf) { w[18] = 0.425f; w[19] = 0.0f; w[20] = 1.35f; }     // 5_cubeA.yaml
     else { w[18] = 0.2f; w[19] = -0.2f; w[20] = 1.06f; }
     w[24] = 1.0f;
-    w[28] = 0.2f; w[29] = 0.2f; w[30] = 1.06f;
+    w[31] = 0.2f; w[32] = 0.2f; w[33] = 1.06f; w[37] = 1.0f;                // 6_cubeB.yaml
+    w[44] = 0.35f; w[45] = 0.0f; w[46] = 1.735f; w[50] = 1.0f;              // 4_obs.yaml
 }
 
 static void default_world(float* w) {
@@ -754,21 +755,25 @@ static void fill_panda_cost_params(const m3_handle* h, PandaCostParams& cp) {
     cp.tilt_cos_theta = 0.5f;  // cost_functions.py:13
 }
 
-// panda_env initial state, 31 floats: q[9] qd[9] | cubeA pos3 quat4(xyzw) linvel3 | cubeB pos3
-extern "C" int m3_set_world_panda_raw(m3_handle* h, const float* w31) {
+// panda_env initial state, 57 floats: q[9] qd[9] | cubeA | cubeB | dyn-obs, each pos3 quat4(xyzw) linvel3 angvel3
+extern "C" int m3_set_world_panda_raw(m3_handle* h, const float* w57) {
+    const float* w31 = w57;
     if (!h || !w31) return M3_ERR_BAD_ARG;
     if (h->cfg.env_type != M3_ENV_PANDA) return fail(h, M3_ERR_STATE, "m3_set_world_panda_raw: not a panda_env handle");
-    std::memcpy(h->pworld0, w31, 31 * sizeof(float));
+    std::memcpy(h->pworld0, w31, 57 * sizeof(float));
     h->bind_dof = nullptr;
     return M3_OK;
 }
 
-extern "C" int m3_bind_sim_panda(m3_handle* h, const float* dof, const float* root, int n_actors, int cubeA_actor, int cubeB_actor) {
+extern "C" int m3_bind_sim_panda(m3_handle* h, const float* dof, const float* root, int n_actors, int cubeA_actor, int cubeB_actor,
+                                 int obs_actor) {
     if (!h || !dof || !root) return M3_ERR_BAD_ARG;
     if (h->cfg.env_type != M3_ENV_PANDA) return fail(h, M3_ERR_STATE, "m3_bind_sim_panda: not a panda_env handle");
-    if (n_actors < 1 || cubeA_actor < 0 || cubeA_actor >= n_actors || cubeB_actor < 0 || cubeB_actor >= n_actors)
+    if (n_actors < 1 || cubeA_actor < 0 || cubeA_actor >= n_actors || cubeB_actor < 0 || cubeB_actor >= n_actors ||
+        obs_actor < 0 || obs_actor >= n_actors)
         return fail(h, M3_ERR_SHAPE, "m3_bind_sim_panda: actor index out of range");
     h->bind_dof = dof; h->bind_root = root; h->bind_nact = n_actors; h->bind_box = cubeA_actor; h->bind_dyn = cubeB_actor;
+    h->bind_obs = obs_actor;
     return M3_OK;
 }
 
@@ -830,7 +835,7 @@ extern "C" int m3_rollout(m3_handle* h) {
     } else {
         PandaArgs pa;
         std::memcpy(pa.world0, h->pworld0, sizeof(pa.world0));
-        pa.cubeA_actor = h->bind_box; pa.cubeB_actor = h->bind_dyn;
+        pa.cubeA_actor = h->bind_box; pa.cubeB_actor = h->bind_dyn; pa.obs_actor = h->bind_obs;
         fill_panda_cost_params(h, pa.cp);
         launch_rollout_panda(a, pa, h->pscene, h->stream);
     }
@@ -1401,6 +1406,7 @@ extern "C" int m3_sim_bind_views(m3_handle* h, float* dof, float* root, float* r
         v.box_actor = 4; v.dyn_actor = 5; v.robot_actor = 6;  // cubeA, cubeB, panda
         v.box_body = 4; v.dyn_body = 5; v.robot_body = 6;
         v.table_body = 0; v.shelf_body = 2;
+        v.obs_actor = 3; v.obs_body = 3;
     }
     h->views_bound = true;
     return M3_OK;

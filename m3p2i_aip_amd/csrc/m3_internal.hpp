@@ -232,6 +232,7 @@ struct SimViews {
     int box_body, dyn_body, robot_body;     // point: robot_body = link_y (last body);
                                             // panda: robot_body = panda_link0 (first of 11)
     int table_body, shelf_body;             // panda_env only
+    int obs_actor, obs_body;                // panda_env only: the dyn-obs plate
 };
 void launch_sim_pull(const SimViews& v, float* world /*[NW][Kl]*/, int Kl, hipStream_t s);
 void launch_sim_shift_pull(const SimViews& v, float* world, int Kl, int actor, float dx, float dy, float dz, hipStream_t s);
@@ -246,12 +247,12 @@ void launch_sim_suction(const SimViews& v, float* world, int Kl, float kp, float
                         const float* action, int apply, float* forces, int* flags, const int* gate, hipStream_t s);
 
 constexpr int NW = 28;  // floats per env in the step-mode SoA world (PointWorld fields)
-constexpr int NWP = 45; // same for the panda_env (PandaWorld fields)
+constexpr int NWP = 77; // same for the panda_env (PandaWorld fields, rollout_panda.hip)
 
 // panda_env
 struct PandaArgs {
-    float world0[31];  // q9 qd9 | cubeA pos3 quat4 vel3 | cubeB pos3
-    int cubeA_actor, cubeB_actor;
+    float world0[57];  // q9 qd9 | cubeA13 | cubeB13 | dyn-obs13 (pos3 quat4 vel3 angvel3)
+    int cubeA_actor, cubeB_actor, obs_actor;
     PandaCostParams cp;
 };
 void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s);
@@ -279,7 +280,7 @@ struct m3_handle {
     bool relabelled = false;       // the noise rows ARE in wavefront order (identity order from then on)
     m3::PointScene scene;
     m3::PandaScene pscene;
-    float pworld0[31];
+    float pworld0[57];
     hipStream_t stream = nullptr;
     std::string err;
     // objective
@@ -292,7 +293,7 @@ struct m3_handle {
     const float* world0_bound = nullptr;  // device, 18 floats (filled by world_from_sim)
     const float* bind_dof = nullptr;
     const float* bind_root = nullptr;
-    int bind_nact = 0, bind_box = 0, bind_dyn = 0;
+    int bind_nact = 0, bind_box = 0, bind_dyn = 0, bind_obs = 0;
     bool have_noise = false;
     bool cov_active = false;       // cfg.update_cov on a single-mode halton-spline planner (mppi.py:508-516)
     float* noise_mats = nullptr;   // device [2][nu][nu]: chol(noise_sigma) | noise_sigma^-1 (cfg.full_sigma)

@@ -22,13 +22,15 @@
 
 namespace m3 {
 
-// Kernel argument: only what depends on dt/substeps (per-dof servo constants, computed once on
-// the host in f32: a = hD/I, rden = 1/(1+a), dv = h*effort/I).  Everything the URDF / yaml
-// files fix is compile-time constant and folds into the (fully unrolled) per-dof code.
+// Kernel argument: only what depends on dt / substeps (per-dof servo and drive-row constants, the free bodies' inverse
+// inertias, computed once on the host in f32 in the oracle's order).  Everything the URDF / yaml files fix is a
+// compile-time constant and folds into the (fully unrolled) per-dof code.
 struct PandaScene {
-    float h;  // substep
-    int substeps;
-    float a[9], rden[9], dv[9];
+    float h, inv_h;  // substep
+    int substeps, iters;
+    float a[9], rden[9], dv[9];      // servo in closed form: a = hD/I, 1/(1+a), h*effort/I
+    float invI[9], pmax[9], hD;      // the drives as rows of the contact passes
+    float invm_cube, invI_cube, invm_obs, sleep_v2, sleep_w2;
     static constexpr float g = 9.8f;
     static constexpr float drive_damping = 600.0f;                       // isaacgym_wrapper.py:344
     static constexpr float base[3] = {-0.45f, 0.0f, 1.125f};             // panda.yaml:8
@@ -38,34 +40,54 @@ struct PandaScene {
     static constexpr float qhi[9] = {2.8973f, 1.7628f, 2.8973f, -0.0698f, 2.8973f, 3.7525f, 2.8973f, 0.04f, 0.04f};
     static constexpr float table[6] = {0.0f, 0.0f, 1.0f, 0.6f, 0.6f, 0.025f};    // 1_table.yaml
     static constexpr float shelf[6] = {0.5f, 0.0f, 1.175f, 0.1f, 0.1f, 0.15f};   // 3_shelf_stand.yaml
-    static constexpr float cube_half = 0.025f, cube_m = 0.125f, cube_mu = 1.0f;  // 5_cubeA.yaml
+    static constexpr float obs_half[3] = {0.1f, 0.1f, 0.01f};                    // 4_obs.yaml
+    static constexpr float cube_half = 0.025f, cube_m = 0.125f;                  // 5_cubeA.yaml, 6_cubeB.yaml
     static constexpr float grasp_z = 0.1034f, grasp_dx = 0.025f, grasp_dz = 0.025f;   // spec v1.1: pad centre on the cube's face
     static constexpr float finger_max = 0.04f;                                          // franka_panda.urdf:226-242
     static constexpr float grasp_align = 0.95f, grasp_tol = 0.002f;
-    static constexpr float k_contact = 5000.0f;
     static constexpr float tip_z = 0.045f, tip_r = 0.012f, hand_z = 0.03f, hand_r = 0.04f;
+    // spec v2: the contact solver (isaacgym_wrapper.py:26-31)
+    static constexpr float contact_offset = 0.01f, slop = 0.001f, baumgarte = 0.2f, max_bias = 2.0f, act_margin = 0.002f;
+    static constexpr float mu = 1.0f;                                                   // actor_utils.py:27
+    static constexpr float rest_gap = 0.002f, cube_rad = 0.0434f;
 };
 
-// the per-dof servo constants from dt / substeps (host side: m3_create, and the host build in tests/native/), in f32
-inline void make_panda_scene(PandaScene& s, float dt, int substeps) {
+// the run-time part of the scene (host side: m3_create, and the host build in tests/native/), in f32, in the oracle's order.
+// Joint inertias: the diagonal of the joint-space mass matrix at the initial pose, from the collision meshes at the
+// default density (tools/panda_inertia.py).
+inline void make_panda_scene(PandaScene& s, float dt, int substeps, int iters = 6) {
     const float h = dt / (float)substeps;
-    s.h = h; s.substeps = substeps;
-    const float inertia[9] = {1.0f, 1.0f, 0.5f, 0.5f, 0.1f, 0.1f, 0.05f, 0.1f, 0.1f};
+    s.h = h; s.inv_h = 1.0f / h; s.substeps = substeps; s.iters = iters;
+    const float inertia[9] = {1.32f, 2.12f, 1.30f, 0.918f, 0.0271f, 0.0366f, 0.0030f, 0.022f, 0.022f};
     const float effort[9] = {87, 87, 87, 87, 12, 12, 12, 20, 20};
+    s.hD = h * 600.0f;
     for (int i = 0; i < 9; ++i) {
-        s.a[i] = (h * 600.0f) / inertia[i];
+        s.a[i] = s.hD / inertia[i];
         s.rden[i] = 1.0f / (1.0f + s.a[i]);
-        s.dv[i] = (h * effort[i]) / inertia[i];
+        s.invI[i] = 1.0f / inertia[i];
+        s.pmax[i] = h * effort[i];
+        s.dv[i] = s.pmax[i] * s.invI[i];
     }
+    const float cube_half = 0.025f, cube_m = 0.125f;
+    s.invm_cube = 1.0f / cube_m;
+    s.invI_cube = 1.0f / ((cube_m * ((2.0f * cube_half) * (2.0f * cube_half))) / 6.0f);
+    s.invm_obs = 1.0f / 0.8f;
+    s.sleep_v2 = 0.02f * 0.02f; s.sleep_w2 = 0.4f * 0.4f;
 }
+
+struct Body {
+    float p[3], q[4], v[3], w[3];   // pos, quaternion xyzw, linear / angular velocity
+};
 
 struct PandaWorld {
     float q[9], qd[9];
-    float cube[3], cube_q[4], cube_v[3];  // cubeA (angular velocity is always 0 in spec v1)
-    float cubeB[3];
+    Body A, B;                       // cubeA, cubeB: free rigid cubes
+    float obs_p[3], obs_v[3];        // the dyn-obs plate: a free body that does not rotate (no gravity: 4_obs.yaml)
     float held;
     float rel_p[3], rel_q[4];
-    float f_table[2], f_shelf[2], f_cubeB[2];
+    float awake[2];                  // cubeA, cubeB
+    float f_table[3], f_shelf[3], f_cubeB[3];
+    float warm_t[4], warm_l[4];      // per collision sphere: 1 + target of the last substep's contact, its normal impulse
 };
 
 struct Frame {
@@ -160,10 +182,23 @@ __device__ __forceinline__ float dot3(const float* a, const float* b) {
     return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
 }
 
-// FK.  STORE: write every link pose (pos3 + quat4) to out[11][7] (step mode views).
-template <bool STORE>
+// FK.  STORE: write every link pose (pos3 + quat4) to out[11][7] (step mode views).  JAC: also the arm's Jacobian
+// columns at the hand origin (joint axis z_i: angular part; z_i x (p_hand - p_i): linear part) into `gj`.
+// gripper geometry of one configuration: hand frame, the arm's Jacobian columns at the hand origin, the spheres
+struct Gripper {
+    Frame hand;
+    float Jv[7][3], Jw[7][3];
+    float c[4][3];       // tip left, tip right, hand, held cube
+};
+__device__ __forceinline__ void fk_cross(const float* a, const float* b, float* c) {   // (cross3 of the contact code, same order)
+    c[0] = mad(a[1], b[2], -(a[2] * b[1]));
+    c[1] = mad(a[2], b[0], -(a[0] * b[2]));
+    c[2] = mad(a[0], b[1], -(a[1] * b[0]));
+}
+template <bool STORE, bool JAC = false>
 __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, Frame& hand,
-                                         float* pl, float* pr, float* out) {
+                                         float* pl, float* pr, float* out, Gripper* gj = nullptr) {
+    float jz[7][3], jp[7][3];
     Frame f;
     f.x[0] = 1; f.x[1] = 0; f.x[2] = 0; f.y[0] = 0; f.y[1] = 1; f.y[2] = 0;
     f.z[0] = 0; f.z[1] = 0; f.z[2] = 1;
@@ -178,16 +213,31 @@ __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, F
         ++li;
     };
     store(f);
+    auto rec = [&](int j) {
+        if constexpr (JAC) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { jz[j][i] = f.z[i]; jp[j][i] = f.p[i]; }
+        }
+    };
     float s, c;
-    trans(f, 0, 0, 0.333f); spec_sincos(q[0], s, c); rot_z(f, s, c); store(f);
-    rot_xm(f); spec_sincos(q[1], s, c); rot_z(f, s, c); store(f);
-    trans(f, 0, -0.316f, 0); rot_xp(f); spec_sincos(q[2], s, c); rot_z(f, s, c); store(f);
-    trans(f, 0.0825f, 0, 0); rot_xp(f); spec_sincos(q[3], s, c); rot_z(f, s, c); store(f);
-    trans(f, -0.0825f, 0.384f, 0); rot_xm(f); spec_sincos(q[4], s, c); rot_z(f, s, c); store(f);
-    rot_xp(f); spec_sincos(q[5], s, c); rot_z(f, s, c); store(f);
-    trans(f, 0.088f, 0, 0); rot_xp(f); spec_sincos(q[6], s, c); rot_z(f, s, c); store(f);
+    trans(f, 0, 0, 0.333f); spec_sincos(q[0], s, c); rot_z(f, s, c); store(f); rec(0);
+    rot_xm(f); spec_sincos(q[1], s, c); rot_z(f, s, c); store(f); rec(1);
+    trans(f, 0, -0.316f, 0); rot_xp(f); spec_sincos(q[2], s, c); rot_z(f, s, c); store(f); rec(2);
+    trans(f, 0.0825f, 0, 0); rot_xp(f); spec_sincos(q[3], s, c); rot_z(f, s, c); store(f); rec(3);
+    trans(f, -0.0825f, 0.384f, 0); rot_xm(f); spec_sincos(q[4], s, c); rot_z(f, s, c); store(f); rec(4);
+    rot_xp(f); spec_sincos(q[5], s, c); rot_z(f, s, c); store(f); rec(5);
+    trans(f, 0.088f, 0, 0); rot_xp(f); spec_sincos(q[6], s, c); rot_z(f, s, c); store(f); rec(6);
     trans(f, 0, 0, 0.107f); rot_z(f, -0.70710678118654752f, 0.70710678118654752f); store(f);
     hand = f;
+    if constexpr (JAC) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            float lever[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { gj->Jw[j][i] = jz[j][i]; lever[i] = f.p[i] - jp[j][i]; }
+            fk_cross(gj->Jw[j], lever, gj->Jv[j]);
+        }
+    }
     trans(f, 0, 0, 0.0584f);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { pl[i] = mad(q[7], f.y[i], f.p[i]); pr[i] = mad(-q[8], f.y[i], f.p[i]); }
@@ -198,28 +248,308 @@ __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, F
     }
 }
 
-__device__ __forceinline__ void sphere_box_force(const PandaScene& sc, const float* c, float r,
-                                                 const float* b, float* f) {
-    float d[3], n2 = 0.0f;
-    bool inside = true;
+// ======================================================================================================
+// spec v2: contact response.  Written with STATIC slots -- four gripper contacts (one per collision sphere) in
+// registers, three face-to-face manifolds (cubeA / its static box, cubeA / cubeB, cubeB / its static box) of four
+// contact points whose per-point data sit in a per-lane store (LDS in the kernels) -- where the oracle keeps dynamic
+// row lists; the arithmetic of every row is the oracle's, operation for operation.
+// ======================================================================================================
+__device__ __forceinline__ float spec_rsqrt_p(float a) {      // (as the planar spec: seed + three Newton steps)
+    float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(a) >> 1));
+    const float hlf = 0.5f * a;
+    y = y * mad(-hlf, y * y, 1.5f);
+    y = y * mad(-hlf, y * y, 1.5f);
+    y = y * mad(-hlf, y * y, 1.5f);
+    return y;
+}
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* c) {
+    c[0] = mad(a[1], b[2], -(a[2] * b[1]));
+    c[1] = mad(a[2], b[0], -(a[0] * b[2]));
+    c[2] = mad(a[0], b[1], -(a[1] * b[0]));
+}
+__device__ __forceinline__ float dotm(const float* a, const float* b) { return mad(a[0], b[0], mad(a[1], b[1], a[2] * b[2])); }
+
+__device__ __forceinline__ void body_rot(const float* q, float* R) {
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    R[0] = mad(-2.0f, yy + zz, 1.0f); R[1] = 2.0f * (xy - wz);          R[2] = 2.0f * (xz + wy);
+    R[3] = 2.0f * (xy + wz);          R[4] = mad(-2.0f, xx + zz, 1.0f); R[5] = 2.0f * (yz - wx);
+    R[6] = 2.0f * (xz - wy);          R[7] = 2.0f * (yz + wx);          R[8] = mad(-2.0f, xx + yy, 1.0f);
+}
+
+// a box: centre, half extents, rotation (ORIENTED: a cube; else axis-aligned: table, shelf_stand, the plate)
+template <bool ORIENTED>
+struct BoxT {
+    float p[3], e[3];
+    const float* R;
+    __device__ __forceinline__ void local(const float* c, float* l) const {
+        const float dl[3] = {c[0] - p[0], c[1] - p[1], c[2] - p[2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) l[i] = ORIENTED ? mad(dl[0], R[0 * 3 + i], mad(dl[1], R[1 * 3 + i], dl[2] * R[2 * 3 + i])) : dl[i];
+    }
+    __device__ __forceinline__ void world(const float* v, float* o) const {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[j] = ORIENTED ? mad(R[j * 3 + 0], v[0], mad(R[j * 3 + 1], v[1], R[j * 3 + 2] * v[2])) : v[j];
+    }
+    __device__ __forceinline__ void dir_local(const float* v, float* o) const {   // rotation only
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o[i] = ORIENTED ? mad(v[0], R[0 * 3 + i], mad(v[1], R[1 * 3 + i], v[2] * R[2 * 3 + i])) : v[i];
+    }
+};
+__device__ __forceinline__ BoxT<false> box_static(const float* b6) {
+    BoxT<false> o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o.p[i] = b6[i]; o.e[i] = b6[3 + i]; }
+    o.R = nullptr;
+    return o;
+}
+__device__ __forceinline__ BoxT<true> box_cube(const PandaScene& sc, const float* p, const float* R) {
+    BoxT<true> o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o.p[i] = p[i]; o.e[i] = sc.cube_half; }
+    o.R = R;
+    return o;
+}
+
+// sphere (centre c, radius r) against a box: the gap, the unit normal from the box to the sphere (world), the contact
+// point on the sphere's surface.  Centre inside (or on the surface): the face of least penetration, lowest axis first.
+template <bool ORIENTED>
+__device__ __forceinline__ float pt_box(const BoxT<ORIENTED>& b, const float* c, float r, float* n, float* x) {
+    float l[3], d[3], nl[3], gap;
+    b.local(c, l);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = l[i] - fminf(fmaxf(l[i], -b.e[i]), b.e[i]);
+    const float d2 = mad(d[0], d[0], mad(d[1], d[1], d[2] * d[2]));
+    if (d2 > 1.0e-12f) {
+        const float rs = spec_rsqrt_p(d2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) nl[i] = d[i] * rs;
+        gap = d2 * rs - r;
+    } else {
+        const float p0 = b.e[0] - fabsf(l[0]), p1 = b.e[1] - fabsf(l[1]), p2 = b.e[2] - fabsf(l[2]);
+        int f = 0;
+        float pen = p0;
+        if (p1 < pen) { pen = p1; f = 1; }
+        if (p2 < pen) { pen = p2; f = 2; }
+        const float lf = (f == 0) ? l[0] : (f == 1) ? l[1] : l[2];
+        const float sg = (lf >= 0.0f) ? 1.0f : -1.0f;
+        nl[0] = (f == 0) ? sg : 0.0f; nl[1] = (f == 1) ? sg : 0.0f; nl[2] = (f == 2) ? sg : 0.0f;
+        gap = -pen - r;
+    }
+    b.world(nl, n);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) x[j] = mad(-r, n[j], c[j]);
+    return gap;
+}
+
+// unit tangents: the coordinate axis least aligned with n, crossed with n and normalised; t2 = n x t1
+__device__ __forceinline__ void tangents(const float* n, float* t1, float* t2) {
+    const float ax = fabsf(n[0]), ay = fabsf(n[1]), az = fabsf(n[2]);
+    float c[3];
+    if (ax <= ay && ax <= az) { c[0] = 0.0f; c[1] = -n[2]; c[2] = n[1]; }
+    else if (ay <= az) { c[0] = n[2]; c[1] = 0.0f; c[2] = -n[0]; }
+    else { c[0] = -n[1]; c[1] = n[0]; c[2] = 0.0f; }
+    const float rs = spec_rsqrt_p(mad(c[0], c[0], mad(c[1], c[1], c[2] * c[2])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t1[i] = c[i] * rs;
+    cross3(n, t1, t2);
+}
+
+enum { T_TABLE = 0, T_SHELF = 1, T_CUBEA = 2, T_CUBEB = 3, T_OBS = 4 };
+
+// a gripper contact (one per collision sphere): the rows are re-formed from these whenever they are needed
+struct RSlot {
+    bool on;
+    int target;          // T_*
+    float d[3][3];       // n, t1, t2
+    float rho[3];        // contact point - hand origin
+    float rt[3];         // contact point - target body's centre
+    float meff[3], bias, lam[3];
+};
+
+// the joint-space row of direction d at the point ph + rho of the gripper (sphere s: the finger columns)
+__device__ __forceinline__ void robot_row(const Gripper& g, int s, bool held, const float* rho, const float* d, float* J) {
+    float m[3];
+    cross3(rho, d, m);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) J[j] = dotm(d, g.Jv[j]) + dotm(m, g.Jw[j]);
+    const float dy = dotm(d, g.hand.y);
+    J[7] = (s == 0 && !held) ? dy : 0.0f;
+    J[8] = (s == 1 && !held) ? -dy : 0.0f;
+}
+
+// the free bodies as the rows see them
+struct BodyVel { float v[3], w[3]; };
+__device__ __forceinline__ void body_get(const PandaWorld& W, int b, BodyVel& o) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float l = c[i] - b[i];
-        const float cl = fminf(fmaxf(l, -b[3 + i]), b[3 + i]);
-        d[i] = l - cl;
-        if (d[i] != 0.0f) inside = false;
-        n2 = mad(d[i], d[i], n2);
+        o.v[i] = (b == 0) ? W.A.v[i] : (b == 1) ? W.B.v[i] : W.obs_v[i];
+        o.w[i] = (b == 0) ? W.A.w[i] : (b == 1) ? W.B.w[i] : 0.0f;
     }
-    // out of range without the correctly rounded sqrtf (~190 cycles for a lone wavefront):
-    // n2 > (r + 1e-4)^2 implies sqrt(n2) > r, i.e. pen < 0 below
-    const float lim = r + 1.0e-4f;
-    if (inside || n2 > lim * lim) return;
-    const float dist = sqrtf(n2);
-    const float pen = r - dist;
-    if (!(pen > 0.0f)) return;
-    const float k = sc.k_contact * pen / dist;
-    f[0] = mad(-k, d[0], f[0]);
-    f[1] = mad(-k, d[1], f[1]);
+}
+__device__ __forceinline__ void body_put(PandaWorld& W, int b, const BodyVel& o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (b == 0) { W.A.v[i] = o.v[i]; W.A.w[i] = o.w[i]; }
+        else if (b == 1) { W.B.v[i] = o.v[i]; W.B.w[i] = o.w[i]; }
+        else W.obs_v[i] = o.v[i];
+    }
+}
+__device__ __forceinline__ float body_k(const PandaScene& sc, int b, const float* a) {
+    return (b < 2) ? mad(sc.invI_cube, dotm(a, a), sc.invm_cube) : sc.invm_obs;
+}
+__device__ __forceinline__ float bodyvel_along(int b, const BodyVel& o, const float* d, const float* a) {
+    const float lin = dotm(d, o.v);
+    return (b < 2) ? lin + dotm(a, o.w) : lin;
+}
+__device__ __forceinline__ void bodyvel_apply(const PandaScene& sc, int b, BodyVel& o, const float* d, const float* a, float dl) {
+    const float im = ((b < 2) ? sc.invm_cube : sc.invm_obs) * dl;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.v[i] = mad(im, d[i], o.v[i]);
+    if (b < 2) {
+        const float ia = sc.invI_cube * dl;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.w[i] = mad(ia, a[i], o.w[i]);
+    }
+}
+__device__ __forceinline__ float contact_bias(const PandaScene& sc, float gap) {
+    if (gap > 0.0f) return gap * sc.inv_h;
+    const float pen = fmaxf(-gap - sc.slop, 0.0f);
+    const float push = fminf((sc.baumgarte * pen) * sc.inv_h, sc.max_bias);
+    return -push;
+}
+
+// ---- face-to-face manifold of a cube against a box (the oracle's cube_manifold) ----------------------------------
+// per-lane store of the manifolds' contact points: slot = manifold * 4 + corner, 10 floats each
+// (x3 | meff3 | bias | lam3); in the kernels it is LDS (stride 64 floats between a lane's consecutive values)
+struct CornerStore {
+    float* base;
+    int stride;
+    __device__ __forceinline__ float& at(int slot, int field) const { return base[(slot * 10 + field) * stride]; }
+};
+struct Manifold {
+    bool any;            // the cube is near the box
+    float n[3], t1[3], t2[3];
+    unsigned on;         // bit j: contact point j is a row
+    int made, up, down;  // contacts made; of them carrying the cube (n_z >= 0.99, gap < rest_gap) / carried by it
+    bool centre_over;
+};
+template <bool ORIENTED>
+__device__ __forceinline__ void manifold_detect(const PandaScene& sc, const float* pb, const float* Rb, const BoxT<ORIENTED>& tgt,
+                                                Manifold& m, float (*X)[3], float* gap) {
+    m.any = false; m.on = 0u; m.made = 0; m.up = 0; m.down = 0; m.centre_over = false;
+    float l[3], dd[3], dw[3], dlc[3];
+    tgt.local(pb, l);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dd[i] = fminf(fmaxf(l[i], -tgt.e[i]), tgt.e[i]) - l[i];
+    const float d2 = mad(dd[0], dd[0], mad(dd[1], dd[1], dd[2] * dd[2]));
+    const float lim = sc.cube_rad + sc.contact_offset;
+    if (!(d2 > 1.0e-12f) || d2 > lim * lim) return;
+    m.any = true;
+    int pref = 0;
+    if (fabsf(dd[1]) > fabsf(dd[0])) pref = 1;
+    if (fabsf(dd[2]) > fabsf((pref == 0) ? dd[0] : dd[1])) pref = 2;
+    auto sel = [](const float* v, int i) { return (i == 0) ? v[0] : (i == 1) ? v[1] : v[2]; };
+    const int a1 = (pref == 2) ? 0 : pref + 1, a2 = (pref == 0) ? 2 : pref - 1;     // (pref + 1) % 3, (pref + 2) % 3
+    const float side = (sel(dd, pref) <= 0.0f) ? 1.0f : -1.0f;
+    m.centre_over = (sel(dd, a1) == 0.0f && sel(dd, a2) == 0.0f);
+    tgt.world(dd, dw);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dlc[i] = mad(dw[0], Rb[0 * 3 + i], mad(dw[1], Rb[1 * 3 + i], dw[2] * Rb[2 * 3 + i]));
+    int f = 0;
+    if (fabsf(dlc[1]) > fabsf(dlc[0])) f = 1;
+    if (fabsf(dlc[2]) > fabsf((f == 0) ? dlc[0] : dlc[1])) f = 2;
+    const float e = sc.cube_half;
+    const float sgn = (sel(dlc, f) >= 0.0f) ? 1.0f : -1.0f;
+    float nmw[3], nml[3], nl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nmw[k] = sgn * ((f == 0) ? Rb[k * 3 + 0] : (f == 1) ? Rb[k * 3 + 1] : Rb[k * 3 + 2]);
+    tgt.dir_local(nmw, nml);
+    const float mz = side * sel(nml, pref);
+    const bool clip = (mz <= -0.7f);
+    const float rz = clip ? 1.0f / mz : 0.0f;
+    nl[0] = (pref == 0) ? side : 0.0f; nl[1] = (pref == 1) ? side : 0.0f; nl[2] = (pref == 2) ? side : 0.0f;
+    tgt.world(nl, m.n);
+    tangents(m.n, m.t1, m.t2);
+    const float e_p = sel(tgt.e, pref), e_1 = sel(tgt.e, a1), e_2 = sel(tgt.e, a2);
+    const float m1 = sel(nml, a1), m2 = sel(nml, a2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float s1 = (j & 1) ? e : -e, s2 = (j & 2) ? e : -e, sf = sgn * e;
+        // cl[f] = sf, cl[(f + 1) % 3] = s1, cl[(f + 2) % 3] = s2
+        const float cl[3] = {(f == 0) ? sf : (f == 1) ? s2 : s1, (f == 0) ? s1 : (f == 1) ? sf : s2, (f == 0) ? s2 : (f == 1) ? s1 : sf};
+        float xw[3], lc[3], lq[3], qw[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xw[k] = pb[k] + mad(Rb[k * 3 + 0], cl[0], mad(Rb[k * 3 + 1], cl[1], Rb[k * 3 + 2] * cl[2]));
+        tgt.local(xw, lc);
+        const float lcp = sel(lc, pref), lc1 = sel(lc, a1), lc2 = sel(lc, a2);
+        const float hgt = side * lcp - e_p;
+        const float q1 = fminf(fmaxf(lc1, -e_1), e_1);
+        const float q2 = fminf(fmaxf(lc2, -e_2), e_2);
+        const float d1 = q1 - lc1, d2_ = q2 - lc2;
+        const bool moved = (d1 != 0.0f) || (d2_ != 0.0f);
+        float gp;
+        if (moved && !clip) gp = 1.0f;
+        else if (moved) gp = hgt - mad(m1, d1, m2 * d2_) * rz;
+        else gp = hgt;
+        gap[j] = gp;
+        const float fp = side * e_p;
+        // lq[a1] = q1, lq[a2] = q2, lq[pref] = fp
+        lq[0] = (pref == 0) ? fp : (a1 == 0) ? q1 : q2;
+        lq[1] = (pref == 1) ? fp : (a1 == 1) ? q1 : q2;
+        lq[2] = (pref == 2) ? fp : (a1 == 2) ? q1 : q2;
+        tgt.world(lq, qw);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X[j][k] = tgt.p[k] + qw[k];
+        if (gp < sc.contact_offset) {
+            m.on |= 1u << j;
+            ++m.made;
+            if (m.n[2] >= 0.99f && gp < sc.rest_gap) ++m.up;
+            if (m.n[2] <= -0.99f && gp < sc.rest_gap) ++m.down;
+        }
+    }
+}
+
+// the static box a cube makes contact with: the nearer to its centre (the table on a tie)
+__device__ __forceinline__ bool nearer_is_table(const PandaScene& sc, const float* pb) {
+    float d2[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float* b = s ? sc.shelf : sc.table;
+        float dd[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float l = pb[i] - b[i];
+            dd[i] = fminf(fmaxf(l, -b[3 + i]), b[3 + i]) - l;
+        }
+        d2[s] = mad(dd[0], dd[0], mad(dd[1], dd[1], dd[2] * dd[2]));
+    }
+    return d2[0] <= d2[1];
+}
+__device__ __forceinline__ bool cube_on_static(const PandaScene& sc, const Body& c) {
+    float R[9], X[4][3], gap[4];
+    body_rot(c.q, R);
+    Manifold m;
+    const BoxT<false> b = box_static(nearer_is_table(sc, c.p) ? sc.table : sc.shelf);
+    manifold_detect<false>(sc, c.p, R, b, m, X, gap);
+    if (!m.any) return false;
+    bool ok = m.n[2] >= 0.99f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ok = ok && (gap[j] < sc.rest_gap);
+    return ok;
+}
+__device__ __forceinline__ bool cube_on_cube(const PandaScene& sc, const Body& up, const Body& lo) {
+    float Ru[9], Rl[9], X[4][3], gap[4];
+    body_rot(up.q, Ru);
+    body_rot(lo.q, Rl);
+    Manifold m;
+    const BoxT<true> b = box_cube(sc, lo.p, Rl);
+    manifold_detect<true>(sc, up.p, Ru, b, m, X, gap);
+    if (!m.any || !m.centre_over || !(m.n[2] >= 0.99f)) return false;
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (gap[j] < sc.rest_gap) ++n;
+    return n >= 3;
 }
 
 // cube pose relative to the hand + alignment test shared by the grasp rule and infer_held
@@ -230,9 +560,9 @@ struct GraspGeom {
 };
 __device__ __forceinline__ void grasp_geom(const PandaScene& sc, const PandaWorld& w, const Frame& hand,
                                            GraspGeom& g) {
-    const float d[3] = {w.cube[0] - hand.p[0], w.cube[1] - hand.p[1], w.cube[2] - hand.p[2]};
+    const float d[3] = {w.A.p[0] - hand.p[0], w.A.p[1] - hand.p[1], w.A.p[2] - hand.p[2]};
     g.cx = dot3(d, hand.x); g.cy = dot3(d, hand.y); g.cz = dot3(d, hand.z);
-    quat2mat(w.cube_q, g.Rc);
+    quat2mat(w.A.q, g.Rc);
     float ay = 0.0f, az = 0.0f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -256,6 +586,8 @@ __device__ __forceinline__ void set_rel_rot(PandaWorld& w, const Frame& hand, co
     mat2quat(r, w.rel_q);
 }
 
+// A world is loaded from the wrapper's tensors, which carry neither a "held" bit nor the cubes' sleep state: both are
+// inferred from geometry (the oracle's m3o_panda_infer_held).
 __device__ __forceinline__ void panda_infer_held(const PandaScene& sc, PandaWorld& w, float* hand_p = nullptr) {
     Frame hand;
     float pl[3], pr[3];
@@ -271,6 +603,16 @@ __device__ __forceinline__ void panda_infer_held(const PandaScene& sc, PandaWorl
         w.rel_p[0] = g.cx; w.rel_p[1] = g.cy; w.rel_p[2] = g.cz;
         set_rel_rot(w, hand, g.Rc);
     }
+    auto still = [](const Body& b) {
+        return b.v[0] == 0.0f && b.v[1] == 0.0f && b.v[2] == 0.0f && b.w[0] == 0.0f && b.w[1] == 0.0f && b.w[2] == 0.0f;
+    };
+    const bool stA = still(w.A), stB = still(w.B);
+    const bool onA = cube_on_static(sc, w.A), onB = cube_on_static(sc, w.B);
+    const bool freeA = (w.held == 0.0f);
+    const bool stackA = freeA && !onA && onB && stA && stB && cube_on_cube(sc, w.A, w.B);
+    const bool stackB = freeA && !onB && onA && stA && stB && cube_on_cube(sc, w.B, w.A);
+    w.awake[0] = (stA && (onA || stackA)) ? 0.0f : 1.0f;
+    w.awake[1] = (stB && (onB || stackB)) ? 0.0f : 1.0f;
 }
 
 // what the costs read after a step
@@ -278,155 +620,470 @@ struct PandaObs {
     float left[3], left_q[4], right[3];
 };
 
-// FORCES: whether the penalty contact forces exist in the generated code at all.  The rollout kernel is
-// instantiated twice and the host launches the one the task needs (only the pick cost reads them):
-// merely carrying the 12 sphere-box tests in the kernel cost 7 % of the reach / place rollouts.
+__device__ __forceinline__ void integrate_quat(float* q, const float* w, float h) {
+    if (w[0] == 0.0f && w[1] == 0.0f && w[2] == 0.0f) return;
+    const float hh = 0.5f * h;
+    const float tx = mad(w[0], q[3], mad(w[1], q[2], -(w[2] * q[1])));
+    const float ty = mad(w[1], q[3], mad(w[2], q[0], -(w[0] * q[2])));
+    const float tz = mad(w[2], q[3], mad(w[0], q[1], -(w[1] * q[0])));
+    const float tw = -mad(w[0], q[0], mad(w[1], q[1], w[2] * q[2]));
+    const float n0 = mad(hh, tx, q[0]), n1 = mad(hh, ty, q[1]), n2 = mad(hh, tz, q[2]), n3 = mad(hh, tw, q[3]);
+    const float rs = spec_rsqrt_p(mad(n0, n0, mad(n1, n1, mad(n2, n2, n3 * n3))));
+    q[0] = n0 * rs; q[1] = n1 * rs; q[2] = n2 * rs; q[3] = n3 * rs;
+}
+
+// FORCES: whether the net contact forces on table / shelf_stand / cubeB are formed (a rollout: only the pick cost reads
+// them, get_motion_cost, cost_functions.py:116-125,158-169; step mode: always).
 //
-// LAZY_FK (rollout): the kinematics of a substep that is not a step's last feed only the grasp test of a FREE
-// cube (cube centre inside the pad channel of the hand frame).  A HELD cube does not need them: it is
-// re-attached to the hand in every substep, so its pose after the step is the last substep's; it cannot be
-// released later in the step (the command is constant over a step's substeps: a release happens in the first,
-// and leaves the cube where it was), its fingers are locked and nothing reads its pose in between.  And the
-// grasp test changes something only under a closing command (sweep / hold) or when the fingers have entered
-// the cube's width (push-back): a lane with neither -- the null-action sample after it has let go -- is idle.
-// The hand origin
-// cannot move farther than LEVER * sum_i |dq_i| (every joint is a revolute with at most LEVER =
-// 1.2 m between its axis and the hand origin: the arm's reach is 0.855 m + flange/hand 0.21 m), and
-// the test can only succeed within REGION = |(grasp_dx, finger_max, |grasp_z| + grasp_dz)| of the
-// hand origin.  So with the hand origin of the last evaluated kinematics (`hp`) and the joint travel
-// since (`trav`), a wave in which no lane holds a cube and every lane's cube is farther from hp than
-// REGION + trav + 1 mm skips the kinematics and the grasp test of that substep: nothing they could
-// have changed.  Identical results (the oracle evaluates them every substep); reach rollout -13 %; pick rollout
-// (every lane carrying its cube, the null sample dropping it) 131 -> see DESIGN.md section 6.
+// LAZY (rollout): kinematics are evaluated only where something can depend on them.  (a) The contact detection of a
+// substep needs the gripper's geometry only if a collision sphere can be within the contact offset of a box: all
+// four spheres lie within GRIP_R0 of the hand's origin, the hand's origin cannot have moved farther than `trav` =
+// LEVER * sum_i |dq_i| from where the last evaluated kinematics had it (`hp`); a wave in which no lane passes that test
+// for any box skips it.  (b) The kinematics AFTER the integration feed the grasp rule of a free cube, the pose of a held
+// one and, in a step's last substep, the finger poses the costs read: as in spec v1 (a held cube is re-attached in the
+// last substep only -- nothing reads its pose in between except the contact detection, which then uses the held
+// sphere at the pose of the last attachment: so a wave with a held cube in a lane that is NEAR a box re-attaches in
+// every substep).  Identical results: the oracle evaluates everything every substep.
 constexpr float PANDA_LEVER = 1.2f;
+constexpr float GRIP_R0 = 0.17f;
 struct HeldYes { static constexpr bool value = true; };
 struct HeldNo { static constexpr bool value = false; };
-template <bool FORCES = true, bool LAZY_FK = false>
-__device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, const float* u,
-                                           PandaObs& obs, float* hp = nullptr, float* trav = nullptr) {
+template <bool FORCES = true, bool LAZY = false>
+__device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, const float* u, PandaObs& obs,
+                                           const CornerStore& cs, float* hp = nullptr, float* trav = nullptr) {
     const float h = sc.h;
-    // One substep in two versions: `may_hold` false is chosen (rollouts) when no lane of the wavefront holds a cube --
-    // the reach task throughout: the held-cube blocks are not in that version at all, instead of five exec-mask regions
-    // that every lane skips (a TAKEN branch each: ~30 cycles for the lone wavefront).  Same operations otherwise.
-    auto substep = [&](int sub, auto may_hold) {
-        auto holds = [&]() { return decltype(may_hold)::value && w.held != 0.0f; };
-        // 1. velocity servo
-        float dq_sum = 0.0f;
+    for (int sub = 0; sub < sc.substeps; ++sub) {
+        const bool last = (sub == sc.substeps - 1);
+        // 0. release
+        if (w.held != 0.0f && (u[7] >= 0.0f || u[8] >= 0.0f)) {
+            w.held = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { w.A.v[i] = 0.0f; w.A.w[i] = 0.0f; }
+            w.awake[0] = 1.0f;
+        }
+        const bool held = (w.held != 0.0f);
+        // 1. the joint servos in closed form
+        float qd1[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            if (holds() && i >= 7) { w.qd[i] = 0.0f; continue; }
-            float qd1 = mad(sc.a[i], u[i], w.qd[i]) * sc.rden[i];
-            const float tau = sc.drive_damping * (u[i] - qd1);
-            if (tau > sc.effort[i]) qd1 = w.qd[i] + sc.dv[i];
-            if (tau < -sc.effort[i]) qd1 = w.qd[i] - sc.dv[i];
-            qd1 = fminf(fmaxf(qd1, -sc.vlim[i]), sc.vlim[i]);
-            float q1 = mad(h, qd1, w.q[i]);
-            const float q1c = __builtin_amdgcn_fmed3f(q1, sc.qlo[i], sc.qhi[i]);   // position limits:
-            qd1 = (q1c == q1) ? qd1 : 0.0f;                                          // clamp and stop
-            q1 = q1c;
-            if (LAZY_FK && i < 7) dq_sum += fabsf(q1 - w.q[i]);
-            w.q[i] = q1; w.qd[i] = qd1;
+            if (held && i >= 7) { qd1[i] = 0.0f; continue; }
+            float v = mad(sc.a[i], u[i], w.qd[i]) * sc.rden[i];
+            const float tau = sc.drive_damping * (u[i] - v);
+            if (tau > sc.effort[i]) v = w.qd[i] + sc.dv[i];
+            if (tau < -sc.effort[i]) v = w.qd[i] - sc.dv[i];
+            qd1[i] = fminf(fmaxf(v, -sc.vlim[i]), sc.vlim[i]);
         }
-        // 2. kinematics
-        Frame hand;
-        float pl[3], pr[3];
-        bool have_fk = true;
-        if constexpr (LAZY_FK) {
-            *trav = *trav + PANDA_LEVER * dq_sum;
-            if (sub != sc.substeps - 1) have_fk = false;   // a step's earlier substeps: only if a grasp test needs them
-        }
-        if (have_fk) {
-            panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
-            if constexpr (LAZY_FK) { hp[0] = hand.p[0]; hp[1] = hand.p[1]; hp[2] = hand.p[2]; *trav = 0.0f; }
-        }
-        float ft[2] = {0.f, 0.f}, fs[2] = {0.f, 0.f}, fb[2] = {0.f, 0.f};
-        const float cubeB_box[6] = {w.cubeB[0], w.cubeB[1], w.cubeB[2], sc.cube_half, sc.cube_half, sc.cube_half};
-
-        // 3. cubeA
-        if (holds() && (u[7] >= 0.0f || u[8] >= 0.0f)) {
-            w.held = 0.0f;
-            w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
-        }
-        if (holds()) {
-          // (LAZY_FK, a step's earlier substeps: a held cube is re-attached to the hand in EVERY substep, so its pose
-          // after the step is the last substep's; it cannot be released later in the step -- the command is constant
-          // over the substeps and a release happens in the first --, its fingers are locked and nothing reads its pose
-          // in between: nothing to do.  The oracle re-attaches it every substep; identical results.)
-          if (!LAZY_FK || sub == sc.substeps - 1) {
+        // 2. gripper contacts
+        RSlot rs[4];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                w.cube[i] = hand.p[i] + ((w.rel_p[0] * hand.x[i] + w.rel_p[1] * hand.y[i]) + w.rel_p[2] * hand.z[i]);
-            float Rr[9];
-            quat2mat(w.rel_q, Rr);
-            Frame c;
+        for (int s = 0; s < 4; ++s) rs[s].on = false;
+        bool robot_rows = false;
+        bool touched[3] = {false, false, false};
+        Gripper g;
+        float RA[9], RB[9];
+        bool near = true;
+        if constexpr (LAZY) {
+            const float reach = GRIP_R0 + *trav + sc.contact_offset;
+            auto box_d2 = [&](const float* b, const float* e) {
+                float d2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float l = hp[i] - b[i];
+                    const float d = l - fminf(fmaxf(l, -e[i]), e[i]);
+                    d2 = mad(d, d, d2);
+                }
+                return d2;
+            };
+            const float rc = reach + sc.cube_rad;
+            const float ce[3] = {0.0f, 0.0f, 0.0f};
+            const bool nr = box_d2(sc.table, sc.table + 3) < reach * reach || box_d2(sc.shelf, sc.shelf + 3) < reach * reach ||
+                            (!held && box_d2(w.A.p, ce) < rc * rc) || box_d2(w.B.p, ce) < rc * rc ||
+                            box_d2(w.obs_p, sc.obs_half) < reach * reach;
+            near = __builtin_amdgcn_ballot_w64(nr) != 0ull;
+        }
+        const bool bodies_awake_wave = __builtin_amdgcn_ballot_w64((!held && w.awake[0] != 0.0f) || w.awake[1] != 0.0f) != 0ull;
+        if (near || bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }
+        if (near) {
+            float pl[3], pr[3];
+            panda_fk<false, true>(sc, w.q, g.hand, pl, pr, nullptr, &g);
+            if constexpr (LAZY) { hp[0] = g.hand.p[0]; hp[1] = g.hand.p[1]; hp[2] = g.hand.p[2]; *trav = 0.0f; }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                c.x[i] = (hand.x[i] * Rr[0] + hand.y[i] * Rr[3]) + hand.z[i] * Rr[6];
-                c.y[i] = (hand.x[i] * Rr[1] + hand.y[i] * Rr[4]) + hand.z[i] * Rr[7];
-                c.z[i] = (hand.x[i] * Rr[2] + hand.y[i] * Rr[5]) + hand.z[i] * Rr[8];
+                g.c[0][i] = mad(sc.tip_z, g.hand.z[i], pl[i]);
+                g.c[1][i] = mad(sc.tip_z, g.hand.z[i], pr[i]);
+                g.c[2][i] = mad(sc.hand_z, g.hand.z[i], g.hand.p[i]);
+                g.c[3][i] = w.A.p[i];
             }
-            mat2quat(c, w.cube_q);
-            w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
-          }
-        } else {
-            w.cube_v[2] = mad(-sc.g, h, w.cube_v[2]);
+            // the pad channel (the grasp rule's region): there the pads, not the tip spheres, act on cubeA
+            bool in_channel = false;
+            if (!held) {
+                GraspGeom gg;
+                grasp_geom(sc, w, g.hand, gg);
+                in_channel = gg.in_region && gg.cy < w.q[7] && gg.cy > -w.q[8];
+            }
+            const BoxT<false> bt = box_static(sc.table), bs = box_static(sc.shelf);
+            const BoxT<true> bA = box_cube(sc, w.A.p, RA), bB = box_cube(sc, w.B.p, RB);
+            BoxT<false> bo;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) w.cube[i] = mad(h, w.cube_v[i], w.cube[i]);
-            const float x = w.cube[0], y = w.cube[1];
-            float sup = -1.0e30f;
-            int which = 0;
-            if (fabsf(x - sc.table[0]) <= sc.table[3] && fabsf(y - sc.table[1]) <= sc.table[4]) {
-                sup = sc.table[2] + sc.table[5]; which = 1;
-            }
-            if (fabsf(x - sc.shelf[0]) <= sc.shelf[3] && fabsf(y - sc.shelf[1]) <= sc.shelf[4]) {
-                const float t = sc.shelf[2] + sc.shelf[5];
-                if (t > sup) { sup = t; which = 2; }
-            }
-            if (fabsf(x - w.cubeB[0]) <= sc.cube_half && fabsf(y - w.cubeB[1]) <= sc.cube_half) {
-                const float t = w.cubeB[2] + sc.cube_half;
-                if (t > sup) { sup = t; which = 3; }
-            }
-            if (which != 0 && w.cube[2] - sc.cube_half < sup) {
-                w.cube[2] = sup + sc.cube_half;
-                w.cube_v[2] = fmaxf(w.cube_v[2], 0.0f);
-                const float vx = w.cube_v[0], vy = w.cube_v[1];
-                // a cube at rest on its support skips the sqrtf: vx = vy = +-0 gives sp = 0
-                const bool sliding = ((__float_as_uint(vx) | __float_as_uint(vy)) << 1) != 0u;
-                const float sp = sliding ? sqrtf(vx * vx + vy * vy) : 0.0f;
-                if (sp > 0.0f) {
-                    const float dec = (sc.cube_mu * sc.g) * h;
-                    float nvx, nvy;
-                    if (sp <= dec) { nvx = 0.0f; nvy = 0.0f; }
-                    else { const float sc_ = 1.0f - dec / sp; nvx = vx * sc_; nvy = vy * sc_; }
-                    const float fx = sc.cube_m * (vx - nvx) / h, fy = sc.cube_m * (vy - nvy) / h;
-                    if (which == 1) { ft[0] = ft[0] + fx; ft[1] = ft[1] + fy; }
-                    else if (which == 2) { fs[0] = fs[0] + fx; fs[1] = fs[1] + fy; }
-                    else { fb[0] = fb[0] + fx; fb[1] = fb[1] + fy; }
-                    w.cube_v[0] = nvx; w.cube_v[1] = nvy;
+            for (int i = 0; i < 3; ++i) { bo.p[i] = w.obs_p[i]; bo.e[i] = sc.obs_half[i]; }
+            bo.R = nullptr;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s == 3 && !held) continue;
+                const float r = (s < 2) ? sc.tip_r : (s == 2) ? sc.hand_r : sc.cube_half;
+                float best_gap = sc.contact_offset, bn[3] = {0.0f, 0.0f, 0.0f}, bx[3] = {0.0f, 0.0f, 0.0f};
+                int best = -1;
+                auto take = [&](float gap, const float* n, const float* x, int t) {
+                    if (gap < best_gap) { best_gap = gap; best = t; bn[0] = n[0]; bn[1] = n[1]; bn[2] = n[2]; bx[0] = x[0]; bx[1] = x[1]; bx[2] = x[2]; }
+                };
+                float n[3], x[3];
+                take(pt_box<false>(bt, g.c[s], r, n, x), n, x, T_TABLE);
+                take(pt_box<false>(bs, g.c[s], r, n, x), n, x, T_SHELF);
+                if (!(held || (s < 2 && in_channel))) take(pt_box<true>(bA, g.c[s], r, n, x), n, x, T_CUBEA);
+                take(pt_box<true>(bB, g.c[s], r, n, x), n, x, T_CUBEB);
+                take(pt_box<false>(bo, g.c[s], r, n, x), n, x, T_OBS);
+                if (best < 0) continue;
+                RSlot& c = rs[s];
+                c.target = best;
+                const int tb = best - T_CUBEA;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { c.d[0][i] = bn[i]; c.rho[i] = bx[i] - g.hand.p[i]; }
+                tangents(c.d[0], c.d[1], c.d[2]);
+                const float* tp = (tb == 0) ? w.A.p : (tb == 1) ? w.B.p : w.obs_p;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) c.rt[i] = (tb >= 0) ? bx[i] - tp[i] : 0.0f;
+                // culling: the gap predicted for the end of the substep from the servo's velocities
+                float J[9], ab[3];
+                robot_row(g, s, held, c.rho, c.d[0], J);
+                float vn0 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) vn0 = mad(J[j], qd1[j], vn0);
+                BodyVel bv;
+                if (tb >= 0) {
+                    body_get(w, tb, bv);
+                    cross3(c.rt, c.d[0], ab);
+                    vn0 = vn0 - bodyvel_along(tb, bv, c.d[0], ab);
                 }
+                if (!(mad(h, vn0, best_gap) < sc.act_margin)) continue;
+                // effective masses, bias
+#pragma unroll
+                for (int r3 = 0; r3 < 3; ++r3) {
+                    if (r3 > 0) robot_row(g, s, held, c.rho, c.d[r3], J);
+                    float k = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) k = mad(J[j] * sc.invI[j], J[j], k);
+                    if (tb >= 0) { cross3(c.rt, c.d[r3], ab); k = k + body_k(sc, tb, ab); }
+                    c.meff[r3] = 1.0f / k;
+                    c.lam[r3] = 0.0f;
+                }
+                c.bias = contact_bias(sc, best_gap);
+                if (w.warm_t[s] == (float)(best + 1)) c.lam[0] = w.warm_l[s];
+                c.on = true;
+                robot_rows = true;
+                if (tb >= 0) { touched[tb] = true; if (tb < 2) w.awake[tb] = 1.0f; }
             }
-            if constexpr (LAZY_FK) {
-                if (!have_fk) {   // (the lanes with a free cube)
-                    const float gz = fabsf(sc.grasp_z) + sc.grasp_dz;
-                    const float lim = sqrtf((sc.grasp_dx * sc.grasp_dx + sc.finger_max * sc.finger_max) + gz * gz) +
-                                      *trav + 1.0e-3f;
-                    const float dx = w.cube[0] - hp[0], dy = w.cube[1] - hp[1], dz = w.cube[2] - hp[2];
-                    // the grasp test below changes something only for a cube in the pad channel AND (fingers that
-                    // have entered the cube's width: pushed back -- or a closing command: swept / held)
-                    const bool idle = !(u[7] < 0.0f && u[8] < 0.0f) && !(w.q[7] + w.q[8] < 2.0f * sc.cube_half);
-                    const bool far = idle || (dx * dx + dy * dy) + dz * dz > lim * lim;
-                    if (__builtin_amdgcn_ballot_w64(!far) != 0ull) {
-                        panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
-                        hp[0] = hand.p[0]; hp[1] = hand.p[1]; hp[2] = hand.p[2]; *trav = 0.0f;
-                        have_fk = true;
+        }
+        // 3. an awake cube wakes the other one when they are close
+        const bool freeA = !held;
+        if (freeA && (w.awake[0] != 0.0f) != (w.awake[1] != 0.0f)) {
+            const float dx = w.A.p[0] - w.B.p[0], dy = w.A.p[1] - w.B.p[1], dz = w.A.p[2] - w.B.p[2];
+            const float lim = 2.0f * sc.cube_rad + sc.contact_offset;
+            if (mad(dx, dx, mad(dy, dy, dz * dz)) < lim * lim) { w.awake[0] = 1.0f; w.awake[1] = 1.0f; }
+        }
+        const bool actA = freeA && w.awake[0] != 0.0f, actB = w.awake[1] != 0.0f;
+        // 4. gravity, then the cubes' face-to-face contacts
+        if (actA) w.A.v[2] = mad(-sc.g, h, w.A.v[2]);
+        if (actB) w.B.v[2] = mad(-sc.g, h, w.B.v[2]);
+        Manifold mA, mAB, mB;
+        mA.any = mAB.any = mB.any = false; mA.on = mAB.on = mB.on = 0u;
+        mA.made = mAB.made = mB.made = 0; mA.up = mAB.up = mB.up = 0; mA.down = mAB.down = mB.down = 0;
+        mA.centre_over = mAB.centre_over = mB.centre_over = false;
+        bool tA = true, tB = true;      // the cube's static box is the table
+        const bool any_act = __builtin_amdgcn_ballot_w64(actA || actB) != 0ull;
+        if (any_act) {
+            if (near == false && !bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }   // (woken just now: cannot happen without `near`)
+            auto prepare = [&](int m_id, const Manifold& m, const float (*X)[3], const float* gap, int ma, const float* pm,
+                               int tb, const float* pt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!((m.on >> j) & 1u)) continue;
+                    const int slot = m_id * 4 + j;
+                    float r[3], rt[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { r[i] = X[j][i] - pm[i]; rt[i] = (tb >= 0) ? X[j][i] - pt[i] : 0.0f; cs.at(slot, i) = X[j][i]; }
+#pragma unroll
+                    for (int r3 = 0; r3 < 3; ++r3) {
+                        const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
+                        float aa[3], ab[3];
+                        cross3(r, d, aa);
+                        float k = body_k(sc, ma, aa);
+                        if (tb >= 0) { cross3(rt, d, ab); k = k + body_k(sc, tb, ab); }
+                        cs.at(slot, 3 + r3) = 1.0f / k;
+                        cs.at(slot, 7 + r3) = 0.0f;
+                    }
+                    cs.at(slot, 6) = contact_bias(sc, gap[j]);
+                }
+            };
+            float X[4][3], gap[4];
+            if (actA) {
+                tA = nearer_is_table(sc, w.A.p);
+                manifold_detect<false>(sc, w.A.p, RA, box_static(tA ? sc.table : sc.shelf), mA, X, gap);
+                prepare(0, mA, X, gap, 0, w.A.p, -1, nullptr);
+            }
+            if (actA && actB) {
+                manifold_detect<true>(sc, w.A.p, RA, box_cube(sc, w.B.p, RB), mAB, X, gap);
+                prepare(1, mAB, X, gap, 0, w.A.p, 1, w.B.p);
+            }
+            if (actB) {
+                tB = nearer_is_table(sc, w.B.p);
+                manifold_detect<false>(sc, w.B.p, RB, box_static(tB ? sc.table : sc.shelf), mB, X, gap);
+                prepare(2, mB, X, gap, 1, w.B.p, -1, nullptr);
+            }
+        }
+        const bool body_rows = (mA.on | mAB.on | mB.on) != 0u;
+        // 5. velocity passes
+        float qds[9], pdrv[9];
+        if (robot_rows) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { qds[i] = (held && i >= 7) ? 0.0f : w.qd[i]; pdrv[i] = 0.0f; }
+        }
+        auto robot_solve = [&](int s, RSlot& c, bool only_warm) {
+            const int tb = c.target - T_CUBEA;
+            BodyVel bv;
+            if (tb >= 0) body_get(w, tb, bv);
+            if (only_warm) {        // the warm-start impulse acts before the first pass
+                const float dl = c.lam[0];
+                if (dl != 0.0f) {
+                    float J[9], ab[3];
+                    robot_row(g, s, held, c.rho, c.d[0], J);
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) qds[j] = mad(J[j] * sc.invI[j], dl, qds[j]);
+                    if (tb >= 0) { cross3(c.rt, c.d[0], ab); bodyvel_apply(sc, tb, bv, c.d[0], ab, -dl); body_put(w, tb, bv); }
+                }
+                return;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const int r3 = (rr + 1) % 3;      // friction rows first, the normal row last
+                float J[9], ab[3];
+                robot_row(g, s, held, c.rho, c.d[r3], J);
+                float v = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) v = mad(J[j], qds[j], v);
+                if (tb >= 0) { cross3(c.rt, c.d[r3], ab); v = v - bodyvel_along(tb, bv, c.d[r3], ab); }
+                float dl = -c.meff[r3] * (v + ((r3 == 0) ? c.bias : 0.0f));
+                const float l0 = c.lam[r3];
+                float l1 = l0 + dl;
+                if (r3 == 0) l1 = fmaxf(l1, 0.0f);
+                else { const float mx = sc.mu * c.lam[0]; l1 = fminf(fmaxf(l1, -mx), mx); }
+                c.lam[r3] = l1;
+                dl = l1 - l0;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) qds[j] = mad(J[j] * sc.invI[j], dl, qds[j]);
+                if (tb >= 0) bodyvel_apply(sc, tb, bv, c.d[r3], ab, -dl);
+            }
+            if (tb >= 0) body_put(w, tb, bv);
+        };
+        auto manifold_solve = [&](int m_id, const Manifold& m, Body& M, const float* pm, Body* T, const float* pt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!((m.on >> j) & 1u)) continue;
+                const int slot = m_id * 4 + j;
+                float r[3], rt[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const float x = cs.at(slot, i); r[i] = x - pm[i]; rt[i] = T ? x - pt[i] : 0.0f; }
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    const int r3 = (rr + 1) % 3;
+                    const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
+                    float aa[3], ab[3];
+                    cross3(r, d, aa);
+                    float v = dotm(d, M.v) + dotm(aa, M.w);
+                    if (T) { cross3(rt, d, ab); v = v - (dotm(d, T->v) + dotm(ab, T->w)); }
+                    float dl = -cs.at(slot, 3 + r3) * (v + ((r3 == 0) ? cs.at(slot, 6) : 0.0f));
+                    const float l0 = cs.at(slot, 7 + r3);
+                    float l1 = l0 + dl;
+                    if (r3 == 0) l1 = fmaxf(l1, 0.0f);
+                    else { const float mx = sc.mu * cs.at(slot, 7); l1 = fminf(fmaxf(l1, -mx), mx); }
+                    cs.at(slot, 7 + r3) = l1;
+                    dl = l1 - l0;
+                    const float im = sc.invm_cube * dl, ia = sc.invI_cube * dl;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { M.v[i] = mad(im, d[i], M.v[i]); M.w[i] = mad(ia, aa[i], M.w[i]); }
+                    if (T) {
+                        const float jm = sc.invm_cube * -dl, ja = sc.invI_cube * -dl;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) { T->v[i] = mad(jm, d[i], T->v[i]); T->w[i] = mad(ja, ab[i], T->w[i]); }
                     }
                 }
             }
-            GraspGeom g;
-            g.in_region = false;
-            if (have_fk) grasp_geom(sc, w, hand, g);
+        };
+        const bool any_rows = __builtin_amdgcn_ballot_w64(robot_rows || body_rows) != 0ull;
+        if (any_rows) {
+            if (robot_rows) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) if (rs[s].on) robot_solve(s, rs[s], true);
+            }
+            for (int pass = 0; pass <= sc.iters; ++pass) {      // the last sweep: the contacts alone (isaacgym_wrapper.py:29)
+                if (robot_rows && pass < sc.iters) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {
+                        if (held && i >= 7) continue;
+                        const float e = mad(sc.hD, u[i] - qds[i], -pdrv[i]);
+                        float dp = e * sc.rden[i];
+                        const float p1 = fminf(fmaxf(pdrv[i] + dp, -sc.pmax[i]), sc.pmax[i]);
+                        dp = p1 - pdrv[i];
+                        pdrv[i] = p1;
+                        qds[i] = mad(sc.invI[i], dp, qds[i]);
+                    }
+                }
+                if (robot_rows) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) if (rs[s].on) robot_solve(s, rs[s], false);
+                }
+                if (mA.on) manifold_solve(0, mA, w.A, w.A.p, nullptr, nullptr);
+                if (mAB.on) manifold_solve(1, mAB, w.A, w.A.p, &w.B, w.B.p);
+                if (mB.on) manifold_solve(2, mB, w.B, w.B.p, nullptr, nullptr);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            float v = robot_rows ? fminf(fmaxf(qds[i], -sc.vlim[i]), sc.vlim[i]) : qd1[i];
+            if (held && i >= 7) v = 0.0f;
+            w.qd[i] = v;
+        }
+        // net contact forces on table / shelf_stand / cubeB: this substep's impulses / h (a step reports its last)
+        if (FORCES && last) {
+            float ft[3] = {0.f, 0.f, 0.f}, fs[3] = {0.f, 0.f, 0.f}, fb[3] = {0.f, 0.f, 0.f};
+            auto add = [&](float* dst, float lam, const float* d, bool neg) {
+                const float sI = lam * sc.inv_h;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dst[i] = mad(neg ? -sI : sI, d[i], dst[i]);
+            };
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (!rs[s].on) continue;
+                float* dst = (rs[s].target == T_TABLE) ? ft : (rs[s].target == T_SHELF) ? fs : (rs[s].target == T_CUBEB) ? fb : nullptr;
+                if (dst) for (int r3 = 0; r3 < 3; ++r3) add(dst, rs[s].lam[r3], rs[s].d[r3], true);
+            }
+            auto add_m = [&](int m_id, const Manifold& m, float* dst, bool mover_is_B) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!((m.on >> j) & 1u)) continue;
+#pragma unroll
+                    for (int r3 = 0; r3 < 3; ++r3) {
+                        const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
+                        const float lam = cs.at(m_id * 4 + j, 7 + r3);
+                        if (dst) add(dst, lam, d, true);
+                        if (mover_is_B) add(fb, lam, d, false);
+                    }
+                }
+            };
+            add_m(0, mA, tA ? ft : fs, false);
+            add_m(1, mAB, fb, false);
+            add_m(2, mB, tB ? ft : fs, true);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { w.f_table[i] = ft[i]; w.f_shelf[i] = fs[i]; w.f_cubeB[i] = fb[i]; }
+        } else if (last) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { w.f_table[i] = 0.0f; w.f_shelf[i] = 0.0f; w.f_cubeB[i] = 0.0f; }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            w.warm_t[s] = rs[s].on ? (float)(rs[s].target + 1) : 0.0f;
+            w.warm_l[s] = rs[s].on ? rs[s].lam[0] : 0.0f;
+        }
+        // 6. sleep
+        if (any_act) {
+            auto slow = [&](const Body& b) { return dotm(b.v, b.v) < sc.sleep_v2 && dotm(b.w, b.w) < sc.sleep_w2; };
+            const bool slA = actA && !touched[0] && slow(w.A), slB = actB && !touched[1] && slow(w.B);
+            const bool onA = mA.up == 4, onB = mB.up == 4;
+            const bool restA = onA || (onB && mAB.centre_over && mAB.up >= 3);
+            const bool restB = onB || (onA && mAB.centre_over && mAB.down >= 3);
+            const bool pair = mAB.made > 0;
+            const bool okA = pair ? (slA && slB && restA && restB) : (slA && onA);
+            const bool okB = pair ? (slA && slB && restA && restB) : (slB && onB);
+            if (okA) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { w.A.v[i] = 0.0f; w.A.w[i] = 0.0f; }
+                w.awake[0] = 0.0f;
+            }
+            if (okB) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { w.B.v[i] = 0.0f; w.B.w[i] = 0.0f; }
+                w.awake[1] = 0.0f;
+            }
+        }
+        // 7. integration
+        float dq_sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            float q1 = mad(h, w.qd[i], w.q[i]);
+            const float q1c = __builtin_amdgcn_fmed3f(q1, sc.qlo[i], sc.qhi[i]);   // position limits: clamp and stop
+            if (q1c != q1) w.qd[i] = 0.0f;
+            q1 = q1c;
+            if (LAZY && i < 7) dq_sum += fabsf(q1 - w.q[i]);
+            w.q[i] = q1;
+        }
+        if (freeA && w.awake[0] != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w.A.p[i] = mad(h, w.A.v[i], w.A.p[i]);
+            integrate_quat(w.A.q, w.A.w, h);
+        }
+        if (w.awake[1] != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w.B.p[i] = mad(h, w.B.v[i], w.B.p[i]);
+            integrate_quat(w.B.q, w.B.w, h);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w.obs_p[i] = mad(h, w.obs_v[i], w.obs_p[i]);
+        // 8. kinematics of the new configuration; the grasp rule (spec v1.1, position level)
+        Frame hand;
+        float pl[3], pr[3];
+        bool have_fk = true;
+        if constexpr (LAZY) {
+            *trav = *trav + PANDA_LEVER * dq_sum;
+            if (!last) {
+                // needed by: a held cube in a wave that is near a box (its sphere's pose), a free cube's grasp test
+                bool need = false;
+                if (w.held != 0.0f) need = near;
+                else {
+                    const float gz = fabsf(sc.grasp_z) + sc.grasp_dz;
+                    const float lim = sqrtf((sc.grasp_dx * sc.grasp_dx + sc.finger_max * sc.finger_max) + gz * gz) + *trav + 1.0e-3f;
+                    const float dx = w.A.p[0] - hp[0], dy = w.A.p[1] - hp[1], dz = w.A.p[2] - hp[2];
+                    const bool idle = !(u[7] < 0.0f && u[8] < 0.0f) && !(w.q[7] + w.q[8] < 2.0f * sc.cube_half);
+                    need = !(idle || (dx * dx + dy * dy) + dz * dz > lim * lim);
+                }
+                have_fk = __builtin_amdgcn_ballot_w64(need) != 0ull;
+            }
+        }
+        if (have_fk) {
+            panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
+            if constexpr (LAZY) { hp[0] = hand.p[0]; hp[1] = hand.p[1]; hp[2] = hand.p[2]; *trav = 0.0f; }
+        }
+        if (w.held != 0.0f) {
+            if (have_fk) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    w.A.p[i] = hand.p[i] + ((w.rel_p[0] * hand.x[i] + w.rel_p[1] * hand.y[i]) + w.rel_p[2] * hand.z[i]);
+                float Rr[9];
+                quat2mat(w.rel_q, Rr);
+                Frame c;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    c.x[i] = (hand.x[i] * Rr[0] + hand.y[i] * Rr[3]) + hand.z[i] * Rr[6];
+                    c.y[i] = (hand.x[i] * Rr[1] + hand.y[i] * Rr[4]) + hand.z[i] * Rr[7];
+                    c.z[i] = (hand.x[i] * Rr[2] + hand.y[i] * Rr[5]) + hand.z[i] * Rr[8];
+                }
+                mat2quat(c, w.A.q);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { w.A.v[i] = 0.0f; w.A.w[i] = 0.0f; }
+            }
+        } else if (have_fk) {
+            GraspGeom gg;
+            grasp_geom(sc, w, hand, gg);
             // spec v1.1, the pad channel: the cube's centre lies between the two pad faces
-            if (g.in_region && g.cy < w.q[7] && g.cy > -w.q[8]) {
+            if (gg.in_region && gg.cy < w.q[7] && gg.cy > -w.q[8]) {
                 float gap = w.q[7] + w.q[8];
                 const float wdt = 2.0f * sc.cube_half;
                 if (gap < wdt) {
@@ -438,79 +1095,28 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                     // closing pads sweep the cube along the hand's y so that it stays between them; it slides on its
                     // support: the horizontal part of the displacement, horizontal velocity lost
                     const float lo = sc.cube_half - w.q[8], hi = w.q[7] - sc.cube_half;
-                    const float cyn = fminf(fmaxf(g.cy, lo), hi);
-                    if (cyn != g.cy) {
-                        const float sh = cyn - g.cy;
-                        w.cube[0] = w.cube[0] + sh * hand.y[0];
-                        w.cube[1] = w.cube[1] + sh * hand.y[1];
-                        w.cube_v[0] = 0.0f; w.cube_v[1] = 0.0f;
-                        const float d[3] = {w.cube[0] - hand.p[0], w.cube[1] - hand.p[1], w.cube[2] - hand.p[2]};
-                        g.cx = dot3(d, hand.x); g.cz = dot3(d, hand.z);
+                    const float cyn = fminf(fmaxf(gg.cy, lo), hi);
+                    if (cyn != gg.cy) {
+                        const float sh = cyn - gg.cy;
+                        w.A.p[0] = w.A.p[0] + sh * hand.y[0];
+                        w.A.p[1] = w.A.p[1] + sh * hand.y[1];
+                        w.A.v[0] = 0.0f; w.A.v[1] = 0.0f;
+                        const float d[3] = {w.A.p[0] - hand.p[0], w.A.p[1] - hand.p[1], w.A.p[2] - hand.p[2]};
+                        gg.cx = dot3(d, hand.x); gg.cz = dot3(d, hand.z);
                     }
                 }
                 if (gap <= wdt + sc.grasp_tol && u[7] < 0.0f && u[8] < 0.0f) {
                     w.held = 1.0f;
                     w.qd[7] = 0.0f; w.qd[8] = 0.0f;
-                    w.rel_p[0] = g.cx; w.rel_p[1] = 0.5f * (w.q[7] - w.q[8]); w.rel_p[2] = g.cz;
-                    set_rel_rot(w, hand, g.Rc);
-                    w.cube_v[0] = w.cube_v[1] = w.cube_v[2] = 0.0f;
+                    w.rel_p[0] = gg.cx; w.rel_p[1] = 0.5f * (w.q[7] - w.q[8]); w.rel_p[2] = gg.cz;
+                    set_rel_rot(w, hand, gg.Rc);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { w.A.v[i] = 0.0f; w.A.w[i] = 0.0f; }
                 }
             }
         }
-        // 4. penalty contact forces.  They are outputs only (nothing of the dynamics reads them) and
-        // a step's value is the LAST substep's, so earlier substeps do not form them; in a rollout
-        // only the pick cost reads them (get_motion_cost, cost_functions.py:116-125,158-169): FORCES.
-        if (FORCES && sub == sc.substeps - 1) {
-            // (finger link origins as given by this substep's FK, i.e. before the pad clamp)
-            float tipl[3], tipr[3], hc[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                tipl[i] = mad(sc.tip_z, hand.z[i], pl[i]);
-                tipr[i] = mad(sc.tip_z, hand.z[i], pr[i]);
-                hc[i] = mad(sc.hand_z, hand.z[i], hand.p[i]);
-            }
-            // Broad phase per box, once per WAVE (it cannot change a result): all four spheres lie inside the ball of
-            // radius GRIP_R around hc -- the finger tips 0.0734 z + q7 y (q7 <= 0.04) + 0.012 = 0.096 from it, the held
-            // cube's centre at most |(0.025, 0.04, 0.1034 + 0.025 - 0.03)| = 0.109 (the pad channel of the grasp rule
-            // bounds rel_p) + its radius 0.025 = 0.134 -- so a box farther than that from hc in every lane gets no
-            // force from any of them: its four tests (each ~15 instructions up to its own early-out) are skipped.
-            // In the pick phase the shelf and, until the place, cubeB are far: 8 of the 12 tests.
-            constexpr float GRIP_R = 0.15f;
-            auto near_box = [&](const float* b) {
-                float d2 = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float l = hc[i] - b[i];
-                    const float d = l - fminf(fmaxf(l, -b[3 + i]), b[3 + i]);
-                    d2 = mad(d, d, d2);
-                }
-                return __builtin_amdgcn_ballot_w64(!(d2 > GRIP_R * GRIP_R)) != 0ull;
-            };
-            if (near_box(sc.table)) {
-                sphere_box_force(sc, tipl, sc.tip_r, sc.table, ft);
-                sphere_box_force(sc, tipr, sc.tip_r, sc.table, ft);
-                sphere_box_force(sc, hc, sc.hand_r, sc.table, ft);
-                if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, sc.table, ft);
-            }
-            if (near_box(sc.shelf)) {
-                sphere_box_force(sc, tipl, sc.tip_r, sc.shelf, fs);
-                sphere_box_force(sc, tipr, sc.tip_r, sc.shelf, fs);
-                sphere_box_force(sc, hc, sc.hand_r, sc.shelf, fs);
-                if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, sc.shelf, fs);
-            }
-            if (near_box(cubeB_box)) {
-                sphere_box_force(sc, tipl, sc.tip_r, cubeB_box, fb);
-                sphere_box_force(sc, tipr, sc.tip_r, cubeB_box, fb);
-                sphere_box_force(sc, hc, sc.hand_r, cubeB_box, fb);
-                if (w.held != 0.0f) sphere_box_force(sc, w.cube, sc.cube_half, cubeB_box, fb);
-            }
-        }
-        w.f_table[0] = ft[0]; w.f_table[1] = ft[1];
-        w.f_shelf[0] = fs[0]; w.f_shelf[1] = fs[1];
-        w.f_cubeB[0] = fb[0]; w.f_cubeB[1] = fb[1];
-        if (sub == sc.substeps - 1) {
-            // observables for the cost: finger link poses at the FINAL joint values (the pad
-            // clamp may have moved q7/q8 after this substep's FK)
+        if (last) {
+            // observables for the cost: finger link poses at the FINAL joint values (the pad clamp may have moved q7/q8)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float fo = mad(0.0584f, hand.z[i], hand.p[i]);   // trans(0, 0, 0.0584), zero terms dropped
@@ -519,10 +1125,6 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
             mat2quat(hand, obs.left_q);
         }
-    };
-    for (int sub = 0; sub < sc.substeps; ++sub) {
-        if (LAZY_FK && __builtin_amdgcn_ballot_w64(w.held != 0.0f) == 0ull) substep(sub, HeldNo{});
-        else substep(sub, HeldYes{});
     }
 }
 
@@ -574,7 +1176,7 @@ struct PandaCostParams {
 __device__ __forceinline__ float panda_cost(const PandaCostParams& cp, const PandaWorld& w,
                                             const PandaObs& o, int k) {
     if (cp.task == 4) {  // reach
-        float goal[3] = {w.cube[0], w.cube[1], w.cube[2]};
+        float goal[3] = {w.A.p[0], w.A.p[1], w.A.p[2]};
         if (!cp.multi_modal || k < cp.half_K) {
             goal[2] = goal[2] + cp.pre_height_diff;
         } else {
@@ -586,13 +1188,13 @@ __device__ __forceinline__ float panda_cost(const PandaCostParams& cp, const Pan
         const float dz = (o.left[2] + o.right[2]) / 2.0f - goal[2];
         const float reach = sqrtf((dx * dx + dy * dy) + dz * dz);
         const float tilt = (cp.multi_modal && k >= cp.half_K) ? cp.tilt_cos_theta : 0.0f;
-        const float ori = ori_ee2cube(o.left_q, w.cube_q, tilt, w.cube_q);
+        const float ori = ori_ee2cube(o.left_q, w.A.q, tilt, w.A.q);
         return 10.0f * reach + 3.0f * ori;
     }
     if (cp.task == 5) {  // pick
-        const float dx = cp.goal[0] - w.cube[0], dy = cp.goal[1] - w.cube[1], dz = cp.goal[2] - w.cube[2];
+        const float dx = cp.goal[0] - w.A.p[0], dy = cp.goal[1] - w.A.p[1], dz = cp.goal[2] - w.A.p[2];
         const float gc = sqrtf((dx * dx + dy * dy) + dz * dz);
-        const float ori = ori_cube2goal(w.cube_q, &cp.goal[3]);
+        const float ori = ori_cube2goal(w.A.q, &cp.goal[3]);
         const float fx = (w.f_table[0] + 4.0f * w.f_shelf[0]) + w.f_cubeB[0];
         const float fy = (w.f_table[1] + 4.0f * w.f_shelf[1]) + w.f_cubeB[1];
         const float coll = fabsf(fx) + fabsf(fy);

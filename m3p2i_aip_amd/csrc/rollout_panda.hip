@@ -12,34 +12,49 @@
 
 namespace m3 {
 
-__device__ __forceinline__ void panda_world_from_raw(const float* p, PandaWorld& w) {
+// raw world, 57 floats: q9 qd9 | cubeA13 | cubeB13 | dyn-obs13 (each: pos3 quat4(xyzw) linvel3 angvel3)
+__device__ __forceinline__ void body_from13(const float* b, Body& o) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { w.q[i] = p[i]; w.qd[i] = p[9 + i]; }
+    for (int i = 0; i < 3; ++i) { o.p[i] = b[i]; o.v[i] = b[7 + i]; o.w[i] = b[10 + i]; }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { w.cube[i] = p[18 + i]; w.cube_v[i] = p[25 + i]; w.cubeB[i] = p[28 + i]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w.cube_q[i] = p[21 + i];
+    for (int i = 0; i < 4; ++i) o.q[i] = b[3 + i];
+}
+__device__ __forceinline__ void panda_world_clear_derived(PandaWorld& w) {
     w.held = 0.0f;
     w.rel_p[0] = w.rel_p[1] = w.rel_p[2] = 0.0f;
     w.rel_q[0] = w.rel_q[1] = w.rel_q[2] = 0.0f; w.rel_q[3] = 1.0f;
-    w.f_table[0] = w.f_table[1] = w.f_shelf[0] = w.f_shelf[1] = w.f_cubeB[0] = w.f_cubeB[1] = 0.0f;
+    w.awake[0] = w.awake[1] = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { w.f_table[i] = 0.0f; w.f_shelf[i] = 0.0f; w.f_cubeB[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w.warm_t[i] = 0.0f; w.warm_l[i] = 0.0f; }
+}
+__device__ __forceinline__ void panda_world_from_raw(const float* p, PandaWorld& w) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { w.q[i] = p[i]; w.qd[i] = p[9 + i]; }
+    body_from13(p + 18, w.A);
+    body_from13(p + 31, w.B);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { w.obs_p[i] = p[44 + i]; w.obs_v[i] = p[51 + i]; }
+    panda_world_clear_derived(w);
 }
 
 // env 0 of the wrapper's tensors: dof_state row = 9 x (pos, vel) interleaved
 // (isaacgym_wrapper.py:98-100), root_state row = pos3 quat4 vel3 ang3 (:102-104)
-__device__ __forceinline__ void panda_world_from_sim(const float* dof, const float* root, int ia, int ib,
+__device__ __forceinline__ void panda_world_from_sim(const float* dof, const float* root, int ia, int ib, int io,
                                                      PandaWorld& w) {
-    float raw[31];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { raw[i] = dof[2 * i]; raw[9 + i] = dof[2 * i + 1]; }
-    const float* a = root + (size_t)ia * 13;
-    const float* b = root + (size_t)ib * 13;
+    for (int i = 0; i < 9; ++i) { w.q[i] = dof[2 * i]; w.qd[i] = dof[2 * i + 1]; }
+    body_from13(root + (size_t)ia * 13, w.A);
+    body_from13(root + (size_t)ib * 13, w.B);
+    const float* o = root + (size_t)io * 13;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) raw[18 + i] = a[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { raw[25 + i] = a[7 + i]; raw[28 + i] = b[i]; }
-    panda_world_from_raw(raw, w);
+    for (int i = 0; i < 3; ++i) { w.obs_p[i] = o[i]; w.obs_v[i] = o[7 + i]; }
+    panda_world_clear_derived(w);
 }
+
+// the manifolds' per-lane contact-point store in LDS: 12 slots x 10 floats per lane, lane-strided (conflict-free)
+#define PANDA_CORNER_LDS() __shared__ float corner_lds[12 * 10 * 64]; const CornerStore cs{corner_lds + threadIdx.x, 64}
 
 __device__ __forceinline__ float in_vgpr(float v) {   // keep a uniform value in a vector register
     asm volatile("" : "+v"(v));
@@ -53,6 +68,7 @@ __device__ __forceinline__ float in_vgpr(float v) {   // keep a uniform value in
 template <bool FORCES, bool GENERAL>
 __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, const PandaArgs pa,
                                                       const PandaScene sc_) {
+    PANDA_CORNER_LDS();
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= a_.Kl) return;
     // The per-joint constants (bounds, noise scale, servo coefficients: 54 floats) are uniform, but
@@ -73,7 +89,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
     const int Kl = a.Kl, T = a.T;
     const int k = a.k0 + i;
     PandaWorld w;
-    if (a.sim_dof) panda_world_from_sim(a.sim_dof, a.sim_root, pa.cubeA_actor, pa.cubeB_actor, w);
+    if (a.sim_dof) panda_world_from_sim(a.sim_dof, a.sim_root, pa.cubeA_actor, pa.cubeB_actor, pa.obs_actor, w);
     else panda_world_from_raw(pa.world0, w);
     float hp[3], trav = 0.0f;   // hand origin at the last evaluated kinematics, joint travel since (panda_step)
     panda_infer_held(sc, w, hp);
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
             e[j] = uj;                                     // :313 (the update consumes the scaled stack)
         }
         PandaObs obs;
-        panda_step<FORCES, true>(sc, w, u, obs, hp, &trav);
+        panda_step<FORCES, true>(sc, w, u, obs, cs, hp, &trav);
         const float c = panda_cost(pa.cp, w, obs, k);
         *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
             make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
@@ -190,39 +206,52 @@ void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const Panda
 }
 
 // ======================= step mode ======================================================
-// SoA world rows: q 0-8 | qd 9-17 | cube 18-20 | cube_q 21-24 | cube_v 25-27 | cubeB 28-30 |
-// held 31 | rel_p 32-34 | rel_q 35-38 | f_table 39-40 | f_shelf 41-42 | f_cubeB 43-44
+// SoA world rows (NWP = 77): q 0-8 | qd 9-17 | cubeA 18-30 (pos3 quat4 vel3 angvel3) | cubeB 31-43 | plate pos 44-46,
+// vel 47-49 | held 50 | rel_p 51-53 | rel_q 54-57 | awake 58-59 | f_table 60-62 | f_shelf 63-65 | f_cubeB 66-68 |
+// warm_t 69-72 | warm_l 73-76
 __device__ __forceinline__ void psoa_load(const float* wd, int Kl, int i, PandaWorld& w) {
     const float* p = wd + i;
+    auto body = [&](int r0, Body& b) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { b.p[j] = p[(r0 + j) * Kl]; b.v[j] = p[(r0 + 7 + j) * Kl]; b.w[j] = p[(r0 + 10 + j) * Kl]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b.q[j] = p[(r0 + 3 + j) * Kl];
+    };
 #pragma unroll
     for (int j = 0; j < 9; ++j) { w.q[j] = p[j * Kl]; w.qd[j] = p[(9 + j) * Kl]; }
+    body(18, w.A);
+    body(31, w.B);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        w.cube[j] = p[(18 + j) * Kl]; w.cube_v[j] = p[(25 + j) * Kl]; w.cubeB[j] = p[(28 + j) * Kl];
-        w.rel_p[j] = p[(32 + j) * Kl];
+        w.obs_p[j] = p[(44 + j) * Kl]; w.obs_v[j] = p[(47 + j) * Kl]; w.rel_p[j] = p[(51 + j) * Kl];
+        w.f_table[j] = p[(60 + j) * Kl]; w.f_shelf[j] = p[(63 + j) * Kl]; w.f_cubeB[j] = p[(66 + j) * Kl];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { w.cube_q[j] = p[(21 + j) * Kl]; w.rel_q[j] = p[(35 + j) * Kl]; }
-    w.held = p[31 * Kl];
-    w.f_table[0] = p[39 * Kl]; w.f_table[1] = p[40 * Kl];
-    w.f_shelf[0] = p[41 * Kl]; w.f_shelf[1] = p[42 * Kl];
-    w.f_cubeB[0] = p[43 * Kl]; w.f_cubeB[1] = p[44 * Kl];
+    for (int j = 0; j < 4; ++j) { w.rel_q[j] = p[(54 + j) * Kl]; w.warm_t[j] = p[(69 + j) * Kl]; w.warm_l[j] = p[(73 + j) * Kl]; }
+    w.held = p[50 * Kl];
+    w.awake[0] = p[58 * Kl]; w.awake[1] = p[59 * Kl];
 }
 __device__ __forceinline__ void psoa_store(float* wd, int Kl, int i, const PandaWorld& w) {
     float* p = wd + i;
+    auto body = [&](int r0, const Body& b) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { p[(r0 + j) * Kl] = b.p[j]; p[(r0 + 7 + j) * Kl] = b.v[j]; p[(r0 + 10 + j) * Kl] = b.w[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[(r0 + 3 + j) * Kl] = b.q[j];
+    };
 #pragma unroll
     for (int j = 0; j < 9; ++j) { p[j * Kl] = w.q[j]; p[(9 + j) * Kl] = w.qd[j]; }
+    body(18, w.A);
+    body(31, w.B);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        p[(18 + j) * Kl] = w.cube[j]; p[(25 + j) * Kl] = w.cube_v[j]; p[(28 + j) * Kl] = w.cubeB[j];
-        p[(32 + j) * Kl] = w.rel_p[j];
+        p[(44 + j) * Kl] = w.obs_p[j]; p[(47 + j) * Kl] = w.obs_v[j]; p[(51 + j) * Kl] = w.rel_p[j];
+        p[(60 + j) * Kl] = w.f_table[j]; p[(63 + j) * Kl] = w.f_shelf[j]; p[(66 + j) * Kl] = w.f_cubeB[j];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { p[(21 + j) * Kl] = w.cube_q[j]; p[(35 + j) * Kl] = w.rel_q[j]; }
-    p[31 * Kl] = w.held;
-    p[39 * Kl] = w.f_table[0]; p[40 * Kl] = w.f_table[1];
-    p[41 * Kl] = w.f_shelf[0]; p[42 * Kl] = w.f_shelf[1];
-    p[43 * Kl] = w.f_cubeB[0]; p[44 * Kl] = w.f_cubeB[1];
+    for (int j = 0; j < 4; ++j) { p[(54 + j) * Kl] = w.rel_q[j]; p[(69 + j) * Kl] = w.warm_t[j]; p[(73 + j) * Kl] = w.warm_l[j]; }
+    p[50 * Kl] = w.held;
+    p[58 * Kl] = w.awake[0]; p[59 * Kl] = w.awake[1];
 }
 
 // SoA world of environment i -> the wrapper's views (link poses through the forward kinematics)
@@ -232,43 +261,53 @@ __device__ __forceinline__ void panda_push_views(const PandaScene& sc, const Sim
 #pragma unroll
         for (int j = 0; j < 9; ++j) { d[2 * j] = w.q[j]; d[2 * j + 1] = w.qd[j]; }
     }
-    float cube13[13];
+    auto body13 = [&](const Body& b, float* o) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { cube13[j] = w.cube[j]; cube13[7 + j] = w.cube_v[j]; cube13[10 + j] = 0.0f; }
+        for (int j = 0; j < 3; ++j) { o[j] = b.p[j]; o[7 + j] = b.v[j]; o[10 + j] = b.w[j]; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cube13[3 + j] = w.cube_q[j];
+        for (int j = 0; j < 4; ++j) o[3 + j] = b.q[j];
+    };
     if (v.root_state) {
-        float* r = v.root_state + ((size_t)i * v.n_actors + v.box_actor) * 13;
+        float* base = v.root_state + (size_t)i * v.n_actors * 13;
+        body13(w.A, base + v.box_actor * 13);
+        body13(w.B, base + v.dyn_actor * 13);
+        float* o = base + v.obs_actor * 13;      // the plate: position and linear velocity (it does not rotate)
 #pragma unroll
-        for (int j = 0; j < 13; ++j) r[j] = cube13[j];
+        for (int j = 0; j < 3; ++j) { o[j] = w.obs_p[j]; o[7 + j] = w.obs_v[j]; }
     }
     if (v.rigid_body_state) {
         float* base = v.rigid_body_state + (size_t)i * v.n_bodies * 13;
-        float* r = base + v.box_body * 13;
+        body13(w.A, base + v.box_body * 13);
+        body13(w.B, base + v.dyn_body * 13);
+        float* o = base + v.obs_body * 13;
 #pragma unroll
-        for (int j = 0; j < 13; ++j) r[j] = cube13[j];
+        for (int j = 0; j < 3; ++j) { o[j] = w.obs_p[j]; o[7 + j] = w.obs_v[j]; }
         // robot links: bodies robot_body .. robot_body + 10 (link0..7, hand, left, right)
         float links[11 * 7];
         Frame hand;
         float pl[3], pr[3];
         panda_fk<true>(sc, w.q, hand, pl, pr, links);
         for (int l = 0; l < 11; ++l) {
-            float* o = base + (v.robot_body + l) * 13;
-            for (int j = 0; j < 7; ++j) o[j] = links[l * 7 + j];
-            for (int j = 7; j < 13; ++j) o[j] = 0.0f;  // link velocities are not modelled (spec v1)
+            float* ol = base + (v.robot_body + l) * 13;
+            for (int j = 0; j < 7; ++j) ol[j] = links[l * 7 + j];
+            for (int j = 7; j < 13; ++j) ol[j] = 0.0f;  // link velocities are not reported
         }
     }
     if (v.net_contact_force) {
         float* f = v.net_contact_force + (size_t)i * v.n_bodies * 3;
-        f[v.table_body * 3 + 0] = w.f_table[0]; f[v.table_body * 3 + 1] = w.f_table[1];
-        f[v.shelf_body * 3 + 0] = w.f_shelf[0]; f[v.shelf_body * 3 + 1] = w.f_shelf[1];
-        f[v.dyn_body * 3 + 0] = w.f_cubeB[0]; f[v.dyn_body * 3 + 1] = w.f_cubeB[1];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            f[v.table_body * 3 + j] = w.f_table[j];
+            f[v.shelf_body * 3 + j] = w.f_shelf[j];
+            f[v.dyn_body * 3 + j] = w.f_cubeB[j];
+        }
     }
 }
 
 // one sim.step() of every environment and the refresh of the wrapper's views in the same launch
 __global__ __launch_bounds__(64) void k_psim_step(const PandaScene sc, const SimViews v, float* wd, const float* u,
                                                   float* u_keep, int Kl) {
+    PANDA_CORNER_LDS();
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= Kl) return;
     PandaWorld w;
@@ -281,7 +320,7 @@ __global__ __launch_bounds__(64) void k_psim_step(const PandaScene sc, const Sim
         for (int j = 0; j < 9; ++j) u_keep[(size_t)i * 9 + j] = uu[j];
     }
     PandaObs obs;
-    panda_step(sc, w, uu, obs);
+    panda_step(sc, w, uu, obs, cs);
     psoa_store(wd, Kl, i, w);
     panda_push_views(sc, v, i, w);
 }
@@ -295,7 +334,7 @@ __global__ __launch_bounds__(64) void k_psim_pull(const PandaScene sc, const Sim
     if (i >= Kl) return;
     PandaWorld w;
     panda_world_from_sim(v.dof_state + (size_t)i * 18, v.root_state + (size_t)i * v.n_actors * 13,
-                         v.box_actor, v.dyn_actor, w);  // box_actor = cubeA, dyn_actor = cubeB here
+                         v.box_actor, v.dyn_actor, v.obs_actor, w);  // box_actor = cubeA, dyn_actor = cubeB here
     panda_infer_held(sc, w);
     psoa_store(wd, Kl, i, w);
 }

@@ -228,15 +228,18 @@ class HipEngine:
         arr = (C.c_float * 18)(*[float(x) for x in w18])
         self._ck(self.lib.m3_set_world_point_raw(self._h, arr))
 
-    def set_world_panda_raw(self, w31):
-        arr = (C.c_float * 31)(*[float(x) for x in w31])
+    def set_world_panda_raw(self, w57):
+        """q9 qd9 | cubeA | cubeB | dyn-obs, each pos3 quat4(xyzw) linvel3 angvel3 (include/m3p2i_hip.h)"""
+        if len(w57) != 57:
+            raise ValueError("set_world_panda_raw: 57 floats (q9 qd9 cubeA13 cubeB13 dyn-obs13), got %d" % len(w57))
+        arr = (C.c_float * 57)(*[float(x) for x in w57])
         self._ck(self.lib.m3_set_world_panda_raw(self._h, arr))
 
-    def bind_sim_panda(self, dof_state, root_state, cubeA_actor, cubeB_actor):
+    def bind_sim_panda(self, dof_state, root_state, cubeA_actor, cubeB_actor, obs_actor):
         assert dof_state.is_cuda and root_state.is_cuda and dof_state.dtype == torch.float32
         self._bound = (dof_state, root_state)
         self._ck(self.lib.m3_bind_sim_panda(self._h, dof_state.data_ptr(), root_state.data_ptr(),
-                                            root_state.shape[-2], cubeA_actor, cubeB_actor))
+                                            root_state.shape[-2], cubeA_actor, cubeB_actor, obs_actor))
 
     def bind_sim_point(self, dof_state, root_state, box_actor, dyn_actor):
         assert dof_state.is_cuda and root_state.is_cuda and dof_state.dtype == torch.float32
@@ -330,7 +333,7 @@ class HipEngine:
             L.BUF_TOP_TRAJS: ((L.TOPK, T, 2), "<f4"),
             L.BUF_REDUCE: ((self.lib.m3_reduce_len(self._h),), "<f4"),
             L.BUF_NOISE: ((T, Kl, nu), "<f4"), L.BUF_PENDING_FORCE: ((4, Kl), "<f4"),
-            L.BUF_SIM_WORLD: ((28 if c.env_type == L.ENV_POINT else 45, Kl), "<f4"),
+            L.BUF_SIM_WORLD: ((28 if c.env_type == L.ENV_POINT else 77, Kl), "<f4"),
             L.BUF_INFO: ((L.INFO_WORDS,), "<i4"),
             L.BUF_NOISE_ALL: ((Kg // Kl, T, Kl, nu), "<f4"),
             L.BUF_COV: ((2, nu), "<f4"),

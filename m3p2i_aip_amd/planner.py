@@ -359,7 +359,8 @@ class MPPI():
             else:
                 self._engine.bind_sim_panda(s._dof_state, s._root_state,
                                             scenes.actor_index(self.env_type, "cubeA"),
-                                            scenes.actor_index(self.env_type, "cubeB"))
+                                            scenes.actor_index(self.env_type, "cubeB"),
+                                            scenes.actor_index(self.env_type, "dyn-obs"))
             self._bound_sim = s
 
     def _exchange(self, phase):

@@ -244,7 +244,7 @@ class OraclePandaSim:
         P = self.P
         base = {"table": P.W_FT, "shelf_stand": P.W_FS, "cubeB": P.W_FB}[actor]
         f = np.zeros((self.num_envs, 3), np.float32)
-        f[:, :2] = self.worlds[:, base:base + 2]
+        f[:, :3] = self.worlds[:, base:base + 3]
         return torch.from_numpy(f)
 
     def set_dof_velocity_target_tensor(self, u):

@@ -120,23 +120,75 @@ def P():
 
 def random_panda_worlds(P, sc, n, rng):
     """Random joint configurations and velocities; cubeA on the table, near the hand or falling onto the shelf (the
-    generator of the GPU fuzz test); every seventh world holds the cube / has the open gripper around it / just off it."""
+    generator of the GPU fuzz test); cubeB on the table, next to / under / on top of cubeA, tilted or moving; the plate
+    where it floats or near the hand; every seventh world holds the cube / has the open gripper around it / just off it;
+    gripper poses with the finger tips at the table, at a cube, at the plate."""
     from tests.panda_worlds import grasp_world
     w = P.init_world(n)
+    w[:, P.W_CUBEA + 2] = 1.05; w[:, P.W_CUBEB + 2] = 1.05          # resting on the table
     qlo, qhi = np.array(sc.qlo), np.array(sc.qhi)
     w[:, P.W_Q:P.W_Q + 9] = qlo + rng.uniform(0.05, 0.95, (n, 9)) * (qhi - qlo)
     w[:, P.W_QD:P.W_QD + 9] = rng.normal(0, 0.3, (n, 9)) * (rng.random((n, 1)) < 0.5)
+
+    def quat(axis, ang):
+        axis = np.asarray(axis, float) / np.linalg.norm(axis)
+        return np.concatenate([axis * np.sin(ang / 2), [np.cos(ang / 2)]])
+
     for i in range(n):
-        if i % 3 == 0:
+        hand = P.fk(sc, w[i, P.W_Q:P.W_Q + 9].astype(np.float32))["pos"][8]
+        k = i % 6
+        if k == 0:
             w[i, P.W_CUBEA:P.W_CUBEA + 2] = rng.uniform(-0.5, 0.5, 2)
-        elif i % 3 == 1:
-            w[i, P.W_CUBEA:P.W_CUBEA + 3] = P.fk(sc, w[i, P.W_Q:P.W_Q + 9].astype(np.float32))["pos"][8] + rng.uniform(-0.12, 0.12, 3)
-        else:
+        elif k == 1:
+            w[i, P.W_CUBEA:P.W_CUBEA + 3] = hand + rng.uniform(-0.12, 0.12, 3)
+        elif k == 2:
             w[i, P.W_CUBEA:P.W_CUBEA + 3] = (0.5 + rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), 1.6)
+        elif k == 3:      # stacked on cubeB (offsets up to beyond the edge), resting or dropped from a few mm
+            w[i, P.W_CUBEA:P.W_CUBEA + 3] = w[i, P.W_CUBEB:P.W_CUBEB + 3] + (rng.uniform(-0.035, 0.035), rng.uniform(-0.035, 0.035), 0.05 + rng.choice([0.0, 0.0005, 0.004]))
+            w[i, P.W_CUBEA + 3:P.W_CUBEA + 7] = quat((0, 0, 1), rng.uniform(-0.5, 0.5))
+        elif k == 4:      # tumbling in the air above the table / next to cubeB
+            w[i, P.W_CUBEA:P.W_CUBEA + 3] = w[i, P.W_CUBEB:P.W_CUBEB + 3] + (rng.uniform(-0.07, 0.07), rng.uniform(-0.07, 0.07), rng.uniform(0.0, 0.08))
+            w[i, P.W_CUBEA + 3:P.W_CUBEA + 7] = quat(rng.normal(0, 1, 3), rng.uniform(0, 3))
+            w[i, P.W_CUBEA + 7:P.W_CUBEA + 13] = rng.normal(0, 1, 6) * (0.3, 0.3, 0.3, 3, 3, 3)
+        else:             # cubeB pushed / near the hand; the plate near the hand
+            w[i, P.W_CUBEB:P.W_CUBEB + 3] = hand + rng.uniform(-0.1, 0.1, 3)
+            w[i, P.W_CUBEB + 7:P.W_CUBEB + 10] = rng.normal(0, 0.3, 3)
+            w[i, P.W_OBS:P.W_OBS + 3] = hand + rng.uniform(-0.15, 0.15, 3)
+        if i % 11 == 0:   # gripper pointing down with the finger tips at the table / at cubeB's height
+            z = rng.choice([1.025 + 0.1154 + rng.uniform(-0.004, 0.02), 1.05 + 0.1034 + rng.uniform(-0.01, 0.01)])
+            tgt = np.array([rng.uniform(0.1, 0.4), rng.uniform(-0.3, 0.3), z])
+            if rng.random() < 0.5:
+                tgt[:2] = w[i, P.W_CUBEB:P.W_CUBEB + 2] + rng.uniform(-0.06, 0.06, 2)
+            w[i, P.W_Q:P.W_Q + 9] = _ik_down(P, sc, tgt)
+            w[i, P.W_Q + 7:P.W_Q + 9] = rng.uniform(0, 0.04, 2)
     special = [grasp_world(P, sc), grasp_world(P, sc, close_gripper=False), grasp_world(P, sc, close_gripper=False, offset=(0.0, 0.012))]
     for i in range(0, n, 7):
         w[i] = special[(i // 7) % 3]
     return w.astype(np.float32)
+
+
+def _ik_down(P, sc, target):
+    """joint angles that put the hand's origin at `target` with the gripper pointing straight down (damped least squares
+    from the elbow-up pose the grasp helper uses; test data only)"""
+    q = np.array([0, 0.3, 0, -2.2, 0, 2.5, 0.785, 0.04, 0.04], np.float64)
+
+    def feat(L):
+        return np.concatenate([L["pos"][8], 0.3 * L["az"][8], 0.3 * L["ay"][8]]).astype(np.float64)
+
+    want = np.concatenate([target, 0.3 * np.array([0, 0, -1.0]), 0.3 * np.array([0, 1.0, 0])])
+    lo, hi = np.array(sc.qlo)[:7] + 0.02, np.array(sc.qhi)[:7] - 0.02
+    for _ in range(400):
+        L = P.fk(sc, q.astype(np.float32))
+        e = want - feat(L)
+        if np.linalg.norm(e) < 1e-5:
+            break
+        Jm = np.zeros((9, 7))
+        for j in range(7):
+            dq = q.copy(); dq[j] += 1e-3
+            Jm[:, j] = (feat(P.fk(sc, dq.astype(np.float32))) - feat(L)) / 1e-3
+        step = Jm.T @ np.linalg.solve(Jm @ Jm.T + 1e-4 * np.eye(9), e)
+        q[:7] = np.clip(q[:7] + np.clip(step, -0.2, 0.2), lo, hi)
+    return q.astype(np.float32)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2], ids=["step_mode", "pick_rollout_lazy_fk", "reach_rollout_lazy_fk_no_forces"])
@@ -144,28 +196,31 @@ def random_panda_worlds(P, sc, n, rng):
 def test_panda_device_header_on_the_host_equals_the_oracle(P, panda_host_lib, seed, mode):
     sc = P.default_scene()
     rng = np.random.default_rng(40 + seed)
-    n, steps = 280, 25
+    n, steps = 330, 25
     a = random_panda_worlds(P, sc, n, rng)
     b = a.copy()
     hp, trav, obs = np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros((n, 10), np.float32)
-    L = P.lib()
-    L.m3o_panda_infer_held.argtypes = [C.POINTER(P.PandaScene), C.POINTER(C.c_float)]
-    for i in range(n):          # a world is loaded: the grasp state is inferred from the geometry
+    for i in range(n):          # a world is loaded: the grasp and sleep states are inferred from the geometry
         row = np.ascontiguousarray(a[i])
-        L.m3o_panda_infer_held(C.byref(sc), row.ctypes.data_as(C.POINTER(C.c_float)))
+        P.infer_state(sc, row)
         a[i] = row
     panda_host_lib.pnh_infer_held(0.01, 2, b.ctypes.data, n, hp.ctypes.data)
     np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
-    assert a[:, P.W_HELD].sum() >= n // 21
-    # (not on the device: cubeA's angular velocity, cubeB beyond its position; the reach rollout forms no contact forces)
-    cols = [c for c in range(58 if mode != 2 else 52) if not (28 <= c < 31) and not (34 <= c < 44)]
+    assert a[:, P.W_HELD].sum() >= n // 21 and 0 < a[:, P.W_AWAKE].sum() < 2 * n
+    # (not on the device: the plate's orientation and angular velocity; the reach rollout forms no contact forces)
+    cols = [c for c in range(P.WORLD_FLOATS) if not (P.W_OBS + 3 <= c < P.W_OBS + 7) and not (P.W_OBS + 10 <= c < P.W_OBS + 13)
+            and not (mode == 2 and P.W_FT <= c < P.W_FT + 9)]
     grip = rng.integers(0, 3, n)
+    rows_seen = np.zeros(2, int)
     for t in range(steps):
         u = rng.uniform(-2, 2, (n, 9)).astype(np.float32)
         u[:, 7:] = rng.uniform(-1.5, 1.5, (n, 2))
         u[grip == 1, 7:] = 1.5          # gripper override open / close (m3p2i.py:10-14) for a third of the worlds each
         u[grip == 2, 7:] = -1.5
-        P.step_batch(sc, a, u)
+        for i in range(n):              # (one world at a time: the oracle's row counters are per call)
+            row = a[i:i + 1]
+            P.step_batch(sc, row, u[i:i + 1])
+            rows_seen += np.minimum(P.last_rows(), 1)
         panda_host_lib.pnh_step(0.01, 2, b.ctypes.data, n, u.ctypes.data, obs.ctypes.data, mode, hp.ctypes.data, trav.ctypes.data)
         neq = a[:, cols].view(np.uint32) != b[:, cols].view(np.uint32)
         if neq.any():
@@ -176,3 +231,4 @@ def test_panda_device_header_on_the_host_equals_the_oracle(P, panda_host_lib, se
             Lk = P.fk(sc, a[i, :9])
             want = np.concatenate([Lk["pos"][9], Lk["quat"][9], Lk["pos"][10]]).astype(np.float32)
             np.testing.assert_array_equal(want.view(np.uint32), obs[i].view(np.uint32))
+    assert rows_seen[0] > 200 and rows_seen[1] > 1000, rows_seen     # gripper contacts and cube contacts really occur

@@ -395,7 +395,10 @@ def test_panda_servo_is_the_implicit_damper_with_the_urdf_effort_limits(P):
             v[~free] = w[0, P.W_QD:P.W_QD + 9][~free]
 
 
-def test_panda_cube_free_fall_and_coulomb_slide(P):
+def test_panda_cube_free_fall_landing_and_coulomb_slide(P):
+    """A free cube: exact free fall (g h^2 sums); it lands on the table top through its four corner contacts, comes to
+    rest within 0.2 mm of it and goes to sleep; pushed sideways it decelerates with mu g (the four friction rows
+    together), the table reporting the reaction mu m g (what get_motion_cost reads), and stops dead."""
     sc = P.default_scene()
     h, z = sc.dt / sc.substeps, np.zeros((1, 9), np.float32)
     w = P.init_world(1)
@@ -410,19 +413,183 @@ def test_panda_cube_free_fall_and_coulomb_slide(P):
         np.testing.assert_allclose(w[0, P.W_CUBEA + 9], v, rtol=1e-5)
     for _ in range(100):
         P.step_batch(sc, w, z)
-    assert w[0, P.W_CUBEA + 2] == pytest.approx(1.025 + sc.cube_half, abs=1e-6)      # landed on the table top, at rest
-    assert np.all(w[0, P.W_CUBEA + 7:P.W_CUBEA + 13] == 0)
-    # sliding on the table: mu g per unit mass, reaction mu m g on the table (what get_motion_cost reads), rest
+    assert w[0, P.W_CUBEA + 2] == pytest.approx(1.025 + sc.cube_half, abs=2e-4)      # landed on the table top, at rest
+    assert np.all(w[0, P.W_CUBEA + 7:P.W_CUBEA + 13] == 0) and w[0, P.W_AWAKE] == 0.0   # ... asleep
+    assert abs(w[0, P.W_CUBEA + 6]) > 0.9999                                          # ... and flat
+    # sliding on the table: mu g per unit mass, reaction mu m g on the table, rest
     w[0, P.W_CUBEA + 7] = 0.5
+    row = np.ascontiguousarray(w[0]); P.infer_state(sc, row); w[0] = row      # (a moving cube is loaded awake)
+    assert w[0, P.W_AWAKE] == 1.0
+    x0 = w[0, P.W_CUBEA]
     vx = 0.5
     for n in range(8):
         P.step_batch(sc, w, z)
         moving = vx > 0
-        vx = max(0.0, vx - 2 * sc.cube_mu * sc.g * h)
-        np.testing.assert_allclose(w[0, P.W_CUBEA + 7], vx, atol=2e-6)
-        if moving and vx > 0:
-            np.testing.assert_allclose(w[0, P.W_FT], sc.cube_mu * sc.cube_m * sc.g, rtol=1e-5)
-    assert w[0, P.W_CUBEA + 7] == 0.0 and w[0, P.W_FT] == 0.0
+        vx = max(0.0, vx - 2 * sc.mu * sc.g * h)
+        np.testing.assert_allclose(w[0, P.W_CUBEA + 7], vx, atol=0.02)
+        if moving and vx > 0.05:
+            np.testing.assert_allclose(w[0, P.W_FT], sc.mu * sc.cube_m * sc.g, rtol=0.05)
+            np.testing.assert_allclose(w[0, P.W_FT + 2], -sc.cube_m * sc.g, rtol=0.02)     # and its weight
+    assert np.all(w[0, P.W_CUBEA + 7:P.W_CUBEA + 13] == 0) and w[0, P.W_AWAKE] == 0.0
+    assert w[0, P.W_CUBEA] - x0 == pytest.approx(0.5 ** 2 / (2 * sc.mu * sc.g), rel=0.25)   # stopping distance v0^2 / 2 mu g
+    assert abs(w[0, P.W_CUBEA + 6]) > 0.999                                            # it slid, it did not tumble
+
+
+def _down_pose(P, sc, x, y, clearance):
+    """gripper pointing straight down, finger tips `clearance` above the table top at (x, y)"""
+    from tests.test_device_dynamics_on_host import _ik_down
+    return _ik_down(P, sc, np.array([x, y, 1.025 + (0.0584 + sc.tip_z + sc.tip_r) + clearance]))
+
+
+def _point_jacobian(P, sc, q, x):
+    L = P.fk(sc, q)
+    J = np.zeros((3, 9))
+    for j in range(7):
+        J[:, j] = np.cross(L["az"][j + 1], x - L["pos"][j + 1])
+    return J, L
+
+
+def test_panda_descent_into_the_table_stops_and_reports_the_effort_limited_force(P):
+    """Spec v2, contact response.  The gripper is driven straight down onto the table at 0.2 m/s: the finger tip
+    stops AT the table top (never deeper than 2 mm while the drives keep pushing), the joints stall, and the table
+    reports the force the saturated drives can exert -- checked as Newton's law per joint with a bounded drive torque:
+    I_i dq'_i / h - (J^T f)_i = tau_i with |tau_i| <= effort_i (franka_panda.urdf: 87 / 12 N m) for every joint that is
+    not on a joint stop, and |tau_i| = effort_i for at least one of them once the descent has stalled."""
+    sc = P.default_scene()
+    sc.substeps, sc.dt = 1, 0.005          # one substep per step: the reported force is the step's
+    h = 0.005
+    w = P.init_world(1)
+    z = np.zeros((1, 9), np.float32)
+    for _ in range(20):
+        P.step_batch(sc, w, z)
+    w[0, :9] = _down_pose(P, sc, 0.35, 0.0, 0.02)
+    w[0, 7], w[0, 8] = 0.04, 0.0
+    I, eff = np.array(sc.inertia), np.array(sc.effort)
+    gaps, ratios, speeds, forces = [], [], [], []
+    for t in range(70):                     # 0.1 s of approach, 0.25 s of pushing
+        q0, qd0 = w[0, :9].copy(), w[0, 9:18].copy()
+        Jh, L = _point_jacobian(P, sc, q0, P.fk(sc, q0)["pos"][8])
+        u = np.zeros((1, 9), np.float32)
+        u[0, :7] = np.clip(np.linalg.pinv(Jh[:, :7]) @ np.array([0, 0, -0.2]), -2.0, 2.0)   # (the planner's bounds, mppi/panda.yaml)
+        tl, tr = L["pos"][9] + sc.tip_z * L["az"][8], L["pos"][10] + sc.tip_z * L["az"][8]
+        P.step_batch(sc, w, u)
+        n_grip = P.last_rows()[0]
+        f = -w[0, P.W_FT:P.W_FT + 3].astype(np.float64)          # on the gripper
+        L1 = P.fk(sc, w[0, :9])
+        gaps.append(min(L1["pos"][9][2], L1["pos"][10][2]) + sc.tip_z * L1["az"][8][2] - sc.tip_r - 1.025)
+        speeds.append(abs((Jh[:, :7] @ w[0, 9:16])[2]))
+        if n_grip == 1 and np.linalg.norm(f) > 0:
+            s = 0 if tl[2] < tr[2] else 1
+            J, _ = _point_jacobian(P, sc, q0, (tl if s == 0 else tr) - np.array([0, 0, sc.tip_r]))
+            J[:, 7 + s] = (1 - 2 * s) * L["ay"][8]
+            tau = I * (w[0, 9:18] - qd0) / h - J.T @ f
+            free = w[0, 9:16] != 0.0                               # (a joint on a stop is held by the stop)
+            ratios.append(np.abs(tau[:7][free] / eff[:7][free]).max())
+            forces.append(f[2])
+    first = next(i for i, g in enumerate(gaps) if g < 1e-3)
+    assert 15 < first < 40 and speeds[first - 5] == pytest.approx(0.2, rel=0.1)   # it arrived at the commanded speed
+    assert min(gaps) > -2e-3 and max(gaps[first:]) < 1e-3             # ... and stays at the surface, within 2 mm
+    assert max(speeds[first + 5:]) < 0.05                              # stalled (the hand only pivots about the tip)
+    assert len(ratios) > 15 and max(ratios) < 1.02                     # bounded drive torques explain every force
+    assert max(ratios[5:]) > 0.98                                      # ... and a drive is at its limit
+    assert 100 < max(forces) < 400                                     # (N: 87 N m over a ~0.4 m lever)
+
+
+def test_panda_finger_sweep_moves_cubeB(P):
+    """A closed gripper swept sideways at cube height pushes the sleeping cubeB away: the cube wakes, moves with the
+    finger, the finger's force on it is reported (get_motion_cost reads cubeB's net contact force), and once the finger
+    has passed it comes to rest on the table and goes back to sleep."""
+    sc = P.default_scene()
+    w = P.init_world(1)
+    z = np.zeros((1, 9), np.float32)
+    for _ in range(10):
+        P.step_batch(sc, w, z)
+    B0 = w[0, P.W_CUBEB:P.W_CUBEB + 3].copy()
+    assert w[0, P.W_AWAKE + 1] == 0.0
+    from tests.test_device_dynamics_on_host import _ik_down
+    w[0, :9] = _ik_down(P, sc, np.array([B0[0] - 0.08, B0[1], 1.05 + 0.0584 + sc.tip_z]))
+    w[0, 7:9] = 0.0
+    woke, fmax = False, 0.0
+    for t in range(60):
+        Jh, _ = _point_jacobian(P, sc, w[0, :9].copy(), P.fk(sc, w[0, :9])["pos"][8])
+        u = np.zeros((1, 9), np.float32)
+        u[0, :7] = np.linalg.pinv(Jh[:, :7]) @ np.array([0.25, 0, 0])
+        u[0, 7:] = -1.5
+        P.step_batch(sc, w, u)
+        woke = woke or w[0, P.W_AWAKE + 1] == 1.0
+        fmax = max(fmax, np.abs(w[0, P.W_FB:P.W_FB + 2]).sum())
+    for t in range(60):                     # the gripper withdraws, the cube stays behind and settles
+        Jh, _ = _point_jacobian(P, sc, w[0, :9].copy(), P.fk(sc, w[0, :9])["pos"][8])
+        u = np.zeros((1, 9), np.float32)
+        if t < 20:
+            u[0, :7] = np.linalg.pinv(Jh[:, :7]) @ np.array([-0.25, 0, 0.1])
+        u[0, 7:] = -1.5
+        P.step_batch(sc, w, u)
+    B1 = w[0, P.W_CUBEB:P.W_CUBEB + 3]
+    assert woke and fmax > 0.5                                   # N, well above get_motion_cost's 0.1 threshold
+    assert np.linalg.norm(B1[:2] - B0[:2]) > 0.03                # pushed away ...
+    assert B1[2] == pytest.approx(1.05, abs=1e-3) and w[0, P.W_AWAKE + 1] == 0.0 and np.all(w[0, P.W_CUBEB + 7:P.W_CUBEB + 13] == 0)
+    assert np.array_equal(w[0, P.W_CUBEA:P.W_CUBEA + 3], P.init_world(1)[0, P.W_CUBEA:P.W_CUBEA + 3]) is False   # (cubeA settled too)
+
+
+@pytest.mark.parametrize("offset,stays", [(0.0, True), (0.011, True), (0.02, True), (0.03, False), (0.04, False)])
+def test_panda_cube_released_on_cubeB_rests_or_tips_over_the_edge(P, offset, stays):
+    """cubeA released 4 mm above cubeB, displaced by `offset` along x (and 4 mm along y, yawed by 2 degrees): with its
+    centre of mass over cubeB's top face (offset < 2.5 cm) it lands, stays and the stack goes to sleep; beyond the
+    edge it tips over it and ends on the table next to cubeB -- angular dynamics of a free cube on its face-to-face
+    contact points."""
+    sc = P.default_scene()
+    w = P.init_world(1)
+    z = np.zeros((1, 9), np.float32)
+    for _ in range(10):
+        P.step_batch(sc, w, z)
+    B = w[0, P.W_CUBEB:P.W_CUBEB + 3].copy()
+    w[0, P.W_CUBEA:P.W_CUBEA + 3] = B + np.array([offset, 0.004, 0.054], np.float32)
+    w[0, P.W_CUBEA + 3:P.W_CUBEA + 7] = (0, 0, np.sin(np.radians(1.0)), np.cos(np.radians(1.0)))
+    w[0, P.W_CUBEA + 7:P.W_CUBEA + 13] = 0
+    row = np.ascontiguousarray(w[0]); P.infer_state(sc, row); w[0] = row
+    assert w[0, P.W_AWAKE] == 1.0                        # in the air: awake
+    for _ in range(150):
+        P.step_batch(sc, w, z)
+    A = w[0, P.W_CUBEA:P.W_CUBEA + 3]
+    assert np.all(w[0, P.W_AWAKE:P.W_AWAKE + 2] == 0.0)   # everything has come to rest
+    if stays:
+        assert A[2] == pytest.approx(1.10, abs=1.5e-3) and abs(A[0] - B[0] - offset) < 5e-3
+        assert abs(w[0, P.W_CUBEA + 6]) > 0.999           # flat (rotated about z only)
+    else:
+        assert A[2] == pytest.approx(1.05, abs=1.5e-3) and A[0] - B[0] > 0.045      # on the table, beyond cubeB
+    assert np.linalg.norm(w[0, P.W_CUBEB:P.W_CUBEB + 2] - B[:2]) < 0.01
+
+
+def test_panda_resting_stack_is_loaded_asleep_and_a_hovering_cube_is_not(P):
+    """The wrapper's tensors carry no sleep bit: a loaded world's cube is asleep iff it is at rest ON something -- the
+    table, the shelf_stand, or the other cube with its centre over it."""
+    sc = P.default_scene()
+    w = P.init_world(1)[0]
+    w[P.W_CUBEA + 2] = w[P.W_CUBEB + 2] = 1.05
+    for dz, dx, want in ((0.05, 0.0, 0.0), (0.0505, 0.011, 0.0), (0.0505, 0.03, 1.0), (0.056, 0.0, 1.0)):
+        v = w.copy()
+        v[P.W_CUBEA:P.W_CUBEA + 3] = v[P.W_CUBEB:P.W_CUBEB + 3] + np.array([dx, 0, dz], np.float32)
+        P.infer_state(sc, v)
+        assert v[P.W_AWAKE] == want and v[P.W_AWAKE + 1] == 0.0, (dz, dx)
+    v = w.copy(); v[P.W_CUBEA + 7] = 1e-3                  # moving: awake
+    P.infer_state(sc, v)
+    assert v[P.W_AWAKE] == 1.0
+    v = P.init_world(1, cube_on_shelf=True)[0]; v[P.W_CUBEA + 2] = 1.325 + 0.025
+    P.infer_state(sc, v)
+    assert v[P.W_AWAKE] == 0.0                             # on the shelf_stand
+
+
+def test_panda_inertias_are_the_mesh_derived_diagonal(P):
+    """The joint inertias of the spec are the diagonal of the joint-space mass matrix at the initial pose, computed from
+    the reference's collision meshes at the default density (tools/panda_inertia.py, run in the build container; the
+    numbers are committed constants) -- here: the constants of the oracle's scene are those, and the servo's time constant
+    I / D stays far below the substep for every joint (the drive dominates: a = h D / I between 1.4 and 1000)."""
+    sc = P.default_scene()
+    want = [1.32, 2.12, 1.30, 0.918, 0.0271, 0.0366, 0.0030, 0.022, 0.022]
+    np.testing.assert_allclose(np.array(sc.inertia), want, rtol=1e-6)
+    a = (sc.dt / sc.substeps) * sc.drive_damping / np.array(sc.inertia)
+    assert a.min() > 1.4 and a.max() < 1001
 
 
 def test_panda_held_cube_is_rigid_with_the_hand(P):

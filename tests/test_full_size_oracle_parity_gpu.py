@@ -113,7 +113,7 @@ def test_panda_full_size_vs_oracle(oracle, task, grip, start):
                                 pre_height_diff=0.05, dt=0.01))
     eng.set_objective(task, goal, gripper_cmd=grip)
     eng.set_noise(delta)
-    eng.set_world_panda_raw(np.concatenate([w0[P.W_Q:P.W_Q + 18], w0[P.W_CUBEA:P.W_CUBEA + 10], w0[P.W_CUBEB:P.W_CUBEB + 3]]))
+    eng.set_world_panda_raw(P.raw57(w0))
     for call in range(3):
         a = eng.command(sync_host=True)
         b = opl.command(w0)

@@ -12,9 +12,9 @@ UMAX = [2.0] * 7 + [1.5] * 2
 SIG = [10.0] * 7 + [0.8] * 2
 
 
-def raw31(P, w58):
-    w = np.asarray(w58, np.float32)
-    return np.concatenate([w[P.W_Q:P.W_Q + 18], w[P.W_CUBEA:P.W_CUBEA + 10], w[P.W_CUBEB:P.W_CUBEB + 3]])
+def raw31(P, world):
+    """what set_world_panda_raw takes (now 57 floats: q9 qd9 cubeA13 cubeB13 dyn-obs13 -- the wrapper's tensors' content)"""
+    return P.raw57(world)
 
 
 from tests.panda_worlds import grasp_world  # noqa: E402

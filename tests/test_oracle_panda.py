@@ -111,7 +111,8 @@ def test_cube_settles_on_table_and_can_be_grasped_and_lifted(P):
     release = np.zeros((1, 9), np.float32); release[0, 7:] = 1.5
     for _ in range(100):
         P.step_batch(sc, w, release)
-    assert w[0, P.W_HELD] == 0.0 and w[0, P.W_CUBEA + 2] == pytest.approx(1.05, abs=1e-5)  # fell back
+    assert w[0, P.W_HELD] == 0.0 and w[0, P.W_CUBEA + 2] == pytest.approx(1.05, abs=2e-4)  # fell back (asleep on the table)
+    assert w[0, P.W_AWAKE] == 0.0
 
 
 def test_pad_channel_spec_v11(P):
@@ -144,12 +145,16 @@ def test_pad_channel_spec_v11(P):
     # 2 cm off along the pads' width (inside the footprint): held off-centre, not moved
     w, c0 = run((0.02, 0.0), close)
     assert w[P.W_HELD] == 1.0 and abs(abs(w[P.W_RELP]) - 0.02) < 1e-3 and np.allclose(w[P.W_CUBEA:P.W_CUBEA + 2], c0[:2], atol=1e-4)
-    # 3 cm off along the width: outside the footprint -- the fingers close on nothing
+    # 3 cm off along the width: outside the pads' footprint -- not captured.  (Spec v2: the finger tips are collision
+    # spheres of radius 1.2 cm, 5 mm of which overlap the cube's extent along the width: they close ON the cube's
+    # side faces and stop there, 3.7 cm from the centre line each, nudging it by a millimetre or two.)
     w, c0 = run((0.03, 0.0), close)
-    assert w[P.W_HELD] == 0.0 and np.array_equal(w[P.W_CUBEA:P.W_CUBEA + 3], c0) and w[P.W_Q + 7] + w[P.W_Q + 8] < 1e-3
-    # 4.5 cm off along the closing direction: the cube's centre is beyond a pad face -- not captured
+    assert w[P.W_HELD] == 0.0 and np.allclose(w[P.W_CUBEA:P.W_CUBEA + 3], c0, atol=4e-3)
+    assert w[P.W_Q + 7] + w[P.W_Q + 8] == pytest.approx(2 * 0.037, abs=4e-3)
+    # 4.5 cm off along the closing direction: the cube's centre is beyond a pad face -- not captured (pushed aside
+    # by the closing finger instead)
     w, c0 = run((0.0, 0.045), close)
-    assert w[P.W_HELD] == 0.0 and np.array_equal(w[P.W_CUBEA:P.W_CUBEA + 3], c0)
+    assert w[P.W_HELD] == 0.0 and np.allclose(w[P.W_CUBEA:P.W_CUBEA + 3], c0, atol=3e-2)
     # 3 cm above the grasp height: out of reach of the pads
     w = grasp_world(P, sc, close_gripper=False, lift=0.03).reshape(1, -1).copy()
     for _ in range(40):
