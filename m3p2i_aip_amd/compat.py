@@ -43,7 +43,11 @@ def torch_to_bytes(t) -> bytes:
 def bytes_to_torch(b: bytes):
     """data_transfer.py:9-12.  The blob comes off a network socket: weights_only=True restricts the unpickler to
     tensors and plain containers (bool / int / float / str / list / dict), which is all the scripts exchange."""
-    return torch.load(io.BytesIO(b), weights_only=True)
+    try:
+        return torch.load(io.BytesIO(b), weights_only=True)
+    except TypeError:       # torch < 1.13 has no weights_only: refuse rather than fall back to the full unpickler
+        raise RuntimeError("bytes_to_torch needs torch >= 1.13 (torch.load(weights_only=True)); this torch is "
+                           + torch.__version__) from None
 
 
 # ------------------------------------------------------------------ task_planner.py (module)

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <new>
@@ -120,6 +121,8 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
         if (c->shard_mix < 0 || c->shard_mix > 3) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: shard_mix must be 0, 1, 2 or 3");
         if (c->shard_mix == 3 && (long long)c->T * c->nu > 2048)
             return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: shard_mix = 3 needs T * nu <= 2048");
+        if (c->shard_mix == 3 && apply_workgroups(c->K_local) > 256)     // (m3_update_b's partial sums: one slot per workgroup)
+            return fail(nullptr, M3_ERR_UNSUPPORTED, "m3_create: shard_mix = 3: K_local too large for the second exchange's partial sums");
         if (c->K_global % c->K_local != 0 || c->k_offset % c->K_local != 0 || c->K_global / c->K_local > MIX_MAX_RANKS)
             return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs equal shards (K_global = n * K_local, n <= 32)");
         if (c->K_local < M3_TOPK) return fail(nullptr, M3_ERR_SHAPE, "m3_create: shard_mix needs K_local >= 20");
@@ -1051,7 +1054,6 @@ extern "C" int m3_update_b(m3_handle* h) {
         a.w = (float*)h->buf[M3_BUF_WEIGHTS] + c.k_offset;
         a.w1 = (float*)h->buf[M3_BUF_WEIGHTS_1] + c.k_offset;
         a.rec_b = recb;
-        if (apply_workgroups(c.K_local) > 256) return fail(h, M3_ERR_UNSUPPORTED, "m3_update_b: K_local too large");
         launch_p3_local_weights(a, h->stream);
     }
     {   // their weighted action sums + the rows of the local best samples
@@ -1080,20 +1082,38 @@ static int after_finalize(m3_handle* h) {
 // ---- device-side exchange of the records (p2p.hip) -------------------------------------------------------------
 static int p2p_ranks(const m3_handle* h) { return h->cfg.K_global / h->cfg.K_local; }
 static int p2p_rank(const m3_handle* h) { return h->cfg.k_offset / h->cfg.K_local; }
+// the device a pointer lives on (-1: unknown)
+static int ptr_device(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return at.device;
+}
 static int p2p_alloc(m3_handle* h) {
     if (h->xb) return M3_OK;
     const m3_config& c = h->cfg;
+    // the block belongs on the HANDLE's device, whatever device is current on the calling thread (a process that
+    // drives several GPUs, torch's current device): set it for the allocation and put the caller's back
+    struct DeviceGuard {
+        int prev = -1;
+        explicit DeviceGuard(int d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(d); }
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard(c.device);
     if (!(c.shard_mix && c.K_local != c.K_global) || !h->buf[M3_BUF_RECORD])
         return fail(h, M3_ERR_STATE, "m3_p2p: the handle has no record to exchange (needs cfg.shard_mix on a sharded handle)");
     const size_t rl = (size_t)m3_record_len(h), rlb = (size_t)m3_record_b_len(h);
     h->xb_bytes = P2P_HDR_BYTES + 2 * (size_t)p2p_ranks(h) * (((rl + 3) & ~(size_t)3) + ((rlb + 3) & ~(size_t)3)) * sizeof(float);
     // uncached: neither the peers' stores nor the owner's loads may be served from a stale L2 line
-    if (hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocUncached) == hipSuccess) h->xb_kind = 1;
-    else if ((void)hipGetLastError(), hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocFinegrained) == hipSuccess) h->xb_kind = 2;
+    // (M3P2I_P2P_MEMORY = finegrained | plain: start further down the fallback chain -- the tests of the fenced paths)
+    const char* force = std::getenv("M3P2I_P2P_MEMORY");
+    const int first = !force ? 1 : (std::strcmp(force, "finegrained") == 0 ? 2 : std::strcmp(force, "plain") == 0 ? 3 : 1);
+    if (first <= 1 && hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocUncached) == hipSuccess) h->xb_kind = 1;
+    else if ((void)hipGetLastError(), first <= 2 && hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocFinegrained) == hipSuccess) h->xb_kind = 2;
     else if ((void)hipGetLastError(), hipMalloc(&h->xb, h->xb_bytes) == hipSuccess) h->xb_kind = 3;
     else { h->xb = nullptr; return fail(h, M3_ERR_HIP, "m3_p2p: allocation of the exchange block failed"); }
     HIPCHK(h, hipMemset(h->xb, 0, h->xb_bytes));
     HIPCHK(h, hipDeviceSynchronize());
+    const int on = ptr_device(h->xb);
+    if (on >= 0 && on != c.device) return fail(h, M3_ERR_HIP, "m3_p2p: the exchange block did not land on the handle's device");
     return M3_OK;
 }
 
@@ -1146,16 +1166,21 @@ extern "C" int m3_p2p_connect_local(m3_handle* h, m3_handle* const* peers, int n
     if (n != p2p_ranks(h)) return fail(h, M3_ERR_SHAPE, "m3_p2p_connect_local: need one handle per rank");
     for (int p = 0; p < n; ++p) {
         m3_handle* q = peers[p];
-        if (!q || p2p_rank(q) != p || m3_record_len(q) != m3_record_len(h) || p2p_ranks(q) != n)
-            return fail(h, M3_ERR_SHAPE, "m3_p2p_connect_local: peers[p] must be the handle of rank p of the same sharding");
+        if (!q || p2p_rank(q) != p || m3_record_len(q) != m3_record_len(h) || p2p_ranks(q) != n ||
+            m3_record_b_len(q) != m3_record_b_len(h) || q->cfg.shard_mix != h->cfg.shard_mix)
+            return fail(h, M3_ERR_SHAPE, "m3_p2p_connect_local: peers[p] must be the handle of rank p of the same sharding and protocol");
         rc = p2p_alloc(q);
         if (rc != M3_OK) return fail(h, rc, "m3_p2p_connect_local: a peer could not allocate its block");
+        const int on = ptr_device(q->xb);
+        if (on >= 0 && on != q->cfg.device) return fail(h, M3_ERR_HIP, "m3_p2p_connect_local: a peer's block is not on that peer's device");
         if (q->cfg.device != h->cfg.device) {
-            int can = 0;
+            int can = 0, prev = -1;
             (void)hipDeviceCanAccessPeer(&can, h->cfg.device, q->cfg.device);
             if (!can) return fail(h, M3_ERR_UNSUPPORTED, "m3_p2p_connect_local: no peer access between the two devices");
+            if (hipGetDevice(&prev) != hipSuccess) prev = -1;
             (void)hipSetDevice(h->cfg.device);
             const hipError_t e = hipDeviceEnablePeerAccess(q->cfg.device, 0);
+            if (prev >= 0) (void)hipSetDevice(prev);       // (the caller's current device is the caller's)
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return fail(h, M3_ERR_HIP, "m3_p2p_connect_local: hipDeviceEnablePeerAccess"); }
             (void)hipGetLastError();
         }
@@ -1176,7 +1201,7 @@ static void p2p_args(m3_handle* h, P2PArgs& a, int ch) {
     a.seq = h->p2p_seq[ch];
     a.slot = a.seq & 1;
     a.timeout_ticks = 100000ull * (unsigned long long)(a.seq <= 1 ? h->p2p_first_ms : h->p2p_ms);   // 100 MHz wall clock
-    a.plain_memory = h->xb_kind == 3;
+    a.plain_memory = h->xb_kind != 1;     // only the uncached block skips both GPUs' L2 for certain: the fine-grained fallback gets the fences too
     a.err = (int*)((char*)h->xb + 2 * MIX_MAX_RANKS * sizeof(int));
     for (int p = 0; p < a.n_ranks; ++p) {
         a.peer_flags[p] = (int*)((char*)h->peer_base[p] + (ch == 0 ? 0 : 512));

@@ -12,8 +12,9 @@
 //               sequence number;
 //   k_p2p_wait  lane p of one wavefront acquires flag [parity][p] of the OWN block until it shows the sequence
 //               number (bounded: the handle's time-out on the 100 MHz wall clock -- 0.5 s, 30 s for the first
-//               exchange --, then the error word is set and the stream moves on: a peer that died must not hang
-//               the GPU).
+//               exchange --, then the error word is set, the missing rank's slot is filled with NaN -- the plan of
+//               that command is NaN, not a silently different one -- and the stream moves on: a peer that died must
+//               not hang the GPU; the planner polls the error word, distributed.attach_p2p).
 //
 // The kernels that follow on the stream (k_mix / k_regen_part / ...) read the records from the own block.  The block
 // is allocated uncached (hipDeviceMallocUncached; fine-grained or plain device memory as fallbacks), so neither the
@@ -58,6 +59,11 @@ __device__ __forceinline__ void p2p_wait_body(const P2PArgs& a) {
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
             if (wall_clock64() - t0 > a.timeout_ticks) {   // the peer never arrived: report, do not hang
                 atomicExch(a.err, 1 + p);
+                // ... and make the miss unmistakable downstream: the slot this rank would have read stale or zeroed
+                // data from is filled with NaN, so the plan of THIS command comes out NaN instead of silently
+                // diverging from the other ranks' (the sticky error word alone is only seen by m3_p2p_status)
+                float* miss = a.peer_data[a.rank] + ((size_t)a.slot * a.n_ranks + p) * a.rec_stride;
+                for (int o = 0; o < a.rec_len; ++o) miss[o] = __builtin_nanf("");
                 break;
             }
             __builtin_amdgcn_s_sleep(2);

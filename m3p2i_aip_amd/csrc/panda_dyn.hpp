@@ -268,6 +268,9 @@ __device__ __forceinline__ void cross3(const float* a, const float* b, float* c)
     c[2] = mad(a[0], b[1], -(a[1] * b[0]));
 }
 __device__ __forceinline__ float dotm(const float* a, const float* b) { return mad(a[0], b[0], mad(a[1], b[1], a[2] * b[2])); }
+// value select.  (`k == 0 ? x[0] : x[1]` on lvalues is an lvalue in C++: the compiler selects the ADDRESS and loads
+// through it, which pins the whole struct / array in scratch memory; passing the candidates by value avoids that.)
+__device__ __forceinline__ float pick3(int k, float a, float b, float c) { return (k == 0) ? a : (k == 1) ? b : c; }
 
 __device__ __forceinline__ void body_rot(const float* q, float* R) {
     const float x = q[0], y = q[1], z = q[2], w = q[3];
@@ -331,7 +334,7 @@ __device__ __forceinline__ float pt_box(const BoxT<ORIENTED>& b, const float* c,
         float pen = p0;
         if (p1 < pen) { pen = p1; f = 1; }
         if (p2 < pen) { pen = p2; f = 2; }
-        const float lf = (f == 0) ? l[0] : (f == 1) ? l[1] : l[2];
+        const float lf = pick3(f, l[0], l[1], l[2]);
         const float sg = (lf >= 0.0f) ? 1.0f : -1.0f;
         nl[0] = (f == 0) ? sg : 0.0f; nl[1] = (f == 1) ? sg : 0.0f; nl[2] = (f == 2) ? sg : 0.0f;
         gap = -pen - r;
@@ -383,16 +386,18 @@ struct BodyVel { float v[3], w[3]; };
 __device__ __forceinline__ void body_get(const PandaWorld& W, int b, BodyVel& o) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        o.v[i] = (b == 0) ? W.A.v[i] : (b == 1) ? W.B.v[i] : W.obs_v[i];
-        o.w[i] = (b == 0) ? W.A.w[i] : (b == 1) ? W.B.w[i] : 0.0f;
+        o.v[i] = pick3(b, W.A.v[i], W.B.v[i], W.obs_v[i]);
+        o.w[i] = pick3(b, W.A.w[i], W.B.w[i], 0.0f);
     }
 }
 __device__ __forceinline__ void body_put(PandaWorld& W, int b, const BodyVel& o) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (b == 0) { W.A.v[i] = o.v[i]; W.A.w[i] = o.w[i]; }
-        else if (b == 1) { W.B.v[i] = o.v[i]; W.B.w[i] = o.w[i]; }
-        else W.obs_v[i] = o.v[i];
+    for (int i = 0; i < 3; ++i) {     // (unconditional value selects: stores in the arms of an if / else chain are merged
+        W.A.v[i] = (b == 0) ? o.v[i] : +W.A.v[i];   //  into ONE store through a selected address -- scratch memory again)
+        W.A.w[i] = (b == 0) ? o.w[i] : +W.A.w[i];
+        W.B.v[i] = (b == 1) ? o.v[i] : +W.B.v[i];
+        W.B.w[i] = (b == 1) ? o.w[i] : +W.B.w[i];
+        W.obs_v[i] = (b == 2) ? o.v[i] : +W.obs_v[i];
     }
 }
 __device__ __forceinline__ float body_k(const PandaScene& sc, int b, const float* a) {
@@ -422,10 +427,13 @@ __device__ __forceinline__ float contact_bias(const PandaScene& sc, float gap) {
 // ---- face-to-face manifold of a cube against a box (the oracle's cube_manifold) ----------------------------------
 // per-lane store of the manifolds' contact points: slot = manifold * 4 + corner, 10 floats each
 // (x3 | meff3 | bias | lam3); in the kernels it is LDS (stride 64 floats between a lane's consecutive values)
+// ... followed by the gripper contacts' joint-space rows: 4 slots x 3 rows x 9 floats (formed once per substep)
+constexpr int PANDA_STORE_FLOATS = 12 * 10 + 4 * 27;
 struct CornerStore {
     float* base;
     int stride;
     __device__ __forceinline__ float& at(int slot, int field) const { return base[(slot * 10 + field) * stride]; }
+    __device__ __forceinline__ float& row(int s, int r3, int j) const { return base[(120 + (s * 3 + r3) * 9 + j) * stride]; }
 };
 struct Manifold {
     bool any;            // the cube is near the box
@@ -448,8 +456,8 @@ __device__ __forceinline__ void manifold_detect(const PandaScene& sc, const floa
     m.any = true;
     int pref = 0;
     if (fabsf(dd[1]) > fabsf(dd[0])) pref = 1;
-    if (fabsf(dd[2]) > fabsf((pref == 0) ? dd[0] : dd[1])) pref = 2;
-    auto sel = [](const float* v, int i) { return (i == 0) ? v[0] : (i == 1) ? v[1] : v[2]; };
+    if (fabsf(dd[2]) > fabsf(pick3(pref, dd[0], dd[1], 0.0f))) pref = 2;
+    auto sel = [](const float* v, int i) __attribute__((always_inline)) { return pick3(i, v[0], v[1], v[2]); };
     const int a1 = (pref == 2) ? 0 : pref + 1, a2 = (pref == 0) ? 2 : pref - 1;     // (pref + 1) % 3, (pref + 2) % 3
     const float side = (sel(dd, pref) <= 0.0f) ? 1.0f : -1.0f;
     m.centre_over = (sel(dd, a1) == 0.0f && sel(dd, a2) == 0.0f);
@@ -458,12 +466,12 @@ __device__ __forceinline__ void manifold_detect(const PandaScene& sc, const floa
     for (int i = 0; i < 3; ++i) dlc[i] = mad(dw[0], Rb[0 * 3 + i], mad(dw[1], Rb[1 * 3 + i], dw[2] * Rb[2 * 3 + i]));
     int f = 0;
     if (fabsf(dlc[1]) > fabsf(dlc[0])) f = 1;
-    if (fabsf(dlc[2]) > fabsf((f == 0) ? dlc[0] : dlc[1])) f = 2;
+    if (fabsf(dlc[2]) > fabsf(pick3(f, dlc[0], dlc[1], 0.0f))) f = 2;
     const float e = sc.cube_half;
     const float sgn = (sel(dlc, f) >= 0.0f) ? 1.0f : -1.0f;
     float nmw[3], nml[3], nl[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) nmw[k] = sgn * ((f == 0) ? Rb[k * 3 + 0] : (f == 1) ? Rb[k * 3 + 1] : Rb[k * 3 + 2]);
+    for (int k = 0; k < 3; ++k) nmw[k] = sgn * pick3(f, Rb[k * 3 + 0], Rb[k * 3 + 1], Rb[k * 3 + 2]);
     tgt.dir_local(nmw, nml);
     const float mz = side * sel(nml, pref);
     const bool clip = (mz <= -0.7f);
@@ -477,7 +485,7 @@ __device__ __forceinline__ void manifold_detect(const PandaScene& sc, const floa
     for (int j = 0; j < 4; ++j) {
         const float s1 = (j & 1) ? e : -e, s2 = (j & 2) ? e : -e, sf = sgn * e;
         // cl[f] = sf, cl[(f + 1) % 3] = s1, cl[(f + 2) % 3] = s2
-        const float cl[3] = {(f == 0) ? sf : (f == 1) ? s2 : s1, (f == 0) ? s1 : (f == 1) ? sf : s2, (f == 0) ? s2 : (f == 1) ? s1 : sf};
+        const float cl[3] = {pick3(f, sf, s2, s1), pick3(f, s1, sf, s2), pick3(f, s2, s1, sf)};
         float xw[3], lc[3], lq[3], qw[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) xw[k] = pb[k] + mad(Rb[k * 3 + 0], cl[0], mad(Rb[k * 3 + 1], cl[1], Rb[k * 3 + 2] * cl[2]));
@@ -603,7 +611,7 @@ __device__ __forceinline__ void panda_infer_held(const PandaScene& sc, PandaWorl
         w.rel_p[0] = g.cx; w.rel_p[1] = g.cy; w.rel_p[2] = g.cz;
         set_rel_rot(w, hand, g.Rc);
     }
-    auto still = [](const Body& b) {
+    auto still = [](const Body& b) __attribute__((always_inline)) {
         return b.v[0] == 0.0f && b.v[1] == 0.0f && b.v[2] == 0.0f && b.w[0] == 0.0f && b.w[1] == 0.0f && b.w[2] == 0.0f;
     };
     const bool stA = still(w.A), stB = still(w.B);
@@ -684,7 +692,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         bool near = true;
         if constexpr (LAZY) {
             const float reach = GRIP_R0 + *trav + sc.contact_offset;
-            auto box_d2 = [&](const float* b, const float* e) {
+            auto box_d2 = [&](const float* b, const float* e) __attribute__((always_inline)) {
                 float d2 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -705,7 +713,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         if (near || bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }
         if (near) {
             float pl[3], pr[3];
-            panda_fk<false, true>(sc, w.q, g.hand, pl, pr, nullptr, &g);
+            panda_fk<false>(sc, w.q, g.hand, pl, pr, nullptr);
             if constexpr (LAZY) { hp[0] = g.hand.p[0]; hp[1] = g.hand.p[1]; hp[2] = g.hand.p[2]; *trav = 0.0f; }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -714,9 +722,30 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 g.c[2][i] = mad(sc.hand_z, g.hand.z[i], g.hand.p[i]);
                 g.c[3][i] = w.A.p[i];
             }
+            // Broad phase per box, once per WAVE (it cannot change a result): all four spheres lie inside the ball of
+            // radius GRIP_R around the hand sphere's centre -- the finger tips 0.0734 z + q7 y (q7 <= 0.04) + 0.012 =
+            // 0.096 from it, the held cube's centre at most |(0.025, 0.04, 0.1034 + 0.025 - 0.03)| = 0.109 (the pad
+            // channel bounds rel_p) + its radius 0.025 = 0.134 -- so a box farther than GRIP_R + contact_offset from that
+            // centre in every lane has no candidate: its tests (each ~40 instructions) are skipped.
+            constexpr float GRIP_R = 0.15f;
+            auto near_box = [&](const float* b, const float* e, float extra) __attribute__((always_inline)) {
+                float d2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float l = g.c[2][i] - b[i];
+                    const float d = l - fminf(fmaxf(l, -e[i]), e[i]);
+                    d2 = mad(d, d, d2);
+                }
+                const float lim = GRIP_R + sc.contact_offset + extra;
+                return __builtin_amdgcn_ballot_w64(!(d2 > lim * lim)) != 0ull;
+            };
+            const float zero3[3] = {0.0f, 0.0f, 0.0f};
+            const bool nt = near_box(sc.table, sc.table + 3, 0.0f), ns = near_box(sc.shelf, sc.shelf + 3, 0.0f);
+            const bool nA = near_box(w.A.p, zero3, sc.cube_rad), nB = near_box(w.B.p, zero3, sc.cube_rad);
+            const bool no = near_box(w.obs_p, sc.obs_half, 0.0f);
             // the pad channel (the grasp rule's region): there the pads, not the tip spheres, act on cubeA
             bool in_channel = false;
-            if (!held) {
+            if (nA && !held) {
                 GraspGeom gg;
                 grasp_geom(sc, w, g.hand, gg);
                 in_channel = gg.in_region && gg.cy < w.q[7] && gg.cy > -w.q[8];
@@ -727,60 +756,76 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #pragma unroll
             for (int i = 0; i < 3; ++i) { bo.p[i] = w.obs_p[i]; bo.e[i] = sc.obs_half[i]; }
             bo.R = nullptr;
+            float bgap[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
+                RSlot& c = rs[s];
+                c.target = -1;
+                bgap[s] = sc.contact_offset;
                 if (s == 3 && !held) continue;
                 const float r = (s < 2) ? sc.tip_r : (s == 2) ? sc.hand_r : sc.cube_half;
-                float best_gap = sc.contact_offset, bn[3] = {0.0f, 0.0f, 0.0f}, bx[3] = {0.0f, 0.0f, 0.0f};
-                int best = -1;
-                auto take = [&](float gap, const float* n, const float* x, int t) {
-                    if (gap < best_gap) { best_gap = gap; best = t; bn[0] = n[0]; bn[1] = n[1]; bn[2] = n[2]; bx[0] = x[0]; bx[1] = x[1]; bx[2] = x[2]; }
+                float bn[3] = {0.0f, 0.0f, 0.0f}, bx[3] = {0.0f, 0.0f, 0.0f};
+                auto take = [&](float gap, const float* n, const float* x, int t) __attribute__((always_inline)) {
+                    if (gap < bgap[s]) { bgap[s] = gap; c.target = t; bn[0] = n[0]; bn[1] = n[1]; bn[2] = n[2]; bx[0] = x[0]; bx[1] = x[1]; bx[2] = x[2]; }
                 };
                 float n[3], x[3];
-                take(pt_box<false>(bt, g.c[s], r, n, x), n, x, T_TABLE);
-                take(pt_box<false>(bs, g.c[s], r, n, x), n, x, T_SHELF);
-                if (!(held || (s < 2 && in_channel))) take(pt_box<true>(bA, g.c[s], r, n, x), n, x, T_CUBEA);
-                take(pt_box<true>(bB, g.c[s], r, n, x), n, x, T_CUBEB);
-                take(pt_box<false>(bo, g.c[s], r, n, x), n, x, T_OBS);
-                if (best < 0) continue;
-                RSlot& c = rs[s];
-                c.target = best;
-                const int tb = best - T_CUBEA;
+                if (nt) take(pt_box<false>(bt, g.c[s], r, n, x), n, x, T_TABLE);
+                if (ns) take(pt_box<false>(bs, g.c[s], r, n, x), n, x, T_SHELF);
+                if (nA && !(held || (s < 2 && in_channel))) take(pt_box<true>(bA, g.c[s], r, n, x), n, x, T_CUBEA);
+                if (nB) take(pt_box<true>(bB, g.c[s], r, n, x), n, x, T_CUBEB);
+                if (no) take(pt_box<false>(bo, g.c[s], r, n, x), n, x, T_OBS);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { c.d[0][i] = bn[i]; c.rho[i] = bx[i] - g.hand.p[i]; }
-                tangents(c.d[0], c.d[1], c.d[2]);
-                const float* tp = (tb == 0) ? w.A.p : (tb == 1) ? w.B.p : w.obs_p;
+                for (int i = 0; i < 3; ++i) { c.d[0][i] = bn[i]; c.rho[i] = bx[i] - g.hand.p[i]; c.rt[i] = bx[i]; }
+            }
+            const bool cand = rs[0].target >= 0 || rs[1].target >= 0 || rs[2].target >= 0 || rs[3].target >= 0;
+            if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
+                // some lane has a candidate: the arm's Jacobian columns (a second pass over the chain, this time keeping
+                // the joint axes and origins), then culling, rows, effective masses
+                Frame h2;
+                panda_fk<false, true>(sc, w.q, h2, pl, pr, nullptr, &g);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) c.rt[i] = (tb >= 0) ? bx[i] - tp[i] : 0.0f;
-                // culling: the gap predicted for the end of the substep from the servo's velocities
-                float J[9], ab[3];
-                robot_row(g, s, held, c.rho, c.d[0], J);
-                float vn0 = 0.0f;
+                for (int s = 0; s < 4; ++s) {
+                    RSlot& c = rs[s];
+                    if (c.target < 0) continue;
+                    const int tb = c.target - T_CUBEA;
+                    tangents(c.d[0], c.d[1], c.d[2]);
 #pragma unroll
-                for (int j = 0; j < 9; ++j) vn0 = mad(J[j], qd1[j], vn0);
-                BodyVel bv;
-                if (tb >= 0) {
-                    body_get(w, tb, bv);
-                    cross3(c.rt, c.d[0], ab);
-                    vn0 = vn0 - bodyvel_along(tb, bv, c.d[0], ab);
+                    for (int i = 0; i < 3; ++i) {
+                        const float tp = pick3(tb, w.A.p[i], w.B.p[i], w.obs_p[i]);
+                        c.rt[i] = (tb >= 0) ? c.rt[i] - tp : 0.0f;
+                    }
+                    // culling: the gap predicted for the end of the substep from the servo's velocities
+                    float J[9], ab[3];
+                    robot_row(g, s, held, c.rho, c.d[0], J);
+                    float vn0 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) vn0 = mad(J[j], qd1[j], vn0);
+                    BodyVel bv;
+                    if (tb >= 0) {
+                        body_get(w, tb, bv);
+                        cross3(c.rt, c.d[0], ab);
+                        vn0 = vn0 - bodyvel_along(tb, bv, c.d[0], ab);
+                    }
+                    if (!(mad(h, vn0, bgap[s]) < sc.act_margin)) continue;
+                    // the rows (kept in the per-lane store), effective masses, bias
+#pragma unroll
+                    for (int r3 = 0; r3 < 3; ++r3) {
+                        if (r3 > 0) robot_row(g, s, held, c.rho, c.d[r3], J);
+                        float k = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) { k = mad(J[j] * sc.invI[j], J[j], k); cs.row(s, r3, j) = J[j]; }
+                        if (tb >= 0) { cross3(c.rt, c.d[r3], ab); k = k + body_k(sc, tb, ab); }
+                        c.meff[r3] = 1.0f / k;
+                        c.lam[r3] = 0.0f;
+                    }
+                    c.bias = contact_bias(sc, bgap[s]);
+                    if (w.warm_t[s] == (float)(c.target + 1)) c.lam[0] = w.warm_l[s];
+                    c.on = true;
+                    robot_rows = true;
+                    touched[0] = touched[0] || tb == 0; touched[1] = touched[1] || tb == 1; touched[2] = touched[2] || tb == 2;
+                    w.awake[0] = (tb == 0) ? 1.0f : +w.awake[0];
+                    w.awake[1] = (tb == 1) ? 1.0f : +w.awake[1];
                 }
-                if (!(mad(h, vn0, best_gap) < sc.act_margin)) continue;
-                // effective masses, bias
-#pragma unroll
-                for (int r3 = 0; r3 < 3; ++r3) {
-                    if (r3 > 0) robot_row(g, s, held, c.rho, c.d[r3], J);
-                    float k = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) k = mad(J[j] * sc.invI[j], J[j], k);
-                    if (tb >= 0) { cross3(c.rt, c.d[r3], ab); k = k + body_k(sc, tb, ab); }
-                    c.meff[r3] = 1.0f / k;
-                    c.lam[r3] = 0.0f;
-                }
-                c.bias = contact_bias(sc, best_gap);
-                if (w.warm_t[s] == (float)(best + 1)) c.lam[0] = w.warm_l[s];
-                c.on = true;
-                robot_rows = true;
-                if (tb >= 0) { touched[tb] = true; if (tb < 2) w.awake[tb] = 1.0f; }
             }
         }
         // 3. an awake cube wakes the other one when they are close
@@ -847,17 +892,16 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #pragma unroll
             for (int i = 0; i < 9; ++i) { qds[i] = (held && i >= 7) ? 0.0f : w.qd[i]; pdrv[i] = 0.0f; }
         }
-        auto robot_solve = [&](int s, RSlot& c, bool only_warm) {
+        auto robot_solve = [&](int s, RSlot& c, bool only_warm) __attribute__((always_inline)) {
             const int tb = c.target - T_CUBEA;
             BodyVel bv;
             if (tb >= 0) body_get(w, tb, bv);
             if (only_warm) {        // the warm-start impulse acts before the first pass
                 const float dl = c.lam[0];
                 if (dl != 0.0f) {
-                    float J[9], ab[3];
-                    robot_row(g, s, held, c.rho, c.d[0], J);
+                    float ab[3];
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) qds[j] = mad(J[j] * sc.invI[j], dl, qds[j]);
+                    for (int j = 0; j < 9; ++j) qds[j] = mad(cs.row(s, 0, j) * sc.invI[j], dl, qds[j]);
                     if (tb >= 0) { cross3(c.rt, c.d[0], ab); bodyvel_apply(sc, tb, bv, c.d[0], ab, -dl); body_put(w, tb, bv); }
                 }
                 return;
@@ -866,7 +910,8 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             for (int rr = 0; rr < 3; ++rr) {
                 const int r3 = (rr + 1) % 3;      // friction rows first, the normal row last
                 float J[9], ab[3];
-                robot_row(g, s, held, c.rho, c.d[r3], J);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) J[j] = cs.row(s, r3, j);
                 float v = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 9; ++j) v = mad(J[j], qds[j], v);
@@ -884,7 +929,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
             if (tb >= 0) body_put(w, tb, bv);
         };
-        auto manifold_solve = [&](int m_id, const Manifold& m, Body& M, const float* pm, Body* T, const float* pt) {
+        auto manifold_solve = [&](int m_id, const Manifold& m, Body& M, const float* pm, Body* T, const float* pt) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!((m.on >> j) & 1u)) continue;
@@ -955,18 +1000,24 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         // net contact forces on table / shelf_stand / cubeB: this substep's impulses / h (a step reports its last)
         if (FORCES && last) {
             float ft[3] = {0.f, 0.f, 0.f}, fs[3] = {0.f, 0.f, 0.f}, fb[3] = {0.f, 0.f, 0.f};
-            auto add = [&](float* dst, float lam, const float* d, bool neg) {
+            // (which of ft / fs / fb a row adds to is data: selected by value, not through a pointer -- a run-time
+            // pointer into local arrays would put them in scratch memory)
+            auto add = [&](int which, float lam, const float* d, bool neg) __attribute__((always_inline)) {     // which: 0 table, 1 shelf_stand, 2 cubeB
                 const float sI = lam * sc.inv_h;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) dst[i] = mad(neg ? -sI : sI, d[i], dst[i]);
+                for (int i = 0; i < 3; ++i) {
+                    const float cur = pick3(which, ft[i], fs[i], fb[i]);
+                    const float nw = mad(neg ? -sI : sI, d[i], cur);
+                    ft[i] = (which == 0) ? nw : ft[i]; fs[i] = (which == 1) ? nw : fs[i]; fb[i] = (which == 2) ? nw : fb[i];
+                }
             };
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!rs[s].on) continue;
-                float* dst = (rs[s].target == T_TABLE) ? ft : (rs[s].target == T_SHELF) ? fs : (rs[s].target == T_CUBEB) ? fb : nullptr;
-                if (dst) for (int r3 = 0; r3 < 3; ++r3) add(dst, rs[s].lam[r3], rs[s].d[r3], true);
+                const int which = (rs[s].target == T_TABLE) ? 0 : (rs[s].target == T_SHELF) ? 1 : (rs[s].target == T_CUBEB) ? 2 : -1;
+                if (which >= 0) for (int r3 = 0; r3 < 3; ++r3) add(which, rs[s].lam[r3], rs[s].d[r3], true);
             }
-            auto add_m = [&](int m_id, const Manifold& m, float* dst, bool mover_is_B) {
+            auto add_m = [&](int m_id, const Manifold& m, int which, bool mover_is_B) __attribute__((always_inline)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (!((m.on >> j) & 1u)) continue;
@@ -974,14 +1025,14 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                     for (int r3 = 0; r3 < 3; ++r3) {
                         const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
                         const float lam = cs.at(m_id * 4 + j, 7 + r3);
-                        if (dst) add(dst, lam, d, true);
-                        if (mover_is_B) add(fb, lam, d, false);
+                        add(which, lam, d, true);
+                        if (mover_is_B) add(2, lam, d, false);
                     }
                 }
             };
-            add_m(0, mA, tA ? ft : fs, false);
-            add_m(1, mAB, fb, false);
-            add_m(2, mB, tB ? ft : fs, true);
+            add_m(0, mA, tA ? 0 : 1, false);
+            add_m(1, mAB, 2, false);
+            add_m(2, mB, tB ? 0 : 1, true);
 #pragma unroll
             for (int i = 0; i < 3; ++i) { w.f_table[i] = ft[i]; w.f_shelf[i] = fs[i]; w.f_cubeB[i] = fb[i]; }
         } else if (last) {
@@ -995,7 +1046,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         }
         // 6. sleep
         if (any_act) {
-            auto slow = [&](const Body& b) { return dotm(b.v, b.v) < sc.sleep_v2 && dotm(b.w, b.w) < sc.sleep_w2; };
+            auto slow = [&](const Body& b) __attribute__((always_inline)) { return dotm(b.v, b.v) < sc.sleep_v2 && dotm(b.w, b.w) < sc.sleep_w2; };
             const bool slA = actA && !touched[0] && slow(w.A), slB = actB && !touched[1] && slow(w.B);
             const bool onA = mA.up == 4, onB = mB.up == 4;
             const bool restA = onA || (onB && mAB.centre_over && mAB.up >= 3);

@@ -53,8 +53,9 @@ __device__ __forceinline__ void panda_world_from_sim(const float* dof, const flo
     panda_world_clear_derived(w);
 }
 
-// the manifolds' per-lane contact-point store in LDS: 12 slots x 10 floats per lane, lane-strided (conflict-free)
-#define PANDA_CORNER_LDS() __shared__ float corner_lds[12 * 10 * 64]; const CornerStore cs{corner_lds + threadIdx.x, 64}
+// the per-lane store of the contact solver in LDS (manifold contact points + the gripper contacts' rows: 228 floats per
+// lane = 57 KB per wavefront), lane-strided: conflict-free, one wavefront per workgroup
+#define PANDA_CORNER_LDS() __shared__ float corner_lds[PANDA_STORE_FLOATS * 64]; const CornerStore cs{corner_lds + threadIdx.x, 64}
 
 __device__ __forceinline__ float in_vgpr(float v) {   // keep a uniform value in a vector register
     asm volatile("" : "+v"(v));

@@ -86,10 +86,21 @@ def attach_collectives(planner, group=None):
     return planner
 
 
-def attach_p2p(planner, group=None):
+P2P_POLL_EVERY = 64      # commands between two reads of the exchange's error word (a stream sync + 4 bytes: ~10 us)
+
+
+def attach_p2p(planner, group=None, poll_every=P2P_POLL_EVERY):
     """The records exchange of a shard_mix planner through peer-mapped device memory instead of RCCL (one process
     per GPU; the IPC handles of the exchange blocks travel once, at set-up, through the process group's object
-    gather).  Planners without the one-collective protocol (shard_mix=False) keep their two RCCL collectives."""
+    gather).  Planners without the one-collective protocol (shard_mix=False) keep their two RCCL collectives.
+
+    Skew bound.  A wait spins for at most the handle's time-out -- 30 s for a channel's first exchange, 0.5 s
+    afterwards (`engine.p2p_set_timeout_ms`) -- so the ranks must reach every command within that of each other (a rank
+    stalled longer: garbage collection, rendering, a failed bench row).  A wait that gives up does NOT hang the GPU and
+    does NOT pass stale data on: the missing rank's slot is filled with NaN (the plan of that command is NaN on the
+    ranks that missed it), a sticky error word is set, and this transport reads that word every `poll_every`
+    commands (and when it is detached) and raises RuntimeError naming the rank that never arrived -- where the RCCL
+    transport would have blocked."""
     if planner.world_size != dist.get_world_size(group):
         raise ValueError("planner.world_size does not match the process group")
     if not planner.shard_mix:
@@ -101,11 +112,24 @@ def attach_p2p(planner, group=None):
     e.p2p_connect(handles)
     dist.barrier(group=group)      # nobody starts exchanging before every rank has mapped every block
 
+    state = {"n": 0}
+
+    def check(pl):
+        missing, _kind = pl._engine.p2p_status()
+        if missing >= 0:
+            raise RuntimeError("p2p exchange: rank %d did not arrive within the wait's time-out (engine.p2p_set_timeout_ms); "
+                               "this rank's plans since then are NaN" % missing)
+
     def exchange(pl, phase):
         if phase not in ("records", "records_b"):
             raise ValueError(phase)
         pl._engine.p2p_exchange(0 if phase == "records" else 1)
+        if phase == "records":
+            state["n"] += 1
+            if poll_every and state["n"] % poll_every == 0:
+                check(pl)
 
     planner.collective = exchange
     planner.transport = "p2p"
+    planner.p2p_check = lambda: check(planner)     # explicit poll (tools, tests, before shutting a rank down)
     return planner

@@ -53,10 +53,23 @@ def _endpoint(ep: str):
 
 
 def _bind_host(host: str) -> str:
-    """Wildcard endpoints listen on the loopback interface unless the operator opts in to all interfaces."""
+    """Wildcard endpoints listen on the loopback interface unless the operator opts in to all interfaces.  That differs
+    from the reference's zerorpc scripts (which bind every interface): it is said at bind time, once per process."""
+    global _warned_narrowed
     if host == "":
-        return "" if os.environ.get("M3P2I_RPC_BIND_ALL") == "1" else "127.0.0.1"
+        if os.environ.get("M3P2I_RPC_BIND_ALL") == "1":
+            return ""
+        if not _warned_narrowed:
+            _warned_narrowed = True
+            import sys
+            print("m3p2i_aip_amd.rpc: wildcard endpoint bound to 127.0.0.1 only (a sim / planner split across two hosts "
+                  "gets connection-refused); set M3P2I_RPC_BIND_ALL=1 to listen on all interfaces as zerorpc does",
+                  file=sys.stderr)
+        return "127.0.0.1"
     return host
+
+
+_warned_narrowed = False
 
 
 def _recv_exact(sock, n):

@@ -153,8 +153,9 @@ def test_panda_planner_options_match_reference_traces(golden, tag):
         dof[0, 0::2] = torch.from_numpy(w[P.W_Q:P.W_Q + 9])
         dof[0, 1::2] = torch.from_numpy(w[P.W_Q + 9:P.W_Q + 18])
         root = sim._root_state[0:1].clone().cpu()
-        root[0, ia, 0:10] = torch.from_numpy(w[P.W_CUBEA:P.W_CUBEA + 10])
-        root[0, ib, 0:3] = torch.from_numpy(w[P.W_CUBEB:P.W_CUBEB + 3])
+        root[0, ia, :] = torch.from_numpy(w[P.W_CUBEA:P.W_CUBEA + 13])
+        root[0, ib, :] = torch.from_numpy(w[P.W_CUBEB:P.W_CUBEB + 13])
+        root[0, int(sim._get_actor_index_by_name("dyn-obs")), :] = torch.from_numpy(w[P.W_OBS:P.W_OBS + 13])
         sim._dof_state[:] = dof.to("cuda:0")
         sim._root_state[:] = root.to("cuda:0")
         sim.set_dof_state_tensor(sim._dof_state)
