@@ -311,6 +311,50 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
                 collective_ms=coll_ms, simple=name in SIMPLE_MODE, walls_ms_per_step=[w / steps * 1e3 for w in walls])
 
 
+MIX_DIR = os.path.join(ROOT, "profiles", "r04")
+
+
+def lib_sha16():
+    """sha256 prefix of the HIP library this process runs (the key of the committed PMC instruction-mix profiles)"""
+    import hashlib
+    from m3p2i_aip_amd import build as b
+    path = os.environ.get("M3P2I_HIP_LIB", b.OUT)
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()[:16]
+
+
+def roofline_valu(name, r, n_waves):
+    """The roofline that binds this path -- VALU issue, not HBM: the rollout kernel's dynamic
+    instruction counts per wavefront from the committed PMC profile of THIS library (profiles/r04/mix_<config>.json,
+    written by tools/pmc_mix_bench.sh; keyed by the library's sha256: a profile of another build is refused), against
+      lone_wave_issue_frac  = VALU instructions / wave cycles -- how close ONE wavefront alone on its SIMD comes to
+                              issuing a VALU instruction every 4 clocks (the bound of every BASELINE size: at most one
+                              wavefront per SIMD, so the dependent-instruction chain of a wave is the command's time)
+      chip_issue_frac       = (VALU instructions of all waves x 4 clocks) / (kernel duration x 1024 SIMDs): how much of
+                              the chip's VALU issue capacity the launch uses (the bound of the saturated regime).
+    Both SQ counters are in units of 4 clocks (MI355X_MICROARCH.md)."""
+    path = os.path.join(MIX_DIR, f"mix_{name}.json")
+    if not os.path.exists(path):
+        return None
+    mix = json.load(open(path))
+    sha = lib_sha16()
+    if mix.get("lib_sha16") != sha:
+        return {"stale": f"{os.path.relpath(path, ROOT)} profiles library {mix.get('lib_sha16')}, this run uses {sha}: "
+                         "re-run tools/pmc_mix_bench.sh"}
+    valu, cyc = mix["SQ_INSTS_VALU"], mix["SQ_WAVE_CYCLES"]
+    clock_ghz = mix.get("clock_ghz", 2.4)
+    kernel_clocks = r["rollout_ms"] * 1e-3 * clock_ghz * 1e9
+    return {"bound": "valu_issue", "kernel": mix.get("kernels"), "valu_per_wave": valu, "wave_cycles_x4": cyc,
+            "lone_wave_issue_frac": valu / cyc, "waves": n_waves, "simds": 1024,
+            "chip_issue_frac": n_waves * valu * 4.0 / (kernel_clocks * 1024),
+            "arithmetic_frac_of_valu": (mix.get("SQ_INSTS_VALU_ADD_F32", 0) + mix.get("SQ_INSTS_VALU_MUL_F32", 0) +
+                                        mix.get("SQ_INSTS_VALU_FMA_F32", 0) + mix.get("SQ_INSTS_VALU_TRANS_F32", 0)) / valu,
+            "clock_ghz_assumed": clock_ghz, "profile": os.path.relpath(path, ROOT), "lib_sha16": sha}
+
+
 def brief(r):
     """Entry of `other_configs`."""
     out = {"workload": f"{r['env']} task={r['task']} K={r['K_global']} T={r['T']} "
@@ -477,6 +521,7 @@ def main():
                                  "DESIGN.md section 6"},
             "kernel_ms": {"rollout": r["rollout_ms"], "update": r["update_ms"], "finalize": r["finalize_ms"]},
         }
+        line["roofline_valu"] = roofline_valu(name, r, (K_local + 63) // 64)
         if r["collective_ms"] is not None:
             line["collective_ms"] = r["collective_ms"]
     delta_np = pl.delta.contiguous().cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
@@ -541,7 +586,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
     if world == 1 and rank == 0 and extras:
-        line["closed_loop"] = closed_loop(r, min(args.steps, 200), device)
+        line["closed_loop"] = closed_loop(r, 200, device)      # (200 ticks whatever --steps says: 20 ticks say nothing)
         others = {}
         pick_scene = None
         try:

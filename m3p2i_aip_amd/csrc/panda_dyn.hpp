@@ -446,6 +446,8 @@ template <bool ORIENTED>
 __device__ __forceinline__ void manifold_detect(const PandaScene& sc, const float* pb, const float* Rb, const BoxT<ORIENTED>& tgt,
                                                 Manifold& m, float (*X)[3], float* gap) {
     m.any = false; m.on = 0u; m.made = 0; m.up = 0; m.down = 0; m.centre_over = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { m.n[i] = 0.0f; m.t1[i] = 0.0f; m.t2[i] = 0.0f; }   // (defined for the masked lanes of a wave)
     float l[3], dd[3], dw[3], dlc[3];
     tgt.local(pb, l);
 #pragma unroll
@@ -684,7 +686,14 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         // 2. gripper contacts
         RSlot rs[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) rs[s].on = false;
+        for (int s = 0; s < 4; ++s) {   // (all fields defined: the passes run branch-free over a wave's slots, masked by `on`)
+            rs[s].on = false; rs[s].target = -1; rs[s].bias = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                rs[s].d[0][i] = rs[s].d[1][i] = rs[s].d[2][i] = 0.0f;
+                rs[s].rho[i] = rs[s].rt[i] = rs[s].meff[i] = rs[s].lam[i] = 0.0f;
+            }
+        }
         bool robot_rows = false;
         bool touched[3] = {false, false, false};
         Gripper g;
@@ -709,6 +718,12 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                             box_d2(w.obs_p, sc.obs_half) < reach * reach;
             near = __builtin_amdgcn_ballot_w64(nr) != 0ull;
         }
+#ifdef M3_PABL_NO_NEAR      // (ablations for tools/time_variants_bench.sh: they change results)
+        near = false;
+#endif
+#ifdef M3_PABL_NO_BODIES
+        w.awake[0] = 0.0f; w.awake[1] = 0.0f;
+#endif
         const bool bodies_awake_wave = __builtin_amdgcn_ballot_w64((!held && w.awake[0] != 0.0f) || w.awake[1] != 0.0f) != 0ull;
         if (near || bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }
         if (near) {
@@ -843,6 +858,10 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         mA.any = mAB.any = mB.any = false; mA.on = mAB.on = mB.on = 0u;
         mA.made = mAB.made = mB.made = 0; mA.up = mAB.up = mB.up = 0; mA.down = mAB.down = mB.down = 0;
         mA.centre_over = mAB.centre_over = mB.centre_over = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            mA.n[i] = mA.t1[i] = mA.t2[i] = 0.0f; mAB.n[i] = mAB.t1[i] = mAB.t2[i] = 0.0f; mB.n[i] = mB.t1[i] = mB.t2[i] = 0.0f;
+        }
         bool tA = true, tB = true;      // the cube's static box is the table
         const bool any_act = __builtin_amdgcn_ballot_w64(actA || actB) != 0ull;
         if (any_act) {
@@ -886,7 +905,8 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
         }
         const bool body_rows = (mA.on | mAB.on | mB.on) != 0u;
-        // 5. velocity passes
+        // 5. velocity passes.  (Tried: wave-uniform control flow with the inactive lanes masked by value selects instead
+        // of per-lane branches -- 15-20 % slower, the selects cost more than the exec-mask regions: docs/NOTEBOOK.md.)
         float qds[9], pdrv[9];
         if (robot_rows) {
 #pragma unroll
@@ -963,14 +983,22 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 }
             }
         };
-        const bool any_rows = __builtin_amdgcn_ballot_w64(robot_rows || body_rows) != 0ull;
+        bool any_rows = __builtin_amdgcn_ballot_w64(robot_rows || body_rows) != 0ull;
+#ifdef M3_PABL_NO_SOLVE
+        any_rows = false;
+#endif
         if (any_rows) {
             if (robot_rows) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) if (rs[s].on) robot_solve(s, rs[s], true);
             }
-            for (int pass = 0; pass <= sc.iters; ++pass) {      // the last sweep: the contacts alone (isaacgym_wrapper.py:29)
-                if (robot_rows && pass < sc.iters) {
+#ifdef M3_PABL_ITERS
+            const int n_iters = M3_PABL_ITERS;
+#else
+            const int n_iters = sc.iters;
+#endif
+            for (int pass = 0; pass <= n_iters; ++pass) {      // the last sweep: the contacts alone (isaacgym_wrapper.py:29)
+                if (robot_rows && pass < n_iters) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) {
                         if (held && i >= 7) continue;
