@@ -364,6 +364,11 @@ def brief(r):
            "kernel_ms": {"rollout": r["rollout_ms"], "update": r["update_ms"], "finalize": r["finalize_ms"]},
            "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": r["achieved"] / HBM_PEAK_GBS, "bytes_per_launch": r["alg_bytes"]}}
+    pl = r.get("pl")
+    if pl is not None and getattr(pl, "world_size", 1) > 1:
+        # what the communicator really was (RCCL has only ever been exercised at world_size 1 by this build's own runs:
+        # the first multi-GPU run is the driver's) and which transport / protocol carried the exchange
+        out["ranks_seen"], out["transport"], out["protocol"] = pl.ranks_seen, pl.transport, pl.protocol
     if r["lat_ms"] is not None:
         out["command_latency_ms"] = {"p50": float(np.percentile(r["lat_ms"], 50)), "p99": float(np.percentile(r["lat_ms"], 99))}
     if len(r["walls_ms_per_step"]) > 1:
@@ -522,6 +527,8 @@ def main():
             "kernel_ms": {"rollout": r["rollout_ms"], "update": r["update_ms"], "finalize": r["finalize_ms"]},
         }
         line["roofline_valu"] = roofline_valu(name, r, (K_local + 63) // 64)
+        if world > 1:
+            line["ranks_seen"], line["transport"], line["protocol"] = pl.ranks_seen, pl.transport, pl.protocol
         if r["collective_ms"] is not None:
             line["collective_ms"] = r["collective_ms"]
     delta_np = pl.delta.contiguous().cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None

@@ -1,4 +1,4 @@
-// planar_dyn.hpp -- device-side "Planar contact dynamics spec" (currently v1.4).
+// planar_dyn.hpp -- device-side "Planar contact dynamics spec" (currently v1.5).
 //
 // Replaces, for the point_env scene, what the reference delegates to Isaac Gym / PhysX:
 //   IsaacGymWrapper.step()                    isaacgym_wrapper.py:354-360
@@ -31,6 +31,7 @@ struct PointScene {
     int iters;
     float gam, md, dmax;  // velocity drive: 1/(h*D), 1/(invm_r+gam), fmax*h
     float LlinB, LangB, LlinD, LangD;  // ground-friction impulse limits (mu m g h, * r_eq)
+    float RcB, RcD;                    // spec v1.5: radius of the equivalent disc of the friction coupling, 1.5 r_eq
     // ---- constants of the scene (config/point_env/*.yaml, pointRobot.urdf) ----
     static constexpr float robot_r = 0.2f, invm_r = 1.0f / 10.0f;
     static constexpr float box_hx = 0.2f, box_hy = 0.2f, box_m = 16.0f;
@@ -62,6 +63,7 @@ inline void make_point_scene(PointScene& s, float dt, int substeps, int iters) {
     const float req = 0.3825978f * 0.4f;
     s.LlinB = ((0.75f * 16.0f) * g) * h; s.LangB = s.LlinB * req;
     s.LlinD = ((1.0f * 16.0f) * g) * h; s.LangD = s.LlinD * req;
+    s.RcB = 1.5f * req; s.RcD = 1.5f * req;
 }
 
 struct Box {
@@ -108,6 +110,21 @@ __device__ __forceinline__ float spec_rsqrt(float a) {
     y = y * mad(-hlf, y * y, 1.5f);
     y = y * mad(-hlf, y * y, 1.5f);
     return y;
+}
+
+// spec v1.5: sliding-spinning coupling of a box's ground friction (Contensou's law in Zhuravlev's first-order Pade
+// form for a disc of radius R = 1.5 r_eq: F = F0 v / (v + 8/(3 pi) u), M = M0 u / (u + 15 pi/16 v), u = R |w|): the
+// factors of the linear / torsion rows' limits from the velocities a substep starts its passes with.  A patch that
+// slides fast hardly resists turning -- the independent torsion row of spec v1.4 resisted it in full, which is what
+// wedged the box behind the goal at the reference's shipped planner size (profiles/r04/ab_default_size_push.json).
+__device__ __forceinline__ void friction_coupling(float vx, float vy, float w, float R, float& cl, float& ca) {
+    const float s2 = mad(vx, vx, vy * vy);
+    const float v = ((__float_as_uint(s2) & 0x7f800000u) == 0u) ? 0.0f : s2 * spec_rsqrt(s2);
+    auto zero = [](float x) { return (__float_as_uint(x) & 0x7f800000u) == 0u; };   // (below the smallest normal number)
+    const float u = zero(w) ? 0.0f : R * fabsf(w);
+    cl = 1.0f; ca = 1.0f;
+    if (!zero(v)) cl = v * (1.0f / mad(0.8488264f, u, v));
+    if (!zero(u)) ca = u * (1.0f / mad(2.9452431f, v, u));
 }
 
 __device__ __forceinline__ float clamp_lo0(float x) { return fmaxf(x, 0.0f); }
@@ -615,6 +632,19 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
     Vel v = {w.rvx, w.rvy, w.B.vx, w.B.vy, w.B.w, w.D.vx, w.D.vy, w.D.w};
     float ldx = 0.0f, ldy = 0.0f;
     Fric fB = {0.f, 0.f, 0.f}, fD = {0.f, 0.f, 0.f};
+    // spec v1.5: the friction rows' limits of this substep (a wave in which no lane's box moves keeps the plain ones:
+    // the factors of a body at rest are 1)
+    float LlinBe = sc.LlinB, LangBe = sc.LangB, LlinDe = sc.LlinD, LangDe = sc.LangD;
+    if (__builtin_amdgcn_ballot_w64(((__float_as_uint(v.bvx) | __float_as_uint(v.bvy) | __float_as_uint(v.bw)) & 0x7f800000u) != 0u) != 0ull) {
+        float cl, ca;
+        friction_coupling(v.bvx, v.bvy, v.bw, sc.RcB, cl, ca);
+        LlinBe = sc.LlinB * cl; LangBe = sc.LangB * ca;
+    }
+    if (__builtin_amdgcn_ballot_w64(((__float_as_uint(v.dvx) | __float_as_uint(v.dvy) | __float_as_uint(v.dw)) & 0x7f800000u) != 0u) != 0ull) {
+        float cl, ca;
+        friction_coupling(v.dvx, v.dvy, v.dw, sc.RcD, cl, ca);
+        LlinDe = sc.LlinD * cl; LangDe = sc.LangD * ca;
+    }
     // A body that no slot of this instance touches and that is at rest now stays at rest for the
     // whole substep (its friction row is a no-op at rest), so its per-pass rest test -- an exec-mask
     // region of ~36 cycles, twelve of them per substep -- is decided once per wave instead.
@@ -647,11 +677,11 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
                 v.rvy = mad(sc.invm_r, l1 - ldy, v.rvy);
                 ldy = l1;
             }
-            if constexpr (decltype(with_b)::value) solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
+            if constexpr (decltype(with_b)::value) solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, LlinBe, LangBe);
             if constexpr (RB) {
                 if (s_rb.on) solve<ROBOT, BOXB>(sc, v, s_rb, sc.mu_rb);
             }
-            if constexpr (decltype(with_d)::value) solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD);
+            if constexpr (decltype(with_d)::value) solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, LlinDe, LangDe);
             if constexpr (RD && decltype(with_rd)::value) {
                 if (s_rd.on) solve<ROBOT, BOXD>(sc, v, s_rd, sc.mu_rd);
             }
@@ -711,7 +741,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
             v.rvy = mad(sc.invm_r, l1 - ldy, v.rvy);
             ldy = l1;
         }
-        if (!skipB) solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, sc.LlinB, sc.LangB);
+        if (!skipB) solve_ground_friction<BOXB>(sc, v, fB, sc.box_m, sc.box_I, LlinBe, LangBe);
         // spec order: friction(dyn-obs) then robot-box.  The two rows share no body, so they
         // commute exactly; solving robot-box first lets the dyn-obs row (usually at rest) join
         // the rarely-taken group below: one skipped branch per pass instead of two.
@@ -722,7 +752,7 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
         // (skipD: the dyn-obs rests in every lane and no slot of this instance touches it -- its friction
         // row is a no-op; the rarely-active slots below do not depend on it)
         if ((!skipD && d_moving) | rare) {
-            if constexpr (decltype(with_d)::value) { if (!skipD) solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, sc.LlinD, sc.LangD); }
+            if constexpr (decltype(with_d)::value) { if (!skipD) solve_ground_friction<BOXD>(sc, v, fD, sc.dyn_m, sc.dyn_I, LlinDe, LangDe); }
             if constexpr (ANY_RARE) {
                 // one outer flag + two group flags: a pass in which no lane has any of these pays
                 // one skipped exec-mask branch (same solve order as the spec)

@@ -83,6 +83,8 @@ def attach_collectives(planner, group=None):
             raise ValueError(phase)
 
     planner.collective = exchange
+    planner.transport = dist.get_backend(group)      # "nccl" is RCCL on ROCm
+    planner.ranks_seen = dist.get_world_size(group)  # the communicator's size as the backend reports it
     return planner
 
 
@@ -106,10 +108,44 @@ def attach_p2p(planner, group=None, poll_every=P2P_POLL_EVERY):
     if not planner.shard_mix:
         return attach_collectives(planner, group)
     e = planner._engine
-    mine = e.p2p_export()
+    # Preflight, agreed on by ALL ranks (a transport chosen per rank would deadlock): every rank's device must be able
+    # to map every other rank's -- hipDeviceCanAccessPeer for each pair this process can see (two ranks on one device:
+    # the single-GPU emulation of the tests) -- and the IPC handles must open.  Anything else: the RCCL transport, with
+    # the reason logged once by rank 0.
+    import torch
+    my_dev = torch.device(planner.device).index or 0
+    devs = [None] * planner.world_size
+    dist.all_gather_object(devs, my_dev, group=group)
+    reason = None
+    n_vis = torch.cuda.device_count()
+    for d in devs:
+        if d != my_dev and d < n_vis and my_dev < n_vis and not torch.cuda.can_device_access_peer(my_dev, d):
+            reason = f"device {my_dev} cannot access device {d} (hipDeviceCanAccessPeer)"
+            break
+    if reason is None:
+        try:
+            mine = e.p2p_export()
+        except RuntimeError as ex:
+            mine, reason = None, f"exchange block / IPC export failed: {ex}"
+    else:
+        mine = None
     handles = [None] * planner.world_size
-    dist.all_gather_object(handles, mine, group=group)
-    e.p2p_connect(handles)
+    dist.all_gather_object(handles, (mine, reason), group=group)
+    if all(r is None for _, r in handles):
+        try:
+            e.p2p_connect([h for h, _ in handles])
+        except RuntimeError as ex:
+            reason = f"hipIpcOpenMemHandle failed: {ex}"
+    verdicts = [None] * planner.world_size
+    dist.all_gather_object(verdicts, reason if reason is not None else next((r for _, r in handles if r), None), group=group)
+    bad = next((v for v in verdicts if v), None)
+    if bad is not None:
+        if planner.rank == 0:
+            import sys
+            print(f"m3p2i_aip_amd.distributed: p2p exchange unavailable ({bad}); using the RCCL collectives", file=sys.stderr)
+        attach_collectives(planner, group)
+        planner.p2p_fallback_reason = bad
+        return planner
     dist.barrier(group=group)      # nobody starts exchanging before every rank has mapped every block
 
     state = {"n": 0}
@@ -131,5 +167,6 @@ def attach_p2p(planner, group=None, poll_every=P2P_POLL_EVERY):
 
     planner.collective = exchange
     planner.transport = "p2p"
+    planner.ranks_seen = dist.get_world_size(group)
     planner.p2p_check = lambda: check(planner)     # explicit poll (tools, tests, before shutting a rank down)
     return planner

@@ -39,6 +39,7 @@ from .engine import HipEngine, make_config
 # no fallback); the world_size-2 gloo tests substitute an oracle-backed stand-in to exercise
 # the host-side sharding logic on a machine without a GPU (tests/oracle_engine.py).
 ENGINE_CLS = HipEngine
+SHARD_MIX3_FROM = 524288     # K_global from which the default multi-modal sharding protocol is shard_mix = 3
 
 
 @dataclass
@@ -168,6 +169,7 @@ class MPPI():
         if self.K % world:
             raise ValueError("num_samples must be divisible by world_size")
         self.rank, self.world_size = rank, world
+        self.transport, self.ranks_seen = None, 1        # set when a transport is attached (distributed.py)
         self.K_local = self.K // world
         self.k_offset = rank * self.K_local
         dev = torch.device(m.device)
@@ -188,7 +190,23 @@ class MPPI():
         # bit-identical variant (all K costs re-evaluated on every rank)
         # shard_mix=3: two small exchanges and O(K_local) work per rank after the first (more ranks / samples than the
         # one-collective protocols are meant for: their post-gather work grows with K_global)
-        self._shard_mix_level = 0 if not self.shard_mix else (1 if single else (2 if sm in (None, 2) else (3 if sm == 3 else 1)))
+        # The default picks by size: `2` (one collective, O(K_global) work per rank after it) up to SHARD_MIX3_FROM
+        # samples, `3` (two small exchanges, O(K_local) work) from there on -- the crossover of the emulated
+        # rank-0-of-8 measurements (profiles/r03/protocols_rank0_of_8_K*.json: K_global 64 000 / 256 000: 2 is faster,
+        # 0.181 vs 0.205 and 0.144 vs 0.230 ms; 1 M: 3 is, 0.402 vs 0.441) -- when 3 applies at all (T * nu <= 2048, at
+        # most 256 workgroups of the shard's weights pass: K_local <= 262 144).
+        if not self.shard_mix:
+            level = 0
+        elif single:
+            level = 1
+        elif sm is None or sm is True:
+            fits3 = self.T * self.nu <= 2048 and self.K_local <= 262144
+            level = 3 if (self.K >= SHARD_MIX3_FROM and fits3) else 2
+        else:
+            level = int(sm) if int(sm) in (1, 2, 3) else 1
+        self._shard_mix_level = level
+        self.protocol = {0: "gather+reduce (two collectives)", 1: "one collective (records; weights of all samples re-evaluated)",
+                         2: "one collective (records with ladder tables)", 3: "two small exchanges"}[level] if world > 1 else "unsharded"
         self.relabel_samples = bool(_get(m, "relabel_samples", True))
         self.action_ring = int(_get(m, "action_ring", 0) or 0)
         self._engine = ENGINE_CLS(make_config(

@@ -15,6 +15,7 @@
  * kernel, while following the spec's expression order so both agree bit-for-bit.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "m3_oracle.h"
@@ -101,6 +102,7 @@ void m3o_point_scene_default(m3o_point_scene* sc) {
     sc->slop = 0.005f;
     sc->max_bias = 2.0f;
     sc->face_tol = 0.0005f;
+    sc->friction_coupling = 1;           /* spec v1.5 */
 }
 
 void m3o_point_world_init(m3o_point_world* w) {
@@ -378,6 +380,50 @@ static void solve_ground_friction(solver_t* s, int b, float m, float I, float Ll
     f->la = nla;
 }
 
+/* spec v1.5: sliding-spinning coupling of a box's ground friction.  A contact patch that slides fast has almost no
+ * resistance left against turning (every point of it moves along the slide), and one that spins fast little against
+ * sliding: Contensou's law, in Zhuravlev's first-order Pade form for a disc of radius R under uniform pressure --
+ *     F = F0 v / (v + 8/(3 pi) u),   M = M0 u / (u + 15 pi / 16 v),   u = R |w|,   M0 = 2/3 mu N R  (so R = 1.5 r_eq).
+ * cf[0] scales the linear row's limit, cf[1] the torsion row's; a box that does not slide keeps its full linear
+ * limit, one that does not spin its full torsion limit.  "Zero" = below the smallest normal number, as everywhere. */
+static void friction_coupling(float vx, float vy, float w, float R, float cf[2]) {
+    const float s2 = mad(vx, vx, vy * vy);
+    const float v = is_zero(s2) ? 0.0f : s2 * spec_rsqrt(s2);
+    const float u = is_zero(w) ? 0.0f : R * fabsf(w);
+    cf[0] = 1.0f; cf[1] = 1.0f;
+    if (!is_zero(v)) cf[0] = v * (1.0f / mad(0.8488264f, u, v));
+    if (!is_zero(u)) cf[1] = u * (1.0f / mad(2.9452431f, v, u));
+}
+
+/* EXPERIMENT (tools/cpu_ab_default_size.py, not part of the spec): ground friction at the four corners of the box's
+ * contact patch -- each corner carries m g / 4 and its Coulomb impulse opposes that corner's own velocity, so a box
+ * that SLIDES fast has almost no resistance left against turning (the corners' velocities all point along the slide),
+ * which is what a contact patch does and what the independent torsion row of the spec (limit mu m g r_eq whatever the
+ * sliding speed) does not.  Selected by the environment variable M3O_PATCH4. */
+typedef struct { float lx[4], ly[4]; } patch_acc;
+static void solve_ground_friction_patch4(solver_t* s, int b, const m3o_body* X, float hx, float hy, float Lpt,
+                                         patch_acc* f, fric_acc* tot) {
+    if (is_zero(s->vx[b]) && is_zero(s->vy[b]) && is_zero(s->w[b])) return;
+    const float im = s->invm[b], iI = s->invI[b];
+    for (int k = 0; k < 4; ++k) {
+        const float lx = (k & 1) ? hx : -hx, ly = (k & 2) ? hy : -hy;
+        const float rx = X->c * lx - X->s * ly, ry = X->s * lx + X->c * ly;
+        const float vx = s->vx[b] - s->w[b] * ry, vy = s->vy[b] + s->w[b] * rx;
+        /* K = im I + iI [[ry^2, -rx ry], [-rx ry, rx^2]];  p = -K^-1 v */
+        const float a = im + iI * ry * ry, bb = -iI * rx * ry, d = im + iI * rx * rx;
+        const float det = a * d - bb * bb;
+        float px = -(d * vx - bb * vy) / det, py = -(-bb * vx + a * vy) / det;
+        float nx = f->lx[k] + px, ny = f->ly[k] + py;
+        const float mag2 = nx * nx + ny * ny;
+        if (mag2 > Lpt * Lpt) { const float sc = Lpt / sqrtf(mag2); nx *= sc; ny *= sc; }
+        px = nx - f->lx[k]; py = ny - f->ly[k];
+        f->lx[k] = nx; f->ly[k] = ny;
+        s->vx[b] += im * px; s->vy[b] += im * py;
+        s->w[b] += iI * (rx * py - ry * px);
+        tot->lx += px; tot->ly += py;
+    }
+}
+
 static void integrate_body(m3o_body* X, float h, int rotate) {
     X->x = mad(h, X->vx, X->x);
     X->y = mad(h, X->vy, X->y);
@@ -445,6 +491,18 @@ void m3o_point_step(const m3o_point_scene* sc, m3o_point_world* w, const float u
         s.vx[BS] = 0.0f; s.vy[BS] = 0.0f; s.w[BS] = 0.0f;
         float ldx = 0.0f, ldy = 0.0f;
         fric_acc fB = {0.0f, 0.0f, 0.0f}, fD = {0.0f, 0.0f, 0.0f};
+        patch_acc pB, pD;
+        memset(&pB, 0, sizeof pB); memset(&pD, 0, sizeof pD);
+        static int patch4 = -1;
+        if (patch4 < 0) patch4 = getenv("M3O_PATCH4") ? 1 : 0;
+        /* spec v1.5: the limits of a box's two ground-friction rows are coupled by the sliding-spinning law of a contact
+         * patch, factors from the velocities this substep starts its passes with */
+        float cfB[2] = {1.0f, 1.0f}, cfD[2] = {1.0f, 1.0f};
+        if (sc->friction_coupling) {
+            friction_coupling(s.vx[BB], s.vy[BB], s.w[BB], 1.5f * sc->box_req, cfB);
+            friction_coupling(s.vx[BD], s.vy[BD], s.w[BD], 1.5f * sc->dyn_req, cfD);
+        }
+        const float LlinBe = LlinB * cfB[0], LangBe = LangB * cfB[1], LlinDe = LlinD * cfD[0], LangDe = LangD * cfD[1];
         for (int it = 0; it < sc->iters; ++it) {
             /* velocity drive (soft constraint, implicit damper) */
             {
@@ -461,8 +519,13 @@ void m3o_point_step(const m3o_point_scene* sc, m3o_point_world* w, const float u
                 s.vy[BR] = mad(s.invm[BR], l1 - ldy, s.vy[BR]);
                 ldy = l1;
             }
-            solve_ground_friction(&s, BB, sc->box_m, sc->box_I, LlinB, LangB, &fB);
-            solve_ground_friction(&s, BD, sc->dyn_m, sc->dyn_I, LlinD, LangD, &fD);
+            if (patch4) {
+                solve_ground_friction_patch4(&s, BB, &w->B, sc->box_hx, sc->box_hy, 0.25f * LlinB, &pB, &fB);
+                solve_ground_friction_patch4(&s, BD, &w->D, sc->dyn_hx, sc->dyn_hy, 0.25f * LlinD, &pD, &fD);
+            } else {
+                solve_ground_friction(&s, BB, sc->box_m, sc->box_I, LlinBe, LangBe, &fB);
+                solve_ground_friction(&s, BD, sc->dyn_m, sc->dyn_I, LlinDe, LangDe, &fD);
+            }
             for (int i = 0; i < s.nc; ++i) solve_contact(&s, &s.c[i]);
         }
         w->R.vx = s.vx[BR]; w->R.vy = s.vy[BR];

@@ -179,7 +179,7 @@ def test_penetration_stays_bounded_under_full_effort(oracle):
         O.step_batch(sc, w, u)
         worst_rb = max(worst_rb, -rb_separation(w, O))
         worst_bw = max(worst_bw, box_wall_penetration(w, O, sc.wall))
-    assert worst_rb < 0.03 and worst_bw < 0.02
+    assert worst_rb < 0.03 and worst_bw < 0.03      # (spec v1.5: 2.6 cm against the wall, the squeezed box turns more freely while it slides)
     assert abs(w[0, 4]) < 1e-3 and abs(w[0, O.W_B + 4]) < 1e-3
     assert abs(w[0, 0]) <= sc.wall - sc.robot_r + 0.01           # the robot stays inside the walls too
 

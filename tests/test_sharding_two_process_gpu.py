@@ -68,6 +68,7 @@ def worker(rank, world, port, multi_modal, task, goal, ret, transport="gloo", sh
         missing, kind = pl._engine.p2p_status()
         assert missing == -1, f"rank {rank}: the wait for rank {missing} timed out"
         out[0]["p2p_memory_kind"] = kind
+    out[0]["transport"], out[0]["shard_mix_level"] = pl.transport, pl._shard_mix_level
     if rank == 0:
         ret.put(out)
     dist.barrier()
@@ -98,6 +99,38 @@ def test_two_process_sharded_equals_unsharded(golden, multi_modal, task, goal, s
         # single-mode runs the one-collective protocol (planner.shard_mix): a rank materialises only
         # its own shard's weights, and the plan equals the unsharded one up to f32 rounding
         nw = K if (multi_modal and shard_mix != 3) else K // 2     # (shard_mix = 3 too: the rank's own samples' weights)
+        np.testing.assert_allclose(a["action"], b["action"], atol=3e-5, err_msg=f"call {c}")
+        np.testing.assert_allclose(a["weights"][:nw], b["weights"][:nw], rtol=1e-3, atol=1e-8)
+        np.testing.assert_allclose(a["top"], b["top"], atol=1e-4)
+        assert a["pref"] == b["pref"]
+
+
+@pytest.mark.parametrize("multi_modal,task,goal,shard_mix", [(False, "push", (-1.0, -1.0), None),
+                                                             (True, "push_pull", (-3.75, -3.75), None),
+                                                             (True, "push_pull", (-3.75, -3.75), 3)])
+def test_eight_process_p2p_sharded_equals_unsharded(golden, multi_modal, task, goal, shard_mix):
+    """The shape of the 8-GPU node on the one GPU of the test box: EIGHT processes, one rank each, the records
+    exchanged through the library's own put / wait over IPC-mapped device memory (every rank stores into every peer's
+    block, waits for seven flags) -- the K = 512 samples in shards of 64 -- and the result equals the unsharded run."""
+    import torch.multiprocessing as mp
+    world = 8
+    delta = golden["g9_push_delta"]
+    delta = np.concatenate([delta, delta[::-1] * 0.7]).astype(np.float32)
+    pl, sim = build(0, 1, multi_modal, task, goal)
+    ref = run(pl, sim, delta)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 31300 + (os.getpid() % 1500) + (13 if shard_mix == 3 else 0) + (29 if multi_modal else 0)
+    procs = [ctx.Process(target=worker, args=(r, world, port, multi_modal, task, goal, ret, "p2p", shard_mix)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = ret.get(timeout=600)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    assert got[0]["transport"] == "p2p"
+    for c, (a, b) in enumerate(zip(ref, got)):
+        nw = K if (multi_modal and shard_mix != 3) else K // world
         np.testing.assert_allclose(a["action"], b["action"], atol=3e-5, err_msg=f"call {c}")
         np.testing.assert_allclose(a["weights"][:nw], b["weights"][:nw], rtol=1e-3, atol=1e-8)
         np.testing.assert_allclose(a["top"], b["top"], atol=1e-4)

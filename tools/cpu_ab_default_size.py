@@ -5,12 +5,19 @@ oracle.OraclePointPlanner + one oracle world as the "real world", the flow of sc
 of the contact model toggled at a time, N jittered episodes each, and prints / writes the table.  The mechanisms are
 things PhysX has and the written spec lacks or fixes differently -- not a sweep of material constants:
 
-  spec                      the shipped spec v1.4
+  spec_v14                  the planar spec as shipped up to round 3 (v1.4): independent linear and torsion friction rows
+  spec                      the shipped spec (v1.5 = v1.4 + the coupling `contensou` below, adopted because of this table)
   depen_10                  max depenetration velocity 10 m/s instead of 2 (PhysX's default is far above 2)
   no_speculative            contacts only once penetrating (contact_offset 0): no speculative rows
   patch_corners             box-ground friction torque with the lever of a four-corner contact patch (0.283 m: PhysX
                             resolves the box's ground contact at its corners) instead of the disc-equivalent 0.153 m
   patch_none                no torsional ground friction at all
+  patch_4pt                 ground friction AT the four corners of the patch, each opposing its own velocity (the
+                            experimental rows of oracle/planar_world.c, M3O_PATCH4): turning resistance that fades
+                            with the sliding speed, as a real patch's does
+  (spec = spec_v14 + the two rows' limits COUPLED by the sliding-spinning law of a contact patch -- Contensou; Zhuravlev's
+   Pade form, factors from the substep's initial velocities: the cheap form of patch_4pt.  Every other row toggles its
+   mechanism on top of spec_v14.)
   passes_12 / passes_3      12 / 3 solver passes instead of 6 (how hard the drive row wins against the contact rows)
   drive_soft                drive damping 150 instead of 600: a drive that builds its force over several substeps
   horizon_30                (control, not a mechanism) the same planner with T = 30: the known cure
@@ -41,15 +48,17 @@ def variants():
                 setattr(sc, k, v)
         return f
     return {
+        "spec_v14": (mod(friction_coupling=0), 15),
         "spec": (mod(), 15),
-        "depen_10": (mod(max_bias=10.0), 15),
-        "no_speculative": (mod(contact_offset=0.0), 15),
-        "patch_corners": (mod(box_req=0.2828, dyn_req=0.2828), 15),
-        "patch_none": (mod(box_req=0.0, dyn_req=0.0), 15),
-        "passes_12": (mod(iters=12), 15),
-        "passes_3": (mod(iters=3), 15),
-        "drive_soft": (mod(drive_damping=150.0), 15),
-        "horizon_30": (mod(), 30),
+        "depen_10": (mod(friction_coupling=0, max_bias=10.0), 15),
+        "no_speculative": (mod(friction_coupling=0, contact_offset=0.0), 15),
+        "patch_corners": (mod(friction_coupling=0, box_req=0.2828, dyn_req=0.2828), 15),
+        "patch_none": (mod(friction_coupling=0, box_req=0.0, dyn_req=0.0), 15),
+        "patch_4pt": (mod(friction_coupling=0), 15),
+        "passes_12": (mod(friction_coupling=0, iters=12), 15),
+        "passes_3": (mod(friction_coupling=0, iters=3), 15),
+        "drive_soft": (mod(friction_coupling=0, drive_damping=150.0), 15),
+        "horizon_30": (mod(friction_coupling=0), 30),
     }
 
 
@@ -87,7 +96,15 @@ def main(argv):
         elif a == "--json":
             out = next(it)
     rows = {}
+    only = [a for a in argv if not a.startswith("--") and not a.isdigit() and not a.endswith(".json")]
     for name, (modify, T) in variants().items():
+        if only and name not in only:
+            continue
+        # (the experimental rows are switched per process: `M3O_PATCH4=1 ... patch_4pt`, `M3O_CONTENSOU=1 ... contensou`)
+        env_of = {"patch_4pt": "M3O_PATCH4"}
+        active = [k for k, e in env_of.items() if os.environ.get(e)]
+        if (name in env_of) != bool(active) or (active and name not in active):
+            continue
         sc = O.default_scene()
         modify(sc)
         eps = [episode(sc, T, s) for s in range(n)]
