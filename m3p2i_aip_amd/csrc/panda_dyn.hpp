@@ -613,6 +613,10 @@ __device__ __forceinline__ void panda_infer_held(const PandaScene& sc, PandaWorl
         w.rel_p[0] = g.cx; w.rel_p[1] = g.cy; w.rel_p[2] = g.cz;
         set_rel_rot(w, hand, g.Rc);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w.warm_t[i] = 0.0f; w.warm_l[i] = 0.0f; }      // nothing is carried over from before the load
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { w.f_table[i] = 0.0f; w.f_shelf[i] = 0.0f; w.f_cubeB[i] = 0.0f; }
     auto still = [](const Body& b) __attribute__((always_inline)) {
         return b.v[0] == 0.0f && b.v[1] == 0.0f && b.v[2] == 0.0f && b.w[0] == 0.0f && b.w[1] == 0.0f && b.w[2] == 0.0f;
     };

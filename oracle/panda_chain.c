@@ -884,6 +884,9 @@ void m3o_panda_infer_held(const m3o_panda_scene* sc, m3o_panda_world* w) {
         }
         mat2quat(&r, w->rel_q);
     }
+    /* nothing is carried over from before the load: no warm-start impulses, no reported forces */
+    for (int i = 0; i < 4; ++i) { w->warm_t[i] = 0.0f; w->warm_l[i] = 0.0f; }
+    for (int i = 0; i < 3; ++i) { w->f_table[i] = 0.0f; w->f_shelf[i] = 0.0f; w->f_cubeB[i] = 0.0f; }
     float* cubes[2] = {w->cubeA, w->cubeB};
     for (int b = 0; b < 2; ++b) {
         int still = 1;

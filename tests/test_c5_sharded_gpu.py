@@ -226,7 +226,7 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
                 assert (i.eta, i.eta_1, i.eta_2, i.wsum_push, i.wsum_pull) == (fi.eta, fi.eta_1, fi.eta_2, fi.wsum_push, fi.wsum_pull)
             else:
                 np.testing.assert_allclose([i.eta, i.eta_1, i.eta_2, i.wsum_push, i.wsum_pull],
-                                           [fi.eta, fi.eta_1, fi.eta_2, fi.wsum_push, fi.wsum_pull], rtol=1e-4, atol=1e-6)
+                                           [fi.eta, fi.eta_1, fi.eta_2, fi.wsum_push, fi.wsum_pull], rtol=5e-4, atol=1e-6)
             if level == 3:   # the weights of the rank's own samples (the other entries are not materialised)
                 h = Kt // 2
                 for name, lo, hi in (("BUF_WEIGHTS", r * kl, (r + 1) * kl), ("BUF_WEIGHTS_1", min(r * kl, h), min((r + 1) * kl, h)),
@@ -244,7 +244,9 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
                     # rounding only, so do their costs, and a cost difference of a few ulp is divided by beta ~ 0.05: 3e-3)
                     np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), rtol=1e-2, atol=1e-8)
                 else:
-                    np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), atol=3e-5,
+                    # (first call: same inputs, summation order only; later calls: the plans the rollouts start from agree to
+                    # 3e-5, and a few of the 32 000 / 64 000 rollouts in contact amplify that -- conftest.assert_close_but_few)
+                    np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), atol=3e-5 if call == 0 else 5e-4,
                                                rtol=1e-4, err_msg=f"call {call} rank {r} {name}")
             if exact:
                 assert torch.equal(e.states, full.states[r * kl:(r + 1) * kl])

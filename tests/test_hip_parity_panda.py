@@ -83,31 +83,25 @@ def test_panda_command_matches_oracle(oracle, task, mm, grip, held):
     eng.close()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(36))
 def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed):
-    """Fuzz: random joint configuration inside the limits, random joint velocities, cubeA anywhere on
-    the table / shelf / in the air (falls), random gripper command and task; strong random controls.
-    The rollout must equal the oracle's bit-for-bit (the lazy kinematics of panda_step decide per wave
-    whether a substep's kinematics can be skipped -- random worlds put cubes at every distance)."""
+    """Fuzz: a random world per seed -- random joint configuration and velocities; cubeA on the table / near the hand /
+    falling onto the shelf / stacked on cubeB (resting, dropped, beyond the edge) / tumbling in the air next to cubeB;
+    cubeB and the plate near the hand, moving; the gripper pointing down with its finger tips at the table or at cubeB;
+    the cube held / the open gripper around it (tests/test_device_dynamics_on_host.random_panda_worlds) --, random
+    gripper command and task, strong random controls.  The rollout must equal the oracle's bit for bit: the contact
+    detection (wave-level rejects, lazy kinematics), the gripper rows, the cubes' manifolds in LDS, sleeping and waking
+    all decide per wave or per lane what to evaluate -- random worlds put everything at every distance."""
     import oracle.panda as P
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
+    from tests.test_device_dynamics_on_host import random_panda_worlds
     rng = np.random.default_rng(500 + seed)
     sc = P.default_scene()
     K, T = 128, 20
     task, grip = [("reach", 1), ("pick", 2), ("place", 1), ("reach", 2)][seed % 4]
-    w0 = P.init_world(1)[0]
-    qlo, qhi = np.array(sc.qlo), np.array(sc.qhi)
-    w0[P.W_Q:P.W_Q + 9] = qlo + rng.uniform(0.05, 0.95, 9) * (qhi - qlo)
-    w0[P.W_QD:P.W_QD + 9] = rng.normal(0, 0.3, 9) * (rng.random() < 0.5)
-    spot = seed % 3
-    if spot == 0:    # on the table, anywhere
-        w0[P.W_CUBEA:P.W_CUBEA + 2] = rng.uniform(-0.5, 0.5, 2)
-    elif spot == 1:  # near the hand: FK of the random configuration, a few cm away
-        Lk = P.fk(sc, w0[P.W_Q:P.W_Q + 9].astype(np.float32))
-        w0[P.W_CUBEA:P.W_CUBEA + 3] = Lk["pos"][8] + rng.uniform(-0.12, 0.12, 3)
-    else:            # in the air above the shelf: falls onto it
-        w0[P.W_CUBEA:P.W_CUBEA + 3] = (0.5 + rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), 1.6)
+    # (the generator cycles through its world kinds by index: take world `seed` of a batch)
+    w0 = random_panda_worlds(P, sc, 42, np.random.default_rng(900 + seed // 42))[seed % 42].copy()
     w0 = w0.astype(np.float32)
     goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
     delta = rng.standard_normal((K, T, 9)).astype(np.float32)
