@@ -33,6 +33,9 @@ def assert_close_but_few(a, b, rtol=0.0, atol=0.0, frac=1e-3, cap=None, err_msg=
     and Coulomb friction are not continuous), which moves a handful of the K rollouts -- and their weights -- by far more
     than the rounding that caused it.  First commands, where the inputs are identical, are compared exactly."""
     a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, f"{err_msg}: shapes {a.shape} vs {b.shape}"
+    if a.size == 0:
+        return
     bad = ~np.isclose(a, b, rtol=rtol, atol=atol)
     allowed = max(1, int(frac * bad.size))
     assert bad.sum() <= allowed, f"{err_msg}: {int(bad.sum())} of {bad.size} elements differ (allowed {allowed}), max |d| = {np.abs(a - b).max():.3g}"

@@ -83,6 +83,16 @@ def test_panda_command_matches_oracle(oracle, task, mm, grip, held):
     eng.close()
 
 
+import functools  # noqa: E402
+
+
+@functools.lru_cache(maxsize=4)
+def _fuzz_batch(b):
+    import oracle.panda as P
+    from tests.test_device_dynamics_on_host import random_panda_worlds
+    return random_panda_worlds(P, P.default_scene(), 42, np.random.default_rng(900 + b))
+
+
 @pytest.mark.parametrize("seed", range(36))
 def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed):
     """Fuzz: a random world per seed -- random joint configuration and velocities; cubeA on the table / near the hand /
@@ -95,14 +105,12 @@ def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed):
     import oracle.panda as P
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
-    from tests.test_device_dynamics_on_host import random_panda_worlds
     rng = np.random.default_rng(500 + seed)
     sc = P.default_scene()
     K, T = 128, 20
     task, grip = [("reach", 1), ("pick", 2), ("place", 1), ("reach", 2)][seed % 4]
     # (the generator cycles through its world kinds by index: take world `seed` of a batch)
-    w0 = random_panda_worlds(P, sc, 42, np.random.default_rng(900 + seed // 42))[seed % 42].copy()
-    w0 = w0.astype(np.float32)
+    w0 = _fuzz_batch(seed // 42)[seed % 42].copy().astype(np.float32)
     goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
     delta = rng.standard_normal((K, T, 9)).astype(np.float32)
     cfg = P.make_cfg(K, T, multi_modal=False, task=task, goal=goal, gripper_cmd=grip)
