@@ -732,7 +732,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         if (near || bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }
         if (near) {
             float pl[3], pr[3];
-            panda_fk<false>(sc, w.q, g.hand, pl, pr, nullptr);
+            // (with the arm's Jacobian columns: keeping the joint axes and origins costs ~60 instructions on top of the
+            // chain's ~400; a second pass over the chain for the lanes that turn out to have a candidate cost all 400)
+            panda_fk<false, true>(sc, w.q, g.hand, pl, pr, nullptr, &g);
             if constexpr (LAZY) { hp[0] = g.hand.p[0]; hp[1] = g.hand.p[1]; hp[2] = g.hand.p[2]; *trav = 0.0f; }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -798,10 +800,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
             const bool cand = rs[0].target >= 0 || rs[1].target >= 0 || rs[2].target >= 0 || rs[3].target >= 0;
             if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
-                // some lane has a candidate: the arm's Jacobian columns (a second pass over the chain, this time keeping
-                // the joint axes and origins), then culling, rows, effective masses
-                Frame h2;
-                panda_fk<false, true>(sc, w.q, h2, pl, pr, nullptr, &g);
+                // some lane has a candidate: culling, rows, effective masses
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     RSlot& c = rs[s];

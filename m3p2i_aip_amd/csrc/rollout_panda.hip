@@ -70,8 +70,9 @@ template <bool FORCES, bool GENERAL>
 __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, const PandaArgs pa,
                                                       const PandaScene sc_) {
     PANDA_CORNER_LDS();
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a_.Kl) return;
+    // (a_.lanes samples per 64-wide wavefront: m3_set_rollout_lanes; the idle lanes leave at once)
+    const int i = blockIdx.x * a_.lanes + threadIdx.x;
+    if ((int)threadIdx.x >= a_.lanes || i >= a_.Kl) return;
     // The per-joint constants (bounds, noise scale, servo coefficients: 54 floats) are uniform, but
     // there are not enough scalar registers to keep them across the step loop, and the compiler
     // re-read them from the kernel arguments every step (~12 scalar loads per step, each followed by
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
 }
 
 void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
-    const dim3 grid((a.Kl + 63) / 64), block(64);
+    const int lanes = (a.lanes >= 1 && a.lanes <= 64) ? a.lanes : 64;
+    const dim3 grid((a.Kl + lanes - 1) / lanes), block(64);
     if (a.sampling_random || a.mode_simple) {
         if (pa.cp.task == 5) hipLaunchKernelGGL((k_rollout_panda<true, true>), grid, block, 0, s, a, pa, sc);
         else hipLaunchKernelGGL((k_rollout_panda<false, true>), grid, block, 0, s, a, pa, sc);

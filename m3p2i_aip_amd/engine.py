@@ -95,6 +95,8 @@ class HipEngine:
         self.use_torch_stream()
         if os.environ.get("M3P2I_WAVE_ORDER", "1") == "0":   # experiments (tools/): samples to wavefronts by index
             self.set_wave_order(False)
+        if os.environ.get("M3P2I_ROLLOUT_LANES"):            # experiments (tools/panda_lanes_sweep.py)
+            self.set_rollout_lanes(int(os.environ["M3P2I_ROLLOUT_LANES"]))
 
     # ---- lifetime ----
     def close(self):
