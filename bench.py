@@ -135,6 +135,19 @@ def corner_scene(pl, sim, obj, cfg):
     sim.set_actor_root_state_tensor(sim._root_state)
 
 
+def settled_panda_scene(pl, sim, obj, cfg):
+    """The configured panda_env scene after the cubes have landed: the yaml files start cubeA and cubeB 1 cm above the
+    table (5_cubeA.yaml, 6_cubeB.yaml), so in the INITIAL scene every rollout first simulates two cubes falling and
+    settling (awake free bodies: corner contacts in every pass) -- true of the first commands of an episode only.  Thirty
+    ticks of the zero action in the 1-env sense (here: every env of the wrapper) put them to sleep on the table."""
+    z = torch.zeros(sim.num_envs, 9, device=sim._dof_state.device)
+    for _ in range(30):
+        sim.set_dof_velocity_target_tensor(z)
+        sim.step()
+    sim.set_dof_state_tensor(sim._dof_state)
+    sim.set_actor_root_state_tensor(sim._root_state)
+
+
 def panda_pick_scene(device):
     """The scene C4's pick phase starts in, produced by the PRODUCT: the closed loop of tools/closed_loop.py
     (1-env world + planner K=4000, T=20 + the active-inference task planner) is run through its reach phase
@@ -601,6 +614,7 @@ def main():
         except Exception as e:
             others["panda_pick"] = {"error": repr(e)}
         for oname, key, scene in (("northstar", "northstar", None), ("hybrid", "hybrid", None), ("panda", "panda", None),
+                                  ("panda", "panda_settled", settled_panda_scene),
                                   ("panda_pick", "panda_pick", pick_scene), ("c5", "c5shard", None),
                                   ("c5_unsharded", "c5_unsharded", None), ("worst_case", "worst_case_scene", corner_scene),
                                   ("c1", "c1", None), ("refsize", "reference_default_size", None)):
@@ -612,6 +626,12 @@ def main():
                 others[key] = brief(ro)
                 if oname == "hybrid":
                     others[key]["closed_loop"] = closed_loop(ro, 200, device)
+                if key == "panda":
+                    others[key]["workload"] += (" -- C4's reach phase in the INITIAL scene: the cubes start 1 cm above the table and "
+                                                "every rollout simulates them landing (world spec v2: free bodies)")
+                if key == "panda_settled":
+                    others[key]["workload"] += (" -- C4's reach phase once the cubes have landed and sleep (every command of an "
+                                                "episode but the first few)")
                 if oname == "panda_pick":
                     others[key]["workload"] += (" -- C4's pick phase: scene = 12 ticks into `pick` of the product's own closed "
                                                 "loop (cube held), gripper override close, k_rollout_panda<FORCES=true>")

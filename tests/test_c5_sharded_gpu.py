@@ -284,6 +284,47 @@ def test_p2p_wait_gives_up_on_a_missing_peer_instead_of_hanging():
         e.close()
 
 
+@pytest.mark.parametrize("memory", [None, "finegrained", "plain"])
+def test_p2p_missed_exchange_poisons_the_plan_and_the_fallback_memory_kinds_work(memory, monkeypatch):
+    """ A wait that gives up must not let the command finish on stale or zeroed records: the missing rank's
+    slot is filled with NaN, so THIS command's plan is NaN on the rank that missed it (and `p2p_status` names the rank;
+    `distributed.attach_p2p` polls it).  And the exchange works on every kind of block the allocation chain can end on:
+    uncached (1), fine-grained (2: fences as for plain memory since round 4), plain device memory (3) -- forced through
+    M3P2I_P2P_MEMORY."""
+    import torch
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    if memory:
+        monkeypatch.setenv("M3P2I_P2P_MEMORY", memory)
+    kw = dict(T=T, nu=2, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+    shards = [HipEngine(make_config(K=512, K_local=256, k_offset=r * 256, shard_mix=1, **kw)) for r in range(2)]
+    g = torch.Generator().manual_seed(3)
+    delta = torch.randn(512, T, 2, generator=g).numpy()
+    for r, e in enumerate(shards):
+        e.set_objective("push", (-1.0, -1.0))
+        e.set_noise(delta[r * 256:(r + 1) * 256])
+        e.p2p_connect_local(shards)
+        e.p2p_set_timeout_ms(first_ms=400, ms=400)
+    want_kind = {None: (1, 2, 3), "finegrained": (2, 3), "plain": (3,)}[memory]
+    # a complete exchange first: both ranks put, both wait -> finite, identical plans
+    for e in shards:
+        e.rollout(); e.update(); e.p2p_put()
+    for e in shards:
+        e.p2p_wait(); e.finalize()
+    torch.cuda.synchronize()
+    plans = [e.buffer(L.BUF_ACTION_OUT).cpu().numpy() for e in shards]
+    assert np.isfinite(plans[0]).all() and np.array_equal(plans[0], plans[1])
+    assert all(e.p2p_status()[0] == -1 and e.p2p_status()[1] in want_kind for e in shards)
+    # now rank 1 stalls: rank 0's wait gives up, its plan must come out NaN, not a finite one built on the old slot
+    e = shards[0]
+    e.rollout(); e.update(); e.p2p_put(); e.p2p_wait(); e.finalize()
+    torch.cuda.synchronize()
+    assert e.p2p_status()[0] == 1
+    assert np.isnan(e.buffer(L.BUF_ACTION_OUT).cpu().numpy()).any()
+    for e in shards:
+        e.close()
+
+
 def test_one_collective_shard_needs_the_global_noise_table():
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config

@@ -39,7 +39,7 @@ if os.path.exists(s):
     json.dump(json.loads(open(s).read().strip().splitlines()[-1]), open(os.path.join(P, "bench_driver_command_line.json"), "w"), indent=1)
     print("copied bench_driver_command_line.json")
 for f in ("behaviour_stats_baseline.json", "behaviour_stats_default_size.json", "behaviour_stats_panda.json", "halton_scramble.json",
-          "codeobj_info.txt", "mix_push_K2000.json", "mixb_panda_pick.json", "mixb_panda.json", "mixb_worst_case.json"):
+          "codeobj_info.txt", "mix_push_K2000.json", "mix_push.json", "mix_panda_pick.json", "mix_panda.json", "mix_worst_case.json"):
     cp(f, f)
 for f in ("collective_overhead_c5.json", "collective_overhead_push.json", "coop_rows_K2000.json", "phase_breakdown.json",
           "mask_count_closed_loop.json", "closed_loop_perf.json"):
