@@ -840,6 +840,9 @@ extern "C" int m3_rollout(m3_handle* h) {
         std::memcpy(pa.world0, h->pworld0, sizeof(pa.world0));
         pa.cubeA_actor = h->bind_box; pa.cubeB_actor = h->bind_dyn; pa.obs_actor = h->bind_obs;
         fill_panda_cost_params(h, pa.cp);
+        // quirk Q8: the reach cost is measured against environment 0's cube (shadow lanes, rollout_panda.hip); a rank of
+        // a sharded command does not hold sample 0's noise row and uses each sample's own cube
+        pa.shadows = (pa.cp.task == 4 && a.k0 == 0 && a.Kl == a.Kg && a.Kg >= 2) ? (pa.cp.multi_modal ? 2 : 1) : 0;
         launch_rollout_panda(a, pa, h->pscene, h->stream);
     }
     HIPCHK(h, hipGetLastError());

@@ -254,6 +254,7 @@ struct PandaArgs {
     float world0[57];  // q9 qd9 | cubeA13 | cubeB13 | dyn-obs13 (pos3 quat4 vel3 angvel3)
     int cubeA_actor, cubeB_actor, obs_actor;
     PandaCostParams cp;
+    int shadows;       // lanes 63 (sample 0) and 62 (sample K / 2) of every wavefront re-simulate those samples: quirk Q8
 };
 void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s);
 void launch_psim_step(const PandaScene& sc, const SimViews& v, float* world, const float* u, float* u_keep, int Kl,

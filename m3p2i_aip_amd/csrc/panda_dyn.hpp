@@ -1251,14 +1251,15 @@ struct PandaCostParams {
     float pre_height_diff, tilt_cos_theta;
 };
 
-// cube0 / cube_q_half0: cubeA position of env 0 and orientation of the slice's first env
-// (cost_functions.py:97, skill_utils.py:274).  Under spec v1 an un-held cube moves
-// independently of the robot and `reach` keeps the gripper open, so they equal the sample's
-// own cube.
+// cube0 / q_half0: cubeA position of env 0 and orientation of the slice's first env -- what the reference's reach cost
+// reads (cost_functions.py:97 `cube_state[0, :3]`, skill_utils.py:274; quirk Q8).  Under world spec v2 a rollout's
+// gripper can move its cube, so these are NOT the sample's own cube: the rollout kernel carries samples 0 and K / 2 as
+// shadow lanes of every wavefront and reads their cube with v_readlane (rollout_panda.hip); callers that cannot
+// (a rank of a sharded command) pass the sample's own.
 __device__ __forceinline__ float panda_cost(const PandaCostParams& cp, const PandaWorld& w,
-                                            const PandaObs& o, int k) {
+                                            const PandaObs& o, int k, const float* cube0, const float* q_half0) {
     if (cp.task == 4) {  // reach
-        float goal[3] = {w.A.p[0], w.A.p[1], w.A.p[2]};
+        float goal[3] = {cube0[0], cube0[1], cube0[2]};
         if (!cp.multi_modal || k < cp.half_K) {
             goal[2] = goal[2] + cp.pre_height_diff;
         } else {
@@ -1270,7 +1271,7 @@ __device__ __forceinline__ float panda_cost(const PandaCostParams& cp, const Pan
         const float dz = (o.left[2] + o.right[2]) / 2.0f - goal[2];
         const float reach = sqrtf((dx * dx + dy * dy) + dz * dz);
         const float tilt = (cp.multi_modal && k >= cp.half_K) ? cp.tilt_cos_theta : 0.0f;
-        const float ori = ori_ee2cube(o.left_q, w.A.q, tilt, w.A.q);
+        const float ori = ori_ee2cube(o.left_q, w.A.q, tilt, q_half0);
         return 10.0f * reach + 3.0f * ori;
     }
     if (cp.task == 5) {  // pick
@@ -1287,6 +1288,9 @@ __device__ __forceinline__ float panda_cost(const PandaCostParams& cp, const Pan
         return 2.0f * (1.0f - sqrtf((dx * dx + dy * dy) + dz * dz));
     }
     return 0.0f;
+}
+__device__ __forceinline__ float panda_cost(const PandaCostParams& cp, const PandaWorld& w, const PandaObs& o, int k) {
+    return panda_cost(cp, w, o, k, w.A.p, w.A.q);
 }
 
 }  // namespace m3

@@ -71,8 +71,16 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
                                                       const PandaScene sc_) {
     PANDA_CORNER_LDS();
     // (a_.lanes samples per 64-wide wavefront: m3_set_rollout_lanes; the idle lanes leave at once)
-    const int i = blockIdx.x * a_.lanes + threadIdx.x;
-    if ((int)threadIdx.x >= a_.lanes || i >= a_.Kl) return;
+    // Shadow lanes (quirk Q8, pa.shadows = 1 or 2; reach on an unsharded handle): the reference's reach cost measures every
+    // rollout against the cube of ENVIRONMENT 0 (and, for the tilted mode, the orientation of the first environment of the
+    // second half), which under world spec v2 is a quantity of THAT rollout's simulation.  Lane 63 of every wavefront
+    // re-simulates sample 0 and lane 62 sample K / 2 in lockstep with the wavefront's own samples (same noise rows, same
+    // operations, so the same bits in every wavefront); their cubes are read with v_readlane after each step.  They store
+    // nothing.  Cost: 64 / 63 (62) more wavefronts, no cross-wavefront synchronisation.
+    const bool shadow = (int)threadIdx.x >= 64 - pa.shadows;
+    int i = blockIdx.x * a_.lanes + threadIdx.x;
+    if (shadow) i = (threadIdx.x == 63) ? 0 : pa.cp.half_K;
+    else if ((int)threadIdx.x >= a_.lanes || i >= a_.Kl) return;
     // The per-joint constants (bounds, noise scale, servo coefficients: 54 floats) are uniform, but
     // there are not enough scalar registers to keep them across the step loop, and the compiler
     // re-read them from the kernel arguments every step (~12 scalar loads per step, each followed by
@@ -163,13 +171,31 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         }
         PandaObs obs;
         panda_step<FORCES, true>(sc, w, u, obs, cs, hp, &trav);
-        const float c = panda_cost(pa.cp, w, obs, k);
-        *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
-            make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
-        float* ap = a.actions + ((size_t)t * Kl + i) * 9;
+        float cube0[3], qh0[4];
+        if (pa.shadows) {
 #pragma unroll
-        for (int j = 0; j < 9; ++j) ap[j] = e[j];
-        a.cost_h[(size_t)t * Kl + i] = c;
+            for (int j = 0; j < 3; ++j) cube0[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w.A.p[j]), 63));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float q0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w.A.q[j]), 63));
+                const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w.A.q[j]), 62));
+                qh0[j] = first_half ? q0 : q1;     // (one shadow: single mode, the tilt term does not read it)
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cube0[j] = w.A.p[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qh0[j] = w.A.q[j];
+        }
+        const float c = panda_cost(pa.cp, w, obs, k, cube0, qh0);
+        if (!shadow) {
+            *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
+                make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
+            float* ap = a.actions + ((size_t)t * Kl + i) * 9;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) ap[j] = e[j];
+            a.cost_h[(size_t)t * Kl + i] = c;
+        }
         J = J + g * c;
         g = g * a.gamma;
         if constexpr (GENERAL) {
@@ -195,11 +221,14 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
             }
         }
     }
-    a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
+    if (!shadow) a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
 }
 
-void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
-    const int lanes = (a.lanes >= 1 && a.lanes <= 64) ? a.lanes : 64;
+void launch_rollout_panda(const RolloutArgs& a_in, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
+    int lanes = (a_in.lanes >= 1 && a_in.lanes <= 64) ? a_in.lanes : 64;
+    if (lanes > 64 - pa.shadows) lanes = 64 - pa.shadows;
+    RolloutArgs a = a_in;
+    a.lanes = lanes;
     const dim3 grid((a.Kl + lanes - 1) / lanes), block(64);
     if (a.sampling_random || a.mode_simple) {
         if (pa.cp.task == 5) hipLaunchKernelGGL((k_rollout_panda<true, true>), grid, block, 0, s, a, pa, sc);
@@ -366,7 +395,15 @@ __global__ __launch_bounds__(64) void k_psim_cost(const PandaScene sc, const Pan
     PandaObs o;
     panda_fk<false>(sc, w.q, hand, o.left, o.right, nullptr);
     mat2quat(hand, o.left_q);
-    cost[i] = panda_cost(cp, w, o, k0 + i);
+    // quirk Q8: environment 0's cube position, the orientation of the first environment of the sample's half (rows 18-24)
+    float cube0[3], qh0[4];
+    const bool env0 = (cp.task == 4 && k0 == 0 && Kl >= 2);
+    const int src = env0 ? ((cp.multi_modal && i >= cp.half_K) ? cp.half_K : 0) : i;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) cube0[j] = wd[(18 + j) * Kl + (env0 ? 0 : i)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qh0[j] = wd[(21 + j) * Kl + src];
+    cost[i] = panda_cost(cp, w, o, k0 + i, cube0, qh0);
 }
 void launch_psim_cost(const PandaScene& sc, const PandaCostParams& cp, const float* world, int Kl, int k0,
                       float* cost, hipStream_t s) {

@@ -963,6 +963,30 @@ void m3o_panda_rollout(const m3o_cfg* cfg, const m3o_panda_scene* sc, const m3o_
                        const float* act, int k0, int k1, float* states, float* actions,
                        float* cost_h, float* J) {
     const int K = cfg->K, T = cfg->T, nu = 9;
+    /* quirk Q8 (cost_functions.py:97, skill_utils.py:274): the reach cost reads environment 0's cube position and, in the
+       tilted mode, the orientation of the first environment of the second half -- quantities of THOSE rollouts' simulations
+       (a gripper can move its cube).  With all K samples in the call they are simulated first; a partial range (a rank of a
+       sharded command, which does not hold sample 0's noise) uses each sample's own cube, as the device does. */
+    const int env0 = (cfg->task == M3O_TASK_REACH && k0 == 0 && k1 == K && K >= 2);
+    float (*cube0)[3] = NULL, (*q_first)[4] = NULL, (*q_second)[4] = NULL;
+    if (env0) {
+        cube0 = malloc(sizeof(float[3]) * T); q_first = malloc(sizeof(float[4]) * T); q_second = malloc(sizeof(float[4]) * T);
+        for (int pass = 0; pass < (cfg->multi_modal ? 2 : 1); ++pass) {
+            const int k = pass ? K / 2 : 0;
+            m3o_panda_world w = *w0;
+            m3o_panda_infer_held(sc, &w);
+            for (int t = 0; t < T; ++t) {
+                float u[9];
+                for (int d = 0; d < nu; ++d) {
+                    u[d] = cfg->u_scale * act[((size_t)k * T + t) * nu + d];
+                    if (cfg->sample_null_action && k == K - 1) u[d] = 0.0f;
+                }
+                m3o_panda_step(sc, &w, u);
+                if (!pass) for (int d = 0; d < 3; ++d) cube0[t][d] = w.cubeA[d];
+                for (int d = 0; d < 4; ++d) (pass ? q_second : q_first)[t][d] = w.cubeA[3 + d];
+            }
+        }
+    }
 #pragma omp parallel for schedule(static)
     for (int k = k0; k < k1; ++k) {
         const int i = k - k0;
@@ -980,6 +1004,11 @@ void m3o_panda_rollout(const m3o_cfg* cfg, const m3o_panda_scene* sc, const m3o_
             st[0] = w.q[0]; st[1] = w.qd[0]; st[2] = w.q[1]; st[3] = w.qd[1]; /* dof 0,1 */
             m3o_panda_obs o;
             m3o_panda_observe(sc, &w, &o);
+            if (env0) {
+                const float* qh = (cfg->multi_modal && k >= K / 2) ? q_second[t] : q_first[t];
+                for (int d = 0; d < 3; ++d) o.cube0[d] = cube0[t][d];
+                for (int d = 0; d < 4; ++d) o.cube_q_half0[d] = qh[d];
+            }
             float c = m3o_panda_cost_obs(cfg, &o, k);
             cost_h[(size_t)i * T + t] = c;
             for (int d = 0; d < nu; ++d) actions[((size_t)i * T + t) * nu + d] = u[d];   /* mppi.py:313 (scaled, as the update sees it) */
@@ -988,6 +1017,7 @@ void m3o_panda_rollout(const m3o_cfg* cfg, const m3o_panda_scene* sc, const m3o_
         }
         J[i] = j;
     }
+    free(cube0); free(q_first); free(q_second);
 }
 
 void m3o_panda_step_batch(const m3o_panda_scene* sc, float* worlds, int n, const float* u) {

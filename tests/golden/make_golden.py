@@ -594,6 +594,13 @@ def g9_panda():
     g9_panda_trace("panda_reach", 256, 20, "reach", False, w_init, goal7)
     g9_panda_trace("panda_reachmm", 256, 20, "reach", True, w_init, goal7)
     g9_panda_trace("panda_pick", 256, 20, "pick", False, grasp_world(P, sc), goal7)
+    # quirk Q8 (cost_functions.py:97 `cube_state[0, :3]`, skill_utils.py:274): the open gripper stands around cubeA, 3 mm
+    # from one finger, so the rollouts' arm motions push the cube -- environment 0's too -- and the reach cost of EVERY
+    # rollout is measured against the cube of environment 0 (tilted mode: + the orientation of the first environment of
+    # the second half)
+    w_touch = grasp_world(P, sc, close_gripper=False, offset=(0.0, 0.012))
+    g9_panda_trace("panda_reach_touch", 256, 20, "reach", False, w_touch, goal7, ncalls=4)
+    g9_panda_trace("panda_reachmm_touch", 256, 20, "reach", True, w_touch, goal7, ncalls=4)
 
 
 # ---------------------------------------------------------------- G7 (skill side): the real world's suction

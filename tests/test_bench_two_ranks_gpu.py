@@ -67,8 +67,8 @@ def test_bench_single_gpu_line_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["reference_shaped"]["value"] > 0
-    assert set(d["other_configs"]) == {"northstar", "hybrid", "panda", "panda_pick", "c5shard", "c5_unsharded",
-                                       "worst_case_scene", "c1", "reference_default_size"}
+    assert set(d["other_configs"]) == {"northstar", "hybrid", "panda", "panda_settled", "panda_pick", "c5shard",
+                                       "c5_unsharded", "worst_case_scene", "c1", "reference_default_size"}
     assert all(v["value"] > 0 and v["scaling"] == "weak" and 0 < v["roofline"]["frac"] < 1
                for v in d["other_configs"].values()), d["other_configs"]
     oc = d["other_configs"]

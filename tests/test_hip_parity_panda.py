@@ -169,6 +169,43 @@ def test_panda_command_traces_vs_reference_golden(golden, tag, task, mm, grip):
     eng.close()
 
 
+@pytest.mark.parametrize("tag,mm", [("panda_reach_touch", False), ("panda_reachmm_touch", True)])
+def test_reach_cost_reads_environment_0_cube_as_the_reference(golden, oracle, tag, mm):
+    """Quirk Q8 with world spec v2 (cost_functions.py:97 `cube_state[0, :3]`, skill_utils.py:274): the open gripper stands
+    around cubeA and the rollouts -- sample 0's too -- push it; the reference measures EVERY rollout's reach cost against
+    environment 0's cube (tilted mode: + the orientation of the first environment of the second half).  The rollout kernel
+    carries those samples as shadow lanes of every wavefront: bit-identical to the oracle (which simulates them first), and
+    within 1e-3 of the reference's own planner + cost code on the first call (later calls: test_oracle_panda.py)."""
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    K, T = 256, 20
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    cfg = P.make_cfg(K, T, multi_modal=mm, task="reach", goal=goal, gripper_cmd=1)
+    opl = P.OraclePandaPlanner(cfg, golden[f"g9_{tag}_delta"])
+    w = golden[f"g9_{tag}_world"][0]
+    opl.command(w)
+    # the quirk is live: with each sample's own cube the costs are other numbers
+    act = opl.last["actions"] / cfg.u_scale
+    own = np.concatenate([P.rollout(cfg, opl.sc, w, act[:K // 2], 0, K // 2)["J"], P.rollout(cfg, opl.sc, w, act[K // 2:], K // 2, K)["J"]])
+    assert np.abs(own - opl.last["J"]).max() > 1.0
+    for lanes in (0, 16):      # (the narrow-wave knob keeps the shadows: lanes per wavefront are clipped to 64 - shadows)
+        eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", multi_modal=mm, u_min=UMIN, u_max=UMAX,
+                                    noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01))
+        eng.set_rollout_lanes(lanes)
+        eng.set_objective("reach", goal, gripper_cmd=1)
+        eng.set_noise(golden[f"g9_{tag}_delta"])
+        eng.set_world_panda_raw(raw31(P, w))
+        a = eng.command(sync_host=True)
+        np.testing.assert_array_equal(eng.states.cpu().numpy(), opl.last["states"])
+        np.testing.assert_array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+        np.testing.assert_array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
+        np.testing.assert_allclose(a, golden[f"g9_{tag}_action"][0], atol=1e-3)
+        np.testing.assert_allclose(eng.buffer(L.BUF_WEIGHTS).cpu().numpy(), golden[f"g9_{tag}_weights"][0], rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(eng.buffer(L.BUF_MEAN).cpu().numpy(), golden[f"g9_{tag}_mean"][0], atol=1e-3)
+        eng.close()
+
+
 @pytest.mark.parametrize("tag", ["panda_opt_cov", "panda_opt_rand", "panda_opt_simple"])
 def test_panda_option_traces_vs_reference_golden(golden, oracle, tag):
     """The MPPIConfig switches no shipped config turns on, on the panda_env (make_golden.py g11): update_cov;

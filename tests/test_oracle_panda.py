@@ -162,7 +162,10 @@ def test_pad_channel_spec_v11(P):
     assert w[0, P.W_HELD] == 0.0
 
 
-PANDA_TRACES = {"panda_reach": ("reach", False, 1), "panda_reachmm": ("reach", True, 1), "panda_pick": ("pick", False, 2)}
+PANDA_TRACES = {"panda_reach": ("reach", False, 1), "panda_reachmm": ("reach", True, 1), "panda_pick": ("pick", False, 2),
+                # quirk Q8: open gripper around cubeA, the rollouts (environment 0's too) push it; every rollout's reach
+                # cost is measured against environment 0's cube (cost_functions.py:97, skill_utils.py:274)
+                "panda_reach_touch": ("reach", False, 1), "panda_reachmm_touch": ("reach", True, 1)}
 
 
 @pytest.mark.parametrize("tag", list(PANDA_TRACES))
@@ -177,17 +180,31 @@ def test_g9_panda_command_traces_vs_reference(golden, oracle, tag):
     goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
     cfg = P.make_cfg(K, T, multi_modal=mm, task=task, goal=goal, gripper_cmd=grip)
     opl = P.OraclePandaPlanner(cfg, golden[f"g9_{tag}_delta"])
+    touch = tag.endswith("_touch")
     for call, w in enumerate(golden[f"g9_{tag}_world"]):
         a = opl.command(w)
-        np.testing.assert_allclose(a, golden[f"g9_{tag}_action"][call], atol=1e-3, err_msg=f"{tag} call {call}")
-        np.testing.assert_allclose(opl.last["w"], golden[f"g9_{tag}_weights"][call], atol=1e-3)
-        np.testing.assert_allclose(opl.mean, golden[f"g9_{tag}_mean"][call], atol=1e-3)
-        if not mm:
+        # In the touch traces EVERY rollout's cost hangs on environment 0's cube, whose flight after the finger's blow is
+        # one contact history: from the second call on the 1e-7 between torch's controls and the oracle's decides
+        # which way it tumbles, and the plans part (observed: 6e-5 / 2e-3 at call 1, 0.05 at call 3).  The first call pins
+        # the semantics: with each sample's own cube instead, J differs by up to 15 and the plan by far more than 1e-3.
+        tol = 1e-3 if (call == 0 or not touch) else 0.15
+        np.testing.assert_allclose(a, golden[f"g9_{tag}_action"][call], atol=tol, err_msg=f"{tag} call {call}")
+        np.testing.assert_allclose(opl.last["w"], golden[f"g9_{tag}_weights"][call], atol=tol)
+        np.testing.assert_allclose(opl.mean, golden[f"g9_{tag}_mean"][call], atol=tol)
+        if not mm and not (touch and call):
             assert opl.beta == pytest.approx(float(golden[f"g9_{tag}_beta"][call]), rel=1e-5)
         top = opl.last["states"][opl.last["top_idx"]][:, :, [0, 2]]
-        np.testing.assert_allclose(top[:5], golden[f"g9_{tag}_top_trajs"][call][:5], atol=1e-3)
+        if not (touch and call):
+            np.testing.assert_allclose(top[:5], golden[f"g9_{tag}_top_trajs"][call][:5], atol=1e-3)
+        if touch and call == 0:      # the quirk is live in this trace: own-cube costs would be different numbers
+            act = opl.last["actions"] / cfg.u_scale
+            own = np.concatenate([P.rollout(cfg, opl.sc, w, act[:K // 2], 0, K // 2)["J"],
+                                  P.rollout(cfg, opl.sc, w, act[K // 2:], K // 2, K)["J"]])
+            assert np.abs(own - opl.last["J"]).max() > 1.0
         # the gripper override: fingers commanded open (reach) / closed (pick) in every sample
         assert np.all(opl.last["actions"][:-1, :, 7:] == (1.5 if grip == 1 else -1.5))
+    if touch:
+        return
     np.testing.assert_allclose(opl.last["actions"], golden[f"g9_{tag}_actions_last"], atol=1e-3)
     # the rollouts themselves: equal for all but a few samples -- the reference forms its controls in torch (1e-7
     # apart from the oracle's), and with spec v2 a rollout that pushes the held cube into the table or sweeps a finger
