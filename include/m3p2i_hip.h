@@ -238,6 +238,11 @@ int m3_enable_timing(m3_handle* h, int on);
  * a power of two in 1..64, or 0 = choose from K_local so that the waves fill the chip
  * (DESIGN.md "Lanes per wavefront").  Results do not depend on it. */
 int m3_set_rollout_lanes(m3_handle* h, int lanes);
+/* launch structure of the unsharded multi-modal update with K beyond the one-launch kernel's range: 0 (default) = three
+ * launches (ladder + search in one grid, weights + sums, combine), 5 = the five launches of round 3 (minima, ladder,
+ * search, weights, sums), whose sums are added in the order of the sharded "exact" protocols (tests compare those bit
+ * for bit).  Pass counts, best samples and the plan (to rounding) do not depend on it. */
+int m3_set_update_launches(m3_handle* h, int launches);
 
 /* assignment of samples to wavefronts in the point_env rollout: 1 (default) = sorted by the
  * direction of each sample's noise path (computed on the device whenever the noise is set, so that

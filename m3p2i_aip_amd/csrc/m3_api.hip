@@ -265,8 +265,16 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (rc == M3_OK && hipMalloc((void**)&h->topk_cand, (size_t)topk_workgroups((int)Kg) * M3_TOPK * sizeof(VI)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->part_min, (size_t)mins_workgroups((int)Kg) * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMalloc((void**)&h->lad, (size_t)ladder_workgroups((int)Kg) * 96 * 3 * f) != hipSuccess) rc = M3_ERR_HIP;
-    if (rc == M3_OK && hipMalloc((void**)&h->wpart, (size_t)(h->regen ? std::max(wsum_chunks((int)Kg), regen_chunks((int)Kg)) : wsum_chunks((int)Kl)) * 3 * T * nu * f) != hipSuccess) rc = M3_ERR_HIP;
-    if (rc == M3_OK && hipMalloc((void**)&h->apart, (size_t)(16 + std::max(apply_workgroups((int)Kg), h->regen ? regen_chunks((int)Kg) : 0) * 8) * f) != hipSuccess) rc = M3_ERR_HIP;
+    // the three-launch update of an unsharded multi-modal handle beyond k_update_small's range (update.hip: k_ladder_search)
+    const bool fused_large = Kl == Kg && c->multi_modal && !c->mode_simple && Kg > 4096 && Kg <= 131072 && T * nu <= 2048;
+    if (rc == M3_OK && hipMalloc((void**)&h->wpart, (size_t)((h->regen || fused_large) ? std::max(wsum_chunks((int)Kg), regen_chunks((int)Kg)) : wsum_chunks((int)Kl)) * 3 * T * nu * f) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && hipMalloc((void**)&h->apart, (size_t)(16 + std::max(apply_workgroups((int)Kg), (h->regen || fused_large) ? regen_chunks((int)Kg) : 0) * 8) * f) != hipSuccess) rc = M3_ERR_HIP;
+    if (rc == M3_OK && fused_large) {
+        const size_t nl = (size_t)ladder_workgroups((int)Kg);
+        if (hipMalloc((void**)&h->wave_min, (size_t)Kl * 3 * f) != hipSuccess) rc = M3_ERR_HIP;      // (one row per rollout workgroup: <= K_local with one lane per wavefront)
+        if (rc == M3_OK && hipMalloc((void**)&h->lflag, nl * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
+        if (rc == M3_OK && hipMemset(h->lflag, 0, nl * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
+    }
     if (rc == M3_OK && hipMalloc((void**)&h->wcount, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMemset(h->wcount, 0, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK) {
@@ -300,6 +308,8 @@ extern "C" void m3_destroy(m3_handle* h) {
     if (h->wpart) (void)hipFree(h->wpart);
     if (h->apart) (void)hipFree(h->apart);
     if (h->wcount) (void)hipFree(h->wcount);
+    if (h->wave_min) (void)hipFree(h->wave_min);
+    if (h->lflag) (void)hipFree(h->lflag);
     if (h->sim_world) (void)hipFree(h->sim_world);
     if (h->sim_u) (void)hipFree(h->sim_u);
     if (h->noise_stage) (void)hipFree(h->noise_stage);
@@ -325,6 +335,13 @@ extern "C" int m3_set_rollout_lanes(m3_handle* h, int lanes) {
     if (lanes != 0 && (lanes < 1 || lanes > 64 || (lanes & (lanes - 1)) != 0))
         return fail(h, M3_ERR_BAD_ARG, "m3_set_rollout_lanes: lanes must be 0 (auto) or a power of two in 1..64");
     h->lanes_override = lanes;
+    return M3_OK;
+}
+
+extern "C" int m3_set_update_launches(m3_handle* h, int launches) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (launches != 0 && launches != 3 && launches != 5) return fail(h, M3_ERR_BAD_ARG, "m3_set_update_launches: 0 (default), 3 or 5");
+    h->five_launches = launches == 5;
     return M3_OK;
 }
 
@@ -832,9 +849,11 @@ extern "C" int m3_rollout(m3_handle* h) {
     a.actions = (float*)h->buf[M3_BUF_ACTIONS];
     a.cost_h = (float*)h->buf[M3_BUF_COST_HORIZON];
     a.J = (float*)h->buf[M3_BUF_TRAJ_COST];
+    a.wave_min = h->wave_min;   // (null unless the handle's update is the three-launch one)
+    h->wave_min_rows = 0;
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     if (c.env_type == M3_ENV_POINT) {
-        launch_rollout_point(a, h->scene, h->stream);
+        if (launch_rollout_point(a, h->scene, h->stream)) h->wave_min_rows = (a.Kl + a.lanes - 1) / a.lanes;
     } else {
         PandaArgs pa;
         std::memcpy(pa.world0, h->pworld0, sizeof(pa.world0));
@@ -844,6 +863,7 @@ extern "C" int m3_rollout(m3_handle* h) {
         // a sharded command does not hold sample 0's noise row and uses each sample's own cube
         pa.shadows = (pa.cp.task == 4 && a.k0 == 0 && a.Kl == a.Kg && a.Kg >= 2) ? (pa.cp.multi_modal ? 2 : 1) : 0;
         launch_rollout_panda(a, pa, h->pscene, h->stream);
+        if (a.wave_min) { const int ln = std::min(a.lanes, 64 - pa.shadows); h->wave_min_rows = (a.Kl + ln - 1) / ln; }
     }
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
@@ -866,6 +886,7 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.srch = (SearchOut*)h->apart;
     a.apart = h->apart + 16;
     a.wcount = h->wcount;
+    a.lflag = h->lflag;
     a.n_chunk = wsum_chunks(c.K_local);
     a.n_lad = ladder_workgroups(c.K_global);
     a.Jall = (const float*)h->buf[M3_BUF_TRAJ_COST_ALL];
@@ -976,6 +997,19 @@ static int update_impl(m3_handle* h, bool fuse) {
     }
     if (update_small_applies(a)) {  // K <= 4096: one launch (update.hip, k_update_small)
         launch_update_small(a, h->stream);
+        HIPCHK(h, hipGetLastError());
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+        return M3_OK;
+    }
+    static const bool five_launches = getenv("M3P2I_UPDATE_FIVE_LAUNCHES") != nullptr;   // (A/B, tests: the round-3 path)
+    if (fuse && h->lflag && c.multi_modal && !c.mode_simple && !five_launches && !h->five_launches) {
+        // three launches (update.hip: k_ladder_search): the minima are the rows the rollout's workgroups left behind
+        // when the costs are this command's rollout's, k_mins' rows otherwise (costs written by the caller)
+        if (h->use_wave_min) { a.part_min = h->wave_min; a.n_mins = h->wave_min_rows; }
+        else launch_mins(a, h->stream);
+        a.epoch = ++h->lad_epoch;
+        launch_ladder_search(a, h->stream);
+        launch_fused_large(a, h->stream);
         HIPCHK(h, hipGetLastError());
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
         return M3_OK;
@@ -1335,7 +1369,9 @@ extern "C" int m3_command(m3_handle* h, float* action_host) {
                                      "m3_finalize with the collective(s) in between (include/m3p2i_hip.h)");
     int rc = m3_rollout(h);
     if (rc != M3_OK) return rc;
+    h->use_wave_min = h->wave_min != nullptr && h->wave_min_rows > 0;   // the costs the update reads are this rollout's
     rc = m3_update_finalize(h);   // weights -> sums + (last workgroup) mean update / filter
+    h->use_wave_min = false;
     if (rc != M3_OK) return rc;
     if (action_host) {
         const m3_config& c = h->cfg;

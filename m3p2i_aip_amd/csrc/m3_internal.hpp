@@ -45,6 +45,7 @@ struct RolloutArgs {
     float* actions;           // [T][Kl][nu]
     float* cost_h;            // [T][Kl]
     float* J;                 // [Kl]
+    float* wave_min;          // [workgroups][3] minima of each workgroup's costs (wave_min.hpp), or null
 };
 
 struct SearchOut;
@@ -67,6 +68,8 @@ struct UpdateArgs {
                       // fused finalize (zero between launches)
     int fuse_finalize;  // k_wsum's last workgroup also does k_finalize's work (unsharded m3_command)
     int ladder_spins;   // k_update_small: bound of the wait for the other workgroups' ladder points
+    int* lflag;         // [n_lad] k_ladder_search: epoch of the launch whose partial table the ladder workgroup has stored
+    int epoch;
     int n_chunk;      // k_wsum workgroups per time step
     int lds_floats;   // costs staged in dynamic LDS by k_weights (set by launch_weights)
     int Kg, Kl, k0, T, nu;
@@ -154,7 +157,7 @@ __host__ __device__ inline int regen_off_table(int Kls, int T) { return regen_of
 __host__ __device__ inline int regen_record_length(int Kls, int T) { return (regen_off_table(Kls, T) + LAD_N * 3 + 3) / 4 * 4; }
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
-void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s);
+bool launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s);
 void launch_rollout_point_nav(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s);
 void launch_rollout_point_push(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s);
 void launch_rollout_point_pull(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s);
@@ -205,6 +208,8 @@ int wsum_chunks(int Kl);
 int apply_workgroups(int Kg);
 void launch_mins(const UpdateArgs& a, hipStream_t s);
 void launch_ladder(const UpdateArgs& a, hipStream_t s);
+void launch_ladder_search(const UpdateArgs& a, hipStream_t s);
+void launch_fused_large(const UpdateArgs& a, hipStream_t s);
 
 // p2p.hip: device-side exchange of the records over peer-mapped memory
 struct P2PArgs {
@@ -318,6 +323,13 @@ struct m3_handle {
     float* wpart = nullptr;
     float* apart = nullptr;  // + 16 floats of SearchOut at the front
     int* wcount = nullptr;
+    // unsharded multi-modal update with K > 8192 in three launches (update.hip: k_ladder_search)
+    float* wave_min = nullptr;     // [rollout workgroups][3] minima left by the rollout (wave_min.hpp)
+    int wave_min_rows = 0;         // rows the last rollout wrote
+    bool use_wave_min = false;     // inside m3_command: the costs are the rollout's
+    int* lflag = nullptr;
+    int lad_epoch = 0;
+    bool five_launches = false;    // m3_set_update_launches(h, 5)
     float* sim_world = nullptr;  // step mode SoA [NW][Kl]
     float* sim_u = nullptr;      // [Kl][nu]
     float* noise_stage = nullptr;

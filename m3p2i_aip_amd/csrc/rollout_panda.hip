@@ -9,6 +9,7 @@
 #include "m3_internal.hpp"
 #include "noise_stream.hpp"
 #include "panda_dyn.hpp"
+#include "wave_min.hpp"
 
 namespace m3 {
 
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         }
     }
     if (!shadow) a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
+    if (a.wave_min) wave_min_store(a.wave_min, J, first_half, !shadow);
 }
 
 void launch_rollout_panda(const RolloutArgs& a_in, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {

@@ -15,7 +15,8 @@ int rollout_lanes_for(int Kl) {
     return 64;
 }
 
-void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s) {
+// returns whether the instance launched leaves the workgroups' cost minima in a.wave_min (wave_min.hpp)
+bool launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_t s) {
     const int blocks = (a.Kl + a.lanes - 1) / a.lanes;
 #if defined(M3_ABL_GENERAL_ONLY) || defined(M3_ABL_COUNT) || defined(M3_ABL_PHASES)   // (experiments: one kernel for all modes;
     // the instrumented builds keep their counters in this translation unit)
@@ -26,13 +27,14 @@ void launch_rollout_point(const RolloutArgs& a, const PointScene& sc, hipStream_
                          (a.cp.task == 3 && !a.multi_modal) || a.scale_dev != nullptr /* update_cov */ ||
                          a.cp.avoid_dyn_obs != 0 /* the extension: the dyn-obs contact force must be formed */;
 #endif
-    if (general) { launch_rollout_point_instance<true, -1>(a, sc, blocks, s); return; }
+    if (general) { launch_rollout_point_instance<true, -1>(a, sc, blocks, s); return a.wave_min != nullptr; }
     switch (a.cp.task) {   // the reference's default sampler: one instance per task (rollout_point_task*.hip)
         case 0: launch_rollout_point_nav(a, sc, blocks, s); break;
         case 1: launch_rollout_point_push(a, sc, blocks, s); break;
         case 2: launch_rollout_point_pull(a, sc, blocks, s); break;
-        default: launch_rollout_point_pushpull(a, sc, blocks, s); break;
+        default: launch_rollout_point_pushpull(a, sc, blocks, s); return a.wave_min != nullptr;
     }
+    return false;
 }
 
 // delta [K][T][nu] (reference layout) -> [T][K][nu]

@@ -17,6 +17,7 @@
 #pragma once
 #include "m3_internal.hpp"
 #include "noise_stream.hpp"
+#include "wave_min.hpp"
 
 namespace m3 {
 
@@ -184,6 +185,11 @@ __device__ __forceinline__ void rollout_point_body(const RolloutArgs& a_, const 
         for (int q = 0; q < 8; ++q) atomicAdd(&g_phase[blockIdx.x * 8 + q], clk.acc[q]);
 #endif
     a.J[i] = a.mode_simple ? (S + pc) : J;
+    // (only the instances a multi-modal command can run carry this epilogue: compiled into the push instance too it cost
+    // the headline 2 us -- 316 instead of 312 VGPRs -- without ever running there; launch_rollout_point says who wrote)
+    if constexpr (GENERAL || TASK == 3) {
+        if (a.wave_min) wave_min_store(a.wave_min, J, first_half, true);
+    }
     a.pend[0 * Kl + i] = w.fRx; a.pend[1 * Kl + i] = w.fRy;
     a.pend[2 * Kl + i] = w.fBx; a.pend[3 * Kl + i] = w.fBy;
 }

@@ -886,7 +886,12 @@ struct SearchOut {   // device scratch, written by k_search
 // on both beta ladders (mixed from the shards' tables when a.fast, summed from k_ladder's partials otherwise), the
 // reference's rule on the table, passes over the costs only for a search that leaves its ladder or reverses.
 // Every thread returns with the result; `publish`: thread 0 also writes a.srch and the diagnostics of m3_info.
-__device__ __forceinline__ void search_body(const UpdateArgs& a, SearchOut& out, bool publish) {
+// COHERENT: the partial tables were written by other workgroups of the SAME launch (k_ladder_search): read them with
+// agent-scope loads (the per-XCD L2s are not coherent with each other inside a launch); `have_table` false (its wait
+// gave up): every search runs the reference's iterative passes over the costs instead.
+template <bool COHERENT = false>
+__device__ __forceinline__ void search_body(const UpdateArgs& a, SearchOut& out, bool publish, bool have_table = true,
+                                            const float* pre_mn = nullptr /* LDS: the three minima, already formed */) {
     __shared__ float red[3 * 16];
     __shared__ float s_beta[3], s_eta[3], s_mn[3];
     __shared__ int s_done[3], s_it[3];
@@ -915,24 +920,66 @@ __device__ __forceinline__ void search_body(const UpdateArgs& a, SearchOut& out,
             s_tab[o] = t;
         }
     } else {
-    if (tid < 3) {
-        float m = INF;
-        for (int b = 0; b < a.n_mins; ++b) m = fminf(m, a.part_min[b * 3 + tid]);
-        s_mn[tid] = m;
+    if (pre_mn) {
+        if (tid < 3) s_mn[tid] = pre_mn[tid];
+    } else if (a.n_mins <= 64) {
+        if (tid < 3) {
+            float m = INF;
+            for (int b = 0; b < a.n_mins; ++b) m = fminf(m, a.part_min[b * 3 + tid]);
+            s_mn[tid] = m;
+        }
+    } else {   // (the rollout workgroups' rows, wave_min.hpp: K / 64 of them)
+        float mn[3] = {INF, INF, INF};
+        for (int b = tid; b < a.n_mins; b += WT) {
+            mn[0] = fminf(mn[0], a.part_min[b * 3 + 0]); mn[1] = fminf(mn[1], a.part_min[b * 3 + 1]); mn[2] = fminf(mn[2], a.part_min[b * 3 + 2]);
+        }
+        block_min<3>(mn, red);
+        if (tid < 3) s_mn[tid] = tid == 0 ? mn[0] : (tid == 1 ? mn[1] : mn[2]);
+        __syncthreads();
     }
-    {   // ladder table (see k_weights)
+    if constexpr (COHERENT) {
+        // k_ladder_search's search workgroup (512 threads): the other workgroups' write-through stores are made visible
+        // by ONE agent-scope acquire (L1 / L2 invalidate: ~3.5 us, once) instead of 72 000 L2-bypassing loads, whose
+        // latency -- eight in flight per thread -- was 36 us here.  Thread = (float4 column of the 288-entry table,
+        // seventh of the workgroups): 16 rows of 16 bytes in flight each, fixed order.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        constexpr int NT = LAD_N * 3, NQ = NT / 4, NSEG = 7;      // 72 x 7 = 504 of the 512 threads
+        __shared__ float4 s_p4[NSEG * NQ];
+        if (tid < NSEG * NQ) {
+            const int q = tid % NQ, sg = tid / NQ;
+            const int b0 = (int)(((long long)a.n_lad * sg) / NSEG), b1 = (int)(((long long)a.n_lad * (sg + 1)) / NSEG);
+            const float4* src = reinterpret_cast<const float4*>(a.lad) + q;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int b = b0; b < b1; b += 16) {
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = src[(size_t)min(b + u, b1 - 1) * NQ];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (b + u < b1) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            s_p4[sg * NQ + q] = acc;
+        }
+        __syncthreads();
+        for (int q = tid; q < NQ; q += WT) {
+            float4 t = s_p4[q];
+            for (int g = 1; g < NSEG; ++g) { const float4 x = s_p4[g * NQ + q]; t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w; }
+            s_tab[4 * q + 0] = t.x; s_tab[4 * q + 1] = t.y; s_tab[4 * q + 2] = t.z; s_tab[4 * q + 3] = t.w;
+        }
+    } else {   // ladder table (see k_weights): the workgroups' partial tables added in a fixed order
         const int NT = LAD_N * 3;
         const int nseg = (WT / NT) > 0 ? (WT / NT) : 1;
-        const int o = tid % NT, sg = tid / NT;
-        if (sg < nseg) {
+        auto ldp = [&](size_t o) -> float { return a.lad[o]; };
+        for (int idx = tid; idx < nseg * NT; idx += WT) {   // (one trip when the workgroup has >= 288 threads)
+            const int o = idx % NT, sg = idx / NT;
             const int b0 = (int)(((long long)a.n_lad * sg) / nseg), b1 = (int)(((long long)a.n_lad * (sg + 1)) / nseg);
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int b = b0;
             for (; b + 7 < b1; b += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] += a.lad[(size_t)(b + u) * NT + o];
+                for (int u = 0; u < 8; ++u) acc[u] += ldp((size_t)(b + u) * NT + o);
             }
-            for (; b < b1; ++b) acc[0] += a.lad[(size_t)b * NT + o];
+            for (; b < b1; ++b) acc[0] += ldp((size_t)b * NT + o);
             s_part[sg * NT + o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         }
         __syncthreads();
@@ -944,7 +991,8 @@ __device__ __forceinline__ void search_body(const UpdateArgs& a, SearchOut& out,
     }
     }
     __syncthreads();
-    if (tid < 3) {  // the reference's rule on the table (m3p2i.py:35-51), as in k_weights
+    if (tid < 3 && !have_table) { s_beta[tid] = 1.0f; s_eta[tid] = 0.0f; s_done[tid] = 0; s_it[tid] = 0; }
+    if (tid < 3 && have_table) {  // the reference's rule on the table (m3p2i.py:35-51), as in k_weights
         const int s = tid;
         float b = 1.0f, et = s_tab[0 * 3 + s];
         int it = 1, done = 0;
@@ -1011,6 +1059,115 @@ __device__ __forceinline__ void search_body(const UpdateArgs& a, SearchOut& out,
         f->beta_1 = s_beta[1]; f->beta_2 = s_beta[2];   // diagnostics; info->beta stays (m3p2i.py:58-60)
     }
 }
+// ---------------------------------------------------------------------------------------
+// The unsharded multi-modal update with K > 8192 in THREE launches instead of five (round 4):
+//   k_ladder_search -- n_lad ladder workgroups (as k_ladder; the three global minima come from the rows the rollout
+//     workgroups left behind, wave_min.hpp, or from k_mins' rows when the costs were not produced by the rollout) +
+//     ONE search workgroup that waits for their partial tables (a flag per ladder workgroup, written after its
+//     write-through stores: no shared counter -- agent-scope atomics on one address retire at ~0.3 us each, 250 of
+//     them would cost more than the launch they save), adds them in workgroup order and walks the table (k_search's
+//     body) + the top-k stage-A workgroups.  The search workgroup is the LAST of the ladder's grid, so every ladder
+//     workgroup has been dispatched before it; its wait is bounded, and a search whose wait gave up runs the
+//     reference's iterative passes over the costs instead (same decisions: tests/test_hip_edge_cases.py).
+//   k_regen_part<NU, false> -- weights formed on the fly from the costs + the weighted action sums of 2048-sample chunks
+//     (the kernel of the shard_mix = 2 protocol, with the actions loaded instead of re-generated) + top-k stage B,
+//   k_regen_done<NU, false> -- chunk combine in chunk order, best rows, finalize.
+constexpr int LS_T = 512, LS_G = 4;   // threads of a k_ladder_search workgroup; element groups per ladder point (LS_G * LAD_N <= LS_T)
+__device__ __forceinline__ void ladder_block(const UpdateArgs& a, float* red /* 48 */) {
+    __shared__ float2 sd[LAD_EL];
+    __shared__ float sacc[LS_G][LAD_N][3];
+    __shared__ float smn[3];
+    const int Kg = a.Kg, half = Kg / 2, tid = threadIdx.x, b = blockIdx.x;
+    const float INF = __builtin_inff();
+    {
+        float mn[3] = {INF, INF, INF};
+        for (int r = tid; r < a.n_mins; r += LS_T) {
+            mn[0] = fminf(mn[0], a.part_min[r * 3 + 0]); mn[1] = fminf(mn[1], a.part_min[r * 3 + 1]); mn[2] = fminf(mn[2], a.part_min[r * 3 + 2]);
+        }
+        block_min<3>(mn, red);
+        if (tid == 0) { smn[0] = mn[0]; smn[1] = mn[1]; smn[2] = mn[2]; }
+    }
+    __syncthreads();
+    if (tid < LAD_EL) {
+        const int k = b * LAD_EL + tid;
+        float2 d = make_float2(INF, INF);
+        if (k < Kg) {
+            const float v = a.Jall[k];
+            d.x = v - smn[0];
+            d.y = v - smn[(k < half) ? 1 : 2];
+        }
+        sd[tid] = d;
+    }
+    __syncthreads();
+    if (tid < LS_G * LAD_N) {   // thread = (ladder point j, element group g): 64 of the workgroup's 256 costs each
+        const int j = tid % LAD_N, g = tid / LAD_N;
+        const float nib = -1.0f / ladder_beta(j);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll 8
+        for (int i = 0; i < LAD_EL / LS_G; ++i) {
+            const int e = LS_G * i + g;
+            const float2 d = sd[e];
+            a0 += m3_exp(nib * d.x);
+            const float xh = m3_exp(nib * d.y);
+            if (b * LAD_EL + e < half) a1 += xh; else a2 += xh;
+        }
+        sacc[g][j][0] = a0; sacc[g][j][1] = a1; sacc[g][j][2] = a2;
+    }
+    __syncthreads();
+    for (int o = tid; o < LAD_N * 3; o += LS_T) {
+        const int j = o / 3, sx = o % 3;
+        float t = sacc[0][j][sx];
+#pragma unroll
+        for (int g = 1; g < LS_G; ++g) t += sacc[g][j][sx];
+        __hip_atomic_store(&a.lad[((size_t)b * LAD_N + j) * 3 + sx], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&a.lflag[b], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(LS_T) void k_ladder_search(const UpdateArgs a) {
+    __shared__ float red[3 * 16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b > a.n_lad) {
+        topk_stage_a(a, b - a.n_lad - 1);   // (its first PREP_T threads work)
+        return;
+    }
+    if (b < a.n_lad) {
+        ladder_block(a, red);
+        return;
+    }
+    __shared__ int s_ok;
+    __shared__ float s_pre[3];
+    {   // (the minima while the ladder workgroups are still at work)
+        const float INF = __builtin_inff();
+        float mn[3] = {INF, INF, INF};
+        for (int r = tid; r < a.n_mins; r += LS_T) {
+            mn[0] = fminf(mn[0], a.part_min[r * 3 + 0]); mn[1] = fminf(mn[1], a.part_min[r * 3 + 1]); mn[2] = fminf(mn[2], a.part_min[r * 3 + 2]);
+        }
+        block_min<3>(mn, red);
+        if (tid == 0) { s_pre[0] = mn[0]; s_pre[1] = mn[1]; s_pre[2] = mn[2]; s_ok = 1; }
+    }
+    __syncthreads();
+    bool ok = a.ladder_spins > 0;      // (0: tests force the give-up branch)
+    for (int q = tid; q < a.n_lad && ok; q += LS_T) {
+        int spins = 0;
+        while (__hip_atomic_load(&a.lflag[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > a.ladder_spins) { ok = false; break; }
+        }
+    }
+    if (!ok) s_ok = 0;
+    __syncthreads();
+    SearchOut so;
+    search_body<true>(a, so, true, s_ok != 0, s_pre);
+}
+void launch_ladder_search(const UpdateArgs& a_, hipStream_t s) {
+    static const int spins = getenv("M3P2I_LADDER_SPINS") ? atoi(getenv("M3P2I_LADDER_SPINS")) : (1 << 18);
+    UpdateArgs a = a_;
+    a.ladder_spins = spins;
+    hipLaunchKernelGGL(k_ladder_search, dim3(a.n_lad + 1 + a.n_cand), dim3(LS_T), 0, s, a);
+}
+
 __global__ __launch_bounds__(WT_MAX) void k_search(const UpdateArgs a) {
     if (blockIdx.x > 0) {  // workgroups 1..n_cand: top-k stage A, concurrent with the search
         if (a.fast) topk_merge_records(a);   // (shard_mix = 2: the global top-k from the shards' own lists)
@@ -1484,20 +1641,25 @@ int regen_chunk_len(int Kg) {          // 2048 = WS_BATCH * ST samples, more bey
 }
 int regen_chunks(int Kg) { const int L = regen_chunk_len(Kg); return (Kg + L - 1) / L; }
 
-template <int NU>
+// REGEN = false (round 4): the same kernel for the UNSHARDED multi-modal update with K > 8192 -- costs from the
+// rollout's buffer, actions loaded from it, beta / eta / minima as k_ladder_search's search workgroup published them
+// (a.srch), top-k stage B as the extra workgroup.
+template <int NU, bool REGEN = true>
 __global__ __launch_bounds__(ST) void k_regen_part(const UpdateArgs a, const int clen) {
     __shared__ float red[3 * 16];
     __shared__ VI redvi[16];
     __shared__ float sred[3 * 9 * (ST / 64)];
     const int tid = threadIdx.x, C = a.n_chunk, Kg = a.Kg, T = a.T, half = a.half_g;
     if ((int)blockIdx.x == T * C) {   // the extra workgroup: the global top-k from the shards' own lists
-        topk_merge_records(a);
+        if constexpr (REGEN) topk_merge_records(a);
+        else topk_stage_b(a);
         return;
     }
     const int t = blockIdx.x / C, c = blockIdx.x % C;
     const float INF = __builtin_inff();
     const float inv_Kls = 1.0f / (float)a.Kls;
     const int iend = min(Kg, (c + 1) * clen);
+    const float* act = a.actions + (size_t)t * Kg * NU;   // (REGEN = false: Kl == Kg, k0 == 0)
     // this workgroup's costs and noise rows (the first batch: all of them up to K = 131072) are requested BEFORE
     // the search, whose table loads and serial walk would otherwise sit in front of their latency
     float v8[WS_BATCH], d8[WS_BATCH][NU];
@@ -1505,9 +1667,15 @@ __global__ __launch_bounds__(ST) void k_regen_part(const UpdateArgs a, const int
 #pragma unroll
         for (int it = 0; it < WS_BATCH; ++it) {
             const int k = min(ib + it * ST + tid, iend - 1);
-            const int r = shard_of(k, a.Kls, inv_Kls), kk = k - r * a.Kls;
-            v8[it] = a.records_all[(size_t)r * a.rec_len + kk];
-            const float* drow = a.noise_all + (((size_t)r * T + t) * a.Kls + kk) * NU;
+            const float* drow;
+            if constexpr (REGEN) {
+                const int r = shard_of(k, a.Kls, inv_Kls), kk = k - r * a.Kls;
+                v8[it] = a.records_all[(size_t)r * a.rec_len + kk];
+                drow = a.noise_all + (((size_t)r * T + t) * a.Kls + kk) * NU;
+            } else {
+                v8[it] = a.Jall[k];
+                drow = act + (size_t)k * NU;
+            }
             if constexpr (NU == 2) {
                 const float2 d2 = *reinterpret_cast<const float2*>(drow);
                 d8[it][0] = d2.x; d8[it][1] = d2.y;
@@ -1522,12 +1690,13 @@ __global__ __launch_bounds__(ST) void k_regen_part(const UpdateArgs a, const int
     // exps and a serial walk: cheaper than a launch of its own in front of this one; same code, same data => the
     // same result in every workgroup); workgroup 0 publishes it
     SearchOut so;
-    search_body(a, so, blockIdx.x == 0);
+    if constexpr (REGEN) search_body(a, so, blockIdx.x == 0);
+    else so = *a.srch;
     const float i0 = uniform_f(1.0f / so.eta[0]), n0 = uniform_f(-1.0f / so.beta[0]);
     const float i1 = uniform_f(1.0f / so.eta[1]), n1 = uniform_f(-1.0f / so.beta[1]);
     const float i2 = uniform_f(1.0f / so.eta[2]), n2 = uniform_f(-1.0f / so.beta[2]);
     RegenRows<NU> rows;
-    regen_rows<NU>(a, t, rows);
+    if constexpr (REGEN) regen_rows<NU>(a, t, rows);
     float acc[3][NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
@@ -1544,7 +1713,11 @@ __global__ __launch_bounds__(ST) void k_regen_part(const UpdateArgs a, const int
         float dv[NU], av[NU];
 #pragma unroll
         for (int j = 0; j < NU; ++j) dv[j] = d8[it][j];
-        regen_action<NU>(a, rows, k, dv, av);
+        if constexpr (REGEN) regen_action<NU>(a, rows, k, dv, av);
+        else {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) av[j] = dv[j];
+        }
         const bool first = k < half;
         float w = i0 * m3_exp(n0 * (v - so.mn[0]));
         float wh = (first ? i1 : i2) * m3_exp((first ? n1 : n2) * (v - (first ? so.mn[1] : so.mn[2])));
@@ -1596,7 +1769,7 @@ __global__ __launch_bounds__(ST) void k_regen_part(const UpdateArgs a, const int
     }
 }
 
-template <int NU>
+template <int NU, bool REGEN = true>
 __global__ __launch_bounds__(ST) void k_regen_done(const UpdateArgs a) {
     extern __shared__ float sm_fin[];
     __shared__ int s_best[3];
@@ -1645,22 +1818,42 @@ __global__ __launch_bounds__(ST) void k_regen_done(const UpdateArgs a) {
     // (c) the best rows: actions of the three argmax samples, re-generated for every time step
     for (int o = tid; o < 3 * T; o += ST) {
         const int which = o / T, tt = o - which * T, gi = s_best[which];
-        RegenRows<NU> rr;
-        regen_rows<NU>(a, tt, rr);
         float dv[NU], ev[NU];
         const bool valid = gi >= 0 && gi < Kg;     // (no argmax at all when every weight is NaN: zero rows then)
         const int gc = valid ? gi : 0;
-        const int r = gc / a.Kls, kk = gc - r * a.Kls;
-        const float* drow = a.noise_all + (((size_t)r * T + tt) * a.Kls + kk) * NU;
+        if constexpr (REGEN) {
+            RegenRows<NU> rr;
+            regen_rows<NU>(a, tt, rr);
+            const int r = gc / a.Kls, kk = gc - r * a.Kls;
+            const float* drow = a.noise_all + (((size_t)r * T + tt) * a.Kls + kk) * NU;
 #pragma unroll
-        for (int j = 0; j < NU; ++j) dv[j] = drow[j];
-        regen_action<NU>(a, rr, gc, dv, ev);
+            for (int j = 0; j < NU; ++j) dv[j] = drow[j];
+            regen_action<NU>(a, rr, gc, dv, ev);
+        } else {
+            const float* arow = a.actions + ((size_t)tt * Kg + gc) * NU;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) ev[j] = arow[j];
+        }
 #pragma unroll
         for (int j = 0; j < NU; ++j) a.reduce[reduce_off_best(which, T, NU) + tt * NU + j] = valid ? ev[j] : 0.0f;
     }
     __threadfence_block();
     __syncthreads();
     finalize_body<false>(a, sm_fin);
+}
+void launch_fused_large(const UpdateArgs& a_, hipStream_t s) {   // (after launch_ladder_search)
+    UpdateArgs a = a_;
+    const int clen = regen_chunk_len(a.Kg);
+    a.n_chunk = regen_chunks(a.Kg);
+    const dim3 grid(a.T * a.n_chunk + (a.n_cand > 1 ? 1 : 0));
+    const size_t lds = (size_t)a.T * a.nu * sizeof(float);
+    if (a.nu == 2) {
+        hipLaunchKernelGGL((k_regen_part<2, false>), grid, dim3(ST), 0, s, a, clen);
+        hipLaunchKernelGGL((k_regen_done<2, false>), dim3(1), dim3(ST), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((k_regen_part<9, false>), grid, dim3(ST), 0, s, a, clen);
+        hipLaunchKernelGGL((k_regen_done<9, false>), dim3(1), dim3(ST), lds, s, a);
+    }
 }
 void launch_regen_fast(const UpdateArgs& a_, hipStream_t s) {
     UpdateArgs a = a_;

@@ -122,6 +122,10 @@ class HipEngine:
     def set_rollout_lanes(self, lanes=0):
         self._ck(self.lib.m3_set_rollout_lanes(self._h, int(lanes)))
 
+    def set_update_launches(self, launches=0):
+        """0 / 3: the three-launch multi-modal update beyond k_update_small's range; 5: round 3's five launches."""
+        self._ck(self.lib.m3_set_update_launches(self._h, int(launches)))
+
     def set_wave_order(self, on=True):
         """Samples sorted into coherent wavefronts (default) or assigned by index; same results."""
         self._ck(self.lib.m3_set_wave_order(self._h, int(bool(on))))

@@ -34,6 +34,8 @@ def _engines(shard_mix):
     from m3p2i_aip_amd.engine import HipEngine, make_config
     kw = dict(T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
     full = HipEngine(make_config(K=K, **kw))
+    full.set_update_launches(5)   # (the launch structure whose summation order the sharded protocols reproduce bit for bit;
+    # the default three-launch update agrees with it to rounding: test_hip_edge_cases.py, test_update_on_synthetic_costs_gpu.py)
     shards = [HipEngine(make_config(K=K, K_local=KL, k_offset=r * KL, shard_mix=shard_mix, **kw)) for r in range(N)]
     return full, shards
 
@@ -159,6 +161,7 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
     delta = _noise()[:Kt]
     kw = dict(T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
     full = HipEngine(make_config(K=Kt, **kw))
+    full.set_update_launches(5)   # (see _engines)
     shards = [HipEngine(make_config(K=Kt, K_local=kl, k_offset=r * kl, shard_mix=level, **kw)) for r in range(Nt)]
     full.set_noise(delta)
     for e in shards:

@@ -184,6 +184,72 @@ print("RESULT" + json.dumps(out))
         np.testing.assert_allclose(a["action"], b["action"], atol=1e-6)
 
 
+@pytest.mark.parametrize("env", ["point", "panda"])
+def test_three_launch_update_equals_the_five_launch_one_and_its_give_up_branch(env):
+    """Unsharded multi-modal command() with K beyond k_update_small's range: k_ladder_search (ladder workgroups + ONE search
+    workgroup that waits for their flags; the minima from the rows the rollout's workgroups left behind) ->
+    k_regen_part<false> -> k_regen_done<false>, against round 3's five launches (M3P2I_UPDATE_FIVE_LAUNCHES: k_mins,
+    k_ladder, k_search, k_apply_weights, k_wsum) and against its own give-up branch (M3P2I_LADDER_SPINS=0: the search
+    workgroup does not wait and runs the reference's iterative passes over the costs): same pass counts and best samples,
+    weights / plan to rounding -- the partial tables are added in another order, the sums in 2048-sample chunks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from m3p2i_aip_amd import _lib as L
+from m3p2i_aip_amd.engine import HipEngine, make_config
+env = %r
+g = torch.Generator().manual_seed(3)
+if env == "point":
+    K, T, nu = 20000, 30, 2
+    eng = HipEngine(make_config(K=K, T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3]))
+    eng.set_objective("push_pull", (-3.75, -3.75))
+    eng.set_world_point_raw(np.array([0.0, 1.5, 0, 0, 0, 2, 1, 0, 0, 0, 0, -2, 2, 1, 0, 0, 0, 0], np.float32))
+else:
+    K, T, nu = 6000, 20, 9
+    eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", multi_modal=True, u_min=[-1.2] * 9, u_max=[1.2] * 9,
+                                noise_sigma_diag=[10.0] * 7 + [0.8, 0.8], lambda_=0.05, pre_height_diff=0.05, dt=0.01))
+    eng.set_objective("reach", [0.2, 0.2, 1.115, 0, 0, 0, 1], gripper_cmd=1)
+knots = torch.randn(K, nu, T // 4, generator=g)
+delta = torch.nn.functional.interpolate(knots, size=T, mode="linear", align_corners=True).permute(0, 2, 1).contiguous().numpy()
+eng.set_noise(delta)
+out = []
+for _ in range(3):
+    a = eng.command(sync_host=True)
+    i = eng.info()
+    out.append(dict(iters=[i.iters, i.iters_1, i.iters_2], eta=[i.eta, i.eta_1, i.eta_2], action=a.tolist(),
+                    best=[i.best_idx, i.best_idx_1, i.best_idx_2], pref=i.pull_preference,
+                    top=eng.buffer(L.BUF_TOP_IDX).cpu().numpy().tolist(),
+                    w=eng.buffer(L.BUF_WEIGHTS).cpu().numpy().tolist(), w1=eng.buffer(L.BUF_WEIGHTS_1).cpu().numpy().tolist(),
+                    m1=eng.buffer(L.BUF_MEAN_1).cpu().numpy().tolist(), m2=eng.buffer(L.BUF_MEAN_2).cpu().numpy().tolist()))
+print("RESULT" + json.dumps(out))
+""" % (root, env)
+
+    def run(env_extra):
+        r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+
+    three, five, gave_up = run({}), run({"M3P2I_UPDATE_FIVE_LAUNCHES": "1"}), run({"M3P2I_LADDER_SPINS": "0"})
+    for other in (five, gave_up):
+        # (the first command: the same costs bit for bit; later ones start from plans that agree to rounding)
+        a, b = three[0], other[0]
+        assert a["iters"] == b["iters"] and a["best"] == b["best"] and a["pref"] == b["pref"] and a["top"] == b["top"]
+        np.testing.assert_allclose(a["eta"], b["eta"], rtol=1e-5)
+        np.testing.assert_allclose(a["w"], b["w"], rtol=2e-5, atol=1e-12)
+        np.testing.assert_allclose(a["w1"], b["w1"], rtol=2e-5, atol=1e-12)
+        for key in ("action", "m1", "m2"):
+            np.testing.assert_allclose(a[key], b[key], atol=2e-5)
+        for a, b in zip(three[1:], other[1:]):
+            np.testing.assert_allclose(a["action"], b["action"], atol=1e-3)
+    assert min(three[0]["iters"]) >= 1 and (env == "panda" or max(three[0]["iters"]) > 1)   # (the point searches walk their ladders)
+
+
 @pytest.mark.parametrize("dt,substeps,iters", [(0.04, 3, 4), (0.05, 1, 6), (0.05, 2, 8), (0.02, 2, 1)])
 def test_rollout_bit_exact_with_other_solver_settings(oracle, dt, substeps, iters):
     """isaacgym/point.yaml dt, isaacgym_wrapper.py:10 substeps and :28 solver iterations are run-time settings of the

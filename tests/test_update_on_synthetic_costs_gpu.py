@@ -70,11 +70,11 @@ def test_multi_modal_weights_on_synthetic_costs(K, scale, path):
     eng.close()
 
 
-@pytest.mark.parametrize("mm", [False, True])
-@pytest.mark.parametrize("K", [1500, 4000])
+@pytest.mark.parametrize("K,mm", [(1500, False), (1500, True), (4000, False), (4000, True), (20000, True), (64000, True), (131072, True)])
 def test_one_launch_update_equals_the_phases(K, mm):
-    """k_update_small (m3_update_finalize, K <= 4096) against m3_update + m3_finalize on the same
-    costs and actions: single mode -> the same bits everywhere (same reductions, same order); the
+    """k_update_small (m3_update_finalize, K <= 4096) -- and, multi-modal beyond its range, the three-launch update
+    (k_ladder_search, k_regen_part<false>, k_regen_done<false>) -- against m3_update + m3_finalize (the multi-launch
+    phases) on the same costs and actions: single mode -> the same bits everywhere (same reductions, same order); the
     multi-modal searches sum eta in a different order than the ladder kernels, so their weights
     agree to rounding and the pass counts unless eta grazes a bound."""
     from m3p2i_aip_amd import _lib as L
