@@ -932,6 +932,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr) {
                 const int r3 = (rr + 1) % 3;      // friction rows first, the normal row last
+#ifdef M3_PABL_NO_ROBOT_FRICTION
+                if (r3 != 0) continue;            // (ablation: what the gripper contacts' friction rows cost)
+#endif
                 float J[9], ab[3];
 #pragma unroll
                 for (int j = 0; j < 9; ++j) J[j] = cs.row(s, r3, j);
@@ -963,6 +966,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr) {
                     const int r3 = (rr + 1) % 3;
+#ifdef M3_PABL_NO_BODY_FRICTION
+                    if (r3 != 0) continue;        // (ablation: what the manifolds' friction rows cost)
+#endif
                     const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
                     float aa[3], ab[3];
                     cross3(r, d, aa);

@@ -41,14 +41,12 @@ if os.path.exists(s):
 for f in ("behaviour_stats_baseline.json", "behaviour_stats_default_size.json", "behaviour_stats_panda.json", "halton_scramble.json",
           "codeobj_info.txt", "mix_push_K2000.json", "mix_push.json", "mix_panda_pick.json", "mix_panda.json", "mix_worst_case.json"):
     cp(f, f)
-for f in ("collective_overhead_c5.json", "collective_overhead_push.json", "coop_rows_K2000.json", "phase_breakdown.json",
-          "mask_count_closed_loop.json", "closed_loop_perf.json"):
+for f in ("collective_overhead_c5.json", "collective_overhead_push.json", "closed_loop_perf.json"):   # (coop_rows / phase_breakdown /
+    # mask_count are one-off experiments of rounds 2-3: their own tools write them, tools/refresh_profiles.sh does not)
     cp(f, f)
 cp("prof_emul/emul_kernel_stats.csv", "rank0_of_8_emulation_kernel_stats.csv")
 cp("host_overhead.txt", "host_overhead.txt")
-cp("iters_sweep.txt", "iters_sweep_push_K2000.txt")
 cp("k_sweep.json", "k_sweep_push_T30.json")
-cp("lanes_sweep.json", "lanes_sweep_final.json")
 cp("pmc_final.txt", "pmc_rollout_push_K2000.txt")
 cp("pmc_panda.txt", "pmc_rollout_panda_K4000.txt")
 
