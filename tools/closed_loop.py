@@ -169,6 +169,7 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
     timeline, lat = [], []
     success_tick = None
     stop_at, captured = None, None
+    full = []
     path = []               # trace=True: per tick [robot x, y, box x, y, box quat z, w, dyn-obs x, y, action x, y] (point_env)
     for i in range(ticks):
         if cfg.env_type == "point_env":
@@ -201,6 +202,8 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
             hand = real.get_actor_link_by_name("panda", "panda_hand")[0, :7].cpu().tolist()
             cube = real.get_actor_link_by_name("cubeA", "box")[0, :7].cpu().tolist()
             path.append([task] + hand + cube + real._dof_state[0, [14, 16]].cpu().tolist() + action_host[7:9].tolist())
+            full.append(dict(tick=i, task=task, dof_state=real._dof_state[0].cpu().tolist(), root_state=real._root_state[0].cpu().tolist(),
+                             action=action_host.reshape(-1).tolist()))     # (enough to replay the world on the CPU oracle)
         real.set_dof_velocity_target_tensor(action.view(1, nu))
         if cfg.env_type == "point_env":
             cfg.suction_active = tamp.suction_active
@@ -233,6 +236,8 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
         res["captured"] = captured
     if trace:
         res["trace"] = path
+        if full:
+            res["full"] = full
     real.stop_sim()
     tamp.close()
     return res
@@ -259,7 +264,7 @@ def main(argv):
     if serve_ep:
         return serve(cn, overrides, serve_ep)
     res = run(cn, overrides, ticks, connect=connect_ep, trace=trace)
-    print(json.dumps({k: v for k, v in res.items() if k != 'trace'}))
+    print(json.dumps({k: v for k, v in res.items() if k not in ('trace', 'full')}))
     if out:
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
         json.dump(res, open(out, "w"), indent=1)
