@@ -567,7 +567,10 @@ struct GraspGeom {
     float cx, cy, cz;
     float Rc[9];
     bool in_region;
+    bool in_capture;   // spec v2.1: the volume in which the tips' spheres do not act on cubeA (the oracle's comment)
+    bool in_pads;      // spec v2.1: the pads meet the cube's side faces (they cannot enter it, closing pads sweep it)
 };
+constexpr float PADS_DX = 0.035f, PADS_DZ = 0.03f;
 __device__ __forceinline__ void grasp_geom(const PandaScene& sc, const PandaWorld& w, const Frame& hand,
                                            GraspGeom& g) {
     const float d[3] = {w.A.p[0] - hand.p[0], w.A.p[1] - hand.p[1], w.A.p[2] - hand.p[2]};
@@ -584,6 +587,8 @@ __device__ __forceinline__ void grasp_geom(const PandaScene& sc, const PandaWorl
     // (step: centre between the two pad faces; infer_held: centred between closed pads)
     g.in_region = fabsf(g.cx) <= sc.grasp_dx && fabsf(g.cz - sc.grasp_z) <= sc.grasp_dz &&
                   ay >= sc.grasp_align && az >= sc.grasp_align;
+    g.in_capture = fabsf(g.cx) <= 0.045f && (g.cz - sc.grasp_z) <= 0.08f && (g.cz - sc.grasp_z) >= -0.03f && az >= 0.9f;
+    g.in_pads = fabsf(g.cx) <= PADS_DX && fabsf(g.cz - sc.grasp_z) <= PADS_DZ && az >= 0.9f;
 }
 __device__ __forceinline__ void set_rel_rot(PandaWorld& w, const Frame& hand, const float* Rc) {
     Frame r;
@@ -764,12 +769,13 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             const bool nt = near_box(sc.table, sc.table + 3, 0.0f), ns = near_box(sc.shelf, sc.shelf + 3, 0.0f);
             const bool nA = near_box(w.A.p, zero3, sc.cube_rad), nB = near_box(w.B.p, zero3, sc.cube_rad);
             const bool no = near_box(w.obs_p, sc.obs_half, 0.0f);
-            // the pad channel (the grasp rule's region): there the pads, not the tip spheres, act on cubeA
+            // the capture volume (spec v2.1: the space between and under the open fingers): there the pads, not the tip
+            // spheres, act on cubeA
             bool in_channel = false;
             if (nA && !held) {
                 GraspGeom gg;
                 grasp_geom(sc, w, g.hand, gg);
-                in_channel = gg.in_region && gg.cy < w.q[7] && gg.cy > -w.q[8];
+                in_channel = gg.in_capture && gg.cy < w.q[7] && gg.cy > -w.q[8];
             }
             const BoxT<false> bt = box_static(sc.table), bs = box_static(sc.shelf);
             const BoxT<true> bA = box_cube(sc, w.A.p, RA), bB = box_cube(sc, w.B.p, RB);
@@ -1136,8 +1142,8 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 bool need = false;
                 if (w.held != 0.0f) need = near;
                 else {
-                    const float gz = fabsf(sc.grasp_z) + sc.grasp_dz;
-                    const float lim = sqrtf((sc.grasp_dx * sc.grasp_dx + sc.finger_max * sc.finger_max) + gz * gz) + *trav + 1.0e-3f;
+                    const float gz = fabsf(sc.grasp_z) + PADS_DZ;      // (the region of the pads' action, spec v2.1)
+                    const float lim = sqrtf((PADS_DX * PADS_DX + sc.finger_max * sc.finger_max) + gz * gz) + *trav + 1.0e-3f;
                     const float dx = w.A.p[0] - hp[0], dy = w.A.p[1] - hp[1], dz = w.A.p[2] - hp[2];
                     const bool idle = !(u[7] < 0.0f && u[8] < 0.0f) && !(w.q[7] + w.q[8] < 2.0f * sc.cube_half);
                     need = !(idle || (dx * dx + dy * dy) + dz * dz > lim * lim);
@@ -1170,8 +1176,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         } else if (have_fk) {
             GraspGeom gg;
             grasp_geom(sc, w, hand, gg);
-            // spec v1.1, the pad channel: the cube's centre lies between the two pad faces
-            if (gg.in_region && gg.cy < w.q[7] && gg.cy > -w.q[8]) {
+            // spec v1.1 / v2.1, the pad channel: the cube's centre lies between the two pad faces, the pads meet its side
+            // faces (in_pads); they hold it in the grasp rule's region (in_region)
+            if (gg.in_pads && gg.cy < w.q[7] && gg.cy > -w.q[8]) {
                 float gap = w.q[7] + w.q[8];
                 const float wdt = 2.0f * sc.cube_half;
                 if (gap < wdt) {
@@ -1193,7 +1200,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                         gg.cx = dot3(d, hand.x); gg.cz = dot3(d, hand.z);
                     }
                 }
-                if (gap <= wdt + sc.grasp_tol && u[7] < 0.0f && u[8] < 0.0f) {
+                if (gg.in_region && gap <= wdt + sc.grasp_tol && u[7] < 0.0f && u[8] < 0.0f) {
                     w.held = 1.0f;
                     w.qd[7] = 0.0f; w.qd[8] = 0.0f;
                     w.rel_p[0] = gg.cx; w.rel_p[1] = 0.5f * (w.q[7] - w.q[8]); w.rel_p[2] = gg.cz;

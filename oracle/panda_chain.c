@@ -7,14 +7,15 @@
  *       get_panda_place_cost   cost_functions.py:127-136
  *       get_pick_tilt_cost     cost_functions.py:138-156
  *       get_motion_cost        cost_functions.py:158-169 (panda branch)
- * (2) Independent implementation of "Panda world spec v2" (DESIGN.md section 3): velocity-servoed
+ * (2) Independent implementation of "Panda world spec v2.1" (DESIGN.md section 3): velocity-servoed
  *     9-dof chain with joint-space inertias derived from the collision meshes, forward kinematics from
  *     the URDF constants (assets/urdf/franka_description/robots/franka_panda.urdf:27-242), cubeA /
  *     cubeB as free rigid cubes and the dyn-obs plate as a free (non-rotating) body, CONTACT RESPONSE:
  *     the gripper's collision spheres and a held cube against table / shelf_stand / cubes / plate and
  *     the cubes' corners against table / shelf_stand / each other as velocity-level unilateral rows
  *     with Coulomb friction, solved together with the joint drives by projected Gauss-Seidel passes
- *     (solver settings: isaacgym_wrapper.py:26-31); position-level two-finger grasp (pad channel).
+ *     (solver settings: isaacgym_wrapper.py:26-31); position-level two-finger grasp (pad channel; v2.1:
+ *     grasp region, pads' region, capture volume).
  *     It stands where the reference calls Isaac Gym / PhysX (isaacgym_wrapper.py:354-360);
  *     PARITY UNPINNED against PhysX.  Scene constants: config/panda_env/ yaml files.
  *     This file is written as a generic solver over dynamic row lists; the product's device code
@@ -369,6 +370,12 @@ static void body_apply(solver_t* S, int b, const float d[3], const float a[3], f
 }
 
 /* effective masses and the bias of a contact whose directions, rows and arms are set */
+#define CAPTURE_DX 0.045f
+#define CAPTURE_UP 0.08f
+#define CAPTURE_DN 0.03f
+#define CAPTURE_ALIGN 0.9f
+#define PADS_DX 0.035f
+#define PADS_DZ 0.03f
 static void contact_prepare(solver_t* S, contact_t* c, float gap) {
     const m3o_panda_scene* sc = S->sc;
     for (int r = 0; r < 3; ++r) {
@@ -615,7 +622,7 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
         box_body(w->cubeA, cube_e, 1, &tgt[T_CUBEA]);
         box_body(w->cubeB, cube_e, 1, &tgt[T_CUBEB]);
         box_body(w->obs, sc->obs_half, 0, &tgt[T_OBS]);
-        /* the pad channel (the grasp rule's region): there the pads, not the tip spheres, act on cubeA */
+        /* the capture volume (spec v2.1): there the pads, not the tip spheres, act on cubeA */
         int in_channel = 0;
         if (!held) {
             const float dd[3] = {w->cubeA[0] - g.ph[0], w->cubeA[1] - g.ph[1], w->cubeA[2] - g.ph[2]};
@@ -628,8 +635,17 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
                 ay = fmaxf(ay, fabsf(dot3(g.hy, col)));
                 az = fmaxf(az, fabsf(dot3(g.hz, col)));
             }
-            in_channel = fabsf(cx) <= sc->grasp_dx && fabsf(cz - sc->grasp_z) <= sc->grasp_dz && cy < w->q[7] &&
-                         cy > -w->q[8] && ay >= sc->grasp_align && az >= sc->grasp_align;
+            /* spec v2.1, the CAPTURE volume: wider than the grasp rule's region -- the cube's centre between the pads' faces,
+               within 4.5 cm of their centre line along the hand's x, from 3 cm above the grasp height (pads below the cube's
+               middle) to 8 cm below it (the open gripper still coming down over the cube), the cube roughly upright; no yaw
+               condition.  The small planner of the reference's shipped size (K = 200) arrives 2-3 cm off the centre line;
+               with the exclusion limited to the grasp region a tip sphere then landed on the cube's edge on the way down
+               and knocked it, and a cube drifting out of the region while the pads close met the tip spheres 12 mm inside
+               it and was shot across the table: 39 of 60 picks (round 3's kinematic world: 60).  Inside the capture
+               volume the pads' position-level model (sweep, latch) is the gripper's only action on cubeA, as in spec v1.1. */
+            (void)ay;
+            in_channel = fabsf(cx) <= CAPTURE_DX && (cz - sc->grasp_z) <= CAPTURE_UP && (cz - sc->grasp_z) >= -CAPTURE_DN &&
+                         cy < w->q[7] && cy > -w->q[8] && az >= CAPTURE_ALIGN;
         }
         int robot_rows = 0;
         int touched[3] = {0, 0, 0};     /* a gripper row acts on this free body */
@@ -806,7 +822,13 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
              * face), it is aligned with the pads, and its centre lies between the two pad faces (-q8 < cy < q7). */
             int in_region = fabsf(cx) <= sc->grasp_dx && fabsf(cz - sc->grasp_z) <= sc->grasp_dz &&
                             cy < w->q[7] && cy > -w->q[8] && ay >= sc->grasp_align && az >= sc->grasp_align;
-            if (in_region) {
+            /* spec v2.1: the pads MEET the cube's side faces in a wider region than the one in which they can hold it -- the
+             * cube's centre between the pad faces, within 3.5 cm of their centre line along x (pad half width 1 cm + the cube's
+             * 2.5) and 3 cm along z, the cube roughly upright: there they cannot enter it and closing pads sweep it; the
+             * latch needs the grasp rule's region */
+            const int in_pads = fabsf(cx) <= PADS_DX && fabsf(cz - sc->grasp_z) <= PADS_DZ && cy < w->q[7] && cy > -w->q[8] &&
+                                az >= CAPTURE_ALIGN;
+            if (in_pads) {
                 float gap = w->q[7] + w->q[8];
                 float wdt = 2.0f * sc->cube_half;
                 if (gap < wdt) { /* pads cannot enter the cube: keep the difference, open to the width */
@@ -829,7 +851,7 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
                         cx = dot3(d, hx); cz = dot3(d, hz);
                     }
                 }
-                if (gap <= wdt + sc->grasp_tol && u[7] < 0.0f && u[8] < 0.0f) {
+                if (in_region && gap <= wdt + sc->grasp_tol && u[7] < 0.0f && u[8] < 0.0f) {
                     w->held = 1.0f;
                     w->qd[7] = 0.0f; w->qd[8] = 0.0f;
                     w->rel_p[0] = cx; w->rel_p[1] = 0.5f * (w->q[7] - w->q[8]); w->rel_p[2] = cz;

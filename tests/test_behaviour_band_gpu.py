@@ -76,15 +76,22 @@ def test_point_env_closed_loop_statistics_inside_the_reference_band(scenario, si
     assert r["dyn_obs_collided_episodes"] <= bound, msg
 
 
-def test_panda_reactive_pick_statistics_inside_the_reference_band():
+@pytest.mark.parametrize("size", ["baseline", "default"])
+def test_panda_reactive_pick_statistics_inside_the_reference_band(size):
+    """`default`: the reference's SHIPPED planner size (config_panda: K = 200, T = 12).  Under world spec v2.0 it succeeded in 39
+    of 60 episodes (the small planner arrives 2-3 cm off the cube's centre line and the tips' spheres knocked / shot the cube
+    away); spec v2.1's capture volume: 60 of 60."""
     band = BAND["panda"]["reactive_pick"]["final_xy_error_m"]          # logged: 11.7 +- 16.6 mm, n = 50
-    r = _stats_tool().panda_episodes(n=N)
+    ov = ("mppi.num_samples=4000", "mppi.horizon=20") if size == "baseline" else ("mppi.num_samples=200", "mppi.horizon=12")
+    r = _stats_tool().panda_episodes(n=N, overrides=ov)
     msg = json.dumps({k: v for k, v in r.items() if k != "runs"})
     assert r["successes"] == N, msg                                      # (chain spec v1 without the pad channel: 7 of 20)
     for run in r["runs"]:
         tasks = [t for _, t in run["timeline"]]
         assert tasks[:3] == ["reach", "pick", "place"], run              # reach -> pick -> place (task_planner.py:41-107)
-        assert abs(run["cube_height_above_goal"] - 0.05) < 0.03, run     # cubeA sits on cubeB (5 cm cubes)
+        # cubeA sits on cubeB (5 cm cubes); read at the tick of success: the small planner lets go up to 4 cm above it
+        assert abs(run["cube_height_above_goal"] - 0.05) < (0.03 if size == "baseline" else 0.045), run
     e = r["final_xy_error_m"]
     assert abs(e["mean"] - band["mean"]) <= 3.0 * band["std"] and e["std"] <= 3.0 * band["std"], msg
-    assert e["max"] <= BAND["panda"]["normal_pick"]["final_xy_error_m"]["max"] + 0.01, msg    # logged max 17 mm
+    # logged max 17 mm; at the shipped size the bar is the reference's own success criterion (task_planner.py:101: 4 cm)
+    assert e["max"] <= (BAND["panda"]["normal_pick"]["final_xy_error_m"]["max"] + 0.01 if size == "baseline" else 0.04), msg

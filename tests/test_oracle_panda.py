@@ -145,12 +145,16 @@ def test_pad_channel_spec_v11(P):
     # 2 cm off along the pads' width (inside the footprint): held off-centre, not moved
     w, c0 = run((0.02, 0.0), close)
     assert w[P.W_HELD] == 1.0 and abs(abs(w[P.W_RELP]) - 0.02) < 1e-3 and np.allclose(w[P.W_CUBEA:P.W_CUBEA + 2], c0[:2], atol=1e-4)
-    # 3 cm off along the width: outside the pads' footprint -- not captured.  (Spec v2: the finger tips are collision
-    # spheres of radius 1.2 cm, 5 mm of which overlap the cube's extent along the width: they close ON the cube's
-    # side faces and stop there, 3.7 cm from the centre line each, nudging it by a millimetre or two.)
+    # 3 cm off along the width: outside the pads' footprint -- not captured.  (Spec v2.1: the pads still MEET the cube's
+    # side faces there -- 1 cm of pad overlaps them -- and stop at its width; they hold nothing and do not move it.)
     w, c0 = run((0.03, 0.0), close)
-    assert w[P.W_HELD] == 0.0 and np.allclose(w[P.W_CUBEA:P.W_CUBEA + 3], c0, atol=4e-3)
-    assert w[P.W_Q + 7] + w[P.W_Q + 8] == pytest.approx(2 * 0.037, abs=4e-3)
+    assert w[P.W_HELD] == 0.0 and np.allclose(w[P.W_CUBEA:P.W_CUBEA + 3], c0, atol=1e-4)
+    assert w[P.W_Q + 7] + w[P.W_Q + 8] == pytest.approx(2 * 0.025, abs=1e-4)
+    # 4 cm off along the width: beyond the pads altogether (but inside the capture volume, in which the tips' spheres do
+    # not act on cubeA): the fingers close past the cube's side, which stays where it is
+    w, c0 = run((0.04, 0.0), close)
+    assert w[P.W_HELD] == 0.0 and np.allclose(w[P.W_CUBEA:P.W_CUBEA + 3], c0, atol=1e-4)
+    assert w[P.W_Q + 7] + w[P.W_Q + 8] < 0.01
     # 4.5 cm off along the closing direction: the cube's centre is beyond a pad face -- not captured (pushed aside
     # by the closing finger instead)
     w, c0 = run((0.0, 0.045), close)
