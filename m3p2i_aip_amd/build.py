@@ -18,7 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libm3p2i_hip.so")
 OBJ = os.path.join(HERE, "_obj")   # object files (git- and gpurun-ignored)
 SOURCES = ["rollout_point.hip", "rollout_point_task0.hip", "rollout_point_task1.hip", "rollout_point_task2.hip",
-           "rollout_point_task3.hip", "rollout_panda.hip", "update.hip", "sampler.hip", "p2p.hip", "m3_api.hip"]
+           "rollout_point_task3.hip", "rollout_panda.hip", "update.hip", "update_small.hip", "update_sharded.hip", "sampler.hip",
+           "p2p.hip", "m3_api.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
           "-Wno-unused-function"]
 # per-source flags, measured on the bench configs (tools/time_variants_cfg.sh; later flags win; none of them changes
