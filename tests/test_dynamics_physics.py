@@ -495,6 +495,57 @@ def test_panda_descent_into_the_table_stops_and_reports_the_effort_limited_force
     assert 100 < max(forces) < 400                                     # (N: 87 N m over a ~0.4 m lever)
 
 
+def _descend_over_cubeA(P, sc, dy, steps=60):
+    """open gripper, pointing straight down, hand `dy` off cubeA's centre along the pads' closing direction, lowered at 0.1 m/s
+    from 4 cm above the grasp height to the grasp height; returns the world, cubeA's start, the rows seen, the hand's heights and
+    the heights of the -y finger tip's lowest point, both above the cube's centre"""
+    from tests.test_device_dynamics_on_host import _ik_down
+    w = P.init_world(1)
+    z = np.zeros((1, 9), np.float32)
+    for _ in range(30):
+        P.step_batch(sc, w, z)
+    c0 = w[0, P.W_CUBEA:P.W_CUBEA + 3].copy()
+    w[0, :9] = _ik_down(P, sc, np.array([c0[0], c0[1] + dy, c0[2] + sc.grasp_z + 0.04]))
+    w[0, 7], w[0, 8] = 0.04, 0.04
+    w[0, 9:18] = 0.0
+    rows, heights, tips = [], [], []
+    for t in range(steps):
+        q0 = w[0, :9].copy()
+        L = P.fk(sc, q0)
+        Jh, _ = _point_jacobian(P, sc, q0, L["pos"][8])
+        u = np.zeros((1, 9), np.float32)
+        vz = -0.1 if L["pos"][8][2] > c0[2] + sc.grasp_z else 0.0
+        u[0, :7] = np.clip(np.linalg.pinv(Jh[:, :7]) @ np.array([0, 0, vz]), -2.0, 2.0)
+        u[0, 7:] = 1.5                                           # fingers commanded open (the reach phase's override)
+        P.step_batch(sc, w, u)
+        rows.append(P.last_rows()[0])
+        L1 = P.fk(sc, w[0, :9])
+        heights.append(L1["pos"][8][2] - c0[2])
+        tips.append(L1["pos"][10][2] + sc.tip_z * L1["az"][8][2] - sc.tip_r - c0[2])     # bottom of the -y finger's tip sphere
+    return w[0], c0, rows, heights, np.array(tips)
+
+
+def test_panda_open_gripper_comes_down_over_an_off_centre_cube(P):
+    """Spec v2.1, the capture volume.  The reference's shipped planner size brings the open gripper down 2-3 cm off the cube's
+    centre line.  With the cube's centre BETWEEN the pads (2.5 cm off: a finger's pad overlaps the cube by a centimetre) the
+    finger tips' spheres do not act on cubeA -- the pads will, position level, once they close -- and the cube is not touched:
+    under v2.0 a tip landed on its edge and knocked it (39 of 60 picks at that size; now 60).  With the cube's centre BEYOND a
+    pad's face (5 cm off) the gripper is not over the cube but on it: the tip lands on the cube's top and stops there."""
+    sc = P.default_scene()
+    w, c0, rows, heights, _ = _descend_over_cubeA(P, sc, 0.025)
+    assert np.array_equal(w[P.W_CUBEA:P.W_CUBEA + 3], c0) and w[P.W_AWAKE] == 0.0 and w[P.W_HELD] == 0.0
+    assert max(rows) == 0 and heights[-1] == pytest.approx(sc.grasp_z, abs=3e-3)          # down at the grasp height, nothing touched
+    w, c0, rows, heights, tip_bottom = _descend_over_cubeA(P, sc, 0.05)
+    on = [i for i, r in enumerate(rows) if r >= 1]                                         # the tip's contact row against cubeA
+    # it stands ON the cube and stalls there for a quarter of a second -- SUNK up to a centimetre into it: a stated limit of
+    # the spec (DESIGN section 3): arm (kilograms, drives of 87 N m) on cube (125 g) on table is a chain of mass ratio 1000 : 1
+    # that seven Gauss-Seidel sweeps do not converge on; the velocity it leaves lets the tip in until Baumgarte balances it
+    assert len(on) >= 15 and tip_bottom[on].min() > sc.cube_half - 0.012
+    assert abs(tip_bottom[on[-1]] - tip_bottom[on[-10]]) < 1e-3
+    # (then the cube, pressed at 1.5 cm from its edge by a hand that drifts sideways, slides out from under the tip)
+    assert w[P.W_HELD] == 0.0 and np.linalg.norm(w[P.W_CUBEA:P.W_CUBEA + 2] - c0[:2]) > 5e-3
+
+
 def test_panda_finger_sweep_moves_cubeB(P):
     """A closed gripper swept sideways at cube height pushes the sleeping cubeB away: the cube wakes, moves with the
     finger, the finger's force on it is reported (get_motion_cost reads cubeB's net contact force), and once the finger
