@@ -440,6 +440,45 @@ def closed_loop(r, ticks, device):
     return out
 
 
+def self_launch(n, argv):
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks (one process per GPU) under
+    torch.distributed.run on a free loopback port -- the command line the driver documents --, pass rank 0's ONE JSON
+    line through, and return non-zero if any rank failed, if there is not exactly one line, or if the communicator the
+    ranks really formed (`ranks_seen`) is not N."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL, hipIpc)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)     # (stderr passes straight through)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    rest = [ln for ln in p.stdout.splitlines() if not ln.startswith("{")]
+    if rest:
+        print("\n".join(rest), file=sys.stderr)
+    if p.returncode != 0:
+        print(f"bench.py: the {n}-rank launch failed with exit code {p.returncode}", file=sys.stderr)
+        return p.returncode or 1
+    if len(lines) != 1:
+        print(f"bench.py: expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    try:
+        d = json.loads(lines[0])
+    except ValueError as e:
+        print(f"bench.py: rank 0's line is not JSON: {e}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    if d.get("n_gpus") != n or d.get("ranks_seen") != n:
+        print(f"bench.py: asked for {n} ranks, the line reports n_gpus={d.get('n_gpus')} ranks_seen={d.get('ranks_seen')}",
+              file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -460,10 +499,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the way the driver starts the N = 1 run (`python3 bench.py --gpus N ...`): launch the ranks ourselves
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # M3_BENCH_SHARE_GPU=1 (tests only, tests/test_bench_two_ranks_gpu.py): all ranks on cuda:0 with

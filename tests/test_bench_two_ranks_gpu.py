@@ -77,3 +77,22 @@ def test_bench_single_gpu_line_contract():
     # the corner scene is the slow end of the same kernel: >= the initial scene's time
     assert oc["worst_case_scene"]["kernel_ms"]["rollout"] > d["kernel_ms"]["rollout"]
     assert d["closed_loop"]["ms_per_step"] > d["ms_per_step"] and d["closed_loop"]["final_pos_error_m"] < 0.5
+
+
+def test_bench_starts_its_own_ranks():
+    """The driver's command line with N > 1 and NO launcher around it -- exactly `python3 bench.py --gpus 2 --steps 3
+    --warmup 1` -- : bench.py launches the two ranks itself (torch.distributed.run on a free loopback port), rank 0's
+    ONE JSON line comes through on stdout, the exit code is 0 only if every rank finished and the communicator the
+    ranks formed really has two members."""
+    env = dict(os.environ, M3_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert "K=4000 (2000/GPU)" in d["config"]["workload"] and d["value"] > 0
+    assert set(d["other_configs"]) == {"c5", "push_saturating"}
