@@ -238,6 +238,11 @@ int m3_enable_timing(m3_handle* h, int on);
  * a power of two in 1..64, or 0 = choose from K_local so that the waves fill the chip
  * (DESIGN.md "Lanes per wavefront").  Results do not depend on it. */
 int m3_set_rollout_lanes(m3_handle* h, int lanes);
+/* panda_env: lanes that simulate ONE sample in the rollout kernel -- 1 (a lane per sample, 64 samples per wavefront) or
+ * 16 (the sixteen lanes of a DPP row share a sample: the contact solver's joint-space rows run across them; four samples per
+ * wavefront), 0 = by size (16 while the launch has no more wavefronts than the chip has SIMDs).  Same results, bit for bit
+ * (world spec v3 defines the rows' sums as the pairwise tree both forms evaluate).  DESIGN.md section 6. */
+int m3_set_panda_lanes_per_sample(m3_handle* h, int lanes_per_sample);
 /* launch structure of the unsharded multi-modal update with K beyond the one-launch kernel's range: 0 (default) = three
  * launches (ladder + search in one grid, weights + sums, combine), 5 = the five launches of round 3 (minima, ladder,
  * search, weights, sums), whose sums are added in the order of the sharded "exact" protocols (tests compare those bit

@@ -78,6 +78,7 @@ SYMBOLS = [
     ("m3_set_stream", C.c_int, [_H, C.c_void_p]),
     ("m3_enable_timing", C.c_int, [_H, C.c_int]),
     ("m3_set_rollout_lanes", C.c_int, [_H, C.c_int]),
+    ("m3_set_panda_lanes_per_sample", C.c_int, [_H, C.c_int]),
     ("m3_set_update_launches", C.c_int, [_H, C.c_int]),
     ("m3_set_wave_order", C.c_int, [_H, C.c_int]),
     ("m3_relabel_samples", C.c_int, [_H]),

@@ -338,6 +338,14 @@ extern "C" int m3_set_rollout_lanes(m3_handle* h, int lanes) {
     return M3_OK;
 }
 
+extern "C" int m3_set_panda_lanes_per_sample(m3_handle* h, int lps) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (lps != 0 && lps != 1 && lps != 8 && lps != 16)
+        return fail(h, M3_ERR_BAD_ARG, "m3_set_panda_lanes_per_sample: 0 (by size), 1, 8 or 16");
+    h->panda_lps = lps;
+    return M3_OK;
+}
+
 extern "C" int m3_set_update_launches(m3_handle* h, int launches) {
     if (!h) return M3_ERR_BAD_ARG;
     if (launches != 0 && launches != 3 && launches != 5) return fail(h, M3_ERR_BAD_ARG, "m3_set_update_launches: 0 (default), 3 or 5");
@@ -862,8 +870,9 @@ extern "C" int m3_rollout(m3_handle* h) {
         // quirk Q8: the reach cost is measured against environment 0's cube (shadow lanes, rollout_panda.hip); a rank of
         // a sharded command does not hold sample 0's noise row and uses each sample's own cube
         pa.shadows = (pa.cp.task == 4 && a.k0 == 0 && a.Kl == a.Kg && a.Kg >= 2) ? (pa.cp.multi_modal ? 2 : 1) : 0;
-        launch_rollout_panda(a, pa, h->pscene, h->stream);
-        if (a.wave_min) { const int ln = std::min(a.lanes, 64 - pa.shadows); h->wave_min_rows = (a.Kl + ln - 1) / ln; }
+        pa.lps = h->panda_lps;
+        const int wgs = launch_rollout_panda(a, pa, h->pscene, h->stream);
+        if (a.wave_min) h->wave_min_rows = wgs;
     }
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));

@@ -259,9 +259,10 @@ struct PandaArgs {
     float world0[57];  // q9 qd9 | cubeA13 | cubeB13 | dyn-obs13 (pos3 quat4 vel3 angvel3)
     int cubeA_actor, cubeB_actor, obs_actor;
     PandaCostParams cp;
-    int shadows;       // lanes 63 (sample 0) and 62 (sample K / 2) of every wavefront re-simulate those samples: quirk Q8
+    int shadows;       // the last (two) sample slot(s) of every wavefront re-simulate sample 0 (and K / 2): quirk Q8
+    int lps;           // lanes per sample of the rollout kernel: 0 = by size, 1, 16 (m3_set_panda_lanes_per_sample)
 };
-void launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s);
+int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s);   // returns its workgroups
 void launch_psim_step(const PandaScene& sc, const SimViews& v, float* world, const float* u, float* u_keep, int Kl,
                       hipStream_t s);
 void launch_psim_pull(const PandaScene& sc, const SimViews& v, float* world, int Kl, hipStream_t s);
@@ -312,6 +313,7 @@ struct m3_handle {
     int* local_top_idx = nullptr;  // regen: top_idx of the local pre-gather selection (scratch)
     unsigned calls = 0;
     int lanes_override = 0;  // 0 = automatic (rollout_lanes_for)
+    int panda_lps = 0;       // 0 = automatic (rollout_panda.hip: panda_lps_for), 1, 16
     // device buffers
     void* buf[M3_BUF_COUNT] = {};
     long long nbytes[M3_BUF_COUNT] = {};

@@ -182,12 +182,198 @@ __device__ __forceinline__ float dot3(const float* a, const float* b) {
     return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
 }
 
+// ---- world spec v3: generalized coordinates (the oracle's comment above sum16 is the definition) ---------------------------
+// A sample's generalized vector has 16 entries: joints 0-8 | linear (9-11) and angular (12-14) velocity of the free body a
+// gripper row touches | 0.  LPS = lanes per sample: with LPS = 1 a lane holds all sixteen (step mode, the host build of the
+// tests, launches with more wavefronts than SIMDs), with LPS = 16 the sixteen lanes of a DPP row hold one each -- a joint-space
+// row is then ONE register, its velocity one multiply + a four-step butterfly across the row, an impulse one fused
+// multiply-add (tools/ubench/coop_panda_rows.hip: 2.3x per pass against nine serial fused multiply-adds fed from LDS).
+// Everything that is not a generalized vector is replicated in the sixteen lanes (same values, same control flow).
+template <int LPS> struct Gen {
+    static_assert(LPS == 1 || LPS == 8 || LPS == 16, "lanes per sample");
+    static constexpr int N = 16 / LPS;      // entries per lane: element e of lane l (of the sample's LPS) is coordinate e * LPS + l
+    float a[N];
+};
+template <int LPS> __device__ __forceinline__ int gen_lane() { return (LPS == 1) ? 0 : (int)(threadIdx.x & (unsigned)(LPS - 1)); }
+// the coordinate element e of this lane's Gen holds
+template <int LPS> __device__ __forceinline__ int gen_coord(int e) { return e * LPS + gen_lane<LPS>(); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// SUM16: the fixed pairwise tree ((x0+x1)+(x2+x3)) + ... ; across lanes: quad_perm xor 1, xor 2, row_half_mirror (, row_mirror) --
+// every step pairs lanes symmetrically, so all lanes of the sample end with the same bits; a lane's elements (eight lanes per
+// sample: the sums of coordinates 0-7 and 8-15) are added last: the tree's top level
+template <int LPS> __device__ __forceinline__ float gen_sum(const Gen<LPS>& x) {
+    if constexpr (LPS == 1) {
+        float a[8], b[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = x.a[2 * i] + x.a[2 * i + 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = a[2 * i] + a[2 * i + 1];
+        return (b[0] + b[1]) + (b[2] + b[3]);
+    } else {
+        float v[Gen<LPS>::N];
+#pragma unroll
+        for (int e = 0; e < Gen<LPS>::N; ++e) {
+            v[e] = x.a[e];
+            v[e] = v[e] + dpp_f<0xB1>(v[e]);
+            v[e] = v[e] + dpp_f<0x4E>(v[e]);
+            v[e] = v[e] + dpp_f<0x141>(v[e]);
+            if constexpr (LPS == 16) v[e] = v[e] + dpp_f<0x140>(v[e]);
+        }
+        if constexpr (LPS == 16) return v[0];
+        else return v[0] + v[1];
+    }
+}
+// the generalized vector whose coordinate c is f(c) (f: replicated values, c a compile-time constant after unrolling).  The
+// selects run from the highest coordinate down so that runs of equal constants (the zeros of coordinates 9-15) fold away.
+template <int LPS, class F> __device__ __forceinline__ Gen<LPS> gen_make(F f) {
+    Gen<LPS> g;
+    const int l = gen_lane<LPS>();
+#pragma unroll
+    for (int e = 0; e < Gen<LPS>::N; ++e) {
+        float a = f(e * LPS + LPS - 1);
+#pragma unroll
+        for (int j = LPS - 2; j >= 0; --j) a = (l == j) ? f(e * LPS + j) : a;
+        g.a[e] = a;
+    }
+    return g;
+}
+// coordinates [lo, hi) <- f(c), the others kept
+template <int LPS, class F> __device__ __forceinline__ void gen_update(Gen<LPS>& g, int lo, int hi, F f) {
+    const int l = gen_lane<LPS>();
+#pragma unroll
+    for (int e = 0; e < Gen<LPS>::N; ++e) {
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) {
+            const int c = e * LPS + j;
+            if (c >= lo && c < hi) g.a[e] = (LPS == 1 || l == j) ? f(c) : g.a[e];
+        }
+    }
+}
+// entries 0-8 <- nine replicated values, 9-15 <- +0
+template <int LPS> __device__ __forceinline__ Gen<LPS> gen_from9(const float* x) {
+    return gen_make<LPS>([&](int c) __attribute__((always_inline)) { return (c < 9) ? x[c < 9 ? c : 0] : 0.0f; });
+}
+// coordinate c of the sample's vector -> replicated
+template <int LPS> __device__ __forceinline__ float gen_entry(const Gen<LPS>& g, int c) {
+    if constexpr (LPS == 1) return g.a[c];
+    else return __int_as_float(__builtin_amdgcn_ds_bpermute((int)((threadIdx.x & ~(unsigned)(LPS - 1)) + (unsigned)(c % LPS)) << 2,
+                                                            __float_as_int(g.a[c / LPS])));
+}
+// entries 9-11 <- v, 12-14 <- w (a free body's velocities; replicated inputs)
+template <int LPS> __device__ __forceinline__ void gen_set_body(Gen<LPS>& g, const float* v, const float* w) {
+    gen_update<LPS>(g, 9, 15, [&](int c) __attribute__((always_inline)) { return (c < 12) ? v[c < 12 ? c - 9 : 0] : w[c >= 12 ? c - 12 : 0]; });
+}
+template <int LPS> __device__ __forceinline__ void gen_clear_body(Gen<LPS>& g) {      // entries 9-15 <- +0
+    gen_update<LPS>(g, 9, 16, [](int) __attribute__((always_inline)) { return 0.0f; });
+}
+
+// ---- the cubes' manifold rows (world spec v3; the oracle's comment above sum8_6 is the definition) -------------------------
+// Body coordinates: c = 8 b + i, b = 0 cubeA, 1 cubeB; i = 0-2 linear, 3-5 angular velocity, 6-7 pads (+0).  With sixteen lanes
+// per sample that is lanes 0-7 | 8-15 of ONE register, with eight lanes one register per cube, with one lane an array.
+enum { BK_A = 0, BK_AB = 1, BK_B = 2 };         // whose coordinates a manifold's rows touch (= the manifold's index)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// SUM8 over cube h's coordinates: ((x0+x1)+(x2+x3)) + ((x4+x5)+(x6+x7)), x6 = x7 = +0; replicated result
+template <int LPS> __device__ __forceinline__ float body_half_sum(const Gen<LPS>& x, int h) {
+    if constexpr (LPS == 1) {
+        return ((x.a[8 * h] + x.a[8 * h + 1]) + (x.a[8 * h + 2] + x.a[8 * h + 3])) + ((x.a[8 * h + 4] + x.a[8 * h + 5]) + 0.0f);
+    } else {
+        float v = x.a[(LPS == 8) ? h : 0];
+        v = v + dpp_f<0xB1>(v);
+        v = v + dpp_f<0x4E>(v);
+        v = v + dpp_f<0x141>(v);
+        if constexpr (LPS == 16) {
+            const float t = dpp_mov<0x140>(v);        // the other half's sum (row_mirror)
+            v = ((int)((threadIdx.x >> 3) & 1u) == h) ? v : t;
+        }
+        return v;
+    }
+}
+template <int LPS> __device__ __forceinline__ float body_sum(const Gen<LPS>& x, int kind) {
+    if (kind == BK_A) return body_half_sum<LPS>(x, 0);
+    if (kind == BK_B) return body_half_sum<LPS>(x, 1);
+    if constexpr (LPS == 16) {
+        float v = x.a[0];
+        v = v + dpp_f<0xB1>(v);
+        v = v + dpp_f<0x4E>(v);
+        v = v + dpp_f<0x141>(v);
+        return v + dpp_f<0x140>(v);                  // SUM8(A) + SUM8(B) (either order: the same bits)
+    } else {
+        return body_half_sum<LPS>(x, 0) + body_half_sum<LPS>(x, 1);
+    }
+}
+// is coordinate (element e of this lane) one of a row of `kind`?  (compile-time for LPS = 1, 8)
+template <int LPS> __device__ __forceinline__ bool body_in_kind(int e, int kind) {
+    if (kind == BK_AB) return true;
+    const int h = (LPS == 16) ? (int)((threadIdx.x >> 3) & 1u) : (LPS == 8) ? e : e / 8;
+    return h == ((kind == BK_B) ? 1 : 0);
+}
+// the row (d | aa | 0 0) on the mover's coordinates and, for a cubeA-against-cubeB row, (-d | -ab | 0 0) on cubeB's
+template <int LPS> __device__ __forceinline__ Gen<LPS> body_row(int kind, const float* d, const float* aa, const float* ab) {
+    return gen_make<LPS>([&](int c) __attribute__((always_inline)) {
+        const int b = c / 8, i = c % 8;
+        const bool mover = (b == ((kind == BK_B) ? 1 : 0));
+        const float vm = (i < 3) ? d[i < 3 ? i : 0] : (i < 6) ? aa[(i >= 3 && i < 6) ? i - 3 : 0] : 0.0f;
+        const float vt = (i < 3) ? -d[i < 3 ? i : 0] : (i < 6) ? -ab[(i >= 3 && i < 6) ? i - 3 : 0] : 0.0f;
+        return mover ? vm : (kind == BK_AB) ? vt : 0.0f;
+    });
+}
+// the two cubes' velocities as a generalized vector, and back (replicated <-> coordinates)
+template <int LPS> __device__ __forceinline__ Gen<LPS> body_vel_load(const Body& A, const Body& B) {
+    return gen_make<LPS>([&](int c) __attribute__((always_inline)) {
+        const int b = c / 8, i = c % 8;
+        const float va = (i < 3) ? A.v[i < 3 ? i : 0] : (i < 6) ? A.w[(i >= 3 && i < 6) ? i - 3 : 0] : 0.0f;
+        const float vb = (i < 3) ? B.v[i < 3 ? i : 0] : (i < 6) ? B.w[(i >= 3 && i < 6) ? i - 3 : 0] : 0.0f;
+        return (b == 0) ? va : vb;
+    });
+}
+template <int LPS> __device__ __forceinline__ void body_vel_store(const Gen<LPS>& VB, int b, Body& M) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { M.v[i] = gen_entry<LPS>(VB, 8 * b + i); M.w[i] = gen_entry<LPS>(VB, 8 * b + 3 + i); }
+}
+// a gripper row's free target cube: its six velocities between the cubes' vector (coordinates 8 tb + 0..5) and the joints'
+// vector (coordinates 9..14) -- a row shift inside the sample's lanes
+template <int LPS> __device__ __forceinline__ void body_to_joint_vec(Gen<LPS>& V, const Gen<LPS>& VB, int tb) {
+    if constexpr (LPS == 1) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) V.a[9 + i] = (tb == 0) ? VB.a[i] : VB.a[8 + i];
+    } else if constexpr (LPS == 8) {
+        const float t = dpp_mov<0x111>((tb == 0) ? VB.a[0] : VB.a[1]);          // row_shr:1 -- lanes 1-6 <- 0-5
+        const int l = gen_lane<LPS>();
+        V.a[1] = (l >= 1 && l <= 6) ? t : V.a[1];
+    } else {
+        const float tA = dpp_mov<0x119>(VB.a[0]), tB = dpp_mov<0x111>(VB.a[0]);  // row_shr:9 / :1 -- lanes 9-14 <- 0-5 / 8-13
+        const int l = gen_lane<LPS>();
+        V.a[0] = (l >= 9 && l <= 14) ? ((tb == 0) ? tA : tB) : V.a[0];
+    }
+}
+template <int LPS> __device__ __forceinline__ void joint_vec_to_body(const Gen<LPS>& V, Gen<LPS>& VB, int tb) {
+    if constexpr (LPS == 1) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { VB.a[i] = (tb == 0) ? V.a[9 + i] : VB.a[i]; VB.a[8 + i] = (tb == 1) ? V.a[9 + i] : VB.a[8 + i]; }
+    } else if constexpr (LPS == 8) {
+        const float t = dpp_mov<0x101>(V.a[1]);                                  // row_shl:1 -- lanes 0-5 <- 1-6
+        const int l = gen_lane<LPS>();
+        VB.a[0] = (tb == 0 && l < 6) ? t : VB.a[0];
+        VB.a[1] = (tb == 1 && l < 6) ? t : VB.a[1];
+    } else {
+        const float tA = dpp_mov<0x109>(V.a[0]), tB = dpp_mov<0x101>(V.a[0]);    // row_shl:9 / :1
+        const int l = gen_lane<LPS>();
+        VB.a[0] = (tb == 0 && l < 6) ? tA : (tb == 1 && l >= 8 && l < 14) ? tB : VB.a[0];
+    }
+}
+
 // FK.  STORE: write every link pose (pos3 + quat4) to out[11][7] (step mode views).  JAC: also the arm's Jacobian
-// columns at the hand origin (joint axis z_i: angular part; z_i x (p_hand - p_i): linear part) into `gj`.
+// columns at the hand origin (joint axis z_i: angular part; z_i x (p_hand - p_i): linear part) into `gj` -- all seven
+// (LPS = 1) or the one of the lane's own joint (LPS = 8, 16: lane l < 7 of the sample owns joint l; the other lanes: zeros).
 // gripper geometry of one configuration: hand frame, the arm's Jacobian columns at the hand origin, the spheres
-struct Gripper {
+template <int LPS> struct GripperT {
+    static constexpr int NJ = (LPS == 1) ? 7 : 1;
     Frame hand;
-    float Jv[7][3], Jw[7][3];
+    float Jv[NJ][3], Jw[NJ][3];
     float c[4][3];       // tip left, tip right, hand, held cube
 };
 __device__ __forceinline__ void fk_cross(const float* a, const float* b, float* c) {   // (cross3 of the contact code, same order)
@@ -195,10 +381,15 @@ __device__ __forceinline__ void fk_cross(const float* a, const float* b, float* 
     c[1] = mad(a[2], b[0], -(a[0] * b[2]));
     c[2] = mad(a[0], b[1], -(a[1] * b[0]));
 }
-template <bool STORE, bool JAC = false>
+template <bool STORE, bool JAC = false, int LPS = 1>
 __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, Frame& hand,
-                                         float* pl, float* pr, float* out, Gripper* gj = nullptr) {
-    float jz[7][3], jp[7][3];
+                                         float* pl, float* pr, float* out, GripperT<LPS>* gj = nullptr) {
+    constexpr int NJ = GripperT<LPS>::NJ;
+    float jz[NJ][3], jp[NJ][3];
+    if constexpr (JAC && LPS != 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { jz[0][i] = 0.0f; jp[0][i] = 0.0f; }
+    }
     Frame f;
     f.x[0] = 1; f.x[1] = 0; f.x[2] = 0; f.y[0] = 0; f.y[1] = 1; f.y[2] = 0;
     f.z[0] = 0; f.z[1] = 0; f.z[2] = 1;
@@ -215,8 +406,14 @@ __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, F
     store(f);
     auto rec = [&](int j) {
         if constexpr (JAC) {
+            if constexpr (LPS == 1) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { jz[j][i] = f.z[i]; jp[j][i] = f.p[i]; }
+                for (int i = 0; i < 3; ++i) { jz[j][i] = f.z[i]; jp[j][i] = f.p[i]; }
+            } else {
+                const bool mine = gen_lane<LPS>() == j;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { jz[0][i] = mine ? f.z[i] : jz[0][i]; jp[0][i] = mine ? f.p[i] : jp[0][i]; }
+            }
         }
     };
     float s, c;
@@ -231,7 +428,7 @@ __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, F
     hand = f;
     if constexpr (JAC) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             float lever[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) { gj->Jw[j][i] = jz[j][i]; lever[i] = f.p[i] - jp[j][i]; }
@@ -370,15 +567,40 @@ struct RSlot {
     float meff[3], bias, lam[3];
 };
 
-// the joint-space row of direction d at the point ph + rho of the gripper (sphere s: the finger columns)
-__device__ __forceinline__ void robot_row(const Gripper& g, int s, bool held, const float* rho, const float* d, float* J) {
+// the row of direction d at the point ph + rho of the gripper (sphere s: the finger columns) in generalized coordinates:
+// (J_0..J_8 | -d | -(r_t x d) | 0), the body entries +0 for a static target (tb < 0), the angular ones for the plate (tb = 2)
+template <int LPS>
+__device__ __forceinline__ Gen<LPS> gen_robot_row(const GripperT<LPS>& g, int s, bool held, const float* rho, const float* d,
+                                                  int tb, const float* rt) {
     float m[3];
     cross3(rho, d, m);
-#pragma unroll
-    for (int j = 0; j < 7; ++j) J[j] = dotm(d, g.Jv[j]) + dotm(m, g.Jw[j]);
     const float dy = dotm(d, g.hand.y);
-    J[7] = (s == 0 && !held) ? dy : 0.0f;
-    J[8] = (s == 1 && !held) ? -dy : 0.0f;
+    const float f7 = (s == 0 && !held) ? dy : 0.0f, f8 = (s == 1 && !held) ? -dy : 0.0f;
+    Gen<LPS> r;
+    if constexpr (LPS == 1) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) r.a[j] = dotm(d, g.Jv[j]) + dotm(m, g.Jw[j]);
+        r.a[7] = f7; r.a[8] = f8;
+#pragma unroll
+        for (int e = 9; e < 16; ++e) r.a[e] = 0.0f;
+        if (tb >= 0) {
+            float ab[3];
+            cross3(rt, d, ab);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { r.a[9 + i] = -d[i]; r.a[12 + i] = (tb < 2) ? -ab[i] : 0.0f; }
+        }
+    } else {
+        const float arm = dotm(d, g.Jv[0]) + dotm(m, g.Jw[0]);       // (the lane's own joint column; lanes >= 7: not used)
+        r = gen_make<LPS>([&](int c) __attribute__((always_inline)) { return (c == 7) ? f7 : (c == 8) ? f8 : 0.0f; });
+        r.a[0] = (gen_lane<LPS>() < 7) ? arm : r.a[0];
+        if (tb >= 0) {
+            float ab[3];
+            cross3(rt, d, ab);
+            gen_update<LPS>(r, 9, 12, [&](int c) __attribute__((always_inline)) { return -d[(c >= 9 && c < 12) ? c - 9 : 0]; });
+            if (tb < 2) gen_update<LPS>(r, 12, 15, [&](int c) __attribute__((always_inline)) { return -ab[(c >= 12 && c < 15) ? c - 12 : 0]; });
+        }
+    }
+    return r;
 }
 
 // the free bodies as the rows see them
@@ -427,14 +649,81 @@ __device__ __forceinline__ float contact_bias(const PandaScene& sc, float gap) {
 // ---- face-to-face manifold of a cube against a box (the oracle's cube_manifold) ----------------------------------
 // per-lane store of the manifolds' contact points: slot = manifold * 4 + corner, 10 floats each
 // (x3 | meff3 | bias | lam3); in the kernels it is LDS (stride 64 floats between a lane's consecutive values)
-// ... followed by the gripper contacts' joint-space rows: 4 slots x 3 rows x 9 floats (formed once per substep)
-constexpr int PANDA_STORE_FLOATS = 12 * 10 + 4 * 27;
+// ... followed, with one lane per sample (LPS = 1), by the gripper contacts' generalized rows: 4 slots x 3 rows x 16 floats
+// (formed once per substep); with sixteen lanes per sample those rows are registers
+// (LPS > 1: a manifold slot holds its three rows' entries of the lane -- 3 x Gen::N floats -- in place of the point: 3 N + 7)
+constexpr int panda_slot_floats(int lps) { return lps == 1 ? 10 : 3 * (16 / lps) + 7; }
+constexpr int panda_store_floats(int lps) { return 12 * panda_slot_floats(lps) + (lps == 1 ? 4 * 3 * 16 : 0); }
+constexpr int PANDA_STORE_FLOATS = panda_store_floats(1);
 struct CornerStore {
     float* base;
     int stride;
     __device__ __forceinline__ float& at(int slot, int field) const { return base[(slot * 10 + field) * stride]; }
-    __device__ __forceinline__ float& row(int s, int r3, int j) const { return base[(120 + (s * 3 + r3) * 9 + j) * stride]; }
+    __device__ __forceinline__ float& row(int s, int r3, int j) const { return base[(120 + (s * 3 + r3) * 16 + j) * stride]; }   // (LPS = 1)
 };
+// the manifold slots of one substep.  LPS = 1: point x3 | meff3 | bias | lam3, the rows re-formed from the point on every visit
+// (36 rows x 16 entries do not fit a lane's share of LDS); LPS > 1: the lane's entries of the three rows | meff3 | bias | lam3
+template <int LPS> struct ManStore {
+    static constexpr int NE = (LPS == 1) ? 1 : Gen<LPS>::N, SF = panda_slot_floats(LPS), RO = (LPS == 1) ? 3 : 3 * NE;
+    const CornerStore& cs;
+    __device__ __forceinline__ explicit ManStore(const CornerStore& c) : cs(c) {}
+    __device__ __forceinline__ float& f(int slot, int k) const { return cs.base[(slot * SF + k) * cs.stride]; }
+    __device__ __forceinline__ float& x(int slot, int i) const { return f(slot, i); }                    // LPS = 1 only
+    __device__ __forceinline__ float& rowf(int slot, int r3, int e) const { return f(slot, r3 * NE + e); }  // LPS > 1 only
+    __device__ __forceinline__ float& meff(int slot, int r3) const { return f(slot, RO + r3); }
+    __device__ __forceinline__ float& bias(int slot) const { return f(slot, RO + 3); }
+    __device__ __forceinline__ float& lam(int slot, int r3) const { return f(slot, RO + 4 + r3); }
+};
+// the gripper contacts' rows of one substep
+template <int LPS> struct GripRows;
+template <> struct GripRows<1> {
+    const CornerStore& cs;
+    __device__ __forceinline__ explicit GripRows(const CornerStore& c) : cs(c) {}
+    __device__ __forceinline__ Gen<1> get(int s, int r3) const {
+        Gen<1> g;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) g.a[l] = cs.row(s, r3, l);
+        return g;
+    }
+    __device__ __forceinline__ void set(int s, int r3, const Gen<1>& g) {
+#pragma unroll
+        for (int l = 0; l < 16; ++l) cs.row(s, r3, l) = g.a[l];
+    }
+};
+template <int LPS> struct GripRows {       // LPS = 8, 16: registers
+    float J[12][Gen<LPS>::N];
+    __device__ __forceinline__ explicit GripRows(const CornerStore&) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+#pragma unroll
+            for (int e = 0; e < Gen<LPS>::N; ++e) J[i][e] = 0.0f;
+    }
+    __device__ __forceinline__ Gen<LPS> get(int s, int r3) const {
+        Gen<LPS> g;
+#pragma unroll
+        for (int e = 0; e < Gen<LPS>::N; ++e) g.a[e] = J[s * 3 + r3][e];
+        return g;
+    }
+    __device__ __forceinline__ void set(int s, int r3, const Gen<LPS>& g) {
+#pragma unroll
+        for (int e = 0; e < Gen<LPS>::N; ++e) J[s * 3 + r3][e] = g.a[e];
+    }
+};
+// per-coordinate constants of the solver (replicated scene values -> generalized vectors, once per kernel)
+template <int LPS> struct GenConst {
+    Gen<LPS> invM_cube, invM_obs;    // inverse masses: joints | the touched body's 1/m x 3, 1/I x 3 | 0 (cube / plate)
+    Gen<LPS> rden, pmax;             // the drive rows (entries 9-15: 0, so they are no-ops there)
+};
+template <int LPS> __device__ __forceinline__ GenConst<LPS> gen_consts(const PandaScene& sc) {
+    GenConst<LPS> k;
+    k.invM_cube = gen_make<LPS>([&](int c) __attribute__((always_inline)) {
+        return (c < 9) ? sc.invI[c < 9 ? c : 0] : (c < 12) ? sc.invm_cube : (c < 15) ? sc.invI_cube : 0.0f; });
+    k.invM_obs = gen_make<LPS>([&](int c) __attribute__((always_inline)) {
+        return (c < 9) ? sc.invI[c < 9 ? c : 0] : (c < 12) ? sc.invm_obs : 0.0f; });
+    k.rden = gen_from9<LPS>(sc.rden);
+    k.pmax = gen_from9<LPS>(sc.pmax);
+    return k;
+}
 struct Manifold {
     bool any;            // the cube is near the box
     float n[3], t1[3], t2[3];
@@ -667,10 +956,29 @@ constexpr float PANDA_LEVER = 1.2f;
 constexpr float GRIP_R0 = 0.17f;
 struct HeldYes { static constexpr bool value = true; };
 struct HeldNo { static constexpr bool value = false; };
-template <bool FORCES = true, bool LAZY = false>
+// The kinematics of a configuration, kept from where a substep evaluates them AFTER its integration to where the next substep's
+// contact detection needs them BEFORE its own (same joint values: the grasp rule in between moves the fingers only, which
+// the hand frame and the arm's Jacobian columns at the hand origin do not depend on).  Rollouts with several lanes per sample
+// only (LPS > 1: one Jacobian column per lane; with one lane per sample the 42 extra live registers would spill).
+template <int LPS> struct FkCarry {
+    bool valid;
+    Frame hand;
+    float Jv[3], Jw[3];
+};
+#ifdef M3_PABL_PROF      // (profiling build, tools/panda_wave_profile.py: shader clocks and substep counts per sample)
+struct PandaProf { long long solve_clk, near_clk, detect_clk, post_clk; int n_robot, n_body, n_near, n_act, n_fk; };
+#define M3_PROF_ARG , PandaProf* prof = nullptr
+#else
+#define M3_PROF_ARG
+#endif
+template <bool FORCES = true, bool LAZY = false, int LPS = 1>
 __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, const float* u, PandaObs& obs,
-                                           const CornerStore& cs, float* hp = nullptr, float* trav = nullptr) {
+                                           const CornerStore& cs, float* hp = nullptr, float* trav = nullptr,
+                                           FkCarry<LPS>* fkc = nullptr M3_PROF_ARG) {
+    constexpr bool CARRY = LAZY && LPS != 1;
     const float h = sc.h;
+    const GenConst<LPS> gk = gen_consts<LPS>(sc);
+    const Gen<LPS> uG = gen_from9<LPS>(u);
     for (int sub = 0; sub < sc.substeps; ++sub) {
         const bool last = (sub == sc.substeps - 1);
         // 0. release
@@ -705,7 +1013,8 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         }
         bool robot_rows = false;
         bool touched[3] = {false, false, false};
-        Gripper g;
+        GripperT<LPS> g;
+        GripRows<LPS> rows(cs);
         float RA[9], RB[9];
         bool near = true;
         if constexpr (LAZY) {
@@ -735,11 +1044,27 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #endif
         const bool bodies_awake_wave = __builtin_amdgcn_ballot_w64((!held && w.awake[0] != 0.0f) || w.awake[1] != 0.0f) != 0ull;
         if (near || bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }
+#ifdef M3_PABL_PROF
+        const long long prof_t0 = __builtin_readcyclecounter();
+#endif
         if (near) {
             float pl[3], pr[3];
             // (with the arm's Jacobian columns: keeping the joint axes and origins costs ~60 instructions on top of the
             // chain's ~400; a second pass over the chain for the lanes that turn out to have a candidate cost all 400)
-            panda_fk<false, true>(sc, w.q, g.hand, pl, pr, nullptr, &g);
+            bool carried = false;
+            if constexpr (CARRY) carried = __builtin_amdgcn_readfirstlane((int)fkc->valid) != 0;
+            if (carried) {
+                if constexpr (CARRY) {
+                    g.hand = fkc->hand;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        g.Jv[0][i] = fkc->Jv[i]; g.Jw[0][i] = fkc->Jw[i];
+                        const float fo = mad(0.0584f, g.hand.z[i], g.hand.p[i]);     // (panda_fk's last translation)
+                        pl[i] = mad(w.q[7], g.hand.y[i], fo);
+                        pr[i] = mad(-w.q[8], g.hand.y[i], fo);
+                    }
+                }
+            } else panda_fk<false, true, LPS>(sc, w.q, g.hand, pl, pr, nullptr, &g);
             if constexpr (LAZY) { hp[0] = g.hand.p[0]; hp[1] = g.hand.p[1]; hp[2] = g.hand.p[2]; *trav = 0.0f; }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -819,27 +1144,25 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                         c.rt[i] = (tb >= 0) ? c.rt[i] - tp : 0.0f;
                     }
                     // culling: the gap predicted for the end of the substep from the servo's velocities
-                    float J[9], ab[3];
-                    robot_row(g, s, held, c.rho, c.d[0], J);
-                    float vn0 = 0.0f;
+                    const Gen<LPS> invMs = (tb == 2) ? gk.invM_obs : gk.invM_cube;
+                    Gen<LPS> row = gen_robot_row<LPS>(g, s, held, c.rho, c.d[0], tb, c.rt);
+                    {
+                        Gen<LPS> u1 = gen_from9<LPS>(qd1), x;
+                        if (tb >= 0) { BodyVel bv; body_get(w, tb, bv); gen_set_body<LPS>(u1, bv.v, bv.w); }
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) vn0 = mad(J[j], qd1[j], vn0);
-                    BodyVel bv;
-                    if (tb >= 0) {
-                        body_get(w, tb, bv);
-                        cross3(c.rt, c.d[0], ab);
-                        vn0 = vn0 - bodyvel_along(tb, bv, c.d[0], ab);
+                        for (int e = 0; e < Gen<LPS>::N; ++e) x.a[e] = row.a[e] * u1.a[e];
+                        const float vn0 = gen_sum<LPS>(x);
+                        if (!(mad(h, vn0, bgap[s]) < sc.act_margin)) continue;
                     }
-                    if (!(mad(h, vn0, bgap[s]) < sc.act_margin)) continue;
-                    // the rows (kept in the per-lane store), effective masses, bias
+                    // the rows (LPS = 1: kept in the per-lane store; LPS = 16: one register each), effective masses, bias
 #pragma unroll
                     for (int r3 = 0; r3 < 3; ++r3) {
-                        if (r3 > 0) robot_row(g, s, held, c.rho, c.d[r3], J);
-                        float k = 0.0f;
+                        if (r3 > 0) row = gen_robot_row<LPS>(g, s, held, c.rho, c.d[r3], tb, c.rt);
+                        Gen<LPS> x;
 #pragma unroll
-                        for (int j = 0; j < 9; ++j) { k = mad(J[j] * sc.invI[j], J[j], k); cs.row(s, r3, j) = J[j]; }
-                        if (tb >= 0) { cross3(c.rt, c.d[r3], ab); k = k + body_k(sc, tb, ab); }
-                        c.meff[r3] = 1.0f / k;
+                        for (int e = 0; e < Gen<LPS>::N; ++e) x.a[e] = (row.a[e] * invMs.a[e]) * row.a[e];
+                        rows.set(s, r3, row);
+                        c.meff[r3] = 1.0f / gen_sum<LPS>(x);
                         c.lam[r3] = 0.0f;
                     }
                     c.bias = contact_bias(sc, bgap[s]);
@@ -852,6 +1175,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 }
             }
         }
+#ifdef M3_PABL_PROF
+        if (prof) { prof->near_clk += __builtin_readcyclecounter() - prof_t0; prof->n_near += near ? 1 : 0; }
+#endif
         // 3. an awake cube wakes the other one when they are close
         const bool freeA = !held;
         if (freeA && (w.awake[0] != 0.0f) != (w.awake[1] != 0.0f)) {
@@ -863,6 +1189,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         // 4. gravity, then the cubes' face-to-face contacts
         if (actA) w.A.v[2] = mad(-sc.g, h, w.A.v[2]);
         if (actB) w.B.v[2] = mad(-sc.g, h, w.B.v[2]);
+        const ManStore<LPS> ms(cs);
+        const Gen<LPS> invMB = gen_make<LPS>([&](int c) __attribute__((always_inline)) {     // the cubes' inverse masses
+            return (c % 8 < 3) ? sc.invm_cube : (c % 8 < 6) ? sc.invI_cube : 0.0f; });
         Manifold mA, mAB, mB;
         mA.any = mAB.any = mB.any = false; mA.on = mAB.on = mB.on = 0u;
         mA.made = mAB.made = mB.made = 0; mA.up = mAB.up = mB.up = 0; mA.down = mAB.down = mB.down = 0;
@@ -873,131 +1202,208 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         }
         bool tA = true, tB = true;      // the cube's static box is the table
         const bool any_act = __builtin_amdgcn_ballot_w64(actA || actB) != 0ull;
+#ifdef M3_PABL_PROF
+        const long long prof_t2 = __builtin_readcyclecounter();
+#endif
         if (any_act) {
             if (near == false && !bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }   // (woken just now: cannot happen without `near`)
-            auto prepare = [&](int m_id, const Manifold& m, const float (*X)[3], const float* gap, int ma, const float* pm,
-                               int tb, const float* pt) {
+            auto prepare = [&](int m_id, const Manifold& m, const float (*X)[3], const float* gap, const float* pm, const float* pt) {
+                // (LPS > 1) the lane's components of the manifold's three directions: d[k], d[(k + 1) % 3], d[(k + 2) % 3], k = (lane & 7) % 3
+                const int li = (LPS == 1) ? 0 : (int)(threadIdx.x & 7u);
+                const bool lane_lin = li < 3, lane_pad = li >= 6, lane_hi = (LPS == 16) && ((threadIdx.x >> 3) & 1u) != 0u;
+                const int lk = (li >= 3) ? li - 3 : li;
+                const bool k_is0 = lk == 0, k_is1 = lk == 1;
+                float dk0[3], dk1[3], dk2[3];
+                if constexpr (LPS != 1) {
+#pragma unroll
+                    for (int r3 = 0; r3 < 3; ++r3) {
+                        const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
+                        dk0[r3] = k_is0 ? d[0] : k_is1 ? d[1] : d[2];
+                        dk1[r3] = k_is0 ? d[1] : k_is1 ? d[2] : d[0];
+                        dk2[r3] = k_is0 ? d[2] : k_is1 ? d[0] : d[1];
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (!((m.on >> j) & 1u)) continue;
                     const int slot = m_id * 4 + j;
                     float r[3], rt[3];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) { r[i] = X[j][i] - pm[i]; rt[i] = (tb >= 0) ? X[j][i] - pt[i] : 0.0f; cs.at(slot, i) = X[j][i]; }
+                    for (int i = 0; i < 3; ++i) { r[i] = X[j][i] - pm[i]; rt[i] = (m_id == BK_AB) ? X[j][i] - pt[i] : 0.0f; }
+                    if constexpr (LPS == 1) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) ms.x(slot, i) = X[j][i];
+                    }
+                    // LPS > 1: the lane's entries are formed in "lane space" -- coordinate i = lane & 7 of a cube is d[i] (i < 3) or
+                    // (r x d)[i - 3]: the lane picks ITS components of r once per point (and of the three directions once per
+                    // manifold, above), then every row is one multiply + one fused multiply-add, the arithmetic of cross3
+                    float rk1[Gen<LPS>::N], rk2[Gen<LPS>::N];
+                    if constexpr (LPS != 1) {
+#pragma unroll
+                        for (int e = 0; e < Gen<LPS>::N; ++e) {
+                            const bool tgt = (m_id == BK_AB) && ((LPS == 8) ? (e == 1) : lane_hi);
+                            const float q0 = tgt ? rt[0] : r[0], q1 = tgt ? rt[1] : r[1], q2 = tgt ? rt[2] : r[2];
+                            rk1[e] = k_is0 ? q1 : k_is1 ? q2 : q0;       // r[(k + 1) % 3]
+                            rk2[e] = k_is0 ? q2 : k_is1 ? q0 : q1;       // r[(k + 2) % 3]
+                        }
+                    }
 #pragma unroll
                     for (int r3 = 0; r3 < 3; ++r3) {
                         const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
-                        float aa[3], ab[3];
-                        cross3(r, d, aa);
-                        float k = body_k(sc, ma, aa);
-                        if (tb >= 0) { cross3(rt, d, ab); k = k + body_k(sc, tb, ab); }
-                        cs.at(slot, 3 + r3) = 1.0f / k;
-                        cs.at(slot, 7 + r3) = 0.0f;
+                        Gen<LPS> row;
+                        if constexpr (LPS == 1) {
+                            float aa[3], ab[3] = {0.0f, 0.0f, 0.0f};
+                            cross3(r, d, aa);
+                            if (m_id == BK_AB) cross3(rt, d, ab);
+                            row = body_row<LPS>(m_id, d, aa, ab);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < Gen<LPS>::N; ++e) {
+                                const float ang = mad(rk1[e], dk2[r3], -(rk2[e] * dk1[r3]));
+                                float ent = lane_lin ? dk0[r3] : ang;
+                                ent = lane_pad ? 0.0f : ent;
+                                const bool hi = (LPS == 8) ? (e == 1) : lane_hi;            // the element's cube: B
+                                const bool mover = hi == (m_id == BK_B), tgt = (m_id == BK_AB) && hi;
+                                row.a[e] = mover ? ent : tgt ? -ent : 0.0f;
+                            }
+                        }
+                        Gen<LPS> x;
+#pragma unroll
+                        for (int e = 0; e < Gen<LPS>::N; ++e) {
+                            x.a[e] = (row.a[e] * invMB.a[e]) * row.a[e];
+                            if constexpr (LPS != 1) ms.rowf(slot, r3, e) = row.a[e];
+                        }
+                        ms.meff(slot, r3) = 1.0f / body_sum<LPS>(x, m_id);
+                        ms.lam(slot, r3) = 0.0f;
                     }
-                    cs.at(slot, 6) = contact_bias(sc, gap[j]);
+                    ms.bias(slot) = contact_bias(sc, gap[j]);
                 }
             };
             float X[4][3], gap[4];
             if (actA) {
                 tA = nearer_is_table(sc, w.A.p);
                 manifold_detect<false>(sc, w.A.p, RA, box_static(tA ? sc.table : sc.shelf), mA, X, gap);
-                prepare(0, mA, X, gap, 0, w.A.p, -1, nullptr);
+                prepare(BK_A, mA, X, gap, w.A.p, nullptr);
             }
             if (actA && actB) {
                 manifold_detect<true>(sc, w.A.p, RA, box_cube(sc, w.B.p, RB), mAB, X, gap);
-                prepare(1, mAB, X, gap, 0, w.A.p, 1, w.B.p);
+                prepare(BK_AB, mAB, X, gap, w.A.p, w.B.p);
             }
             if (actB) {
                 tB = nearer_is_table(sc, w.B.p);
                 manifold_detect<false>(sc, w.B.p, RB, box_static(tB ? sc.table : sc.shelf), mB, X, gap);
-                prepare(2, mB, X, gap, 1, w.B.p, -1, nullptr);
+                prepare(BK_B, mB, X, gap, w.B.p, nullptr);
             }
         }
-        const bool body_rows = (mA.on | mAB.on | mB.on) != 0u;
         // 5. velocity passes.  (Tried: wave-uniform control flow with the inactive lanes masked by value selects instead
         // of per-lane branches -- 15-20 % slower, the selects cost more than the exec-mask regions: docs/NOTEBOOK.md.)
-        float qds[9], pdrv[9];
-        if (robot_rows) {
+        const bool body_rows = (mA.on | mAB.on | mB.on) != 0u;
+        Gen<LPS> V, P;         // generalized velocity (joints; entries 9-15 are +0 outside a slot with a free target) and drive impulses
 #pragma unroll
-            for (int i = 0; i < 9; ++i) { qds[i] = (held && i >= 7) ? 0.0f : w.qd[i]; pdrv[i] = 0.0f; }
+        for (int e = 0; e < Gen<LPS>::N; ++e) { V.a[e] = 0.0f; P.a[e] = 0.0f; }
+        if (robot_rows) {
+            float qds0[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) qds0[i] = (held && i >= 7) ? 0.0f : w.qd[i];
+            V = gen_from9<LPS>(qds0);
         }
+        // the cubes' velocities as a generalized vector while rows act on them (manifold rows, gripper rows on a cube)
+        const bool use_vb = body_rows || touched[0] || touched[1];
+        Gen<LPS> VB;
+#pragma unroll
+        for (int e = 0; e < Gen<LPS>::N; ++e) VB.a[e] = 0.0f;
+        if (use_vb) VB = body_vel_load<LPS>(w.A, w.B);
         auto robot_solve = [&](int s, RSlot& c, bool only_warm) __attribute__((always_inline)) {
             const int tb = c.target - T_CUBEA;
-            BodyVel bv;
-            if (tb >= 0) body_get(w, tb, bv);
-            if (only_warm) {        // the warm-start impulse acts before the first pass
-                const float dl = c.lam[0];
-                if (dl != 0.0f) {
-                    float ab[3];
+            const Gen<LPS> invMs = (tb == 2) ? gk.invM_obs : gk.invM_cube;
+            if (only_warm && c.lam[0] == 0.0f) return;        // the warm-start impulse acts before the first pass
+            if (tb == 2) { const float z3[3] = {0.0f, 0.0f, 0.0f}; gen_set_body<LPS>(V, w.obs_v, z3); }
+            else if (tb >= 0) body_to_joint_vec<LPS>(V, VB, tb);
+            auto apply = [&](const Gen<LPS>& row, float dl) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) qds[j] = mad(cs.row(s, 0, j) * sc.invI[j], dl, qds[j]);
-                    if (tb >= 0) { cross3(c.rt, c.d[0], ab); bodyvel_apply(sc, tb, bv, c.d[0], ab, -dl); body_put(w, tb, bv); }
-                }
-                return;
-            }
+                for (int e = 0; e < Gen<LPS>::N; ++e) V.a[e] = mad(row.a[e] * invMs.a[e], dl, V.a[e]);
+            };
+            if (only_warm) apply(rows.get(s, 0), c.lam[0]);
+            else {
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
-                const int r3 = (rr + 1) % 3;      // friction rows first, the normal row last
+                for (int rr = 0; rr < 3; ++rr) {
+                    const int r3 = (rr + 1) % 3;      // friction rows first, the normal row last
 #ifdef M3_PABL_NO_ROBOT_FRICTION
-                if (r3 != 0) continue;            // (ablation: what the gripper contacts' friction rows cost)
+                    if (r3 != 0) continue;            // (ablation: what the gripper contacts' friction rows cost)
 #endif
-                float J[9], ab[3];
+                    const Gen<LPS> row = rows.get(s, r3);
+                    Gen<LPS> x;
 #pragma unroll
-                for (int j = 0; j < 9; ++j) J[j] = cs.row(s, r3, j);
-                float v = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 9; ++j) v = mad(J[j], qds[j], v);
-                if (tb >= 0) { cross3(c.rt, c.d[r3], ab); v = v - bodyvel_along(tb, bv, c.d[r3], ab); }
-                float dl = -c.meff[r3] * (v + ((r3 == 0) ? c.bias : 0.0f));
-                const float l0 = c.lam[r3];
-                float l1 = l0 + dl;
-                if (r3 == 0) l1 = fmaxf(l1, 0.0f);
-                else { const float mx = sc.mu * c.lam[0]; l1 = fminf(fmaxf(l1, -mx), mx); }
-                c.lam[r3] = l1;
-                dl = l1 - l0;
-#pragma unroll
-                for (int j = 0; j < 9; ++j) qds[j] = mad(J[j] * sc.invI[j], dl, qds[j]);
-                if (tb >= 0) bodyvel_apply(sc, tb, bv, c.d[r3], ab, -dl);
+                    for (int e = 0; e < Gen<LPS>::N; ++e) x.a[e] = row.a[e] * V.a[e];
+                    const float v = gen_sum<LPS>(x);
+                    float dl = -c.meff[r3] * ((r3 == 0) ? v + c.bias : v);
+                    const float l0 = c.lam[r3];
+                    float l1 = l0 + dl;
+                    if (r3 == 0) l1 = fmaxf(l1, 0.0f);
+                    else { const float mx = sc.mu * c.lam[0]; l1 = fminf(fmaxf(l1, -mx), mx); }
+                    c.lam[r3] = l1;
+                    dl = l1 - l0;
+                    apply(row, dl);
+                }
             }
-            if (tb >= 0) body_put(w, tb, bv);
+            if (tb == 2) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w.obs_v[i] = gen_entry<LPS>(V, 9 + i);
+            } else if (tb >= 0) joint_vec_to_body<LPS>(V, VB, tb);
+            if (tb >= 0) gen_clear_body<LPS>(V);
         };
-        auto manifold_solve = [&](int m_id, const Manifold& m, Body& M, const float* pm, Body* T, const float* pt) __attribute__((always_inline)) {
+        auto manifold_solve = [&](int m_id, const Manifold& m, const float* pm, const float* pt) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!((m.on >> j) & 1u)) continue;
                 const int slot = m_id * 4 + j;
-                float r[3], rt[3];
+                float r[3] = {0.0f, 0.0f, 0.0f}, rt[3] = {0.0f, 0.0f, 0.0f};
+                if constexpr (LPS == 1) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { const float x = cs.at(slot, i); r[i] = x - pm[i]; rt[i] = T ? x - pt[i] : 0.0f; }
+                    for (int i = 0; i < 3; ++i) { const float x = ms.x(slot, i); r[i] = x - pm[i]; rt[i] = (m_id == BK_AB) ? x - pt[i] : 0.0f; }
+                }
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr) {
                     const int r3 = (rr + 1) % 3;
 #ifdef M3_PABL_NO_BODY_FRICTION
                     if (r3 != 0) continue;        // (ablation: what the manifolds' friction rows cost)
 #endif
-                    const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
-                    float aa[3], ab[3];
-                    cross3(r, d, aa);
-                    float v = dotm(d, M.v) + dotm(aa, M.w);
-                    if (T) { cross3(rt, d, ab); v = v - (dotm(d, T->v) + dotm(ab, T->w)); }
-                    float dl = -cs.at(slot, 3 + r3) * (v + ((r3 == 0) ? cs.at(slot, 6) : 0.0f));
-                    const float l0 = cs.at(slot, 7 + r3);
+                    Gen<LPS> row;
+                    if constexpr (LPS == 1) {
+                        const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
+                        float aa[3], ab[3] = {0.0f, 0.0f, 0.0f};
+                        cross3(r, d, aa);
+                        if (m_id == BK_AB) cross3(rt, d, ab);
+                        row = body_row<LPS>(m_id, d, aa, ab);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < Gen<LPS>::N; ++e) row.a[e] = ms.rowf(slot, r3, e);
+                    }
+                    Gen<LPS> x;
+#pragma unroll
+                    for (int e = 0; e < Gen<LPS>::N; ++e) x.a[e] = row.a[e] * VB.a[e];
+                    const float v = body_sum<LPS>(x, m_id);
+                    float dl = -ms.meff(slot, r3) * ((r3 == 0) ? v + ms.bias(slot) : v);
+                    const float l0 = ms.lam(slot, r3);
                     float l1 = l0 + dl;
                     if (r3 == 0) l1 = fmaxf(l1, 0.0f);
-                    else { const float mx = sc.mu * cs.at(slot, 7); l1 = fminf(fmaxf(l1, -mx), mx); }
-                    cs.at(slot, 7 + r3) = l1;
+                    else { const float mx = sc.mu * ms.lam(slot, 0); l1 = fminf(fmaxf(l1, -mx), mx); }
+                    ms.lam(slot, r3) = l1;
                     dl = l1 - l0;
-                    const float im = sc.invm_cube * dl, ia = sc.invI_cube * dl;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) { M.v[i] = mad(im, d[i], M.v[i]); M.w[i] = mad(ia, aa[i], M.w[i]); }
-                    if (T) {
-                        const float jm = sc.invm_cube * -dl, ja = sc.invI_cube * -dl;
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) { T->v[i] = mad(jm, d[i], T->v[i]); T->w[i] = mad(ja, ab[i], T->w[i]); }
+                    for (int e = 0; e < Gen<LPS>::N; ++e) {
+                        if (LPS == 1 && (e % 8 >= 6 || !body_in_kind<LPS>(e, m_id))) continue;      // (pads and the other cube: untouched)
+                        if (LPS == 8 && !body_in_kind<LPS>(e, m_id)) continue;
+                        const float nv = mad(row.a[e] * invMB.a[e], dl, VB.a[e]);
+                        VB.a[e] = (LPS == 16 && !body_in_kind<LPS>(e, m_id)) ? VB.a[e] : nv;
                     }
                 }
             }
         };
+#ifdef M3_PABL_PROF
+        const long long prof_t1 = __builtin_readcyclecounter();
+        if (prof) { prof->n_robot += robot_rows ? 1 : 0; prof->n_body += body_rows ? 1 : 0; prof->n_act += any_act ? 1 : 0; prof->detect_clk += prof_t1 - prof_t2; }
+#endif
         bool any_rows = __builtin_amdgcn_ballot_w64(robot_rows || body_rows) != 0ull;
 #ifdef M3_PABL_NO_SOLVE
         any_rows = false;
@@ -1013,33 +1419,38 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             const int n_iters = sc.iters;
 #endif
             for (int pass = 0; pass <= n_iters; ++pass) {      // the last sweep: the contacts alone (isaacgym_wrapper.py:29)
-                if (robot_rows && pass < n_iters) {
+                if (robot_rows && pass < n_iters) {       // the nine drive rows (one lane-parallel row with LPS = 16)
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) {
-                        if (held && i >= 7) continue;
-                        const float e = mad(sc.hD, u[i] - qds[i], -pdrv[i]);
-                        float dp = e * sc.rden[i];
-                        const float p1 = fminf(fmaxf(pdrv[i] + dp, -sc.pmax[i]), sc.pmax[i]);
-                        dp = p1 - pdrv[i];
-                        pdrv[i] = p1;
-                        qds[i] = mad(sc.invI[i], dp, qds[i]);
+                    for (int e = 0; e < ((LPS == 1) ? 9 : Gen<LPS>::N); ++e) {
+                        const int l = gen_coord<LPS>(e);
+                        const bool skip = held && l >= 7 && l < 9;
+                        const float er = mad(sc.hD, uG.a[e] - V.a[e], -P.a[e]);
+                        float dp = er * gk.rden.a[e];
+                        const float p1 = fminf(fmaxf(P.a[e] + dp, -gk.pmax.a[e]), gk.pmax.a[e]);
+                        dp = p1 - P.a[e];
+                        P.a[e] = skip ? P.a[e] : p1;
+                        V.a[e] = skip ? V.a[e] : mad(gk.invM_cube.a[e], dp, V.a[e]);
                     }
                 }
                 if (robot_rows) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) if (rs[s].on) robot_solve(s, rs[s], false);
                 }
-                if (mA.on) manifold_solve(0, mA, w.A, w.A.p, nullptr, nullptr);
-                if (mAB.on) manifold_solve(1, mAB, w.A, w.A.p, &w.B, w.B.p);
-                if (mB.on) manifold_solve(2, mB, w.B, w.B.p, nullptr, nullptr);
+                if (mA.on) manifold_solve(BK_A, mA, w.A.p, nullptr);
+                if (mAB.on) manifold_solve(BK_AB, mAB, w.A.p, w.B.p);
+                if (mB.on) manifold_solve(BK_B, mB, w.B.p, nullptr);
             }
         }
+#ifdef M3_PABL_PROF
+        if (prof) prof->solve_clk += __builtin_readcyclecounter() - prof_t1;
+#endif
+        if (use_vb && any_rows) { body_vel_store<LPS>(VB, 0, w.A); body_vel_store<LPS>(VB, 1, w.B); }
+        if (robot_rows) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            float v = robot_rows ? fminf(fmaxf(qds[i], -sc.vlim[i]), sc.vlim[i]) : qd1[i];
-            if (held && i >= 7) v = 0.0f;
-            w.qd[i] = v;
+            for (int i = 0; i < 9; ++i) qd1[i] = fminf(fmaxf(gen_entry<LPS>(V, i), -sc.vlim[i]), sc.vlim[i]);
         }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w.qd[i] = (held && i >= 7) ? 0.0f : qd1[i];
         // net contact forces on table / shelf_stand / cubeB: this substep's impulses / h (a step reports its last)
         if (FORCES && last) {
             float ft[3] = {0.f, 0.f, 0.f}, fs[3] = {0.f, 0.f, 0.f}, fb[3] = {0.f, 0.f, 0.f};
@@ -1067,7 +1478,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #pragma unroll
                     for (int r3 = 0; r3 < 3; ++r3) {
                         const float* d = (r3 == 0) ? m.n : (r3 == 1) ? m.t1 : m.t2;
-                        const float lam = cs.at(m_id * 4 + j, 7 + r3);
+                        const float lam = ms.lam(m_id * 4 + j, r3);
                         add(which, lam, d, true);
                         if (mover_is_B) add(2, lam, d, false);
                     }
@@ -1131,6 +1542,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) w.obs_p[i] = mad(h, w.obs_v[i], w.obs_p[i]);
+#ifdef M3_PABL_PROF
+        const long long prof_t3 = __builtin_readcyclecounter();
+#endif
         // 8. kinematics of the new configuration; the grasp rule (spec v1.1, position level)
         Frame hand;
         float pl[3], pr[3];
@@ -1152,9 +1566,16 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
         }
         if (have_fk) {
-            panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
+            if constexpr (CARRY) {
+                GripperT<LPS> gn;
+                panda_fk<false, true, LPS>(sc, w.q, hand, pl, pr, nullptr, &gn);
+                fkc->hand = hand;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { fkc->Jv[i] = gn.Jv[0][i]; fkc->Jw[i] = gn.Jw[0][i]; }
+            } else panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
             if constexpr (LAZY) { hp[0] = hand.p[0]; hp[1] = hand.p[1]; hp[2] = hand.p[2]; *trav = 0.0f; }
         }
+        if constexpr (CARRY) fkc->valid = have_fk;
         if (w.held != 0.0f) {
             if (have_fk) {
 #pragma unroll
@@ -1210,6 +1631,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 }
             }
         }
+#ifdef M3_PABL_PROF
+        if (prof) { prof->post_clk += __builtin_readcyclecounter() - prof_t3; prof->n_fk += have_fk ? 1 : 0; }
+#endif
         if (last) {
             // observables for the cost: finger link poses at the FINAL joint values (the pad clamp may have moved q7/q8)
 #pragma unroll

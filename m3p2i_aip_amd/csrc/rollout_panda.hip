@@ -11,6 +11,8 @@
 #include "panda_dyn.hpp"
 #include "wave_min.hpp"
 
+#include <cstdlib>
+
 namespace m3 {
 
 // raw world, 57 floats: q9 qd9 | cubeA13 | cubeB13 | dyn-obs13 (each: pos3 quat4(xyzw) linvel3 angvel3)
@@ -54,9 +56,10 @@ __device__ __forceinline__ void panda_world_from_sim(const float* dof, const flo
     panda_world_clear_derived(w);
 }
 
-// the per-lane store of the contact solver in LDS (manifold contact points + the gripper contacts' rows: 228 floats per
-// lane = 57 KB per wavefront), lane-strided: conflict-free, one wavefront per workgroup
-#define PANDA_CORNER_LDS() __shared__ float corner_lds[PANDA_STORE_FLOATS * 64]; const CornerStore cs{corner_lds + threadIdx.x, 64}
+// the per-lane store of the contact solver in LDS (manifold contact points: 120 floats per lane = 30 KB per wavefront; with one
+// lane per sample also the gripper contacts' generalized rows: 312 floats, 78 KB), lane-strided: conflict-free, one wavefront
+// per workgroup
+#define PANDA_CORNER_LDS(LPS) __shared__ float corner_lds[panda_store_floats(LPS) * 64]; const CornerStore cs{corner_lds + threadIdx.x, 64}
 
 __device__ __forceinline__ float in_vgpr(float v) {   // keep a uniform value in a vector register
     asm volatile("" : "+v"(v));
@@ -67,21 +70,30 @@ __device__ __forceinline__ float in_vgpr(float v) {   // keep a uniform value in
 // config.  GENERAL = true adds what no shipped config turns on: the in-kernel random stream with a noise mean and a
 // full covariance (sampling_method = 'random', mppi.py:129-131, :481; quirk Q4: that sample is scaled by
 // sqrt(diag Sigma) once more) and mppi_mode = 'simple' (mppi.py:220-233, :335-372).
-template <bool FORCES, bool GENERAL>
+// LPS = lanes per sample (panda_dyn.hpp, world spec v3): 1 -- a lane simulates a sample on its own, 64 samples per wavefront;
+// 16 -- the sixteen lanes of a DPP row simulate ONE sample together: everything but the contact solver's generalized vectors
+// is replicated in them, the joint-space rows of the gripper contacts run across them.  Four samples per wavefront, so K = 4000
+// is 1000 wavefronts, one per SIMD, instead of 63: the launch is as long as its slowest wavefront either way, and a wavefront's
+// velocity passes are ~2.3x shorter (tools/ubench/coop_panda_rows.hip).  Chosen by launch_rollout_panda.
+template <bool FORCES, bool GENERAL, int LPS>
 __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, const PandaArgs pa,
                                                       const PandaScene sc_) {
-    PANDA_CORNER_LDS();
+    PANDA_CORNER_LDS(LPS);
     // (a_.lanes samples per 64-wide wavefront: m3_set_rollout_lanes; the idle lanes leave at once)
     // Shadow lanes (quirk Q8, pa.shadows = 1 or 2; reach on an unsharded handle): the reference's reach cost measures every
     // rollout against the cube of ENVIRONMENT 0 (and, for the tilted mode, the orientation of the first environment of the
-    // second half), which under world spec v2 is a quantity of THAT rollout's simulation.  Lane 63 of every wavefront
-    // re-simulates sample 0 and lane 62 sample K / 2 in lockstep with the wavefront's own samples (same noise rows, same
-    // operations, so the same bits in every wavefront); their cubes are read with v_readlane after each step.  They store
-    // nothing.  Cost: 64 / 63 (62) more wavefronts, no cross-wavefront synchronisation.
-    const bool shadow = (int)threadIdx.x >= 64 - pa.shadows;
-    int i = blockIdx.x * a_.lanes + threadIdx.x;
-    if (shadow) i = (threadIdx.x == 63) ? 0 : pa.cp.half_K;
-    else if ((int)threadIdx.x >= a_.lanes || i >= a_.Kl) return;
+    // second half), which under world spec v2 is a quantity of THAT rollout's simulation.  The last sample slot of every
+    // wavefront (lane 63; with LPS = 16 the last group of sixteen) re-simulates sample 0 and the one before it sample K / 2 in
+    // lockstep with the wavefront's own samples (same noise rows, same operations, so the same bits in every wavefront);
+    // their cubes are read with v_readlane after each step.  They store nothing.  Cost: 64 / 63 (62) more wavefronts
+    // (LPS = 16: 4 / 3, 4 / 2), no cross-wavefront synchronisation.
+    constexpr int SPW = 64 / LPS;                       // sample slots per wavefront
+    const int slot = (int)threadIdx.x / LPS, gl = (int)threadIdx.x % LPS;
+    const bool shadow = slot >= SPW - pa.shadows;
+    const bool writer = !shadow && gl == 0;             // the lane that stores the sample's scalars
+    int i = blockIdx.x * a_.lanes + slot;
+    if (shadow) i = (slot == SPW - 1) ? 0 : pa.cp.half_K;
+    else if (slot >= a_.lanes || i >= a_.Kl) return;
     // The per-joint constants (bounds, noise scale, servo coefficients: 54 floats) are uniform, but
     // there are not enough scalar registers to keep them across the step loop, and the compiler
     // re-read them from the kernel arguments every step (~12 scalar loads per step, each followed by
@@ -127,7 +139,13 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         }
     };
     fetch(0);
+    FkCarry<LPS> fkc;
+    fkc.valid = false;
     float J = 0.0f, g = 1.0f, S = 0.0f, pc = 0.0f;
+#ifdef M3_PABL_PROF
+    PandaProf prof = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long prof_start = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < T; ++t) {
         float cd[9], cm[9];
 #pragma unroll
@@ -171,7 +189,11 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
             e[j] = uj;                                     // :313 (the update consumes the scaled stack)
         }
         PandaObs obs;
-        panda_step<FORCES, true>(sc, w, u, obs, cs, hp, &trav);
+#ifdef M3_PABL_PROF
+        panda_step<FORCES, true, LPS>(sc, w, u, obs, cs, hp, &trav, &fkc, &prof);
+#else
+        panda_step<FORCES, true, LPS>(sc, w, u, obs, cs, hp, &trav, &fkc);
+#endif
         float cube0[3], qh0[4];
         if (pa.shadows) {
 #pragma unroll
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float q0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w.A.q[j]), 63));
-                const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w.A.q[j]), 62));
+                const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w.A.q[j]), 63 - LPS));
                 qh0[j] = first_half ? q0 : q1;     // (one shadow: single mode, the tilt term does not read it)
             }
         } else {
@@ -189,13 +211,24 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
             for (int j = 0; j < 4; ++j) qh0[j] = w.A.q[j];
         }
         const float c = panda_cost(pa.cp, w, obs, k, cube0, qh0);
-        if (!shadow) {
+        if (writer) {
             *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
                 make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
-            float* ap = a.actions + ((size_t)t * Kl + i) * 9;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) ap[j] = e[j];
             a.cost_h[(size_t)t * Kl + i] = c;
+        }
+        if constexpr (LPS == 1) {
+            if (!shadow) {
+                float* ap = a.actions + ((size_t)t * Kl + i) * 9;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) ap[j] = e[j];
+            }
+        } else {          // the sample's lanes store one control each
+            const Gen<LPS> eo = gen_from9<LPS>(e);
+#pragma unroll
+            for (int el = 0; el < Gen<LPS>::N; ++el) {
+                const int cj = gen_coord<LPS>(el);
+                if (!shadow && cj < 9) a.actions[((size_t)t * Kl + i) * 9 + cj] = eo.a[el];
+            }
         }
         J = J + g * c;
         g = g * a.gamma;
@@ -222,21 +255,60 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
             }
         }
     }
-    if (!shadow) a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
-    if (a.wave_min) wave_min_store(a.wave_min, J, first_half, !shadow);
+#ifdef M3_PABL_PROF     // (cost_horizon rows 0-5 of the sample: total / solver / near-path clocks, substeps with gripper rows / body rows / near)
+    if (writer && T >= 6) {
+        a.cost_h[(size_t)0 * Kl + i] = (float)(__builtin_readcyclecounter() - prof_start);
+        a.cost_h[(size_t)1 * Kl + i] = (float)prof.solve_clk;
+        a.cost_h[(size_t)2 * Kl + i] = (float)prof.near_clk;
+        a.cost_h[(size_t)3 * Kl + i] = (float)prof.n_robot;
+        a.cost_h[(size_t)4 * Kl + i] = (float)prof.n_body;
+        a.cost_h[(size_t)5 * Kl + i] = (float)prof.n_near;
+        if (T >= 10) {
+            a.cost_h[(size_t)6 * Kl + i] = (float)prof.detect_clk;
+            a.cost_h[(size_t)7 * Kl + i] = (float)prof.post_clk;
+            a.cost_h[(size_t)8 * Kl + i] = (float)prof.n_act;
+            a.cost_h[(size_t)9 * Kl + i] = (float)prof.n_fk;
+        }
+    }
+#endif
+    if (writer) a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
+    if (a.wave_min) wave_min_store(a.wave_min, J, first_half, writer);
 }
 
-void launch_rollout_panda(const RolloutArgs& a_in, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
-    int lanes = (a_in.lanes >= 1 && a_in.lanes <= 64) ? a_in.lanes : 64;
-    if (lanes > 64 - pa.shadows) lanes = 64 - pa.shadows;
+// Lanes per sample: sixteen or eight while every wavefront of the launch still gets a SIMD of its own (<= 1024 wavefronts: the
+// launch is latency-bound and lasts as long as its slowest wavefront, and a wavefront is the union of what its samples do);
+// one beyond that (throughput-bound: the work replicated across a sample's lanes is 16x / 8x more instructions per sample
+// outside the solver).  Shadow slots (quirk Q8) take 1-2 of a wavefront's 4 / 8 sample slots: reach runs eight lanes per
+// sample.  pa.lps / M3P2I_PANDA_LPS force a form.
+static int panda_lps_for(const RolloutArgs& a, const PandaArgs& pa) {
+    if (pa.lps == 1 || pa.lps == 8 || pa.lps == 16) return pa.lps;
+    static const int env = [] { const char* e = getenv("M3P2I_PANDA_LPS"); return e ? atoi(e) : 0; }();
+    if (env == 1 || env == 8 || env == 16) return env;
+    auto waves = [&](int lps) { const int per = 64 / lps - pa.shadows; return (a.Kl + per - 1) / per; };
+    if (pa.shadows == 0 && waves(16) <= 1024) return 16;
+    if (waves(8) <= 1024) return 8;
+    return 1;
+}
+template <int LPS>
+static int launch_rollout_panda_lps(const RolloutArgs& a_in, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
+    constexpr int SPW = 64 / LPS;
+    int lanes = (a_in.lanes >= 1 && a_in.lanes <= SPW) ? a_in.lanes : SPW;
+    if (lanes > SPW - pa.shadows) lanes = SPW - pa.shadows;
     RolloutArgs a = a_in;
     a.lanes = lanes;
     const dim3 grid((a.Kl + lanes - 1) / lanes), block(64);
     if (a.sampling_random || a.mode_simple) {
-        if (pa.cp.task == 5) hipLaunchKernelGGL((k_rollout_panda<true, true>), grid, block, 0, s, a, pa, sc);
-        else hipLaunchKernelGGL((k_rollout_panda<false, true>), grid, block, 0, s, a, pa, sc);
-    } else if (pa.cp.task == 5) hipLaunchKernelGGL((k_rollout_panda<true, false>), grid, block, 0, s, a, pa, sc);
-    else hipLaunchKernelGGL((k_rollout_panda<false, false>), grid, block, 0, s, a, pa, sc);
+        if (pa.cp.task == 5) hipLaunchKernelGGL((k_rollout_panda<true, true, LPS>), grid, block, 0, s, a, pa, sc);
+        else hipLaunchKernelGGL((k_rollout_panda<false, true, LPS>), grid, block, 0, s, a, pa, sc);
+    } else if (pa.cp.task == 5) hipLaunchKernelGGL((k_rollout_panda<true, false, LPS>), grid, block, 0, s, a, pa, sc);
+    else hipLaunchKernelGGL((k_rollout_panda<false, false, LPS>), grid, block, 0, s, a, pa, sc);
+    return (int)grid.x;
+}
+// returns the number of workgroups (= rows of the wave_min table)
+int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
+    const int lps = panda_lps_for(a, pa);
+    return lps == 16 ? launch_rollout_panda_lps<16>(a, pa, sc, s) : lps == 8 ? launch_rollout_panda_lps<8>(a, pa, sc, s)
+                                                                              : launch_rollout_panda_lps<1>(a, pa, sc, s);
 }
 
 // ======================= step mode ======================================================
@@ -341,7 +413,7 @@ __device__ __forceinline__ void panda_push_views(const PandaScene& sc, const Sim
 // one sim.step() of every environment and the refresh of the wrapper's views in the same launch
 __global__ __launch_bounds__(64) void k_psim_step(const PandaScene sc, const SimViews v, float* wd, const float* u,
                                                   float* u_keep, int Kl) {
-    PANDA_CORNER_LDS();
+    PANDA_CORNER_LDS(1);
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= Kl) return;
     PandaWorld w;

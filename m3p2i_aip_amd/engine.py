@@ -122,6 +122,11 @@ class HipEngine:
     def set_rollout_lanes(self, lanes=0):
         self._ck(self.lib.m3_set_rollout_lanes(self._h, int(lanes)))
 
+    def set_panda_lanes_per_sample(self, lps=0):
+        """panda_env rollout: 1 = a lane per sample, 16 = the sixteen lanes of a DPP row share a sample (the contact rows run
+        across them), 0 = by size; same results bit for bit."""
+        self._ck(self.lib.m3_set_panda_lanes_per_sample(self._h, int(lps)))
+
     def set_update_launches(self, launches=0):
         """0 / 3: the three-launch multi-modal update beyond k_update_small's range; 5: round 3's five launches."""
         self._ck(self.lib.m3_set_update_launches(self._h, int(launches)))

@@ -7,7 +7,7 @@
  *       get_panda_place_cost   cost_functions.py:127-136
  *       get_pick_tilt_cost     cost_functions.py:138-156
  *       get_motion_cost        cost_functions.py:158-169 (panda branch)
- * (2) Independent implementation of "Panda world spec v2.1" (DESIGN.md section 3): velocity-servoed
+ * (2) Independent implementation of "Panda world spec v3" (DESIGN.md section 3): velocity-servoed
  *     9-dof chain with joint-space inertias derived from the collision meshes, forward kinematics from
  *     the URDF constants (assets/urdf/franka_description/robots/franka_panda.urdf:27-242), cubeA /
  *     cubeB as free rigid cubes and the dyn-obs plate as a free (non-rotating) body, CONTACT RESPONSE:
@@ -288,7 +288,7 @@ typedef struct {
     int ma, tb;              /* mover / target free body: 0 cubeA, 1 cubeB, 2 plate; -1 none (static target) */
     int target;              /* T_* */
     float d[3][3];           /* n, t1, t2 */
-    float J[3][9];           /* robot rows */
+    float g[3][16];          /* robot rows in generalized coordinates (world spec v3, below) */
     float aa[3][3], ab[3][3];/* (mover arm) x d, (target arm) x d */
     float meff[3], bias, lam[3];
     int sphere;
@@ -353,19 +353,83 @@ static void robot_row(const gripper_t* g, int s, int held, const float x[3], con
     J[8] = (s == 1 && !held) ? -dy : 0.0f;
 }
 
-static float body_k(const solver_t* S, int b, const float a[3]) {
-    return S->rotates[b] ? mad(S->invI[b], dotm(a, a), S->invm[b]) : S->invm[b];
+/* ---- world spec v3: the gripper contacts' rows in GENERALIZED coordinates ---------------------------------------------
+ * A sample's generalized velocity has 16 entries: the 9 joint velocities | the linear (3) and angular (3) velocity of the
+ * free body the row's sphere touches | 0.  A gripper contact's row of direction d is g = (J_0..J_8 | -d | -(r_t x d) | 0):
+ * the joint-space row as before, minus the direction and minus the target arm crossed with it (zeros for a static target;
+ * the plate does not rotate: zeros in its angular entries); inverse masses m = (1/I_0..1/I_8 | 1/m_b x 3 | 1/I_b x 3 | 0).
+ *   row velocity        v = SUM16(g_l u_l)
+ *   effective mass      1 / SUM16((g_l m_l) g_l)
+ *   impulse dl applied  u_l <- mad(g_l m_l, dl, u_l)
+ * where SUM16 is the FIXED pairwise tree ((x0+x1)+(x2+x3)) + ((x4+x5)+(x6+x7)) ... of the sixteen rounded products (no fused
+ * multiply-add inside the sum).  Why: the product's kernel holds one generalized coordinate per lane, sixteen lanes per
+ * sample, and forms the sum with a four-step butterfly across them (csrc/panda_dyn.hpp, LPS = 16); v2's serial chain of
+ * nine fused multiply-adds per row and visit was what C4's pick rollout spent its time in.  The entries of a row that has
+ * no free target body are +0 and so are the velocities they multiply. */
+static float sum16(const float x[16]) {
+    float a[8], b[4];
+    for (int i = 0; i < 8; ++i) a[i] = x[2 * i] + x[2 * i + 1];
+    for (int i = 0; i < 4; ++i) b[i] = a[2 * i] + a[2 * i + 1];
+    return (b[0] + b[1]) + (b[2] + b[3]);
 }
-static float body_vel(const solver_t* S, int b, const float d[3], const float a[3]) {
-    const float lin = dotm(d, S->bv[b]);
-    return S->rotates[b] ? lin + dotm(a, S->bw[b]) : lin;
+static void gen_inv_mass(const solver_t* S, const contact_t* c, float m[16]) {
+    const int b = (c->tb == 2) ? 2 : 0;       /* (both cubes have the same mass; a static target's entries multiply zeros) */
+    for (int j = 0; j < 9; ++j) m[j] = S->invIj[j];
+    for (int i = 0; i < 3; ++i) { m[9 + i] = S->invm[b]; m[12 + i] = S->invI[b]; }
+    m[15] = 0.0f;
 }
-static void body_apply(solver_t* S, int b, const float d[3], const float a[3], float dl) {   /* dl signed */
-    const float im = S->invm[b] * dl;
-    for (int i = 0; i < 3; ++i) S->bv[b][i] = mad(im, d[i], S->bv[b][i]);
-    if (S->rotates[b]) {
-        const float ia = S->invI[b] * dl;
-        for (int i = 0; i < 3; ++i) S->bw[b][i] = mad(ia, a[i], S->bw[b][i]);
+static void gen_get(const solver_t* S, const contact_t* c, const float* qd, float u[16]) {
+    for (int j = 0; j < 9; ++j) u[j] = qd[j];
+    for (int i = 0; i < 3; ++i) {
+        u[9 + i] = (c->tb >= 0) ? S->bv[c->tb][i] : 0.0f;
+        u[12 + i] = (c->tb >= 0) ? S->bw[c->tb][i] : 0.0f;
+    }
+    u[15] = 0.0f;
+}
+static void gen_put(solver_t* S, const contact_t* c, const float u[16]) {
+    for (int j = 0; j < 9; ++j) S->qd[j] = u[j];
+    if (c->tb >= 0) for (int i = 0; i < 3; ++i) { S->bv[c->tb][i] = u[9 + i]; S->bw[c->tb][i] = u[12 + i]; }
+}
+static float gen_vrel(const solver_t* S, const contact_t* c, int r, const float* qd) {
+    float u[16], x[16];
+    gen_get(S, c, qd, u);
+    for (int l = 0; l < 16; ++l) x[l] = c->g[r][l] * u[l];
+    return sum16(x);
+}
+static void gen_apply(solver_t* S, const contact_t* c, int r, float dl) {
+    float u[16], m[16];
+    gen_get(S, c, S->qd, u);
+    gen_inv_mass(S, c, m);
+    for (int l = 0; l < 16; ++l) u[l] = mad(c->g[r][l] * m[l], dl, u[l]);
+    gen_put(S, c, u);
+}
+
+/* ---- world spec v3: the cubes' manifold rows.  A free cube has 8 generalized coordinates (v_x v_y v_z w_x w_y w_z 0 0); a
+ * manifold row of direction d at the point X is (d | (X - p_M) x d | 0 0) on the mover and, for a cubeA-against-cubeB row,
+ * (-d | -(X - p_T) x d | 0 0) on the target; inverse masses (1/m x 3 | 1/I x 3 | 0 0).
+ *   row velocity   SUM8(g_M u_M) [+ SUM8(g_T u_T)]      SUM8 = ((x0+x1)+(x2+x3)) + ((x4+x5)+(x6+x7)), x6 = x7 = +0
+ *   effective mass 1 / (SUM8((g_M m) g_M) [+ SUM8((g_T m) g_T)])
+ *   impulse        u_l <- mad(g_l m_l, dl, u_l)
+ * (the product's kernel: cubeA's coordinates on lanes 0-7 of a sample's sixteen, cubeB's on 8-15; SUM8 = a three-step
+ * butterfly inside each half). */
+static float sum8_6(float x0, float x1, float x2, float x3, float x4, float x5) {
+    return ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + 0.0f);
+}
+static float bodyrow_vel(const solver_t* S, int b, const float d[3], const float a[3], float sgn) {
+    const float* v = S->bv[b];
+    const float* w = S->bw[b];
+    return sum8_6((sgn * d[0]) * v[0], (sgn * d[1]) * v[1], (sgn * d[2]) * v[2], (sgn * a[0]) * w[0], (sgn * a[1]) * w[1], (sgn * a[2]) * w[2]);
+}
+static float bodyrow_k(const solver_t* S, int b, const float d[3], const float a[3], float sgn) {
+    const float im = S->invm[b], iI = S->invI[b];
+    float g[6] = {sgn * d[0], sgn * d[1], sgn * d[2], sgn * a[0], sgn * a[1], sgn * a[2]};
+    return sum8_6((g[0] * im) * g[0], (g[1] * im) * g[1], (g[2] * im) * g[2], (g[3] * iI) * g[3], (g[4] * iI) * g[4], (g[5] * iI) * g[5]);
+}
+static void bodyrow_apply(solver_t* S, int b, const float d[3], const float a[3], float sgn, float dl) {
+    const float im = S->invm[b], iI = S->invI[b];
+    for (int i = 0; i < 3; ++i) {
+        S->bv[b][i] = mad((sgn * d[i]) * im, dl, S->bv[b][i]);
+        S->bw[b][i] = mad((sgn * a[i]) * iI, dl, S->bw[b][i]);
     }
 }
 
@@ -381,12 +445,14 @@ static void contact_prepare(solver_t* S, contact_t* c, float gap) {
     for (int r = 0; r < 3; ++r) {
         float k;
         if (c->robot) {
-            k = 0.0f;
-            for (int j = 0; j < 9; ++j) k = mad(c->J[r][j] * S->invIj[j], c->J[r][j], k);
+            float m[16], x[16];
+            gen_inv_mass(S, c, m);
+            for (int l = 0; l < 16; ++l) x[l] = (c->g[r][l] * m[l]) * c->g[r][l];
+            k = sum16(x);
         } else {
-            k = body_k(S, c->ma, c->aa[r]);
+            k = bodyrow_k(S, c->ma, c->d[r], c->aa[r], 1.0f);
+            if (c->tb >= 0) k = k + bodyrow_k(S, c->tb, c->d[r], c->ab[r], -1.0f);
         }
-        if (c->tb >= 0) k = k + body_k(S, c->tb, c->ab[r]);
         c->meff[r] = 1.0f / k;
         c->lam[r] = 0.0f;
     }
@@ -400,14 +466,9 @@ static void contact_prepare(solver_t* S, contact_t* c, float gap) {
 }
 
 static float contact_vrel(const solver_t* S, const contact_t* c, int r, const float* qd) {
-    float v;
-    if (c->robot) {
-        v = 0.0f;
-        for (int j = 0; j < 9; ++j) v = mad(c->J[r][j], qd[j], v);
-    } else {
-        v = body_vel(S, c->ma, c->d[r], c->aa[r]);
-    }
-    if (c->tb >= 0) v = v - body_vel(S, c->tb, c->d[r], c->ab[r]);
+    if (c->robot) return gen_vrel(S, c, r, qd);
+    float v = bodyrow_vel(S, c->ma, c->d[r], c->aa[r], 1.0f);
+    if (c->tb >= 0) v = v + bodyrow_vel(S, c->tb, c->d[r], c->ab[r], -1.0f);
     return v;
 }
 
@@ -417,16 +478,18 @@ static void contact_solve(solver_t* S, contact_t* c) {
     for (int rr = 0; rr < 3; ++rr) {
         const int r = (rr + 1) % 3;
         const float v = contact_vrel(S, c, r, S->qd);
-        float dl = -c->meff[r] * (v + ((r == 0) ? c->bias : 0.0f));
+        float dl = -c->meff[r] * ((r == 0) ? v + c->bias : v);
         const float l0 = c->lam[r];
         float l1 = l0 + dl;
         if (r == 0) l1 = fmaxf(l1, 0.0f);
         else { const float mx = S->sc->mu * c->lam[0]; l1 = fminf(fmaxf(l1, -mx), mx); }
         c->lam[r] = l1;
         dl = l1 - l0;
-        if (c->robot) { for (int j = 0; j < 9; ++j) S->qd[j] = mad(c->J[r][j] * S->invIj[j], dl, S->qd[j]); }
-        else body_apply(S, c->ma, c->d[r], c->aa[r], dl);
-        if (c->tb >= 0) body_apply(S, c->tb, c->d[r], c->ab[r], -dl);
+        if (c->robot) gen_apply(S, c, r, dl);
+        else {
+            bodyrow_apply(S, c->ma, c->d[r], c->aa[r], 1.0f, dl);
+            if (c->tb >= 0) bodyrow_apply(S, c->tb, c->d[r], c->ab[r], -1.0f, dl);
+        }
     }
 }
 
@@ -668,8 +731,15 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
             float rt[3] = {0, 0, 0};
             if (c.tb >= 0) for (int i = 0; i < 3; ++i) rt[i] = bx[i] - bodies[c.tb][i];
             for (int r = 0; r < 3; ++r) {
-                robot_row(&g, s, held, bx, c.d[r], c.J[r]);
-                if (c.tb >= 0) cross3(rt, c.d[r], c.ab[r]);
+                robot_row(&g, s, held, bx, c.d[r], c.g[r]);
+                for (int l = 9; l < 16; ++l) c.g[r][l] = 0.0f;
+                if (c.tb >= 0) {
+                    cross3(rt, c.d[r], c.ab[r]);
+                    for (int i = 0; i < 3; ++i) {
+                        c.g[r][9 + i] = -c.d[r][i];
+                        c.g[r][12 + i] = (c.tb < 2) ? -c.ab[r][i] : 0.0f;      /* the plate does not rotate */
+                    }
+                }
             }
             /* culling: the gap predicted for the end of the substep from the servo's velocities */
             const float vn0 = contact_vrel(&S, &c, 0, qd1);
@@ -704,8 +774,7 @@ void m3o_panda_step(const m3o_panda_scene* sc, m3o_panda_world* w, const float u
             contact_t* c = &S.c[k];
             const float dl = c->lam[0];
             if (dl == 0.0f) continue;
-            for (int j = 0; j < 9; ++j) S.qd[j] = mad(c->J[0][j] * S.invIj[j], dl, S.qd[j]);
-            if (c->tb >= 0) body_apply(&S, c->tb, c->d[0], c->ab[0], -dl);
+            gen_apply(&S, c, 0, dl);
         }
         for (int pass = 0; pass < sc->iters; ++pass) {
             if (robot_rows) {

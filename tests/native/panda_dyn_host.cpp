@@ -45,7 +45,7 @@ extern "C" void pnh_step(float dt, int substeps, float* worlds, int n, const flo
                          float* trav) {
     m3::PandaScene sc;
     scene(sc, dt, substeps);
-    float corner[m3::PANDA_STORE_FLOATS];
+    float corner[m3::PANDA_STORE_FLOATS];      // (one lane per sample: manifold points + the gripper rows)
     const m3::CornerStore cs{corner, 1};
     for (int i = 0; i < n; ++i) {
         m3::PandaWorld p;

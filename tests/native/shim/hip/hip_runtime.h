@@ -14,3 +14,11 @@ static inline float m3_host_med3(float x, float lo, float hi) { return x > hi ? 
 #define __builtin_amdgcn_fmed3f(x, lo, hi) m3_host_med3((x), (lo), (hi))
 // a wavefront of one lane
 #define __builtin_amdgcn_ballot_w64(p) ((p) ? 1ull : 0ull)
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+// lane index: the host build instantiates the one-lane-per-sample forms only (LPS = 1), which never read it
+static const struct { unsigned x, y, z; } threadIdx = {0u, 0u, 0u};
+// cross-lane operations of the sixteen-lanes-per-sample forms (never instantiated on the host)
+int __builtin_amdgcn_update_dpp(int, int, int, int, int, bool);
+int __builtin_amdgcn_ds_bpermute(int, int);
+int __builtin_amdgcn_readfirstlane(int);
