@@ -887,6 +887,7 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.filter_u = c.filter_u; a.u_per_command = c.u_per_command;
     a.lambda_ = c.lambda_; a.step_size_mean = c.step_size_mean;
     a.cand = h->topk_cand;
+    a.p2p_err = (h->p2p_ready && h->xb) ? (const int*)((const char*)h->xb + 2 * MIX_MAX_RANKS * sizeof(int)) : nullptr;
     a.part_min = h->part_min;
     a.n_cand = topk_workgroups(c.K_global);
     a.n_mins = mins_workgroups(c.K_global);
@@ -1585,7 +1586,9 @@ extern "C" int m3_cost(m3_handle* h, float* cost) {
     } else {
         PandaCostParams cp;
         fill_panda_cost_params(h, cp);
-        launch_psim_cost(h->pscene, cp, h->sim_world, h->cfg.K_local, h->cfg.k_offset, cost, h->stream);
+        // quirk Q8 exactly where m3_rollout applies it (its shadow lanes): reach on an unsharded handle
+        const bool env0_cube = cp.task == 4 && h->cfg.k_offset == 0 && h->cfg.K_local == h->cfg.K_global && h->cfg.K_global >= 2;
+        launch_psim_cost(h->pscene, cp, h->sim_world, h->cfg.K_local, h->cfg.k_offset, env0_cube, cost, h->stream);
     }
     HIPCHK(h, hipGetLastError());
     return M3_OK;

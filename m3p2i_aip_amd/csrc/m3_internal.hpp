@@ -91,6 +91,7 @@ struct UpdateArgs {
     float* best1;
     float* best2;
     float* action_out;   // [T][nu]
+    const int* p2p_err;  // device-side exchange attached: its sticky error word (a rank that never arrived: the records hold NaN)
     float* top_trajs;    // [M3_TOPK][T][2]
     // shard_mix (one-collective sharding): k_weights / top-k see the LOCAL shard (Kg = Kl,
     // Jall = local costs, w = weights + k0); kbase maps their sample numbers to global indices
@@ -267,7 +268,7 @@ void launch_psim_step(const PandaScene& sc, const SimViews& v, float* world, con
                       hipStream_t s);
 void launch_psim_pull(const PandaScene& sc, const SimViews& v, float* world, int Kl, hipStream_t s);
 void launch_psim_push(const PandaScene& sc, const SimViews& v, const float* world, int Kl, hipStream_t s);
-void launch_psim_cost(const PandaScene& sc, const PandaCostParams& cp, const float* world, int Kl, int k0,
+void launch_psim_cost(const PandaScene& sc, const PandaCostParams& cp, const float* world, int Kl, int k0, bool env0_cube,
                       float* cost, hipStream_t s);
 
 }  // namespace m3

@@ -460,7 +460,7 @@ void launch_psim_push(const PandaScene& sc, const SimViews& v, const float* worl
 }
 
 __global__ __launch_bounds__(64) void k_psim_cost(const PandaScene sc, const PandaCostParams cp, const float* wd,
-                                                  int Kl, int k0, float* cost) {
+                                                  int Kl, int k0, int env0_cube, float* cost) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= Kl) return;
     PandaWorld w;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64) void k_psim_cost(const PandaScene sc, const Pan
     mat2quat(hand, o.left_q);
     // quirk Q8: environment 0's cube position, the orientation of the first environment of the sample's half (rows 18-24)
     float cube0[3], qh0[4];
-    const bool env0 = (cp.task == 4 && k0 == 0 && Kl >= 2);
+    const bool env0 = env0_cube != 0;      // (the host's condition, the one m3_rollout uses for its shadow lanes)
     const int src = env0 ? ((cp.multi_modal && i >= cp.half_K) ? cp.half_K : 0) : i;
 #pragma unroll
     for (int j = 0; j < 3; ++j) cube0[j] = wd[(18 + j) * Kl + (env0 ? 0 : i)];
@@ -479,9 +479,9 @@ __global__ __launch_bounds__(64) void k_psim_cost(const PandaScene sc, const Pan
     for (int j = 0; j < 4; ++j) qh0[j] = wd[(21 + j) * Kl + src];
     cost[i] = panda_cost(cp, w, o, k0 + i, cube0, qh0);
 }
-void launch_psim_cost(const PandaScene& sc, const PandaCostParams& cp, const float* world, int Kl, int k0,
+void launch_psim_cost(const PandaScene& sc, const PandaCostParams& cp, const float* world, int Kl, int k0, bool env0_cube,
                       float* cost, hipStream_t s) {
-    hipLaunchKernelGGL(k_psim_cost, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, cp, world, Kl, k0, cost);
+    hipLaunchKernelGGL(k_psim_cost, dim3((Kl + 63) / 64), dim3(64), 0, s, sc, cp, world, Kl, k0, env0_cube ? 1 : 0, cost);
 }
 
 }  // namespace m3

@@ -808,6 +808,14 @@ __device__ __forceinline__ float rd_reduce(const float* p) {
 template <bool SC1>
 __device__ __forceinline__ void finalize_body(const UpdateArgs& a, float* sm /* LDS [T*nu] */) {
     const int T = a.T, nu = a.nu, n = T * nu, tid = threadIdx.x;
+    // A device-side exchange that gave up on a rank (p2p.hip: sticky error word, that rank's record filled with NaN): the plan
+    // of this command is NaN -- handed out as such, so that nothing acts on a plan built from a part of the samples -- but the
+    // warm-start state (means, best trajectories) is NOT overwritten with it: once the peer is back and the word is cleared
+    // the planner continues from its last good plan.  The host raises at its next poll (distributed.attach_p2p).
+    if (a.p2p_err && __hip_atomic_load(a.p2p_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+        for (int o = tid; o < n; o += blockDim.x) a.action_out[o] = __builtin_nanf("");
+        return;
+    }
     const bool multi = a.multi_modal && !a.mode_simple;
     const float* ps = a.reduce + reduce_off_psum(0, T, nu);
     const float wtot = a.info->wsum_push + a.info->wsum_pull;

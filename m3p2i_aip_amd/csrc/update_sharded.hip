@@ -193,7 +193,9 @@ __global__ __launch_bounds__(ST) void k_regen_done(const UpdateArgs a) {
         const VI c2 = wave_argmin(on ? VI{x[6], __float_as_int(x[7])} : none);
         if (tid == 0) {
             m3_info* f = a.info;
-            f->best_idx = c0.i; f->best_idx_1 = c1.i; f->best_idx_2 = c2.i;
+            f->best_idx = c0.i == 0x7fffffff ? -1 : c0.i;      // (no argmax: -1, as every other path reports it)
+            f->best_idx_1 = c1.i == 0x7fffffff ? -1 : c1.i;
+            f->best_idx_2 = c2.i == 0x7fffffff ? -1 : c2.i;
             f->wsum_push = h0; f->wsum_pull = h1;
             f->pull_preference = h1 > h0;
             s_best[0] = c0.i; s_best[1] = c1.i; s_best[2] = c2.i;

@@ -99,10 +99,13 @@ def attach_p2p(planner, group=None, poll_every=P2P_POLL_EVERY):
     Skew bound.  A wait spins for at most the handle's time-out -- 30 s for a channel's first exchange, 0.5 s
     afterwards (`engine.p2p_set_timeout_ms`) -- so the ranks must reach every command within that of each other (a rank
     stalled longer: garbage collection, rendering, a failed bench row).  A wait that gives up does NOT hang the GPU and
-    does NOT pass stale data on: the missing rank's slot is filled with NaN (the plan of that command is NaN on the
-    ranks that missed it), a sticky error word is set, and this transport reads that word every `poll_every`
-    commands (and when it is detached) and raises RuntimeError naming the rank that never arrived -- where the RCCL
-    transport would have blocked."""
+    does NOT pass stale data on: the missing rank's slot is filled with NaN and a sticky error word is set; while it is set
+    the finalize kernels hand out NaN plans (this command's and every later one's) and leave the warm-start state -- means,
+    best trajectories -- untouched, so nothing can act on a plan built from a part of the samples and nothing is poisoned.
+    The host learns of it by reading the word, which synchronises the stream: this transport does so every `poll_every`
+    commands (an asynchronous command loop; `poll_every=1` for a loop that reads every action back anyway, where the read
+    is a synchronisation point already), in `planner.p2p_check()`, and in `detach_p2p(planner)`; each raises RuntimeError
+    naming the rank that never arrived -- where the RCCL transport would have blocked."""
     if planner.world_size != dist.get_world_size(group):
         raise ValueError("planner.world_size does not match the process group")
     if not planner.shard_mix:
@@ -169,4 +172,18 @@ def attach_p2p(planner, group=None, poll_every=P2P_POLL_EVERY):
     planner.transport = "p2p"
     planner.ranks_seen = dist.get_world_size(group)
     planner.p2p_check = lambda: check(planner)     # explicit poll (tools, tests, before shutting a rank down)
+    planner._p2p_group = group
+    return planner
+
+
+def detach_p2p(planner):
+    """Back to the RCCL collectives; reads the exchange's error word first (raises if a wait ever gave up)."""
+    chk = getattr(planner, "p2p_check", None)
+    if chk is None:
+        return planner
+    try:
+        chk()
+    finally:
+        planner.p2p_check = None
+        attach_collectives(planner, getattr(planner, "_p2p_group", None))
     return planner

@@ -185,9 +185,9 @@ class MPPI():
         if sm and not can_mix:
             raise ValueError("shard_mix=True with multi_modal needs sampling_method='halton' (a noise table)")
         self.shard_mix = bool(world > 1 and can_mix and (True if sm is None else sm))
-        # multi-modal: shard_mix=2 (default) adds per-shard ladder tables to the records -- half the per-rank work
-        # after the collective, equal to the unsharded run up to f32 rounding; shard_mix=True/1 keeps the
-        # bit-identical variant (all K costs re-evaluated on every rank)
+        # multi-modal: shard_mix=2 adds per-shard ladder tables to the records -- half the per-rank work after the
+        # collective, equal to the unsharded run up to f32 rounding; the INTEGER 1 keeps the bit-identical variant (all K
+        # costs re-evaluated on every rank); None / True (the bool: "use the one-collective family") = chosen by size, below
         # shard_mix=3: two small exchanges and O(K_local) work per rank after the first (more ranks / samples than the
         # one-collective protocols are meant for: their post-gather work grows with K_global)
         # The default picks by size: `2` (one collective, O(K_global) work per rank after it) up to SHARD_MIX3_FROM

@@ -69,7 +69,7 @@ typedef struct {
     float mu_rb, mu_rd, mu_ro, mu_rw, mu_bw, mu_dw, mu_bd, mu_bo, mu_do;
     float contact_offset; /* isaacgym_wrapper.py:30 (0.01) */
     float baumgarte, slop, max_bias, face_tol;
-    int friction_coupling;   /* spec v1.5: sliding-spinning coupling of the boxes' ground friction (0: spec v1.4) */
+    int friction_coupling;   /* 1 = spec v1.5: sliding-spinning coupling of the boxes' ground friction; 0: spec v1.4; 2: the experimental four-corner patch rows (tools/cpu_ab_default_size.py only) */
 } m3o_point_scene;
 
 typedef struct { float x, y, c, s, vx, vy, w; } m3o_body;

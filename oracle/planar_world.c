@@ -399,7 +399,7 @@ static void friction_coupling(float vx, float vy, float w, float R, float cf[2])
  * contact patch -- each corner carries m g / 4 and its Coulomb impulse opposes that corner's own velocity, so a box
  * that SLIDES fast has almost no resistance left against turning (the corners' velocities all point along the slide),
  * which is what a contact patch does and what the independent torsion row of the spec (limit mu m g r_eq whatever the
- * sliding speed) does not.  Selected by the environment variable M3O_PATCH4. */
+ * sliding speed) does not.  Selected by the scene field friction_coupling = 2 (0: spec v1.4, 1: spec v1.5). */
 typedef struct { float lx[4], ly[4]; } patch_acc;
 static void solve_ground_friction_patch4(solver_t* s, int b, const m3o_body* X, float hx, float hy, float Lpt,
                                          patch_acc* f, fric_acc* tot) {
@@ -493,12 +493,11 @@ void m3o_point_step(const m3o_point_scene* sc, m3o_point_world* w, const float u
         fric_acc fB = {0.0f, 0.0f, 0.0f}, fD = {0.0f, 0.0f, 0.0f};
         patch_acc pB, pD;
         memset(&pB, 0, sizeof pB); memset(&pD, 0, sizeof pD);
-        static int patch4 = -1;
-        if (patch4 < 0) patch4 = getenv("M3O_PATCH4") ? 1 : 0;
+        const int patch4 = (sc->friction_coupling == 2);   /* (experiment of tools/cpu_ab_default_size.py only: a scene field, not an environment variable) */
         /* spec v1.5: the limits of a box's two ground-friction rows are coupled by the sliding-spinning law of a contact
          * patch, factors from the velocities this substep starts its passes with */
         float cfB[2] = {1.0f, 1.0f}, cfD[2] = {1.0f, 1.0f};
-        if (sc->friction_coupling) {
+        if (sc->friction_coupling == 1) {
             friction_coupling(s.vx[BB], s.vy[BB], s.w[BB], 1.5f * sc->box_req, cfB);
             friction_coupling(s.vx[BD], s.vy[BD], s.w[BD], 1.5f * sc->dyn_req, cfD);
         }

@@ -320,10 +320,17 @@ def test_p2p_missed_exchange_poisons_the_plan_and_the_fallback_memory_kinds_work
     assert all(e.p2p_status()[0] == -1 and e.p2p_status()[1] in want_kind for e in shards)
     # now rank 1 stalls: rank 0's wait gives up, its plan must come out NaN, not a finite one built on the old slot
     e = shards[0]
+    mean_before = e.buffer(L.BUF_MEAN).cpu().numpy().copy()
     e.rollout(); e.update(); e.p2p_put(); e.p2p_wait(); e.finalize()
     torch.cuda.synchronize()
     assert e.p2p_status()[0] == 1
-    assert np.isnan(e.buffer(L.BUF_ACTION_OUT).cpu().numpy()).any()
+    assert np.isnan(e.buffer(L.BUF_ACTION_OUT).cpu().numpy()).all()
+    # ... while the warm-start state is NOT overwritten with it: the planner keeps its last good plan
+    assert np.array_equal(e.buffer(L.BUF_MEAN).cpu().numpy(), mean_before) and np.isfinite(e.buffer(L.BUF_BEST).cpu().numpy()).all()
+    # and the error is sticky: every later command hands out NaN, never a plan built from a part of the samples
+    e.rollout(); e.update(); e.p2p_put(); e.p2p_wait(); e.finalize()
+    torch.cuda.synchronize()
+    assert np.isnan(e.buffer(L.BUF_ACTION_OUT).cpu().numpy()).all() and np.array_equal(e.buffer(L.BUF_MEAN).cpu().numpy(), mean_before)
     for e in shards:
         e.close()
 

@@ -93,15 +93,18 @@ def _fuzz_batch(b):
     return random_panda_worlds(P, P.default_scene(), 42, np.random.default_rng(900 + b))
 
 
+@pytest.mark.parametrize("lps", [1, 8, 16])
 @pytest.mark.parametrize("seed", range(36))
-def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed):
+def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed, lps):
     """Fuzz: a random world per seed -- random joint configuration and velocities; cubeA on the table / near the hand /
     falling onto the shelf / stacked on cubeB (resting, dropped, beyond the edge) / tumbling in the air next to cubeB;
     cubeB and the plate near the hand, moving; the gripper pointing down with its finger tips at the table or at cubeB;
     the cube held / the open gripper around it (tests/test_device_dynamics_on_host.random_panda_worlds) --, random
     gripper command and task, strong random controls.  The rollout must equal the oracle's bit for bit: the contact
     detection (wave-level rejects, lazy kinematics), the gripper rows, the cubes' manifolds in LDS, sleeping and waking
-    all decide per wave or per lane what to evaluate -- random worlds put everything at every distance."""
+    all decide per wave or per lane what to evaluate -- random worlds put everything at every distance.  In all three forms
+    of the kernel (world spec v3): a lane per sample, and eight / sixteen lanes sharing a sample with the contact rows across
+    them (DPP butterflies, row shifts between the joints' and the cubes' vectors, rows in registers / lane-distributed LDS)."""
     import oracle.panda as P
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
@@ -118,6 +121,7 @@ def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed):
     eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", u_min=UMIN, u_max=UMAX,
                                 noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01))
     eng.set_objective(task, goal, gripper_cmd=grip)
+    eng.set_panda_lanes_per_sample(lps)
     eng.set_noise(delta)
     eng.set_world_panda_raw(raw31(P, w0))
     eng.command(sync_host=True)

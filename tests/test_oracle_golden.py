@@ -218,6 +218,10 @@ def g9_planner(oracle, golden, tag, seed=7):
     return cfg, oracle.OraclePointPlanner(cfg, delta, seed=seed, update_cov=update_cov)
 
 
+# (trace, mode) whose per-mode mean at the trace's LAST call is ill-conditioned (see the end of test_g9_command_traces)
+ILL_CONDITIONED = {("hybrid", 0)}
+
+
 @pytest.mark.parametrize("tag", list(G9))
 def test_g9_command_traces(golden, oracle, tag):
     """The reference's M3P2I.command() driven through its plugin API (reactive_tamp.py
@@ -258,15 +262,18 @@ def test_g9_command_traces(golden, oracle, tag):
     ds = np.abs(pl.last["states"] - golden[f"g9_{tag}_states_last"]).max(axis=(1, 2))
     if cfg.multi_modal:
         # A per-mode mean is ONE such sum per mode: when a mode's search ends at beta = 0.9^15 and two samples compete
-        # for the softmin, 1e-4 in J moves that mode's mean by 0.1 (observed in the push half of this trace under spec
-        # v1.5, last call; every earlier call, the blended mean and the returned control agree to 1e-4 -- asserted
-        # above).  So: the better-conditioned mode strictly, the other one in the median.
+        # for the softmin, 1e-4 in J moves that mode's mean by 0.1.  That is the case in exactly one place of the fixtures:
+        # the PUSH half (mode 0) of the `hybrid` trace at its LAST call under spec v1.5 (ILL_CONDITIONED below: a fixed,
+        # known (trace, mode), not one picked from the data).  Every earlier call of that trace, its blended mean, its
+        # returned control, its weights and its pull preference agree to 1e-3 / 1e-4 and are asserted strictly in the loop
+        # above; the other mode and every other trace are strict here too.  The named mode is bounded in the median and in
+        # the maximum -- a regression of that mode's mean update would show in the calls before it.
         half = cfg.K // 2
-        worse = 0 if da[:half].max() > da[half:].max() else 1
-        good = slice(half, None) if worse == 0 else slice(0, half)
-        bad = slice(0, half) if worse == 0 else slice(half, None)
-        assert da[good].max() < tol and np.quantile(ds[good], 0.5) < 1e-3 and ds[good].max() < 2e-2
-        assert np.median(da[bad]) < 0.05 and da[bad].max() < 0.3
+        for mode, sl in ((0, slice(0, half)), (1, slice(half, None))):
+            if (tag, mode) in ILL_CONDITIONED:
+                assert np.median(da[sl]) < 0.05 and da[sl].max() < 0.3, (tag, mode)
+            else:
+                assert da[sl].max() < tol and np.quantile(ds[sl], 0.5) < 1e-3 and ds[sl].max() < 2e-2, (tag, mode)
     else:
         assert da.max() < tol
         assert np.quantile(ds, 0.5) < 1e-3 and ds.max() < 2e-2

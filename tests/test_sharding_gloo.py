@@ -132,3 +132,20 @@ def test_sharded_command_equals_single_process(case, world, golden):
         np.testing.assert_allclose(a["best"], b["best"], atol=1e-5)
         np.testing.assert_allclose(a["best1"], b["best1"], atol=1e-5)
         assert a["pref"] == b["pref"]
+
+@pytest.mark.parametrize("sm,mm,want", [(None, True, 2), (True, True, 2), (1, True, 1), (2, True, 2), (3, True, 3),
+                                        (False, True, 0), (None, False, 1), (True, False, 1), (False, False, 0)])
+def test_shard_mix_values_map_to_protocols(sm, mm, want):
+    """MPPIConfig.shard_mix: None and the BOOL True mean "the one-collective family, protocol by size" (2 below
+    planner.SHARD_MIX3_FROM samples), the INTEGERS 1 / 2 / 3 force a protocol (1 = the bit-identical variant), False = gather +
+    reduce; single-mode planners have one protocol (1: k_mix).  (`True` and `1` are different requests.)"""
+    from m3p2i_aip_amd import planner as P
+    from tests.oracle_engine import OracleEngine
+    P.ENGINE_CLS = OracleEngine
+    m = P.MPPIConfig(num_samples=K, horizon=T, nx=4, device="cpu", lambda_=0.5, u_min=[-3.0, -3.0], u_max=[3.0, 3.0],
+                     noise_sigma=[[3.0, 0.0], [0.0, 3.0]], u_per_command=T, sample_null_action=True, filter_u=True, fused=True,
+                     rank=0, world_size=2, shard_mix=sm)
+    cfg = SimpleNamespace(env_type="point_env", multi_modal=mm, suction_active=True, kp_suction=400, pre_height_diff=0.0,
+                          task="push_pull" if mm else "push", goal=[-1.0, -1.0], cube_on_shelf=False, mppi=m)
+    pl = P.M3P2I(cfg)
+    assert pl._shard_mix_level == want and pl.shard_mix == (want > 0)

@@ -13,7 +13,7 @@ things PhysX has and the written spec lacks or fixes differently -- not a sweep 
                             resolves the box's ground contact at its corners) instead of the disc-equivalent 0.153 m
   patch_none                no torsional ground friction at all
   patch_4pt                 ground friction AT the four corners of the patch, each opposing its own velocity (the
-                            experimental rows of oracle/planar_world.c, M3O_PATCH4): turning resistance that fades
+                            experimental rows of oracle/planar_world.c, scene.friction_coupling = 2): turning resistance that fades
                             with the sliding speed, as a real patch's does
   (spec = spec_v14 + the two rows' limits COUPLED by the sliding-spinning law of a contact patch -- Contensou; Zhuravlev's
    Pade form, factors from the substep's initial velocities: the cheap form of patch_4pt.  Every other row toggles its
@@ -54,7 +54,7 @@ def variants():
         "no_speculative": (mod(friction_coupling=0, contact_offset=0.0), 15),
         "patch_corners": (mod(friction_coupling=0, box_req=0.2828, dyn_req=0.2828), 15),
         "patch_none": (mod(friction_coupling=0, box_req=0.0, dyn_req=0.0), 15),
-        "patch_4pt": (mod(friction_coupling=0), 15),
+        "patch_4pt": (mod(friction_coupling=2), 15),
         "passes_12": (mod(friction_coupling=0, iters=12), 15),
         "passes_3": (mod(friction_coupling=0, iters=3), 15),
         "drive_soft": (mod(friction_coupling=0, drive_damping=150.0), 15),
@@ -99,11 +99,6 @@ def main(argv):
     only = [a for a in argv if not a.startswith("--") and not a.isdigit() and not a.endswith(".json")]
     for name, (modify, T) in variants().items():
         if only and name not in only:
-            continue
-        # (the experimental rows are switched per process: `M3O_PATCH4=1 ... patch_4pt`, `M3O_CONTENSOU=1 ... contensou`)
-        env_of = {"patch_4pt": "M3O_PATCH4"}
-        active = [k for k, e in env_of.items() if os.environ.get(e)]
-        if (name in env_of) != bool(active) or (active and name not in active):
             continue
         sc = O.default_scene()
         modify(sc)

@@ -13,7 +13,11 @@ n2 = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 oracle.build()
 bad = []
 t0 = time.time()
-for name, fn, n in (("point", tp.test_rollout_bit_exact_on_random_worlds, n1), ("panda", tq.test_panda_rollout_bit_exact_on_random_worlds, n2)):
+def panda(o, seed):     # the three forms of the Panda kernel in turn (lanes per sample: world spec v3)
+    tq.test_panda_rollout_bit_exact_on_random_worlds(o, seed, (16, 8, 1)[seed % 3])
+
+
+for name, fn, n in (("point", tp.test_rollout_bit_exact_on_random_worlds, n1), ("panda", panda, n2)):
     for seed in range(s0, s0 + n):
         try:
             fn(oracle, seed)
