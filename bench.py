@@ -324,25 +324,20 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
                 collective_ms=coll_ms, simple=name in SIMPLE_MODE, walls_ms_per_step=[w / steps * 1e3 for w in walls])
 
 
-MIX_DIR = os.path.join(ROOT, "profiles", "r04")
+MIX_DIR = os.path.join(ROOT, "profiles", "r05")
 
 
-def lib_sha16():
-    """sha256 prefix of the HIP library this process runs (the key of the committed PMC instruction-mix profiles)"""
-    import hashlib
-    from m3p2i_aip_amd import build as b
-    path = os.environ.get("M3P2I_HIP_LIB", b.OUT)
-    h = hashlib.sha256()
-    with open(path, "rb") as f:
-        for chunk in iter(lambda: f.read(1 << 20), b""):
-            h.update(chunk)
-    return h.hexdigest()[:16]
+def lib_build_id():
+    """m3_build_id() of the HIP library this process runs: a hash of the kernel sources + compiler flags that is the same for
+    every rebuild of the same tree (the .so's own sha256 is not) -- the key of the committed PMC instruction-mix profiles"""
+    from m3p2i_aip_amd import _lib as L
+    return L.load().m3_build_id().decode()
 
 
 def roofline_valu(name, r, n_waves):
     """The roofline that binds this path -- VALU issue, not HBM: the rollout kernel's dynamic
-    instruction counts per wavefront from the committed PMC profile of THIS library (profiles/r04/mix_<config>.json,
-    written by tools/pmc_mix_bench.sh; keyed by the library's sha256: a profile of another build is refused), against
+    instruction counts per wavefront from the committed PMC profile of THIS build (profiles/r05/mix_<config>.json,
+    written by tools/pmc_mix_bench.sh; keyed by m3_build_id(): a profile of other sources / flags is refused), against
       lone_wave_issue_frac  = VALU instructions / wave cycles -- how close ONE wavefront alone on its SIMD comes to
                               issuing a VALU instruction every 4 clocks (the bound of every BASELINE size: at most one
                               wavefront per SIMD, so the dependent-instruction chain of a wave is the command's time)
@@ -353,11 +348,12 @@ def roofline_valu(name, r, n_waves):
     if not os.path.exists(path):
         return None
     mix = json.load(open(path))
-    sha = lib_sha16()
-    if mix.get("lib_sha16") != sha:
-        return {"stale": f"{os.path.relpath(path, ROOT)} profiles library {mix.get('lib_sha16')}, this run uses {sha}: "
+    sha = lib_build_id()
+    if mix.get("build_id") != sha:
+        return {"stale": f"{os.path.relpath(path, ROOT)} profiles build {mix.get('build_id')}, this run uses {sha}: "
                          "re-run tools/pmc_mix_bench.sh"}
     valu, cyc = mix["SQ_INSTS_VALU"], mix["SQ_WAVE_CYCLES"]
+    n_waves = int(mix.get("waves") or n_waves)      # (what the launch really had: the Panda kernel shares a sample among 8 / 16 lanes)
     clock_ghz = mix.get("clock_ghz", 2.4)
     kernel_clocks = r["rollout_ms"] * 1e-3 * clock_ghz * 1e9
     return {"bound": "valu_issue", "kernel": mix.get("kernels"), "valu_per_wave": valu, "wave_cycles_x4": cyc,
@@ -365,10 +361,10 @@ def roofline_valu(name, r, n_waves):
             "chip_issue_frac": n_waves * valu * 4.0 / (kernel_clocks * 1024),
             "arithmetic_frac_of_valu": (mix.get("SQ_INSTS_VALU_ADD_F32", 0) + mix.get("SQ_INSTS_VALU_MUL_F32", 0) +
                                         mix.get("SQ_INSTS_VALU_FMA_F32", 0) + mix.get("SQ_INSTS_VALU_TRANS_F32", 0)) / valu,
-            "clock_ghz_assumed": clock_ghz, "profile": os.path.relpath(path, ROOT), "lib_sha16": sha}
+            "clock_ghz_assumed": clock_ghz, "profile": os.path.relpath(path, ROOT), "build_id": sha}
 
 
-def brief(r):
+def brief(r, mix_name=None):
     """Entry of `other_configs`."""
     out = {"workload": f"{r['env']} task={r['task']} K={r['K_global']} T={r['T']} "
                        f"{'multi-modal' if r['multi_modal'] else 'single-mode'}" + (" simple mode, in-kernel noise" if r.get("simple") else ""),
@@ -382,6 +378,11 @@ def brief(r):
         # what the communicator really was (RCCL has only ever been exercised at world_size 1 by this build's own runs:
         # the first multi-GPU run is the driver's) and which transport / protocol carried the exchange
         out["ranks_seen"], out["transport"], out["protocol"] = pl.ranks_seen, pl.transport, pl.protocol
+    if mix_name is not None:
+        # (samples per wavefront: the Panda kernel's forms share a sample among 8 / 16 lanes; SQ_WAVES of the profile says how many)
+        rv = roofline_valu(mix_name, r, (r["K_local"] + 63) // 64)
+        if rv is not None:
+            out["roofline_valu"] = rv
     if r["lat_ms"] is not None:
         out["command_latency_ms"] = {"p50": float(np.percentile(r["lat_ms"], 50)), "p99": float(np.percentile(r["lat_ms"], 99))}
     if len(r["walls_ms_per_step"]) > 1:
@@ -663,7 +664,9 @@ def main():
             try:
                 ro = run_config(oname, args, 1, 0, device, None, max(200, min(args.steps, 400)), args.warmup, scene=scene,
                                 repeats=2)
-                others[key] = brief(ro)
+                others[key] = brief(ro, mix_name={"northstar": "northstar", "hybrid": "hybrid", "panda": "panda", "panda_settled": None,
+                                                  "panda_pick": "panda_pick", "c5shard": "c5", "c5_unsharded": "c5_unsharded",
+                                                  "worst_case_scene": "worst_case"}.get(key))
                 if oname == "hybrid":
                     others[key]["closed_loop"] = closed_loop(ro, 200, device)
                 if key == "panda":

@@ -229,6 +229,9 @@ typedef struct m3_handle m3_handle;
 int m3_abi_version(void);
 const char* m3_last_error(const m3_handle* h); /* h may be NULL: error of the last failed
                                                   m3_create on this thread */
+/* sha256 prefix (16 hex digits) of the kernel sources + compiler flags this library was built from (m3p2i_aip_amd/build.py:
+ * source_hash); identical for a rebuild of the same tree: the key of the committed PMC profiles (profiles/, bench.py). */
+const char* m3_build_id(void);
 void m3_default_config(m3_config* cfg, int env_type);
 int m3_create(const m3_config* cfg, m3_handle** out);
 void m3_destroy(m3_handle* h);

@@ -71,6 +71,7 @@ _H = C.c_void_p
 _FP = C.c_void_p  # float* (host or device), passed as integer addresses
 SYMBOLS = [
     ("m3_abi_version", C.c_int, []),
+    ("m3_build_id", C.c_char_p, []),
     ("m3_last_error", C.c_char_p, [_H]),
     ("m3_default_config", None, [C.POINTER(Config), C.c_int]),
     ("m3_create", C.c_int, [C.POINTER(Config), C.POINTER(_H)]),

@@ -32,6 +32,21 @@ PER_SOURCE = {
 }
 
 
+def source_hash(extra_flags=()):
+    """Identity of a build that survives a rebuild: sha256 over the kernel sources, the public header and every compiler flag
+    (the .so's own bytes differ from one link to the next).  Compiled into the library (m3_build_id) -- the key of the committed
+    PMC profiles that bench.py's roofline_valu reads."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "m3p2i_hip.h")]
+    for f in files:
+        path = os.path.join(CSRC, f)
+        if os.path.isfile(path):
+            h.update(f.encode()); h.update(open(path, "rb").read())
+    h.update(repr((CFLAGS, sorted(PER_SOURCE.items()), list(extra_flags))).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(OUT):
         return True
@@ -46,12 +61,14 @@ def build(force=False, verbose=False, extra_flags=(), out=OUT):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.dirname(out), exist_ok=True)
+    build_id = source_hash(extra_flags)
     objdir = OBJ if out == OUT else os.path.join(OBJ, os.path.basename(out) + ".d")
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + CFLAGS + PER_SOURCE.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        ident = ['-DM3_BUILD_ID="%s"' % build_id] if src == "m3_api.hip" else []
+        cmd = [hipcc] + CFLAGS + PER_SOURCE.get(src, []) + list(extra_flags) + ident + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

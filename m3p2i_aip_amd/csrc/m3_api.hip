@@ -324,6 +324,11 @@ extern "C" void m3_destroy(m3_handle* h) {
     delete h;
 }
 
+#ifndef M3_BUILD_ID
+#define M3_BUILD_ID "unknown"
+#endif
+extern "C" const char* m3_build_id(void) { return M3_BUILD_ID; }
+
 extern "C" int m3_set_stream(m3_handle* h, void* s) {
     if (!h) return M3_ERR_BAD_ARG;
     h->stream = (hipStream_t)s;

@@ -232,10 +232,13 @@ template <int LPS, class F> __device__ __forceinline__ Gen<LPS> gen_make(F f) {
     const int l = gen_lane<LPS>();
 #pragma unroll
     for (int e = 0; e < Gen<LPS>::N; ++e) {
-        float a = f(e * LPS + LPS - 1);
+        if constexpr (LPS == 1) g.a[e] = f(e);
+        else {
+            float a = f(e * LPS + LPS - 1);
 #pragma unroll
-        for (int j = LPS - 2; j >= 0; --j) a = (l == j) ? f(e * LPS + j) : a;
-        g.a[e] = a;
+            for (int j = LPS - 2; j >= 0; --j) a = (l == j) ? f(e * LPS + j) : a;
+            g.a[e] = a;
+        }
     }
     return g;
 }
@@ -1207,7 +1210,8 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #endif
         if (any_act) {
             if (near == false && !bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }   // (woken just now: cannot happen without `near`)
-            auto prepare = [&](int m_id, const Manifold& m, const float (*X)[3], const float* gap, const float* pm, const float* pt) {
+            auto prepare = [&](int m_id, const Manifold& m, const float (*X)[3], const float* gap, const float* pm, const float* pt)
+                               __attribute__((always_inline)) {     // (m_id must be a constant in the body: it indexes a lane's elements)
                 // (LPS > 1) the lane's components of the manifold's three directions: d[k], d[(k + 1) % 3], d[(k + 2) % 3], k = (lane & 7) % 3
                 const int li = (LPS == 1) ? 0 : (int)(threadIdx.x & 7u);
                 const bool lane_lin = li < 3, lane_pad = li >= 6, lane_hi = (LPS == 16) && ((threadIdx.x >> 3) & 1u) != 0u;

@@ -275,17 +275,22 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
     if (a.wave_min) wave_min_store(a.wave_min, J, first_half, writer);
 }
 
-// Lanes per sample: sixteen or eight while every wavefront of the launch still gets a SIMD of its own (<= 1024 wavefronts: the
-// launch is latency-bound and lasts as long as its slowest wavefront, and a wavefront is the union of what its samples do);
-// one beyond that (throughput-bound: the work replicated across a sample's lanes is 16x / 8x more instructions per sample
-// outside the solver).  Shadow slots (quirk Q8) take 1-2 of a wavefront's 4 / 8 sample slots: reach runs eight lanes per
-// sample.  pa.lps / M3P2I_PANDA_LPS force a form.
+// Lanes per sample, by what was measured at C4's size (profiles/r05/panda_lps_bench.json; K = 4000, T = 20):
+//   pick (no shadow slots, gripper + manifold rows in most wavefronts): 16 lanes 0.77 ms, 8 lanes 0.85, 1 lane 1.62 -- a wavefront
+//     is the union of what its samples do and its rows run across the lanes: sixteen while the launch has <= 1024 wavefronts
+//     (one per SIMD: the launch lasts as long as its slowest wavefront), eight up to there, else one;
+//   reach (quirk Q8: 1-2 of a wavefront's 4 / 8 sample slots are shadows): 1 lane 0.167 ms with the cubes asleep / 0.36 while
+//     they land, 8 lanes 0.201 / 0.346, 16 lanes two rounds of wavefronts -- nothing touches anything in a reach rollout, the
+//     time is the replicated part of the step, which more lanes per sample only repeat in more wavefronts: one lane.
+// Beyond 1024 wavefronts the launch is throughput-bound and the replicated work (16x / 8x more instructions per sample
+// outside the solver) decides: one lane.  pa.lps / M3P2I_PANDA_LPS force a form.
 static int panda_lps_for(const RolloutArgs& a, const PandaArgs& pa) {
     if (pa.lps == 1 || pa.lps == 8 || pa.lps == 16) return pa.lps;
     static const int env = [] { const char* e = getenv("M3P2I_PANDA_LPS"); return e ? atoi(e) : 0; }();
     if (env == 1 || env == 8 || env == 16) return env;
-    auto waves = [&](int lps) { const int per = 64 / lps - pa.shadows; return (a.Kl + per - 1) / per; };
-    if (pa.shadows == 0 && waves(16) <= 1024) return 16;
+    if (pa.shadows != 0) return 1;
+    auto waves = [&](int lps) { const int per = 64 / lps; return (a.Kl + per - 1) / per; };
+    if (waves(16) <= 1024) return 16;
     if (waves(8) <= 1024) return 8;
     return 1;
 }

@@ -5,7 +5,7 @@ import json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-P = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "profiles/r03")
+P = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "profiles/r05")
 os.makedirs(P, exist_ok=True)
 NAMES = {"push": "push_K2000_T30", "hybrid": "hybrid_K4000_T30", "panda": "panda_K4000_T20", "panda_pick": "panda_pick_K4000_T20",
          "northstar": "northstar_K10000_T30", "c5": "c5shard_K8000_T30", "c5_unsharded": "c5_unsharded_K64000_T30",
@@ -39,7 +39,8 @@ if os.path.exists(s):
     json.dump(json.loads(open(s).read().strip().splitlines()[-1]), open(os.path.join(P, "bench_driver_command_line.json"), "w"), indent=1)
     print("copied bench_driver_command_line.json")
 for f in ("behaviour_stats_baseline.json", "behaviour_stats_default_size.json", "behaviour_stats_panda.json", "halton_scramble.json",
-          "codeobj_info.txt", "mix_push_K2000.json", "mix_push.json", "mix_panda_pick.json", "mix_panda.json", "mix_worst_case.json"):
+          "codeobj_info.txt", "mix_push_K2000.json", "mix_push.json", "mix_hybrid.json", "mix_panda_pick.json", "mix_panda.json",
+          "mix_northstar.json", "mix_c5.json", "mix_c5_unsharded.json", "mix_worst_case.json"):
     cp(f, f)
 for f in ("collective_overhead_c5.json", "collective_overhead_push.json", "closed_loop_perf.json"):   # (coop_rows / phase_breakdown /
     # mask_count are one-off experiments of rounds 2-3: their own tools write them, tools/refresh_profiles.sh does not)

@@ -16,7 +16,7 @@ the opposite force on the robot, clamp +-500; acts during the NEXT step) -- with
   avoid                 (not a mechanism: the opt-in extension) the pull cost WITH get_motion_cost, as the logged files' names
                         (case2_halton_pull_coll.npy) suggest those runs had
 
-    python tools/cpu_ab_pull.py [--n 20] [--json profiles/r05/ab_pull.json] [variant ...]
+    python tools/cpu_ab_pull.py [--n 20] [--seed-offset 0] [--json profiles/r05/ab_pull.json] [variant ...]
 
 Reported per variant: successes, task time, episodes in which the dyn-obs felt a contact force above 0.1 N (the test of
 get_motion_cost, cost_functions.py:158-169, applied to the real world), and the ratio of the task time to the logged 9.97 s."""
@@ -57,14 +57,23 @@ def variants():
     }
 
 
+SEED_OFFSET = 0          # --seed-offset: episodes seed_offset .. seed_offset + n - 1 (episodes >= 20 are further draws of the same jitter)
+
+
 def episode(sc, opt, seed, K=200, T=15):
-    rng = np.random.default_rng([7, seed])
+    # the jitter of tools/band_stats.py's episodes of this scenario (jitter_of("case2_halton_pull_coll", seed): scenario index 0),
+    # so that episode e here and episode e of the product's GPU statistics start from the same world
+    rng = np.random.default_rng([0, seed])
     phase = 0 if seed == 0 else int(rng.integers(0, 100))
     jb = (0.0, 0.0) if seed == 0 else rng.uniform(-0.05, 0.05, 2)
     jr = (0.0, 0.0) if seed == 0 else rng.uniform(-0.05, 0.05, 2)
     w = O.init_world(1)
     w[0, O.W_B:O.W_B + 2] += jb
     w[0, O.W_R:O.W_R + 2] += jr
+    # the dyn-obs where its walk has taken it after `phase` ticks: the same track as an unjittered run, entered later
+    # (tools/closed_loop.py does the same for the product's episodes)
+    off = sum(0.01 if 25 < (i % 100) < 75 else -0.01 for i in range(phase))
+    w[0, O.W_D] += off; w[0, O.W_D + 1] += off
     delta = sampling.halton_spline_delta(K, T, 2)
     cfg = O.make_cfg(K, T, 2, task="pull", goal=GOAL, kp_suction=opt["kp"])
     if opt["avoid"]:
@@ -93,8 +102,8 @@ def episode(sc, opt, seed, K=200, T=15):
         hit, hit_ticks = hit or h, hit_ticks + int(h)
         err = float(np.hypot(w[0, O.W_B] - GOAL[0], w[0, O.W_B + 1] - GOAL[1]))
         if err < 0.1:                           # PLANNER_SIMPLE.check_task_success (task_planner.py:24-39)
-            return dict(success=True, ticks=i + 1, err=err, hit=hit, hit_ticks=hit_ticks)
-    return dict(success=False, ticks=TIME_LIMIT_TICKS, err=err, hit=hit, hit_ticks=hit_ticks)
+            return dict(success=True, ticks=i + 1, err=err, hit=hit, hit_ticks=hit_ticks, phase=phase)
+    return dict(success=False, ticks=TIME_LIMIT_TICKS, err=err, hit=hit, hit_ticks=hit_ticks, phase=phase)
 
 
 def main(argv):
@@ -105,17 +114,20 @@ def main(argv):
             n = int(next(it))
         elif a == "--json":
             out = next(it)
-    only = [a for a in argv if not a.startswith("--") and not a.isdigit() and not a.endswith(".json")]
+        elif a == "--seed-offset":
+            global SEED_OFFSET
+            SEED_OFFSET = int(next(it))
+    only = [a for a in argv if a in variants()]
     rows = {}
     for name, (modify, opt) in variants().items():
         if only and name not in only:
             continue
         sc = O.default_scene()
         modify(sc)
-        eps = [episode(sc, opt, s) for s in range(n)]
+        eps = [episode(sc, opt, SEED_OFFSET + s) for s in range(n)]
         ok = [e for e in eps if e["success"]]
         t = float(np.mean([e["ticks"] for e in ok]) * DT) if ok else None
-        rows[name] = dict(success=len(ok), n=n, time_s_mean=t, time_s_std=float(np.std([e["ticks"] for e in ok]) * DT) if ok else None,
+        rows[name] = dict(success=len(ok), n=n, episodes=[dict(phase=e["phase"], hit_ticks=e["hit_ticks"], ticks=e["ticks"]) for e in eps], time_s_mean=t, time_s_std=float(np.std([e["ticks"] for e in ok]) * DT) if ok else None,
                           time_ratio_to_logged=(t / LOGGED_TIME_S) if t else None, dyn_obs_hit=sum(e["hit"] for e in eps),
                           hit_ticks_mean=float(np.mean([e["hit_ticks"] for e in eps if e["hit"]])) if any(e["hit"] for e in eps) else 0.0)
         print("%-14s success %2d / %d   time %s s (x%s of the logged %.2f)   dyn-obs hit in %d episodes (%.1f ticks each)" % (
@@ -123,7 +135,7 @@ def main(argv):
             rows[name]["dyn_obs_hit"], rows[name]["hit_ticks_mean"]), flush=True)
     if out:
         os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
-        json.dump(dict(scenario="pull to (-3, 3), dyn-obs walking, K = 200, T = 15, halton-spline, CPU oracle closed loop",
+        json.dump(dict(scenario="pull to (-3, 3), dyn-obs walking, K = 200, T = 15, halton-spline, CPU oracle closed loop", seed_offset=SEED_OFFSET,
                        logged=dict(dyn_obs_collisions=LOGGED_HITS, task_time_s="9.97 +- 5.81", source="plot/point/case2_halton_pull_coll.npy cols 17, 18"),
                        rows=rows), open(out, "w"), indent=1)
 

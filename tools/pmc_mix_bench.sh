@@ -30,11 +30,13 @@ per["waves"] = w
 per["kernels"] = sorted(names)
 if "SQ_INSTS" in per:
     per["MISC_derived"] = per["SQ_INSTS"] - sum(per.get(k, 0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM", "SQ_INSTS_BRANCH"))
-# the key bench.py's roofline_valu checks: the library these counters were taken from
-import hashlib, os
-lib = os.environ.get("M3P2I_HIP_LIB", "$ROOT/m3p2i_aip_amd/lib/libm3p2i_hip.so")
-per["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+# the key bench.py's roofline_valu checks: the build these counters were taken from (m3_build_id: a hash of the kernel
+# sources + compiler flags, the same for every rebuild of the same tree)
+import sys
+sys.path.insert(0, "$ROOT")
+from m3p2i_aip_amd import _lib as L
+per["build_id"] = L.load().m3_build_id().decode()
 print("$CFG per wave:", json.dumps({k: (round(v, 1) if isinstance(v, float) else v) for k, v in per.items()}, indent=1))
 json.dump(per, open("$OUT/../mixb_$CFG.json", "w"), indent=1)
-json.dump(per, open("$OUT/../mix_$CFG.json", "w"), indent=1)      # (the name bench.py looks for under profiles/r04/)
+json.dump(per, open("$OUT/../mix_$CFG.json", "w"), indent=1)      # (the name bench.py looks for under profiles/r05/)
 PY

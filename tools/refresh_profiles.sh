@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): regenerates everything under profiles/<round>/ into gpurun_out/.
-# usage: tools/refresh_profiles.sh     (then, in the build container: python tools/collect_profiles.py profiles/r04)
+# usage: tools/refresh_profiles.sh     (then, in the build container: python tools/collect_profiles.py profiles/r05)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 O=$ROOT/gpurun_out
 mkdir -p $O
@@ -31,10 +31,9 @@ tools/pmc_rollout.sh final 2000 0 push > $O/pmc_final.txt 2>&1
 tools/pmc_rollout.sh pandaf 4000 0 reach > $O/pmc_panda.txt 2>&1
 # dynamic instruction mix of the rollout kernels (the thread-trace decoder is not in this image: tools/att_rollout.sh)
 tools/pmc_mix.sh push_K2000 2000 push > $O/pmc_mix_push.log 2>&1
-tools/pmc_mix_bench.sh push > $O/pmc_mix_bench_push.log 2>&1      # (mix_push.json: what bench.py's roofline_valu reads, keyed by the library hash)
-tools/pmc_mix_bench.sh panda_pick > $O/pmc_mix_panda_pick.log 2>&1
-tools/pmc_mix_bench.sh panda > $O/pmc_mix_panda.log 2>&1
-tools/pmc_mix_bench.sh worst_case > $O/pmc_mix_worst_case.log 2>&1
+for c in push hybrid panda panda_pick northstar c5 c5_unsharded worst_case; do    # (mix_<config>.json: what bench.py's roofline_valu reads, keyed by m3_build_id)
+  tools/pmc_mix_bench.sh $c > $O/pmc_mix_bench_$c.log 2>&1
+done
 python tools/codeobj_info.py --isa "k_rollout_point<false, 1>" --json $O/codeobj_info.json > $O/codeobj_info.txt 2>&1
 # behaviour: N = 20 jittered episodes per scenario (tests/test_behaviour_band_gpu.py asserts on the first and the last)
 python tools/band_stats.py --n 20 --json $O/behaviour_stats_baseline.json > $O/behaviour_stats_baseline.log 2>&1
