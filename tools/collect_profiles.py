@@ -48,6 +48,8 @@ for f in ("collective_overhead_c5.json", "collective_overhead_push.json", "close
 cp("prof_emul/emul_kernel_stats.csv", "rank0_of_8_emulation_kernel_stats.csv")
 cp("host_overhead.txt", "host_overhead.txt")
 cp("k_sweep.json", "k_sweep_push_T30.json")
+cp("k_sweep_panda.json", "k_sweep_panda_T20.json")
+cp("panda_lps_bench.json", "panda_lps_bench.json")
 cp("pmc_final.txt", "pmc_rollout_push_K2000.txt")
 cp("pmc_panda.txt", "pmc_rollout_panda_K4000.txt")
 
