@@ -961,8 +961,10 @@ struct HeldYes { static constexpr bool value = true; };
 struct HeldNo { static constexpr bool value = false; };
 // The kinematics of a configuration, kept from where a substep evaluates them AFTER its integration to where the next substep's
 // contact detection needs them BEFORE its own (same joint values: the grasp rule in between moves the fingers only, which
-// the hand frame and the arm's Jacobian columns at the hand origin do not depend on).  Rollouts with several lanes per sample
-// only (LPS > 1: one Jacobian column per lane; with one lane per sample the 42 extra live registers would spill).
+// the hand frame and the arm's Jacobian columns at the hand origin do not depend on).  Rollouts only (LAZY).  With several
+// lanes per sample the lane's own Jacobian column travels along (6 registers); with one lane per sample only the hand frame
+// does (the 42 registers of seven columns would spill) and the columns are formed -- by a pass over the chain of their own --
+// in the substeps in which some lane of the wavefront has a contact candidate: never, in a reach rollout that touches nothing.
 template <int LPS> struct FkCarry {
     bool valid;
     Frame hand;
@@ -978,7 +980,7 @@ template <bool FORCES = true, bool LAZY = false, int LPS = 1>
 __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, const float* u, PandaObs& obs,
                                            const CornerStore& cs, float* hp = nullptr, float* trav = nullptr,
                                            FkCarry<LPS>* fkc = nullptr M3_PROF_ARG) {
-    constexpr bool CARRY = LAZY && LPS != 1;
+    constexpr bool CARRY = LAZY, CARRY_JAC = LAZY && LPS != 1;
     const float h = sc.h;
     const GenConst<LPS> gk = gen_consts<LPS>(sc);
     const Gen<LPS> uG = gen_from9<LPS>(u);
@@ -1061,13 +1063,14 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                     g.hand = fkc->hand;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        g.Jv[0][i] = fkc->Jv[i]; g.Jw[0][i] = fkc->Jw[i];
+                        if constexpr (CARRY_JAC) { g.Jv[0][i] = fkc->Jv[i]; g.Jw[0][i] = fkc->Jw[i]; }
                         const float fo = mad(0.0584f, g.hand.z[i], g.hand.p[i]);     // (panda_fk's last translation)
                         pl[i] = mad(w.q[7], g.hand.y[i], fo);
                         pr[i] = mad(-w.q[8], g.hand.y[i], fo);
                     }
                 }
-            } else panda_fk<false, true, LPS>(sc, w.q, g.hand, pl, pr, nullptr, &g);
+            } else if constexpr (CARRY && !CARRY_JAC) panda_fk<false, false, LPS>(sc, w.q, g.hand, pl, pr, nullptr);
+            else panda_fk<false, true, LPS>(sc, w.q, g.hand, pl, pr, nullptr, &g);
             if constexpr (LAZY) { hp[0] = g.hand.p[0]; hp[1] = g.hand.p[1]; hp[2] = g.hand.p[2]; *trav = 0.0f; }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -1135,6 +1138,11 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             const bool cand = rs[0].target >= 0 || rs[1].target >= 0 || rs[2].target >= 0 || rs[3].target >= 0;
             if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
                 // some lane has a candidate: culling, rows, effective masses
+                if constexpr (CARRY && !CARRY_JAC) {     // (one lane per sample: the Jacobian columns only now, see FkCarry)
+                    Frame h2;
+                    float a2[3], b2[3];
+                    panda_fk<false, true, LPS>(sc, w.q, h2, a2, b2, nullptr, &g);
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     RSlot& c = rs[s];
@@ -1570,13 +1578,13 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
         }
         if (have_fk) {
-            if constexpr (CARRY) {
+            if constexpr (CARRY_JAC) {
                 GripperT<LPS> gn;
                 panda_fk<false, true, LPS>(sc, w.q, hand, pl, pr, nullptr, &gn);
-                fkc->hand = hand;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { fkc->Jv[i] = gn.Jv[0][i]; fkc->Jw[i] = gn.Jw[0][i]; }
             } else panda_fk<false>(sc, w.q, hand, pl, pr, nullptr);
+            if constexpr (CARRY) fkc->hand = hand;
             if constexpr (LAZY) { hp[0] = hand.p[0]; hp[1] = hand.p[1]; hp[2] = hand.p[2]; *trav = 0.0f; }
         }
         if constexpr (CARRY) fkc->valid = have_fk;

@@ -3,6 +3,8 @@
 //   g++ -O2 -std=c++17 -shared -fPIC -ffp-contract=off -Itests/native/shim panda_dyn_host.cpp -o libpanda_dyn_host.so
 #include "../../m3p2i_aip_amd/csrc/panda_dyn.hpp"
 
+#include <vector>
+
 namespace {
 void scene(m3::PandaScene& s, float dt, int substeps) { m3::make_panda_scene(s, dt, substeps); }
 // oracle row (84 floats, m3o_panda_world): q9 qd9 | cubeA13 cubeB13 obs13 (pos3 quat4 vel3 angvel3) | held | rel_p3 rel_q4 |
@@ -35,6 +37,9 @@ void store(const m3::PandaWorld& p, float* w) {
     w[65] = p.awake[0]; w[66] = p.awake[1];
     for (int i = 0; i < 3; ++i) { w[67 + i] = p.f_table[i]; w[70 + i] = p.f_shelf[i]; w[73 + i] = p.f_cubeB[i]; }
 }
+// the kinematics a rollout carries from one substep to the next (panda_dyn.hpp: FkCarry), per world, from the world's load
+// (pnh_infer_held) on -- so that the host build exercises the carried path the kernels take
+std::vector<m3::FkCarry<1>> g_fk;
 }  // namespace
 
 // n worlds, one step each with controls u[n][9]; obs[n][10] = left pos3, left quat4, right pos3 (what the costs read).
@@ -51,9 +56,12 @@ extern "C" void pnh_step(float dt, int substeps, float* worlds, int n, const flo
         m3::PandaWorld p;
         load(worlds + 84 * (long long)i, p);
         m3::PandaObs o;
+        m3::FkCarry<1> local;
+        local.valid = false;
+        m3::FkCarry<1>* fk = ((int)g_fk.size() == n) ? &g_fk[i] : &local;
         if (mode == 0) m3::panda_step<true, false>(sc, p, u + 9 * i, o, cs);
-        else if (mode == 1) m3::panda_step<true, true>(sc, p, u + 9 * i, o, cs, hp + 3 * i, trav + i);
-        else m3::panda_step<false, true>(sc, p, u + 9 * i, o, cs, hp + 3 * i, trav + i);
+        else if (mode == 1) m3::panda_step<true, true>(sc, p, u + 9 * i, o, cs, hp + 3 * i, trav + i, fk);
+        else m3::panda_step<false, true>(sc, p, u + 9 * i, o, cs, hp + 3 * i, trav + i, fk);
         store(p, worlds + 84 * (long long)i);
         for (int j = 0; j < 3; ++j) { obs[10 * i + j] = o.left[j]; obs[10 * i + 7 + j] = o.right[j]; }
         for (int j = 0; j < 4; ++j) obs[10 * i + 3 + j] = o.left_q[j];
@@ -63,7 +71,9 @@ extern "C" void pnh_step(float dt, int substeps, float* worlds, int n, const flo
 extern "C" void pnh_infer_held(float dt, int substeps, float* worlds, int n, float* hp) {
     m3::PandaScene sc;
     scene(sc, dt, substeps);
+    g_fk.assign(n, m3::FkCarry<1>());
     for (int i = 0; i < n; ++i) {
+        g_fk[i].valid = false;
         m3::PandaWorld p;
         load(worlds + 84 * (long long)i, p);
         m3::panda_infer_held(sc, p, hp + 3 * i);

@@ -21,4 +21,4 @@ static const struct { unsigned x, y, z; } threadIdx = {0u, 0u, 0u};
 // cross-lane operations of the sixteen-lanes-per-sample forms (never instantiated on the host)
 int __builtin_amdgcn_update_dpp(int, int, int, int, int, bool);
 int __builtin_amdgcn_ds_bpermute(int, int);
-int __builtin_amdgcn_readfirstlane(int);
+#define __builtin_amdgcn_readfirstlane(x) (x)      // a wavefront of one lane

@@ -26,6 +26,8 @@ def main():
     pl, sim, obj, cfg = bench.build_tamp(env, task, goal, mm, K, 0, 1, T, device)
     if name == "panda_pick":
         bench.make_pick_scene(bench.panda_pick_scene(device))(pl, sim, obj, cfg)
+    if "--settled" in sys.argv:
+        bench.settled_panda_scene(pl, sim, obj, cfg)
     state = sim._dof_state[0]
     for _ in range(5):
         pl.command(state)
