@@ -970,6 +970,13 @@ template <int LPS> struct FkCarry {
     Frame hand;
     float Jv[3], Jw[3];
 };
+// the friction rows' clamp to +-mx (mx >= 0, no NaN): one v_med3_f32 or a max / min pair -- the same value; which one is the
+// faster instruction stream was measured per kernel form (pick, K = 4000: one lane 1.67 -> 1.59 ms and eight lanes 0.833 ->
+// 0.825 with v_med3, sixteen lanes 0.764 -> 0.784: there the pair schedules better between the DPP steps)
+template <int LPS> __device__ __forceinline__ float friction_clamp(float l, float mx) {
+    if constexpr (LPS == 16) return fminf(fmaxf(l, -mx), mx);
+    else return __builtin_amdgcn_fmed3f(l, -mx, mx);
+}
 #ifdef M3_PABL_PROF      // (profiling build, tools/panda_wave_profile.py: shader clocks and substep counts per sample)
 struct PandaProf { long long solve_clk, near_clk, detect_clk, post_clk; int n_robot, n_body, n_near, n_act, n_fk; };
 #define M3_PROF_ARG , PandaProf* prof = nullptr
@@ -1352,7 +1359,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                     const float l0 = c.lam[r3];
                     float l1 = l0 + dl;
                     if (r3 == 0) l1 = fmaxf(l1, 0.0f);
-                    else { const float mx = sc.mu * c.lam[0]; l1 = fminf(fmaxf(l1, -mx), mx); }
+                    else { const float mx = sc.mu * c.lam[0]; l1 = friction_clamp<LPS>(l1, mx); }
                     c.lam[r3] = l1;
                     dl = l1 - l0;
                     apply(row, dl);
@@ -1399,7 +1406,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                     const float l0 = ms.lam(slot, r3);
                     float l1 = l0 + dl;
                     if (r3 == 0) l1 = fmaxf(l1, 0.0f);
-                    else { const float mx = sc.mu * ms.lam(slot, 0); l1 = fminf(fmaxf(l1, -mx), mx); }
+                    else { const float mx = sc.mu * ms.lam(slot, 0); l1 = friction_clamp<LPS>(l1, mx); }
                     ms.lam(slot, r3) = l1;
                     dl = l1 - l0;
 #pragma unroll

@@ -255,6 +255,11 @@ float m3o_ori_cube2goal(const float qc[4], const float qg[4]);
 float m3o_ori_ee2cube(const float qe[4], const float qc[4], float tilt_value,
                       const float qc_env0[4]);
 
+/* world spec v3: the fixed summation trees of the contact rows (panda_chain.c) -- exported for the tests that emulate the
+ * product kernel's cross-lane butterflies against them */
+float m3o_sum16(const float x[16]);
+float m3o_sum8_6(const float x[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -372,6 +372,8 @@ static float sum16(const float x[16]) {
     for (int i = 0; i < 4; ++i) b[i] = a[2 * i] + a[2 * i + 1];
     return (b[0] + b[1]) + (b[2] + b[3]);
 }
+/* (exported for tests/test_oracle_panda.py: the lane butterflies of the product's kernel, emulated, against these trees) */
+float m3o_sum16(const float x[16]) { return sum16(x); }
 static void gen_inv_mass(const solver_t* S, const contact_t* c, float m[16]) {
     const int b = (c->tb == 2) ? 2 : 0;       /* (both cubes have the same mass; a static target's entries multiply zeros) */
     for (int j = 0; j < 9; ++j) m[j] = S->invIj[j];
@@ -415,6 +417,7 @@ static void gen_apply(solver_t* S, const contact_t* c, int r, float dl) {
 static float sum8_6(float x0, float x1, float x2, float x3, float x4, float x5) {
     return ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + 0.0f);
 }
+float m3o_sum8_6(const float x[6]) { return sum8_6(x[0], x[1], x[2], x[3], x[4], x[5]); }
 static float bodyrow_vel(const solver_t* S, int b, const float d[3], const float a[3], float sgn) {
     const float* v = S->bv[b];
     const float* w = S->bw[b];

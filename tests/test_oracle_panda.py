@@ -261,3 +261,49 @@ def test_g11_panda_option_traces_vs_reference(golden, oracle, tag):
             np.testing.assert_allclose([cfg.scale_tril[j] for j in range(9)], golden[f"g9_{tag}_extra"][call], rtol=1e-4)
     np.testing.assert_allclose(opl.last["states"], golden[f"g9_{tag}_states_last"], atol=1e-3)
     np.testing.assert_allclose(opl.last["actions"] / np.float32(cfg.u_scale), golden[f"g9_{tag}_actions_last"], atol=1e-3)
+
+
+def test_lane_butterflies_reproduce_the_spec_summation_trees(oracle):
+    """World spec v3 defines a gripper row's velocity as SUM16 and a manifold row's as SUM8 -- fixed pairwise trees over rounded
+    products (oracle/panda_chain.c) -- because the product's kernel forms them ACROSS LANES: a butterfly of DPP steps that pair
+    lanes symmetrically (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), so that every lane of a sample ends with the same
+    bits.  Emulated here step by step in binary32: all sixteen (eight) lanes equal the oracle's tree bit for bit, for sixteen
+    lanes per sample, for eight (two coordinates per lane: the halves are added last) and for the cubes' half-row sums with their
+    two +0 pads; signed zeros included."""
+    import ctypes as C
+    lib = oracle.load()
+    lib.m3o_sum16.restype = C.c_float
+    lib.m3o_sum16.argtypes = [C.POINTER(C.c_float)]
+    lib.m3o_sum8_6.restype = C.c_float
+    lib.m3o_sum8_6.argtypes = [C.POINTER(C.c_float)]
+    f32 = np.float32
+    rng = np.random.default_rng(11)
+
+    def butterfly(v, steps):
+        v = v.astype(f32).copy()
+        n = len(v)
+        lanes = np.arange(n)
+        perms = {"xor1": lanes ^ 1, "xor2": lanes ^ 2, "half_mirror": (lanes & ~7) | (7 - (lanes & 7)), "mirror": 15 - lanes}
+        for st in steps:
+            v = (v + v[perms[st]]).astype(f32)          # v_add_f32_dpp: every lane adds its partner's value
+        return v
+
+    def bits(x):
+        return np.asarray(x, f32).view(np.uint32)
+
+    for trial in range(2000):
+        x = (rng.standard_normal(16) * 10.0 ** rng.integers(-6, 4, 16)).astype(f32)
+        if trial % 5 == 0:
+            x[rng.integers(0, 16, 6)] = f32(0.0) * rng.choice([-1.0, 1.0], 6).astype(f32)     # signed zeros
+        if trial % 7 == 0:
+            x[9:] = 0.0                                                                     # a row without a free target
+        want = lib.m3o_sum16(x.ctypes.data_as(C.POINTER(C.c_float)))
+        got16 = butterfly(x, ["xor1", "xor2", "half_mirror", "mirror"])
+        assert (bits(got16) == bits(want)).all(), (trial, x)
+        # eight lanes per sample: element 0 = coordinates 0-7, element 1 = 8-15; three steps each, then the two elements
+        e0, e1 = butterfly(x[:8], ["xor1", "xor2", "half_mirror"]), butterfly(x[8:], ["xor1", "xor2", "half_mirror"])
+        assert (bits((e0 + e1).astype(f32)) == bits(want)).all(), (trial, x)
+        # a cube's half row: six products and two pads of +0
+        h = np.concatenate([x[:6], np.zeros(2, f32)])
+        want8 = lib.m3o_sum8_6(h[:6].ctypes.data_as(C.POINTER(C.c_float)))
+        assert (bits(butterfly(h, ["xor1", "xor2", "half_mirror"])) == bits(want8)).all(), (trial, h)
