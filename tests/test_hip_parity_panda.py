@@ -258,3 +258,37 @@ def test_panda_option_traces_vs_reference_golden(golden, oracle, tag):
     np.testing.assert_allclose(eng.states.cpu().numpy(), golden[f"g9_{tag}_states_last"], atol=1e-3)
     np.testing.assert_allclose(eng.actions.cpu().numpy() / np.float32(ocfg.u_scale), golden[f"g9_{tag}_actions_last"], atol=1e-3)
     eng.close()
+
+
+@pytest.mark.parametrize("lps", [1, 8, 16])
+@pytest.mark.parametrize("K,task,mm", [(203, "pick", False), (61, "reach", False), (90, "reach", True), (22, "place", False)])
+def test_panda_ragged_sample_counts_in_every_kernel_form(oracle, K, task, mm, lps):
+    """Sample counts that fill no wavefront evenly -- a last wavefront with one, two or three of its four (eight) sample slots
+    used, fewer samples than one wavefront of the one-lane form, the shadow slots of quirk Q8 (reach: one, multi-modal: two) taking
+    their share -- in the three forms of the kernel: every state, action, cost and trajectory cost equals the oracle's bit for
+    bit, nothing is written past the K rows."""
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    sc = P.default_scene()
+    T = 20
+    rng = np.random.default_rng(900 + K)
+    delta = rng.standard_normal((K, T, 9)).astype(np.float32)
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    grip = 2 if task == "pick" else 1
+    w0 = grasp_world(P, sc) if task in ("pick", "place") else grasp_world(P, sc, close_gripper=False, lift=0.0)
+    cfg = P.make_cfg(K, T, multi_modal=mm, task=task, goal=goal, gripper_cmd=grip)
+    opl = P.OraclePandaPlanner(cfg, delta, sc)
+    eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", multi_modal=mm, u_min=UMIN, u_max=UMAX,
+                                noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01))
+    eng.set_objective(task, goal, gripper_cmd=grip)
+    eng.set_panda_lanes_per_sample(lps)
+    eng.set_noise(delta)
+    eng.set_world_panda_raw(raw31(P, w0))
+    eng.command(sync_host=True)
+    opl.command(w0)
+    np.testing.assert_array_equal(eng.actions.cpu().numpy(), opl.last["actions"])
+    np.testing.assert_array_equal(eng.states.cpu().numpy(), opl.last["states"])
+    np.testing.assert_array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+    np.testing.assert_array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
+    eng.close()
