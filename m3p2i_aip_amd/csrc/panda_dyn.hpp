@@ -978,7 +978,7 @@ template <int LPS> __device__ __forceinline__ float friction_clamp(float l, floa
     else return __builtin_amdgcn_fmed3f(l, -mx, mx);
 }
 #ifdef M3_PABL_PROF      // (profiling build, tools/panda_wave_profile.py: shader clocks and substep counts per sample)
-struct PandaProf { long long solve_clk, near_clk, detect_clk, post_clk; int n_robot, n_body, n_near, n_act, n_fk; };
+struct PandaProf { long long solve_clk, near_clk, detect_clk, post_clk, pre_clk, mid_clk, wake_clk; int n_robot, n_body, n_near, n_act, n_fk; };
 #define M3_PROF_ARG , PandaProf* prof = nullptr
 #else
 #define M3_PROF_ARG
@@ -992,6 +992,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
     const GenConst<LPS> gk = gen_consts<LPS>(sc);
     const Gen<LPS> uG = gen_from9<LPS>(u);
     for (int sub = 0; sub < sc.substeps; ++sub) {
+#ifdef M3_PABL_PROF
+        const long long prof_ts = __builtin_readcyclecounter();
+#endif
         const bool last = (sub == sc.substeps - 1);
         // 0. release
         if (w.held != 0.0f && (u[7] >= 0.0f || u[8] >= 0.0f)) {
@@ -1058,6 +1061,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         if (near || bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }
 #ifdef M3_PABL_PROF
         const long long prof_t0 = __builtin_readcyclecounter();
+        if (prof) prof->pre_clk += prof_t0 - prof_ts;
 #endif
         if (near) {
             float pl[3], pr[3];
@@ -1194,7 +1198,8 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
         }
 #ifdef M3_PABL_PROF
-        if (prof) { prof->near_clk += __builtin_readcyclecounter() - prof_t0; prof->n_near += near ? 1 : 0; }
+        const long long prof_tn = __builtin_readcyclecounter();
+        if (prof) { prof->near_clk += prof_tn - prof_t0; prof->n_near += near ? 1 : 0; }
 #endif
         // 3. an awake cube wakes the other one when they are close
         const bool freeA = !held;
@@ -1222,6 +1227,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         const bool any_act = __builtin_amdgcn_ballot_w64(actA || actB) != 0ull;
 #ifdef M3_PABL_PROF
         const long long prof_t2 = __builtin_readcyclecounter();
+        if (prof) prof->wake_clk += prof_t2 - prof_tn;
 #endif
         if (any_act) {
             if (near == false && !bodies_awake_wave) { body_rot(w.A.q, RA); body_rot(w.B.q, RB); }   // (woken just now: cannot happen without `near`)
@@ -1461,7 +1467,8 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             }
         }
 #ifdef M3_PABL_PROF
-        if (prof) prof->solve_clk += __builtin_readcyclecounter() - prof_t1;
+        const long long prof_t4 = __builtin_readcyclecounter();
+        if (prof) prof->solve_clk += prof_t4 - prof_t1;
 #endif
         if (use_vb && any_rows) { body_vel_store<LPS>(VB, 0, w.A); body_vel_store<LPS>(VB, 1, w.B); }
         if (robot_rows) {
@@ -1563,6 +1570,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
         for (int i = 0; i < 3; ++i) w.obs_p[i] = mad(h, w.obs_v[i], w.obs_p[i]);
 #ifdef M3_PABL_PROF
         const long long prof_t3 = __builtin_readcyclecounter();
+        if (prof) prof->mid_clk += prof_t3 - prof_t4;
 #endif
         // 8. kinematics of the new configuration; the grasp rule (spec v1.1, position level)
         Frame hand;

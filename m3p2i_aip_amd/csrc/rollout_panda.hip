@@ -143,7 +143,8 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
     fkc.valid = false;
     float J = 0.0f, g = 1.0f, S = 0.0f, pc = 0.0f;
 #ifdef M3_PABL_PROF
-    PandaProf prof = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    PandaProf prof = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_step = 0;
     const long long prof_start = __builtin_readcyclecounter();
 #endif
     for (int t = 0; t < T; ++t) {
@@ -190,7 +191,9 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         }
         PandaObs obs;
 #ifdef M3_PABL_PROF
+        const long long prof_s0 = __builtin_readcyclecounter();
         panda_step<FORCES, true, LPS>(sc, w, u, obs, cs, hp, &trav, &fkc, &prof);
+        prof_step += __builtin_readcyclecounter() - prof_s0;
 #else
         panda_step<FORCES, true, LPS>(sc, w, u, obs, cs, hp, &trav, &fkc);
 #endif
@@ -268,6 +271,12 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
             a.cost_h[(size_t)7 * Kl + i] = (float)prof.post_clk;
             a.cost_h[(size_t)8 * Kl + i] = (float)prof.n_act;
             a.cost_h[(size_t)9 * Kl + i] = (float)prof.n_fk;
+        }
+        if (T >= 14) {
+            a.cost_h[(size_t)10 * Kl + i] = (float)prof.pre_clk;
+            a.cost_h[(size_t)11 * Kl + i] = (float)prof.mid_clk;
+            a.cost_h[(size_t)12 * Kl + i] = (float)prof.wake_clk;
+            a.cost_h[(size_t)13 * Kl + i] = (float)prof_step;
         }
     }
 #endif

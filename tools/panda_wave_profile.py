@@ -39,6 +39,7 @@ def main():
     ch = eng.cost_horizon.cpu().numpy()          # [K, T]
     tot, solve, near, n_rob, n_body, n_near = (ch[:, j] for j in range(6))
     detect, post, n_act, n_fk = (ch[:, j] for j in range(6, 10))
+    pre, mid, wake, in_step = (ch[:, j] for j in range(10, 14))
     per_wave = (64 // lps if lps else 64) - (1 if task == "reach" else 0)
     nw = (K + per_wave - 1) // per_wave
     w_tot = np.array([tot[i * per_wave:(i + 1) * per_wave].max() for i in range(nw)])
@@ -50,7 +51,10 @@ def main():
                                  "substeps_with_gripper_rows": float(n_rob.mean()), "substeps_with_body_rows": float(n_body.mean()),
                                  "substeps_near": float(n_near.mean()), "manifold_detect_prepare": float(detect.mean()),
                                  "post_integration_kinematics_grasp": float(post.mean()), "substeps_with_an_awake_cube_in_the_wave": float(n_act.mean()),
-                                 "substeps_with_post_kinematics": float(n_fk.mean())},
+                                 "substeps_with_post_kinematics": float(n_fk.mean()),
+                                 "servo_and_lazy_tests": float(pre.mean()), "wake_gravity_manifold_init": float(wake.mean()),
+                                 "forces_warm_sleep_integration": float(mid.mean()), "inside_panda_step": float(in_step.mean()),
+                                 "outside_panda_step_assembly_cost_stores": float((tot - in_step).mean())},
            "slowest_waves": []}
     for wv in order[:3]:
         sl = slice(wv * per_wave, (wv + 1) * per_wave)
