@@ -1184,7 +1184,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
 #pragma unroll
                         for (int e = 0; e < Gen<LPS>::N; ++e) x.a[e] = (row.a[e] * invMs.a[e]) * row.a[e];
                         rows.set(s, r3, row);
-                        c.meff[r3] = 1.0f / gen_sum<LPS>(x);
+                        c.meff[r3] = spec_rcp(gen_sum<LPS>(x));          // world spec v3.1
                         c.lam[r3] = 0.0f;
                     }
                     c.bias = contact_bias(sc, bgap[s]);
@@ -1298,7 +1298,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                             x.a[e] = (row.a[e] * invMB.a[e]) * row.a[e];
                             if constexpr (LPS != 1) ms.rowf(slot, r3, e) = row.a[e];
                         }
-                        ms.meff(slot, r3) = 1.0f / body_sum<LPS>(x, m_id);
+                        ms.meff(slot, r3) = spec_rcp(body_sum<LPS>(x, m_id));   // world spec v3.1
                         ms.lam(slot, r3) = 0.0f;
                     }
                     ms.bias(slot) = contact_bias(sc, gap[j]);

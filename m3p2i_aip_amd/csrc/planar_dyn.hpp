@@ -112,6 +112,9 @@ __device__ __forceinline__ float spec_rsqrt(float a) {
     return y;
 }
 
+// spec v1.6: the reciprocals of a substep (a contact's effective masses, the coupling factors below, the orientation update's
+// 1 / (1 + a^2)) are spec_rcp (spec_fma.hpp), not IEEE divisions.
+
 // spec v1.5: sliding-spinning coupling of a box's ground friction (Contensou's law in Zhuravlev's first-order Pade
 // form for a disc of radius R = 1.5 r_eq: F = F0 v / (v + 8/(3 pi) u), M = M0 u / (u + 15 pi/16 v), u = R |w|): the
 // factors of the linear / torsion rows' limits from the velocities a substep starts its passes with.  A patch that
@@ -123,8 +126,8 @@ __device__ __forceinline__ void friction_coupling(float vx, float vy, float w, f
     auto zero = [](float x) { return (__float_as_uint(x) & 0x7f800000u) == 0u; };   // (below the smallest normal number)
     const float u = zero(w) ? 0.0f : R * fabsf(w);
     cl = 1.0f; ca = 1.0f;
-    if (!zero(v)) cl = v * (1.0f / mad(0.8488264f, u, v));
-    if (!zero(u)) ca = u * (1.0f / mad(2.9452431f, v, u));
+    if (!zero(v)) cl = v * spec_rcp(mad(0.8488264f, u, v));
+    if (!zero(u)) ca = u * spec_rcp(mad(2.9452431f, v, u));
 }
 
 __device__ __forceinline__ float clamp_lo0(float x) { return fmaxf(x, 0.0f); }
@@ -201,8 +204,8 @@ __device__ __forceinline__ void prepare(const PointScene& sc, Slot& c, float nx,
         kn = mad(invI<B>(sc) * c.rnb, c.rnb, kn);
         kt = mad(invI<B>(sc) * c.rtb, c.rtb, kt);
     }
-    c.mn = 1.0f / kn;
-    c.mt = 1.0f / kt;
+    c.mn = spec_rcp(kn);
+    c.mt = spec_rcp(kt);
     if (sep > 0.0f) {
         c.bias = sep * sc.inv_h;
     } else {
@@ -480,7 +483,7 @@ __device__ __forceinline__ void integrate_box(Box& X, float h) {
     const float a = 0.5f * (h * X.w);
     const float a2 = a * a;
     const float den = 1.0f + a2;
-    const float rden = 1.0f / den;
+    const float rden = spec_rcp(den);
     const float cd = (1.0f - a2) * rden;
     const float sd = (2.0f * a) * rden;
     const float c = mad(X.c, cd, -(X.s * sd));

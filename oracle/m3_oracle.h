@@ -260,6 +260,9 @@ float m3o_ori_ee2cube(const float qe[4], const float qc[4], float tilt_value,
 float m3o_sum16(const float x[16]);
 float m3o_sum8_6(const float x[6]);
 
+/* planar spec v1.6: the substep's reciprocal (planar_world.c), exported for the test that bounds its error */
+float m3o_spec_rcp(float x);
+
 #ifdef __cplusplus
 }
 #endif

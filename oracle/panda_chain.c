@@ -193,6 +193,20 @@ static float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] *
  * Panda world spec v2: contact response.
  * ===================================================================================================== */
 /* spec: reciprocal square root = bit-trick seed + three Newton steps in binary32, in this order (as the planar spec) */
+/* world spec v3.1: a contact row's effective mass is this reciprocal of its (positive) denominator, not an IEEE division -- the
+ * planar spec's sequence (planar_world.c, spec v1.6): minimax bit-trick seed, three Newton steps in residual form */
+static float spec_rcp(float x) {
+    unsigned int i;
+    float y, r;
+    memcpy(&i, &x, 4);
+    i = 0x7EF311C7u - i;
+    memcpy(&y, &i, 4);
+    r = mad(-x, y, 1.0f); y = mad(y, r, y);
+    r = mad(-x, y, 1.0f); y = mad(y, r, y);
+    r = mad(-x, y, 1.0f); y = mad(y, r, y);
+    return y;
+}
+
 static float spec_rsqrt(float a) {
     union { float f; unsigned u; } c;
     c.f = a;
@@ -456,7 +470,7 @@ static void contact_prepare(solver_t* S, contact_t* c, float gap) {
             k = bodyrow_k(S, c->ma, c->d[r], c->aa[r], 1.0f);
             if (c->tb >= 0) k = k + bodyrow_k(S, c->tb, c->d[r], c->ab[r], -1.0f);
         }
-        c->meff[r] = 1.0f / k;
+        c->meff[r] = spec_rcp(k); /* world spec v3.1 */
         c->lam[r] = 0.0f;
     }
     if (gap > 0.0f) {

@@ -30,6 +30,21 @@
  * hardware FMA) -- every product-plus-sum of the dynamics is written with it, here and in the HIP kernel alike. */
 static inline float mad(float a, float b, float c) { return fmaf(a, b, c); }
 
+/* spec v1.6: a substep's reciprocals -- minimax bit-trick seed, three Newton steps in residual form (x positive, normal) */
+static inline float spec_rcp(float x) {
+    uint32_t i;
+    float y, r;
+    memcpy(&i, &x, 4);
+    i = 0x7EF311C7u - i;
+    memcpy(&y, &i, 4);
+    r = mad(-x, y, 1.0f); y = mad(y, r, y);
+    r = mad(-x, y, 1.0f); y = mad(y, r, y);
+    r = mad(-x, y, 1.0f); y = mad(y, r, y);
+    return y;
+}
+
+float m3o_spec_rcp(float x) { return spec_rcp(x); }
+
 static inline float spec_rsqrt(float a) {
     uint32_t i;
     float y;
@@ -298,8 +313,8 @@ static void prepare_contacts(const m3o_point_scene* sc, solver_t* s, float h) {
                        mad(s->invI[c->a] * c->rna, c->rna, s->invm[c->a] + s->invm[c->b]));
         float kt = mad(s->invI[c->b] * c->rtb, c->rtb,
                        mad(s->invI[c->a] * c->rta, c->rta, s->invm[c->a] + s->invm[c->b]));
-        c->mn = 1.0f / kn;
-        c->mt = 1.0f / kt;
+        c->mn = spec_rcp(kn);
+        c->mt = spec_rcp(kt);
         if (c->sep > 0.0f) {
             c->bias = c->sep * inv_h;
         } else {
@@ -391,8 +406,8 @@ static void friction_coupling(float vx, float vy, float w, float R, float cf[2])
     const float v = is_zero(s2) ? 0.0f : s2 * spec_rsqrt(s2);
     const float u = is_zero(w) ? 0.0f : R * fabsf(w);
     cf[0] = 1.0f; cf[1] = 1.0f;
-    if (!is_zero(v)) cf[0] = v * (1.0f / mad(0.8488264f, u, v));
-    if (!is_zero(u)) cf[1] = u * (1.0f / mad(2.9452431f, v, u));
+    if (!is_zero(v)) cf[0] = v * spec_rcp(mad(0.8488264f, u, v));
+    if (!is_zero(u)) cf[1] = u * spec_rcp(mad(2.9452431f, v, u));
 }
 
 /* EXPERIMENT (tools/cpu_ab_default_size.py, not part of the spec): ground friction at the four corners of the box's
@@ -431,7 +446,7 @@ static void integrate_body(m3o_body* X, float h, int rotate) {
         float a = 0.5f * (h * X->w);
         float a2 = a * a;
         float den = 1.0f + a2;
-        float rden = 1.0f / den;
+        float rden = spec_rcp(den);
         float cd = (1.0f - a2) * rden;
         float sd = (2.0f * a) * rden;
         float c = mad(X->c, cd, -(X->s * sd));

@@ -118,7 +118,11 @@ def test_c5_gather_reduce_protocol_8x8000_equals_unsharded():
         for e in shards:
             e.buffer(L.BUF_REDUCE).copy_(red)
             e.finalize()
-        fi = _compare(L, full, shards, call, atol=3e-5)
+        # call 0 starts every handle from the same plan: only the order of the 64000-term f32 sums differs (3e-5).  From then on
+        # the plans the rollouts start from differ by that much and contacts amplify it here and there; the bar for the
+        # warm-started calls is a tenth of the control output's contract (1e-3, BASELINE.json), which planar spec v1.6's
+        # trajectories come within 7.4e-5 of (v1.5's stayed inside 3e-5).
+        fi = _compare(L, full, shards, call, atol=3e-5 if call == 0 else 1e-4)
         # every rank computed the weights of all K costs with the same kernels as the unsharded handle
         for e in shards:
             if call == 0:

@@ -287,6 +287,26 @@ def _sim(world_row):
     return sim, torch
 
 
+def test_spec_reciprocal_is_a_division_to_the_last_place(oracle):
+    """Planar spec v1.6 replaces the substep's IEEE divisions (a contact's effective masses, the friction coupling's factors, the
+    orientation update's 1 / (1 + a^2)) by a fixed sequence: bit-trick seed + three Newton steps in residual form.  Mechanics does
+    not notice: over the range those sites see (1e-6 .. 1e6 and the neighbourhoods of powers of two) the result is the correctly
+    rounded quotient for more than 99.9 % of inputs and within one unit in the last place for every one of them."""
+    import ctypes as C
+    lib = oracle.load()
+    lib.m3o_spec_rcp.restype = C.c_float
+    lib.m3o_spec_rcp.argtypes = [C.c_float]
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([np.exp(rng.uniform(np.log(1e-6), np.log(1e6), 20000)), 1.0 + rng.uniform(0.0, 1e-3, 2000),
+                         2.0 ** rng.integers(-20, 20, 200) * (1.0 + rng.choice([-1, 0, 1], 200) * 2.0 ** -23),
+                         [1.0, 2.0, 0.5, 3.0, 1.0 / 16.0, 1.0 / 10.0, 0.1625]]).astype(np.float32)
+    got = np.array([lib.m3o_spec_rcp(float(x)) for x in xs], np.float32)
+    exact = np.float32(1.0) / xs
+    ulps = np.abs(got.view(np.int32).astype(np.int64) - exact.view(np.int32).astype(np.int64))
+    assert ulps.max() <= 1 and (ulps == 0).mean() > 0.999, (ulps.max(), (ulps == 0).mean())
+    assert lib.m3o_spec_rcp(1.0) == 1.0 and lib.m3o_spec_rcp(2.0) == 0.5 and lib.m3o_spec_rcp(0.0625) == 16.0
+
+
 @pytest.mark.gpu
 def test_product_step_obeys_the_same_closed_forms(oracle):
     O = oracle
