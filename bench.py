@@ -259,10 +259,10 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        pl.command(state)
+    for _ in range(min(warmup, 5)):
+        pl.command(state)        # (first calls: sampler + sort of the wave order; the W warm-up commands proper come below)
     # dominant kernel: average launch duration from HIP events recorded by the library on the
-    # stream it launches on, over min(steps, 50) commands of the same workload run between the
+    # stream it launches on, over min(steps, 50) commands of the same workload run BEFORE the
     # warm-up and the timed region (reading the events back synchronises, so they are not read
     # inside it)
     eng.enable_timing(True)
@@ -291,6 +291,11 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
     for _ in range(repeats):     # (the headline: exactly once; `other_configs` rows: the better of two timed regions,
         gc.collect()             #  both reported -- a one-off host hiccup of ~65 ms has been seen inside a 40 ms region;
         gc.disable()             #  the collector is kept out of the region)
+        # the W untimed warm-up commands, IMMEDIATELY before the timed ones: a full collection (~30 ms over torch's objects)
+        # leaves the interpreter's working set cold, which a 20-command region that started right after it paid for with
+        # +6 % (tools: 0.1284 -> 0.1365 ms per command; a 50 ms sleep instead costs 1 %) -- that is what a warm-up is for
+        for _ in range(warmup):
+            pl.command(state)
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):

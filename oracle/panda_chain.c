@@ -7,7 +7,7 @@
  *       get_panda_place_cost   cost_functions.py:127-136
  *       get_pick_tilt_cost     cost_functions.py:138-156
  *       get_motion_cost        cost_functions.py:158-169 (panda branch)
- * (2) Independent implementation of "Panda world spec v3" (DESIGN.md section 3): velocity-servoed
+ * (2) Independent implementation of "Panda world spec v3.1" (DESIGN.md section 3): velocity-servoed
  *     9-dof chain with joint-space inertias derived from the collision meshes, forward kinematics from
  *     the URDF constants (assets/urdf/franka_description/robots/franka_panda.urdf:27-242), cubeA /
  *     cubeB as free rigid cubes and the dyn-obs plate as a free (non-rotating) body, CONTACT RESPONSE:
