@@ -241,11 +241,19 @@ int m3_enable_timing(m3_handle* h, int on);
  * a power of two in 1..64, or 0 = choose from K_local so that the waves fill the chip
  * (DESIGN.md "Lanes per wavefront").  Results do not depend on it. */
 int m3_set_rollout_lanes(m3_handle* h, int lanes);
-/* panda_env: lanes that simulate ONE sample in the rollout kernel -- 1 (a lane per sample, 64 samples per wavefront) or
- * 16 (the sixteen lanes of a DPP row share a sample: the contact solver's joint-space rows run across them; four samples per
- * wavefront), 0 = by size (16 while the launch has no more wavefronts than the chip has SIMDs).  Same results, bit for bit
- * (world spec v3 defines the rows' sums as the pairwise tree both forms evaluate).  DESIGN.md section 6. */
+/* panda_env: lanes that simulate ONE sample in the rollout kernel -- 1 (a lane per sample, 64 samples per wavefront), 8 or
+ * 16 (the lanes of a DPP row share a sample: the contact solver's joint-space rows run across them; eight / four sample
+ * slots per wavefront), 0 = automatic: by size (16 while the launch has no more wavefronts than the chip has SIMDs, then 8,
+ * then 1) and, for the reach task (whose wavefronts give 1-2 slots to quirk Q8's shadow samples), by what the last
+ * commands' rollouts met -- 1 while no gripper came within reach of a box, 8 since one did.  Same results, bit for bit
+ * (world spec v3 defines the rows' sums as the pairwise tree all forms evaluate).  DESIGN.md section 6. */
 int m3_set_panda_lanes_per_sample(m3_handle* h, int lanes_per_sample);
+/* the form the last panda rollout ran in (1, 8, 16; 0 before the first) */
+int m3_panda_lanes_per_sample_used(m3_handle* h);
+/* what the automatic choice for reach reads: the share, in 1/1000, of the last FINISHED panda rollout launch's (sample,
+ * substep) pairs in which the gripper was within reach of a box (the kernel's last wavefront reports it into mapped host
+ * memory; no synchronisation); -1 before the first report */
+int m3_panda_near_share(m3_handle* h);
 /* launch structure of the unsharded multi-modal update with K beyond the one-launch kernel's range: 0 (default) = three
  * launches (ladder + search in one grid, weights + sums, combine), 5 = the five launches of round 3 (minima, ladder,
  * search, weights, sums), whose sums are added in the order of the sharded "exact" protocols (tests compare those bit

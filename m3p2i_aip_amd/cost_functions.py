@@ -48,6 +48,9 @@ class Objective(object):
         self.task = task
         if torch.is_tensor(goal):
             self.goal = goal
+            host = getattr(goal, "_m3_host", None)   # (a tensor made from host values that carries them: task_planner.py)
+            if host is not None:
+                self._goal_host = (host, id(goal), goal._version)
         else:
             self.goal = torch.tensor(goal, device=self.device)
             self._goal_host = ([float(x) for x in np.ravel(goal)], id(self.goal), self.goal._version)

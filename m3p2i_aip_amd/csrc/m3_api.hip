@@ -319,6 +319,8 @@ extern "C" void m3_destroy(m3_handle* h) {
     for (int p = 0; p < MIX_MAX_RANKS; ++p)
         if (h->peer_ipc[p] && h->peer_base[p]) (void)hipIpcCloseMemHandle(h->peer_base[p]);
     if (h->xb) (void)hipFree(h->xb);
+    if (h->panda_busy_hint) (void)hipHostFree(h->panda_busy_hint);
+    if (h->panda_busy_count) (void)hipFree(h->panda_busy_count);
     for (auto& ev : h->ev)
         if (ev) (void)hipEventDestroy(ev);
     delete h;
@@ -349,6 +351,14 @@ extern "C" int m3_set_panda_lanes_per_sample(m3_handle* h, int lps) {
         return fail(h, M3_ERR_BAD_ARG, "m3_set_panda_lanes_per_sample: 0 (by size), 1, 8 or 16");
     h->panda_lps = lps;
     return M3_OK;
+}
+
+extern "C" int m3_panda_near_share(m3_handle* h) {
+    return (h && h->panda_busy_hint) ? *(volatile const int*)h->panda_busy_hint - 1 : -1;
+}
+
+extern "C" int m3_panda_lanes_per_sample_used(m3_handle* h) {
+    return h ? h->panda_lps_used : 0;
 }
 
 extern "C" int m3_set_update_launches(m3_handle* h, int launches) {
@@ -703,6 +713,7 @@ extern "C" int m3_set_beta(m3_handle* h, float beta) {
 extern "C" int m3_set_call_count(m3_handle* h, unsigned calls) {
     if (!h) return M3_ERR_BAD_ARG;
     h->calls = calls;
+    if (h->panda_busy_hint) { *h->panda_busy_hint = 0; h->panda_reach_busy = 0; }
     return M3_OK;
 }
 
@@ -730,6 +741,7 @@ extern "C" int m3_reset(m3_handle* h) {
     HIPCHK(h, hipMemcpyAsync(h->buf[M3_BUF_COV], cv, (size_t)(2 * nu) * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->calls = 0;
+    if (h->panda_busy_hint) { *h->panda_busy_hint = 0; h->panda_reach_busy = 0; }
     return M3_OK;
 }
 
@@ -810,6 +822,14 @@ extern "C" int m3_bind_sim_panda(m3_handle* h, const float* dof, const float* ro
     return M3_OK;
 }
 
+// m3_rollout's choice of the reach command's kernel form: share (1/1000) of the last finished command's (sample, substep) pairs with
+// the gripper within reach of a box from which eight lanes per sample take over / below which one lane does again
+// (tools/panda_reach_mid_bench.py, profiles/r05/panda_reach_mid_bench.json; K = 4000, T = 20, rollout ms with 1 / 8 lanes: the arm at
+// its initial pose 148 per mille 0.166 / 0.210, 20 ticks into an episode 116: 0.179 / 0.206, 30 ticks 442: 0.383 / 0.287, 40 ticks
+// 842: 0.784 / 0.450, 60 ticks 993: 1.530 / 0.831 -- the forms cross near 240; the eight-lane form's own count runs ~10 % higher,
+// its shadow slots included)
+static constexpr int PANDA_BUSY_ON = 300, PANDA_BUSY_OFF = 220;
+
 extern "C" int m3_rollout(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
     const m3_config& c = h->cfg;
@@ -876,7 +896,36 @@ extern "C" int m3_rollout(m3_handle* h) {
         // a sharded command does not hold sample 0's noise row and uses each sample's own cube
         pa.shadows = (pa.cp.task == 4 && a.k0 == 0 && a.Kl == a.Kg && a.Kg >= 2) ? (pa.cp.multi_modal ? 2 : 1) : 0;
         pa.lps = h->panda_lps;
-        const int wgs = launch_rollout_panda(a, pa, h->pscene, h->stream);
+        // the reach command's kernel form follows what the last command's rollouts met (rollout_panda.hip: panda_lps_for): the
+        // kernel's last wavefront reports the share of (sample, substep) pairs with the gripper within reach of a box into a word
+        // of mapped host memory, read here without a synchronisation (so it is the report of the last FINISHED command); eight
+        // lanes per sample from PANDA_BUSY_ON per mille, one lane again below PANDA_BUSY_OFF.  No word, no adaptation.
+        if (h->panda_busy_hint == nullptr && !h->panda_busy_hint_tried) {
+            h->panda_busy_hint_tried = true;
+            void* p = nullptr;
+            void* q = nullptr;
+            if (hipHostMalloc(&p, sizeof(int), hipHostMallocMapped) == hipSuccess && hipMalloc(&q, 2 * sizeof(unsigned)) == hipSuccess &&
+                hipMemsetAsync(q, 0, 2 * sizeof(unsigned), h->stream) == hipSuccess) {
+                h->panda_busy_hint = (int*)p;
+                h->panda_busy_count = (unsigned*)q;
+                *h->panda_busy_hint = 0;
+            } else {
+                (void)hipGetLastError();
+                if (p) (void)hipHostFree(p);
+                if (q) (void)hipFree(q);
+            }
+        }
+        pa.busy_hint = nullptr; pa.busy_count = h->panda_busy_count; pa.reach_busy = 0;
+        if (h->panda_busy_hint) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, h->panda_busy_hint, 0) == hipSuccess) pa.busy_hint = (int*)d;
+            else (void)hipGetLastError();
+            const int share = *(volatile const int*)h->panda_busy_hint - 1;    // (-1: nothing reported yet)
+            if (share >= PANDA_BUSY_ON) h->panda_reach_busy = 1;
+            else if (share >= 0 && share < PANDA_BUSY_OFF) h->panda_reach_busy = 0;
+            pa.reach_busy = h->panda_reach_busy;
+        }
+        const int wgs = launch_rollout_panda(a, pa, h->pscene, h->stream, &h->panda_lps_used);
         if (a.wave_min) h->wave_min_rows = wgs;
     }
     HIPCHK(h, hipGetLastError());

@@ -261,9 +261,14 @@ struct PandaArgs {
     int cubeA_actor, cubeB_actor, obs_actor;
     PandaCostParams cp;
     int shadows;       // the last (two) sample slot(s) of every wavefront re-simulate sample 0 (and K / 2): quirk Q8
-    int lps;           // lanes per sample of the rollout kernel: 0 = by size, 1, 16 (m3_set_panda_lanes_per_sample)
+    int lps;           // lanes per sample of the rollout kernel: 0 = by size, 1, 8, 16 (m3_set_panda_lanes_per_sample)
+    int* busy_hint;              // device address of the handle's hint word (host memory, mapped): 1 + the share, in 1/1000, of the
+                                 // launch's (sample, substep) pairs with the gripper within reach of a box; written by the last wavefront
+    unsigned* busy_count;        // device scratch of that: [0] the sum so far, [1] wavefronts finished
+    int reach_busy;              // the host's reading of the last reports, with hysteresis: the reach command runs with 8 lanes per sample
 };
-int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s);   // returns its workgroups
+int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s,
+                         int* lps_used = nullptr);   // returns its workgroups; *lps_used = the kernel form it chose
 void launch_psim_step(const PandaScene& sc, const SimViews& v, float* world, const float* u, float* u_keep, int Kl,
                       hipStream_t s);
 void launch_psim_pull(const PandaScene& sc, const SimViews& v, float* world, int Kl, hipStream_t s);
@@ -314,6 +319,11 @@ struct m3_handle {
     int* local_top_idx = nullptr;  // regen: top_idx of the local pre-gather selection (scratch)
     unsigned calls = 0;
     int lanes_override = 0;  // 0 = automatic (rollout_lanes_for)
+    int* panda_busy_hint = nullptr;   // hipHostMalloc: see PandaArgs::busy_hint
+    bool panda_busy_hint_tried = false;
+    unsigned* panda_busy_count = nullptr;
+    int panda_reach_busy = 0;
+    int panda_lps_used = 0;           // the form of the last panda rollout (m3_panda_lanes_per_sample_used)
     int panda_lps = 0;       // 0 = automatic (rollout_panda.hip: panda_lps_for), 1, 16
     // device buffers
     void* buf[M3_BUF_COUNT] = {};

@@ -969,6 +969,7 @@ template <int LPS> struct FkCarry {
     bool valid;
     Frame hand;
     float Jv[3], Jw[3];
+    int near_lane_substeps; // sum over the substeps so far of the lanes whose gripper was within reach of a box (wave-uniform)
 };
 // the friction rows' clamp to +-mx (mx >= 0, no NaN): one v_med3_f32 or a max / min pair -- the same value; which one is the
 // faster instruction stream was measured per kernel form (pick, K = 4000: one lane 1.67 -> 1.59 ms and eight lanes 0.833 ->
@@ -1049,7 +1050,9 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             const bool nr = box_d2(sc.table, sc.table + 3) < reach * reach || box_d2(sc.shelf, sc.shelf + 3) < reach * reach ||
                             (!held && box_d2(w.A.p, ce) < rc * rc) || box_d2(w.B.p, ce) < rc * rc ||
                             box_d2(w.obs_p, sc.obs_half) < reach * reach;
-            near = __builtin_amdgcn_ballot_w64(nr) != 0ull;
+            const unsigned long long nrm = __builtin_amdgcn_ballot_w64(nr);
+            near = nrm != 0ull;
+            if constexpr (CARRY) fkc->near_lane_substeps += __builtin_popcountll(nrm);
         }
 #ifdef M3_PABL_NO_NEAR      // (ablations for tools/time_variants_bench.sh: they change results)
         near = false;

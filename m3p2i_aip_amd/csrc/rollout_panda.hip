@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
     fetch(0);
     FkCarry<LPS> fkc;
     fkc.valid = false;
+    fkc.near_lane_substeps = 0;
     float J = 0.0f, g = 1.0f, S = 0.0f, pc = 0.0f;
 #ifdef M3_PABL_PROF
     PandaProf prof = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -282,6 +283,20 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
 #endif
     if (writer) a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
     if (a.wave_min) wave_min_store(a.wave_min, J, first_half, writer);
+    // What the NEXT reach commands' kernel form is chosen by (panda_lps_for): the share of (sample, substep) pairs of this launch
+    // in which the gripper was within reach of a box, in 1/1000.  Every wavefront adds its count; the last one to finish (a
+    // ticket) turns the sum into the share, stores it into a word of mapped host memory and clears the counters for the next
+    // launch.  A hint: results do not depend on the form.
+    if (pa.busy_hint != nullptr && threadIdx.x == 0) {
+        atomicAdd(pa.busy_count, (unsigned)(fkc.near_lane_substeps / LPS));
+        __threadfence();
+        if (atomicAdd(pa.busy_count + 1, 1u) == gridDim.x - 1u) {
+            const unsigned long long total = atomicExch(pa.busy_count, 0u);
+            pa.busy_count[1] = 0u;
+            const unsigned long long all = (unsigned long long)Kl * (unsigned long long)(T * sc.substeps);
+            *(volatile int*)pa.busy_hint = (int)((total * 1000ull) / (all ? all : 1ull)) + 1;    // (+ 1: 0 = nothing reported yet)
+        }
+    }
 }
 
 // Lanes per sample, by what was measured at C4's size (profiles/r05/panda_lps_bench.json; K = 4000, T = 20):
@@ -297,8 +312,16 @@ static int panda_lps_for(const RolloutArgs& a, const PandaArgs& pa) {
     if (pa.lps == 1 || pa.lps == 8 || pa.lps == 16) return pa.lps;
     static const int env = [] { const char* e = getenv("M3P2I_PANDA_LPS"); return e ? atoi(e) : 0; }();
     if (env == 1 || env == 8 || env == 16) return env;
-    if (pa.shadows != 0) return 1;
-    auto waves = [&](int lps) { const int per = 64 / lps; return (a.Kl + per - 1) / per; };
+    auto waves = [&](int lps) { const int per = 64 / lps - pa.shadows; return (a.Kl + per - 1) / per; };
+    if (pa.shadows != 0) {
+        // reach: one lane while next to nothing is near anything; eight lanes (one round of wavefronts with the shadow slots) once
+        // the last command's rollouts had the gripper within reach of the cubes / the table often enough (pa.reach_busy: the share
+        // the kernel reports, with hysteresis; m3_api.hip) -- the scenes 20 / 40 / 60 ticks
+        // into an episode's reach phase (tools/panda_reach_mid_bench.py): 1 lane 0.174 / 0.778 / 1.535 ms, 8 lanes 0.198 /
+        // 0.445 / 0.828, 16 lanes 0.271 / 0.561 / 1.265
+        const bool busy = pa.reach_busy != 0;
+        return (busy && waves(8) <= 1024) ? 8 : 1;
+    }
     if (waves(16) <= 1024) return 16;
     if (waves(8) <= 1024) return 8;
     return 1;
@@ -319,8 +342,9 @@ static int launch_rollout_panda_lps(const RolloutArgs& a_in, const PandaArgs& pa
     return (int)grid.x;
 }
 // returns the number of workgroups (= rows of the wave_min table)
-int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s) {
+int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s, int* lps_used) {
     const int lps = panda_lps_for(a, pa);
+    if (lps_used) *lps_used = lps;
     return lps == 16 ? launch_rollout_panda_lps<16>(a, pa, sc, s) : lps == 8 ? launch_rollout_panda_lps<8>(a, pa, sc, s)
                                                                               : launch_rollout_panda_lps<1>(a, pa, sc, s);
 }

@@ -127,6 +127,15 @@ class HipEngine:
         across them), 0 = by size; same results bit for bit."""
         self._ck(self.lib.m3_set_panda_lanes_per_sample(self._h, int(lps)))
 
+    def panda_lanes_per_sample_used(self):
+        """The form the last panda rollout ran in (automatic choice: by size; for reach, by whether the last commands' rollouts
+        brought the gripper within reach of a box)."""
+        return int(self.lib.m3_panda_lanes_per_sample_used(self._h))
+
+    def panda_near_share(self):
+        """1/1000 of the last finished panda rollout's (sample, substep) pairs with the gripper within reach of a box (-1: none yet)."""
+        return int(self.lib.m3_panda_near_share(self._h))
+
     def set_update_launches(self, launches=0):
         """0 / 3: the three-launch multi-modal update beyond k_update_small's range; 5: round 3's five launches."""
         self._ck(self.lib.m3_set_update_launches(self._h, int(launches)))

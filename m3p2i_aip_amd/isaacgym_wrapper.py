@@ -113,6 +113,7 @@ class IsaacGymWrapper:
                                     self._net_contact_force)
         self._engine.sim_pull_state()
         self._engine.sim_push_state()
+        self._body_index_cache, self._rb_host, self._state_version = {}, None, 0
         self._idx02 = torch.tensor([0, 2], device=dev)
         self._idx13 = torch.tensor([1, 3], device=dev)
         _LIVE.add(self)
@@ -163,8 +164,25 @@ class IsaacGymWrapper:
         return torch.index_select(self._rigid_body_state, 1, rigid_body_idx.reshape(1))[:, 0, :]
 
     def _body_index(self, actor_name: str, link_name: str):
-        return torch.tensor(scenes.body_index(self.env_type, actor_name, link_name),
-                            device=self.device)
+        # (one index tensor per link, made once: torch.tensor(..., device=) is a synchronous host-to-device copy)
+        key = (actor_name, link_name)
+        t = self._body_index_cache.get(key)
+        if t is None:
+            t = self._body_index_cache[key] = torch.tensor(scenes.body_index(self.env_type, actor_name, link_name),
+                                                           device=self.device)
+        return t
+
+    def env0_link_states_host(self):
+        """Env 0's rigid-body states [bodies_per_env, 13] on the HOST (numpy f32): one device-to-host copy per world state,
+        shared by everything that reads link poses of env 0 until the next step() / state upload.  For host-side consumers
+        that branch on poses every tick -- the task planner (task_planner.py:62-107 reads four links and syncs on each)."""
+        c = self._rb_host
+        if c is None or c[0] != self._state_version:
+            c = self._rb_host = (self._state_version, self._rigid_body_state[0].cpu().numpy())
+        return c[1]
+
+    def link_row(self, actor_name: str, link_name: str) -> int:
+        return scenes.body_index(self.env_type, actor_name, link_name)
 
     def get_actor_link_by_name(self, actor_name: str, link_name: str):
         return self.get_rigid_body_by_rigid_body_index(self._body_index(actor_name, link_name))
@@ -180,10 +198,12 @@ class IsaacGymWrapper:
     def set_dof_state_tensor(self, u):
         self._adopt(self._dof_state, u)
         self._engine.sim_pull_state()
+        self._state_version += 1
 
     def set_actor_root_state_tensor(self, u):
         self._adopt(self._root_state, u)
         self._engine.sim_pull_state()
+        self._state_version += 1
 
     # True: set_dof_velocity_target_tensor hands the caller's tensor to the next step() instead of copying it (the
     # closed-loop tools, which own their tensors; see HipEngine.sim_set_velocity_target)
@@ -214,6 +234,7 @@ class IsaacGymWrapper:
 
     def step(self):
         self._engine.sim_step()
+        self._state_version += 1
 
     def stop_sim(self):
         self._engine.close()

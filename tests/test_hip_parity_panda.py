@@ -292,3 +292,55 @@ def test_panda_ragged_sample_counts_in_every_kernel_form(oracle, K, task, mm, lp
     np.testing.assert_array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
     np.testing.assert_array_equal(eng.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle):
+    """The automatic form of the REACH command (m3_set_panda_lanes_per_sample 0): one lane per sample while the gripper is within
+    reach of a box in few of the rollouts' (sample, substep) pairs, eight lanes per sample from the command after the kernel
+    reported many (m3_panda_near_share; quirk Q8's shadow slots rule out sixteen) -- and the plans do not depend on it: the same
+    commands with the form forced to one lane give the same bits."""
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    sc = P.default_scene()
+    K, T = 512, 20
+    delta = np.random.default_rng(9).standard_normal((K, T, 9)).astype(np.float32)
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+
+    def engine(lps):
+        eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", u_min=UMIN, u_max=UMAX, noise_sigma_diag=SIG,
+                                    lambda_=0.05, pre_height_diff=0.05, dt=0.01))
+        eng.set_objective("reach", goal, gripper_cmd=1)
+        eng.set_noise(delta)
+        eng.set_panda_lanes_per_sample(lps)
+        return eng
+    # the initial scene, arm up: few pairs near anything -> one lane, command after command
+    far = engine(0)
+    assert far.panda_near_share() == -1
+    far.set_world_panda_raw(raw31(P, P.init_world(1)[0]))
+    used = []
+    for _ in range(4):
+        far.command(sync_host=True)
+        used.append(far.panda_lanes_per_sample_used())
+    assert used == [1, 1, 1, 1] and 0 <= far.panda_near_share() < 300, (used, far.panda_near_share())
+    # open gripper 3 cm above the cube: the rollouts are next to it all the time
+    near = grasp_world(P, sc, close_gripper=False, lift=0.03)
+    auto, one = engine(0), engine(1)
+    used = []
+    for call in range(4):
+        for e in (auto, one):
+            e.set_world_panda_raw(raw31(P, near))
+        a, b = auto.command(sync_host=True), one.command(sync_host=True)
+        used.append(auto.panda_lanes_per_sample_used())
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+        for buf in (L.BUF_TRAJ_COST, L.BUF_MEAN):
+            assert torch.equal(auto.buffer(buf), one.buffer(buf))
+    assert used == [1, 8, 8, 8] and auto.panda_near_share() >= 300, (used, auto.panda_near_share())
+    # back in the initial scene: one lane again from the command after the first report from there
+    used = []
+    for _ in range(3):
+        auto.set_world_panda_raw(raw31(P, P.init_world(1)[0]))
+        auto.command(sync_host=True)
+        used.append(auto.panda_lanes_per_sample_used())
+    assert used == [8, 1, 1], used

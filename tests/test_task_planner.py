@@ -157,3 +157,31 @@ def test_patrolling_planner_and_template_exports():
     p.goal_id = 2
     p.reset_plan()
     assert p.goal_id == 0 and p.check_task_success(None) is False
+
+
+def test_planner_aif_panda_memoised_ticks_are_the_agents_own():
+    """PLANNER_AIF_PANDA looks a tick up once (stage, belief D) has been seen before -- D reaches an exact fixed point within a
+    stage.  Same decisions and the same agent state (C, D, E, F, G, posteriors, u), tick by tick, as an agent that runs every
+    tick; and the look-ups do happen."""
+    import types
+    pytest.importorskip("torch")
+    cfg = types.SimpleNamespace(mppi=types.SimpleNamespace(device="cpu"), pre_height_diff=0.05, env_type="panda_env")
+    memo, plain = tp.set_task_planner(cfg), tp.set_task_planner(cfg)
+    hits = 0
+    for stage, ticks in ((0, 40), (1, 30), (2, 12)):
+        for _ in range(ticks):
+            memo.stage = plain.stage = stage
+            known = (stage, memo.ai_agent_task[0]._mdp.D.tobytes()) in memo._aif_memo
+            hits += known
+            got = memo._select_action()
+            agent = plain.ai_agent_task[0]
+            agent.set_preferences(np.array(plain.STAGE_PREFERENCE[stage], dtype=float).reshape(-1, 1))
+            want = tp.adapt_act_sel(plain.ai_agent_task, [stage])
+            assert got == want
+            a, b = memo.ai_agent_task[0], agent
+            assert a.u == b.u
+            for k in ("C", "D", "E"):
+                np.testing.assert_array_equal(getattr(a._mdp, k), getattr(b._mdp, k))
+            for k in ("F", "G", "post_x", "post_x_bma"):
+                np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
+    assert hits > 40
