@@ -248,6 +248,12 @@ int m3_set_rollout_lanes(m3_handle* h, int lanes);
  * commands' rollouts met -- 1 while no gripper came within reach of a box, 8 since one did.  Same results, bit for bit
  * (world spec v3 defines the rows' sums as the pairwise tree all forms evaluate).  DESIGN.md section 6. */
 int m3_set_panda_lanes_per_sample(m3_handle* h, int lanes_per_sample);
+/* panda_env, reach task on an unsharded handle (quirk Q8: every rollout's cost is measured against environment 0's cube):
+ * 1 (default) = with K <= 8192 and the default sampler the rollout kernel runs WITHOUT shadow sample slots in a many-lane form
+ * and leaves what the cost reads per (step, sample) behind; a second kernel forms the costs (same values, same operations, same
+ * bits).  0 = the shadow slots (every wavefront re-simulates samples 0 and K / 2), as for larger K, the random sampler and
+ * mppi_mode 'simple'. */
+int m3_set_panda_reach_cost_kernel(m3_handle* h, int on);
 /* the form the last panda rollout ran in (1, 8, 16; 0 before the first) */
 int m3_panda_lanes_per_sample_used(m3_handle* h);
 /* what the automatic choice for reach reads: the share, in 1/1000, of the last FINISHED panda rollout launch's (sample,

@@ -82,6 +82,7 @@ SYMBOLS = [
     ("m3_set_panda_lanes_per_sample", C.c_int, [_H, C.c_int]),
     ("m3_panda_lanes_per_sample_used", C.c_int, [_H]),
     ("m3_panda_near_share", C.c_int, [_H]),
+    ("m3_set_panda_reach_cost_kernel", C.c_int, [_H, C.c_int]),
     ("m3_set_update_launches", C.c_int, [_H, C.c_int]),
     ("m3_set_wave_order", C.c_int, [_H, C.c_int]),
     ("m3_relabel_samples", C.c_int, [_H]),

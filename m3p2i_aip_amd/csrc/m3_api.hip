@@ -321,6 +321,7 @@ extern "C" void m3_destroy(m3_handle* h) {
     if (h->xb) (void)hipFree(h->xb);
     if (h->panda_busy_hint) (void)hipHostFree(h->panda_busy_hint);
     if (h->panda_busy_count) (void)hipFree(h->panda_busy_count);
+    if (h->panda_reach_rec) (void)hipFree(h->panda_reach_rec);
     for (auto& ev : h->ev)
         if (ev) (void)hipEventDestroy(ev);
     delete h;
@@ -350,6 +351,12 @@ extern "C" int m3_set_panda_lanes_per_sample(m3_handle* h, int lps) {
     if (lps != 0 && lps != 1 && lps != 8 && lps != 16)
         return fail(h, M3_ERR_BAD_ARG, "m3_set_panda_lanes_per_sample: 0 (by size), 1, 8 or 16");
     h->panda_lps = lps;
+    return M3_OK;
+}
+
+extern "C" int m3_set_panda_reach_cost_kernel(m3_handle* h, int on) {
+    if (!h) return M3_ERR_BAD_ARG;
+    h->panda_reach_deferred = on != 0;
     return M3_OK;
 }
 
@@ -829,6 +836,7 @@ extern "C" int m3_bind_sim_panda(m3_handle* h, const float* dof, const float* ro
 // 842: 0.784 / 0.450, 60 ticks 993: 1.530 / 0.831 -- the forms cross near 240; the eight-lane form's own count runs ~10 % higher,
 // its shadow slots included)
 static constexpr int PANDA_BUSY_ON = 300, PANDA_BUSY_OFF = 220;
+static constexpr int PANDA_REACH_REC_MAX_K = 8192, PANDA_BUSY_ON_REC = 260, PANDA_BUSY_OFF_REC = 190;   // (the forms tie between 116 and ~250 per mille; the arm's initial pose reads 148)
 
 extern "C" int m3_rollout(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
@@ -896,6 +904,19 @@ extern "C" int m3_rollout(m3_handle* h) {
         // a sharded command does not hold sample 0's noise row and uses each sample's own cube
         pa.shadows = (pa.cp.task == 4 && a.k0 == 0 && a.Kl == a.Kg && a.Kg >= 2) ? (pa.cp.multi_modal ? 2 : 1) : 0;
         pa.lps = h->panda_lps;
+        // reach on a handle that would need shadow slots: with room for one round of wavefronts in a many-lane form (K <= 8192)
+        // the cost moves into a kernel of its own behind the rollout (rollout_panda.hip: k_panda_reach_cost) -- 17 floats per
+        // (step, sample) in between
+        pa.reach_rec = nullptr;
+        if (pa.shadows != 0 && a.Kl <= PANDA_REACH_REC_MAX_K && h->panda_reach_deferred) {
+            if (h->panda_reach_rec == nullptr && !h->panda_reach_rec_tried) {
+                h->panda_reach_rec_tried = true;
+                void* p = nullptr;
+                if (hipMalloc(&p, (size_t)a.T * REACH_REC * (size_t)a.Kl * sizeof(float)) == hipSuccess) h->panda_reach_rec = (float*)p;
+                else (void)hipGetLastError();
+            }
+            pa.reach_rec = h->panda_reach_rec;
+        }
         // the reach command's kernel form follows what the last command's rollouts met (rollout_panda.hip: panda_lps_for): the
         // kernel's last wavefront reports the share of (sample, substep) pairs with the gripper within reach of a box into a word
         // of mapped host memory, read here without a synchronisation (so it is the report of the last FINISHED command); eight
@@ -921,8 +942,10 @@ extern "C" int m3_rollout(m3_handle* h) {
             if (hipHostGetDevicePointer(&d, h->panda_busy_hint, 0) == hipSuccess) pa.busy_hint = (int*)d;
             else (void)hipGetLastError();
             const int share = *(volatile const int*)h->panda_busy_hint - 1;    // (-1: nothing reported yet)
-            if (share >= PANDA_BUSY_ON) h->panda_reach_busy = 1;
-            else if (share >= 0 && share < PANDA_BUSY_OFF) h->panda_reach_busy = 0;
+            // (with the cost kernel available the many-lane form has no shadow slots and takes over earlier)
+            const int on = pa.reach_rec ? PANDA_BUSY_ON_REC : PANDA_BUSY_ON, off = pa.reach_rec ? PANDA_BUSY_OFF_REC : PANDA_BUSY_OFF;
+            if (share >= on) h->panda_reach_busy = 1;
+            else if (share >= 0 && share < off) h->panda_reach_busy = 0;
             pa.reach_busy = h->panda_reach_busy;
         }
         const int wgs = launch_rollout_panda(a, pa, h->pscene, h->stream, &h->panda_lps_used);

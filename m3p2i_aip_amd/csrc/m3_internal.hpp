@@ -256,12 +256,14 @@ constexpr int NW = 28;  // floats per env in the step-mode SoA world (PointWorld
 constexpr int NWP = 77; // same for the panda_env (PandaWorld fields, rollout_panda.hip)
 
 // panda_env
+constexpr int REACH_REC = 17;   // floats the reach cost reads of a (step, sample): rollout_panda.hip
 struct PandaArgs {
     float world0[57];  // q9 qd9 | cubeA13 | cubeB13 | dyn-obs13 (pos3 quat4 vel3 angvel3)
     int cubeA_actor, cubeB_actor, obs_actor;
     PandaCostParams cp;
     int shadows;       // the last (two) sample slot(s) of every wavefront re-simulate sample 0 (and K / 2): quirk Q8
     int lps;           // lanes per sample of the rollout kernel: 0 = by size, 1, 8, 16 (m3_set_panda_lanes_per_sample)
+    float* reach_rec;            // [T][REACH_REC][Kl] or null: the reach cost is formed after the rollout (k_panda_reach_cost), no shadow slots
     int* busy_hint;              // device address of the handle's hint word (host memory, mapped): 1 + the share, in 1/1000, of the
                                  // launch's (sample, substep) pairs with the gripper within reach of a box; written by the last wavefront
     unsigned* busy_count;        // device scratch of that: [0] the sum so far, [1] wavefronts finished
@@ -322,6 +324,9 @@ struct m3_handle {
     int* panda_busy_hint = nullptr;   // hipHostMalloc: see PandaArgs::busy_hint
     bool panda_busy_hint_tried = false;
     unsigned* panda_busy_count = nullptr;
+    float* panda_reach_rec = nullptr;     // PandaArgs::reach_rec, allocated by the first reach rollout that can use it
+    bool panda_reach_rec_tried = false;
+    bool panda_reach_deferred = true;     // m3_set_panda_reach_cost_kernel
     int panda_reach_busy = 0;
     int panda_lps_used = 0;           // the form of the last panda rollout (m3_panda_lanes_per_sample_used)
     int panda_lps = 0;       // 0 = automatic (rollout_panda.hip: panda_lps_for), 1, 16

@@ -199,7 +199,21 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         panda_step<FORCES, true, LPS>(sc, w, u, obs, cs, hp, &trav, &fkc);
 #endif
         float cube0[3], qh0[4];
-        if (pa.shadows) {
+        if (pa.reach_rec != nullptr) {
+            // the reach cost of this step is formed by k_panda_reach_cost (below) from what it reads of the sample -- and of
+            // samples 0 and K / 2, whose cube it is measured against (quirk Q8): no shadow slots in this launch
+            if (writer) {
+                float* r = pa.reach_rec + (size_t)t * REACH_REC * Kl + i;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { r[(0 + j) * Kl] = obs.left[j]; r[(3 + j) * Kl] = obs.right[j]; r[(14 + j) * Kl] = w.A.p[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { r[(6 + j) * Kl] = obs.left_q[j]; r[(10 + j) * Kl] = w.A.q[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cube0[j] = w.A.p[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qh0[j] = w.A.q[j];
+        } else if (pa.shadows) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) cube0[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w.A.p[j]), 63));
 #pragma unroll
@@ -214,11 +228,11 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) qh0[j] = w.A.q[j];
         }
-        const float c = panda_cost(pa.cp, w, obs, k, cube0, qh0);
+        const float c = (pa.reach_rec != nullptr) ? 0.0f : panda_cost(pa.cp, w, obs, k, cube0, qh0);
         if (writer) {
             *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
                 make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
-            a.cost_h[(size_t)t * Kl + i] = c;
+            if (pa.reach_rec == nullptr) a.cost_h[(size_t)t * Kl + i] = c;
         }
         if constexpr (LPS == 1) {
             if (!shadow) {
@@ -281,8 +295,10 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         }
     }
 #endif
-    if (writer) a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
-    if (a.wave_min) wave_min_store(a.wave_min, J, first_half, writer);
+    if (pa.reach_rec == nullptr) {      // (else: k_panda_reach_cost writes the costs and leaves the minima behind)
+        if (writer) a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
+        if (a.wave_min) wave_min_store(a.wave_min, J, first_half, writer);
+    }
     // What the NEXT reach commands' kernel form is chosen by (panda_lps_for): the share of (sample, substep) pairs of this launch
     // in which the gripper was within reach of a box, in 1/1000.  Every wavefront adds its count; the last one to finish (a
     // ticket) turns the sum into the share, stores it into a word of mapped host memory and clears the counters for the next
@@ -297,6 +313,40 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
             *(volatile int*)pa.busy_hint = (int)((total * 1000ull) / (all ? all : 1ull)) + 1;    // (+ 1: 0 = nothing reported yet)
         }
     }
+}
+
+// The reach cost of a launch that ran WITHOUT shadow slots (PandaArgs::reach_rec): quirk Q8 measures every rollout against the
+// cube of environment 0 (and the tilted mode's orientation term against the first environment of the second half), which a
+// rollout kernel can only know inside a wavefront by re-simulating those samples in it -- a quarter (half) of the sample slots
+// with sixteen lanes per sample, a second round of wavefronts at K = 4000.  Instead the rollout leaves, per (step, sample), the
+// seventeen floats the cost reads (finger positions 6, finger orientation 4, the sample's cube orientation 4 and position 3:
+// [T][17][Kl], 5.4 MB at C4) and this kernel -- one lane per sample, the same panda_cost on the same values, the same
+// discounted sum in the same order -- forms cost_horizon, the trajectory costs and the update's minima rows.
+__global__ __launch_bounds__(64) void k_panda_reach_cost(const RolloutArgs a, const PandaArgs pa) {
+    const int Kl = a.Kl, T = a.T;
+    const int i0 = blockIdx.x * 64 + (int)threadIdx.x;
+    const bool mine = i0 < Kl;
+    const int i = mine ? i0 : 0;          // (every lane stays for wave_min_store's barriers)
+    const int k = a.k0 + i;
+    const bool first_half = k < pa.cp.half_K;
+    const int h = (pa.cp.multi_modal && !first_half) ? pa.cp.half_K : 0;    // whose cube orientation the tilt term reads
+    float J = 0.0f, g = 1.0f;
+    for (int t = 0; t < T; ++t) {
+        const float* r = pa.reach_rec + (size_t)t * REACH_REC * Kl;
+        PandaObs o;
+        PandaWorld w;
+        float cube0[3], qh0[4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o.left[j] = r[(0 + j) * Kl + i]; o.right[j] = r[(3 + j) * Kl + i]; cube0[j] = r[(14 + j) * Kl]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o.left_q[j] = r[(6 + j) * Kl + i]; w.A.q[j] = r[(10 + j) * Kl + i]; qh0[j] = r[(10 + j) * Kl + h]; }
+        const float c = panda_cost(pa.cp, w, o, k, cube0, qh0);
+        if (mine) a.cost_h[(size_t)t * Kl + i] = c;
+        J = J + g * c;
+        g = g * a.gamma;
+    }
+    if (mine) a.J[i] = J;
+    if (a.wave_min) wave_min_store(a.wave_min, J, first_half, mine);
 }
 
 // Lanes per sample, by what was measured at C4's size (profiles/r05/panda_lps_bench.json; K = 4000, T = 20):
@@ -342,9 +392,30 @@ static int launch_rollout_panda_lps(const RolloutArgs& a_in, const PandaArgs& pa
     return (int)grid.x;
 }
 // returns the number of workgroups (= rows of the wave_min table)
-int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s, int* lps_used) {
-    const int lps = panda_lps_for(a, pa);
+int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa_in, const PandaScene& sc, hipStream_t s, int* lps_used) {
+    PandaArgs pa = pa_in;
+    // reach without shadow slots (k_panda_reach_cost): when the handle holds the record buffer (m3_api.hip: K up to 8192), the
+    // sampler is the default one and a many-lane form is what the launch
+    // sixteen (eight) lanes per sample run in; automatic choice: while few of the last command's (sample, substep) pairs had the
+    // gripper within reach of a box the one-lane form with its shadow slots is the faster launch (pa.reach_busy, m3_api.hip:
+    // K = 4000, rollout ms one lane / sixteen lanes + cost kernel: arm at its initial pose 0.169 / 0.190, 20 ticks into an episode
+    // 0.182 / 0.187, 30 ticks 0.388 / 0.248, 40 ticks 0.798 / 0.419, 60 ticks 1.541 / 0.778; profiles/r05/panda_reach_mid_bench.json)
+    int lps = 0;
+    if (pa.reach_rec != nullptr) {
+        pa.shadows = 0;
+        const bool want = pa_in.shadows != 0 && !(a.sampling_random || a.mode_simple) && (pa.lps != 0 || pa.reach_busy != 0);
+        lps = want ? panda_lps_for(a, pa) : 1;
+        if (lps == 1) pa = pa_in, pa.reach_rec = nullptr;
+    }
+    if (pa.reach_rec == nullptr) lps = panda_lps_for(a, pa);
     if (lps_used) *lps_used = lps;
+    if (pa.reach_rec != nullptr) {
+        if (lps == 16) (void)launch_rollout_panda_lps<16>(a, pa, sc, s);
+        else (void)launch_rollout_panda_lps<8>(a, pa, sc, s);
+        const dim3 grid((a.Kl + 63) / 64), block(64);
+        hipLaunchKernelGGL(k_panda_reach_cost, grid, block, 0, s, a, pa);
+        return (int)grid.x;
+    }
     return lps == 16 ? launch_rollout_panda_lps<16>(a, pa, sc, s) : lps == 8 ? launch_rollout_panda_lps<8>(a, pa, sc, s)
                                                                               : launch_rollout_panda_lps<1>(a, pa, sc, s);
 }

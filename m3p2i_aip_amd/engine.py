@@ -132,6 +132,11 @@ class HipEngine:
         brought the gripper within reach of a box)."""
         return int(self.lib.m3_panda_lanes_per_sample_used(self._h))
 
+    def set_panda_reach_cost_kernel(self, on=True):
+        """reach, unsharded, K <= 8192, default sampler: the cost in a kernel of its own behind a rollout without shadow slots
+        (default) or the shadow slots; same bits."""
+        self._ck(self.lib.m3_set_panda_reach_cost_kernel(self._h, int(bool(on))))
+
     def panda_near_share(self):
         """1/1000 of the last finished panda rollout's (sample, substep) pairs with the gripper within reach of a box (-1: none yet)."""
         return int(self.lib.m3_panda_near_share(self._h))

@@ -122,6 +122,7 @@ def test_panda_rollout_bit_exact_on_random_worlds(oracle, seed, lps):
                                 noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01))
     eng.set_objective(task, goal, gripper_cmd=grip)
     eng.set_panda_lanes_per_sample(lps)
+    eng.set_panda_reach_cost_kernel((seed // 4) % 2 == 0)   # reach: the cost kernel behind a rollout without shadow slots / the shadows
     eng.set_noise(delta)
     eng.set_world_panda_raw(raw31(P, w0))
     eng.command(sync_host=True)
@@ -260,16 +261,20 @@ def test_panda_option_traces_vs_reference_golden(golden, oracle, tag):
     eng.close()
 
 
-@pytest.mark.parametrize("lps", [1, 8, 16])
+@pytest.mark.parametrize("lps", [1, 8, 16, -8, -16])
 @pytest.mark.parametrize("K,task,mm", [(203, "pick", False), (61, "reach", False), (90, "reach", True), (22, "place", False)])
 def test_panda_ragged_sample_counts_in_every_kernel_form(oracle, K, task, mm, lps):
     """Sample counts that fill no wavefront evenly -- a last wavefront with one, two or three of its four (eight) sample slots
     used, fewer samples than one wavefront of the one-lane form, the shadow slots of quirk Q8 (reach: one, multi-modal: two) taking
     their share -- in the three forms of the kernel: every state, action, cost and trajectory cost equals the oracle's bit for
-    bit, nothing is written past the K rows."""
+    bit, nothing is written past the K rows.  (lps < 0: that many lanes with the reach cost's shadow slots instead of the cost
+    kernel behind a rollout without them -- the default for lps = 8 / 16.)"""
     import oracle.panda as P
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
+    if lps < 0 and task != "reach":
+        pytest.skip("the switch concerns the reach cost only")
+    shadows, lps = lps < 0, abs(lps)
     sc = P.default_scene()
     T = 20
     rng = np.random.default_rng(900 + K)
@@ -283,10 +288,12 @@ def test_panda_ragged_sample_counts_in_every_kernel_form(oracle, K, task, mm, lp
                                 noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01))
     eng.set_objective(task, goal, gripper_cmd=grip)
     eng.set_panda_lanes_per_sample(lps)
+    eng.set_panda_reach_cost_kernel(not shadows)
     eng.set_noise(delta)
     eng.set_world_panda_raw(raw31(P, w0))
     eng.command(sync_host=True)
     opl.command(w0)
+    assert eng.panda_lanes_per_sample_used() == lps
     np.testing.assert_array_equal(eng.actions.cpu().numpy(), opl.last["actions"])
     np.testing.assert_array_equal(eng.states.cpu().numpy(), opl.last["states"])
     np.testing.assert_array_equal(eng.cost_horizon.cpu().numpy(), opl.last["cost_h"])
@@ -295,11 +302,14 @@ def test_panda_ragged_sample_counts_in_every_kernel_form(oracle, K, task, mm, lp
 
 
 @pytest.mark.gpu
-def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle):
-    """The automatic form of the REACH command (m3_set_panda_lanes_per_sample 0): one lane per sample while the gripper is within
-    reach of a box in few of the rollouts' (sample, substep) pairs, eight lanes per sample from the command after the kernel
-    reported many (m3_panda_near_share; quirk Q8's shadow slots rule out sixteen) -- and the plans do not depend on it: the same
-    commands with the form forced to one lane give the same bits."""
+@pytest.mark.parametrize("cost_kernel", [False, True])
+def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle, cost_kernel):
+    """The automatic form of the REACH command (m3_set_panda_lanes_per_sample 0): one lane per sample (with quirk Q8's shadow
+    slots) while the gripper is within reach of a box in few of the rollouts' (sample, substep) pairs; from the command after the
+    kernel reported many (m3_panda_near_share) sixteen lanes per sample without shadow slots + the cost kernel -- or, where that
+    is not available (m3_set_panda_reach_cost_kernel 0, as beyond K = 8192), eight lanes with them.  The plans do not depend on
+    it: the same commands with the form forced to one lane give the same bits."""
+    many = 16 if cost_kernel else 8
     import oracle.panda as P
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
@@ -314,16 +324,18 @@ def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle):
         eng.set_objective("reach", goal, gripper_cmd=1)
         eng.set_noise(delta)
         eng.set_panda_lanes_per_sample(lps)
+        eng.set_panda_reach_cost_kernel(cost_kernel)
         return eng
     # the initial scene, arm up: few pairs near anything -> one lane, command after command
     far = engine(0)
     assert far.panda_near_share() == -1
     far.set_world_panda_raw(raw31(P, P.init_world(1)[0]))
-    used = []
+    used, shares = [], []
     for _ in range(4):
         far.command(sync_host=True)
         used.append(far.panda_lanes_per_sample_used())
-    assert used == [1, 1, 1, 1] and 0 <= far.panda_near_share() < 300, (used, far.panda_near_share())
+        shares.append(far.panda_near_share())
+    assert used == [1, 1, 1, 1] and 0 <= max(shares) < 260, (used, shares)
     # open gripper 3 cm above the cube: the rollouts are next to it all the time
     near = grasp_world(P, sc, close_gripper=False, lift=0.03)
     auto, one = engine(0), engine(1)
@@ -336,11 +348,58 @@ def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle):
         assert np.array_equal(np.asarray(a), np.asarray(b))
         for buf in (L.BUF_TRAJ_COST, L.BUF_MEAN):
             assert torch.equal(auto.buffer(buf), one.buffer(buf))
-    assert used == [1, 8, 8, 8] and auto.panda_near_share() >= 300, (used, auto.panda_near_share())
+    assert used == [1, many, many, many] and auto.panda_near_share() >= 300, (used, auto.panda_near_share())
     # back in the initial scene: one lane again from the command after the first report from there
     used = []
     for _ in range(3):
         auto.set_world_panda_raw(raw31(P, P.init_world(1)[0]))
         auto.command(sync_host=True)
         used.append(auto.panda_lanes_per_sample_used())
-    assert used == [8, 1, 1], used
+    assert used == [many, 1, 1], used
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mm", [False, True])
+def test_reach_cost_kernel_equals_the_shadow_slots(oracle, mm):
+    """Quirk Q8 two ways: every wavefront re-simulates samples 0 (and K / 2) in shadow slots and reads their cube after each step,
+    or -- the default up to K = 8192 -- the rollout runs without shadow slots in the sixteen-lane form, leaves the 17 floats per
+    (step, sample) the reach cost reads, and k_panda_reach_cost forms the costs.  Three warm-started commands from a scene in
+    which rollouts push the cube around (so that environment 0's cube is NOT the sample's own): every buffer of the command equal
+    bit for bit, and equal to the oracle's on the first call."""
+    import oracle.panda as P
+    from m3p2i_aip_amd import _lib as L
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    sc = P.default_scene()
+    K, T = 300, 20
+    delta = np.random.default_rng(21).standard_normal((K, T, 9)).astype(np.float32)
+    goal = np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32)
+    w0 = grasp_world(P, sc, close_gripper=False, lift=0.0)
+    cfg = P.make_cfg(K, T, multi_modal=mm, task="reach", goal=goal, gripper_cmd=2)
+    opl = P.OraclePandaPlanner(cfg, delta, sc)
+
+    def engine(deferred):
+        eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", multi_modal=mm, u_min=UMIN, u_max=UMAX,
+                                    noise_sigma_diag=SIG, lambda_=0.05, pre_height_diff=0.05, dt=0.01))
+        eng.set_objective("reach", goal, gripper_cmd=2)
+        eng.set_noise(delta)
+        eng.set_panda_reach_cost_kernel(deferred)
+        eng.set_panda_lanes_per_sample(16 if deferred else 0)
+        eng.set_world_panda_raw(raw31(P, w0))
+        return eng
+    a, b = engine(True), engine(False)
+    bufs = [L.BUF_TRAJ_COST, L.BUF_COST_HORIZON, L.BUF_STATES, L.BUF_ACTIONS, L.BUF_MEAN, L.BUF_WEIGHTS, L.BUF_TOP_TRAJS]
+    if mm:
+        bufs += [L.BUF_MEAN_1, L.BUF_MEAN_2, L.BUF_BEST_1, L.BUF_BEST_2]
+    for call in range(3):
+        pa, pb = a.command(sync_host=True), b.command(sync_host=True)
+        assert a.panda_lanes_per_sample_used() == 16 and b.panda_lanes_per_sample_used() in (1, 8)
+        assert np.array_equal(np.asarray(pa), np.asarray(pb))
+        for buf in bufs:
+            assert torch.equal(a.buffer(buf), b.buffer(buf)), (call, buf)
+        if call == 0:
+            opl.command(w0)
+            np.testing.assert_array_equal(a.cost_horizon.cpu().numpy(), opl.last["cost_h"])
+            np.testing.assert_array_equal(a.buffer(L.BUF_TRAJ_COST).cpu().numpy(), opl.last["J"])
+    # the cubes did move in some rollouts: the quirk is exercised
+    ch = a.cost_horizon.cpu().numpy()
+    assert np.isfinite(ch).all() and ch.std() > 0

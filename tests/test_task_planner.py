@@ -185,3 +185,77 @@ def test_planner_aif_panda_memoised_ticks_are_the_agents_own():
             for k in ("F", "G", "post_x", "post_x_bma"):
                 np.testing.assert_array_equal(getattr(a, k), getattr(b, k))
     assert hits > 40
+
+
+@pytest.mark.gpu
+def test_planner_aif_panda_host_path_equals_the_per_link_path_gpu():
+    """On the HIP wrapper PLANNER_AIF_PANDA reads env 0's link states with ONE device-to-host copy per tick
+    (IsaacGymWrapper.env0_link_states_host) and hands its goal over with the host values attached; on any other sim it reads four
+    link tensors one by one (task_planner.py:62-107 does).  Same f32 operations either way: a closed loop of 90 ticks run twice --
+    once with the wrapper's host copy hidden from the planner -- hands out the same tasks, the same goals bit for bit and ends in
+    the same world; the host copy is made once per world state and follows step() / the state uploads."""
+    import torch
+    from m3p2i_aip_amd import compat
+    compat.install(force_standins=True)
+    from m3p2i_aip.planners.motion_planner import m3p2i
+    from m3p2i_aip.planners.task_planner import task_planner
+    import m3p2i_aip.utils.isaacgym_utils.isaacgym_wrapper as wrapper
+    from m3p2i_aip.planners.motion_planner.cost_functions import Objective
+
+    class Hidden:
+        """the wrapper without its host-copy entry points: what a sim that is not ours looks like to the planner"""
+        def __init__(self, sim):
+            self._sim = sim
+
+        def __getattr__(self, k):
+            if k in ("env0_link_states_host", "link_row"):
+                raise AttributeError(k)
+            return getattr(self._sim, k)
+
+    def episode(hide):
+        cfg = compat.make_config("config_panda", ["mppi.num_samples=512"])
+        sim = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=cfg.mppi.num_samples, viewer=False,
+                                      device=cfg.mppi.device, cube_on_shelf=cfg.cube_on_shelf)
+        real = wrapper.IsaacGymWrapper(cfg.isaacgym, cfg.env_type, num_envs=1, device=cfg.mppi.device, cube_on_shelf=cfg.cube_on_shelf)
+        obj, tpl = Objective(cfg), task_planner.set_task_planner(cfg)
+
+        def dynamics(_, u, t=None):
+            sim.set_dof_velocity_target_tensor(u)
+            sim.step()
+            return torch.stack([sim.robot_pos[:, 0], sim.robot_vel[:, 0], sim.robot_pos[:, 1], sim.robot_vel[:, 1]], dim=1), u
+        mp = m3p2i.M3P2I(cfg, dynamics=dynamics, running_cost=lambda _: obj.compute_cost(sim))
+        mp.attach(sim, obj)
+        seen = Hidden(sim) if hide else sim
+        log = []
+        for _ in range(90):
+            sim._dof_state[:] = real._dof_state
+            sim._root_state[:] = real._root_state
+            sim.set_dof_state_tensor(sim._dof_state)
+            sim.set_actor_root_state_tensor(sim._root_state)
+            tpl.update_plan(seen)
+            mp.update_gripper_command(tpl.task)
+            obj.update_objective(tpl.task, tpl.curr_goal)
+            done = bool(tpl.check_task_success(seen))
+            log.append((tpl.task, tpl.stage, tuple(tpl.curr_goal.float().cpu().tolist()), tuple(tpl.ee_state.float().cpu().tolist()),
+                        tuple(obj.goal_list()), done))
+            if done:
+                break
+            a = mp.command(sim._dof_state[0])[0]
+            real.set_dof_velocity_target_tensor(a.view(1, 9))
+            real.step()
+        return log, real._dof_state.cpu().clone(), real._root_state.cpu().clone(), sim
+
+    fast, dof_f, root_f, sim = episode(hide=False)
+    slow, dof_s, root_s, _ = episode(hide=True)
+    assert fast == slow
+    assert torch.equal(dof_f, dof_s) and torch.equal(root_f, root_s)
+    assert {"reach", "pick"} <= {t[0] for t in fast}
+    # one copy per world state
+    a = sim.env0_link_states_host()
+    assert sim.env0_link_states_host() is a
+    np.testing.assert_array_equal(a[sim.link_row("cubeA", "box"), :7], sim.get_actor_link_by_name("cubeA", "box")[0, :7].cpu().numpy())
+    sim.step()
+    b = sim.env0_link_states_host()
+    assert b is not a
+    sim.set_dof_state_tensor(sim._dof_state)
+    assert sim.env0_link_states_host() is not b

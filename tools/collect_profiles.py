@@ -52,6 +52,10 @@ cp("k_sweep_panda.json", "k_sweep_panda_T20.json")
 cp("panda_lps_bench.json", "panda_lps_bench.json")
 cp("pmc_final.txt", "pmc_rollout_push_K2000.txt")
 cp("pmc_panda.txt", "pmc_rollout_panda_K4000.txt")
+for f in ("panda_reach_mid_bench.json", "tamp_tick_profile.json", "behaviour_stats_baseline_n60.json", "behaviour_stats_default_size_n60.json",
+          "behaviour_stats_panda_n60.json", "soak_6000.txt", "rcp_ab.txt", "prcp_ab.txt"):    # (written by their own tools when run)
+    if os.path.exists(os.path.join(G, f)):
+        cp(f, f)
 
 tf = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tf)) if os.path.exists(tf) else {}
