@@ -925,10 +925,10 @@ extern "C" int m3_rollout(m3_handle* h) {
             h->panda_busy_hint_tried = true;
             void* p = nullptr;
             void* q = nullptr;
-            if (hipHostMalloc(&p, sizeof(int), hipHostMallocMapped) == hipSuccess && hipMalloc(&q, 2 * sizeof(unsigned)) == hipSuccess &&
-                hipMemsetAsync(q, 0, 2 * sizeof(unsigned), h->stream) == hipSuccess) {
+            if (hipHostMalloc(&p, sizeof(int), hipHostMallocMapped) == hipSuccess && hipMalloc(&q, sizeof(unsigned long long)) == hipSuccess &&
+                hipMemsetAsync(q, 0, sizeof(unsigned long long), h->stream) == hipSuccess) {
                 h->panda_busy_hint = (int*)p;
-                h->panda_busy_count = (unsigned*)q;
+                h->panda_busy_count = (unsigned long long*)q;
                 *h->panda_busy_hint = 0;
             } else {
                 (void)hipGetLastError();

@@ -266,7 +266,7 @@ struct PandaArgs {
     float* reach_rec;            // [T][REACH_REC][Kl] or null: the reach cost is formed after the rollout (k_panda_reach_cost), no shadow slots
     int* busy_hint;              // device address of the handle's hint word (host memory, mapped): 1 + the share, in 1/1000, of the
                                  // launch's (sample, substep) pairs with the gripper within reach of a box; written by the last wavefront
-    unsigned* busy_count;        // device scratch of that: [0] the sum so far, [1] wavefronts finished
+    unsigned long long* busy_count;   // device scratch of that: bits 0-23 wavefronts finished, bits 24-63 the sum so far
     int reach_busy;              // the host's reading of the last reports, with hysteresis: the reach command runs with 8 lanes per sample
 };
 int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa, const PandaScene& sc, hipStream_t s,
@@ -323,7 +323,7 @@ struct m3_handle {
     int lanes_override = 0;  // 0 = automatic (rollout_lanes_for)
     int* panda_busy_hint = nullptr;   // hipHostMalloc: see PandaArgs::busy_hint
     bool panda_busy_hint_tried = false;
-    unsigned* panda_busy_count = nullptr;
+    unsigned long long* panda_busy_count = nullptr;
     float* panda_reach_rec = nullptr;     // PandaArgs::reach_rec, allocated by the first reach rollout that can use it
     bool panda_reach_rec_tried = false;
     bool panda_reach_deferred = true;     // m3_set_panda_reach_cost_kernel

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
     // their cubes are read with v_readlane after each step.  They store nothing.  Cost: 64 / 63 (62) more wavefronts
     // (LPS = 16: 4 / 3, 4 / 2), no cross-wavefront synchronisation.
     constexpr int SPW = 64 / LPS;                       // sample slots per wavefront
+    const bool deferred = LPS != 1 && pa.reach_rec != nullptr;   // (the one-lane form keeps its shadow slots: launch_rollout_panda)
     const int slot = (int)threadIdx.x / LPS, gl = (int)threadIdx.x % LPS;
     const bool shadow = slot >= SPW - pa.shadows;
     const bool writer = !shadow && gl == 0;             // the lane that stores the sample's scalars
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         panda_step<FORCES, true, LPS>(sc, w, u, obs, cs, hp, &trav, &fkc);
 #endif
         float cube0[3], qh0[4];
-        if (pa.reach_rec != nullptr) {
+        if (deferred) {
             // the reach cost of this step is formed by k_panda_reach_cost (below) from what it reads of the sample -- and of
             // samples 0 and K / 2, whose cube it is measured against (quirk Q8): no shadow slots in this launch
             if (writer) {
@@ -228,11 +229,11 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) qh0[j] = w.A.q[j];
         }
-        const float c = (pa.reach_rec != nullptr) ? 0.0f : panda_cost(pa.cp, w, obs, k, cube0, qh0);
+        const float c = deferred ? 0.0f : panda_cost(pa.cp, w, obs, k, cube0, qh0);
         if (writer) {
             *reinterpret_cast<float4*>(a.states + ((size_t)t * Kl + i) * 4) =
                 make_float4(w.q[0], w.qd[0], w.q[1], w.qd[1]);                   // reactive_tamp.py:66-69
-            if (pa.reach_rec == nullptr) a.cost_h[(size_t)t * Kl + i] = c;
+            if (!deferred) a.cost_h[(size_t)t * Kl + i] = c;
         }
         if constexpr (LPS == 1) {
             if (!shadow) {
@@ -295,20 +296,21 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         }
     }
 #endif
-    if (pa.reach_rec == nullptr) {      // (else: k_panda_reach_cost writes the costs and leaves the minima behind)
+    if (!deferred) {      // (else: k_panda_reach_cost writes the costs and leaves the minima behind)
         if (writer) a.J[i] = (GENERAL && a.mode_simple) ? (S + pc) : J;
         if (a.wave_min) wave_min_store(a.wave_min, J, first_half, writer);
     }
     // What the NEXT reach commands' kernel form is chosen by (panda_lps_for): the share of (sample, substep) pairs of this launch
-    // in which the gripper was within reach of a box, in 1/1000.  Every wavefront adds its count; the last one to finish (a
-    // ticket) turns the sum into the share, stores it into a word of mapped host memory and clears the counters for the next
+    // in which the gripper was within reach of a box, in 1/1000.  Every wavefront adds its count; the last one to finish (the
+    // same atomic is its ticket) turns the sum into the share, stores it into a word of mapped host memory and clears the counters for the next
     // launch.  A hint: results do not depend on the form.
     if (pa.busy_hint != nullptr && threadIdx.x == 0) {
-        atomicAdd(pa.busy_count, (unsigned)(fkc.near_lane_substeps / LPS));
-        __threadfence();
-        if (atomicAdd(pa.busy_count + 1, 1u) == gridDim.x - 1u) {
-            const unsigned long long total = atomicExch(pa.busy_count, 0u);
-            pa.busy_count[1] = 0u;
+        // ONE atomic carries both: bits 0-23 wavefronts finished, bits 24-63 the sum of their counts
+        const unsigned long long mine = ((unsigned long long)(unsigned)(fkc.near_lane_substeps / LPS) << 24) | 1ull;
+        const unsigned long long old = atomicAdd(pa.busy_count, mine);
+        if ((old & 0xffffffull) == (unsigned long long)(gridDim.x - 1u)) {
+            const unsigned long long total = (old + mine) >> 24;
+            *pa.busy_count = 0ull;
             const unsigned long long all = (unsigned long long)Kl * (unsigned long long)(T * sc.substeps);
             *(volatile int*)pa.busy_hint = (int)((total * 1000ull) / (all ? all : 1ull)) + 1;    // (+ 1: 0 = nothing reported yet)
         }
