@@ -76,7 +76,9 @@ def test_bench_single_gpu_line_contract():
     assert "task=pick" in oc["panda_pick"]["workload"] and oc["panda_pick"]["roofline"]["bytes_per_launch"] == 92 * 4000 * 20
     # the corner scene is the slow end of the same kernel: >= the initial scene's time
     assert oc["worst_case_scene"]["kernel_ms"]["rollout"] > d["kernel_ms"]["rollout"]
-    assert d["closed_loop"]["ms_per_step"] > d["ms_per_step"] and d["closed_loop"]["final_pos_error_m"] < 0.5
+    # (a contract test, not a timing test: under `pytest -n 6` other tests' kernels share the GPU with this bench run, and a
+    # 40-command region of 5 ms has been seen to take 40 -- the closed loop is checked for what it did, not for how long it took)
+    assert d["closed_loop"]["ms_per_step"] > 0 and d["closed_loop"]["ticks"] == 200 and d["closed_loop"]["final_pos_error_m"] < 0.5
 
 
 def test_bench_starts_its_own_ranks():
