@@ -162,6 +162,26 @@ def panda_pick_scene(device):
     return cap
 
 
+def panda_reach_mid_scene(device, tick=40):
+    """The world `tick` ticks into the reach phase of the product's own closed loop (the pick starts at tick ~66): the gripper on
+    its way down to cubeA, rollouts next to the cube -- what most reach commands of an episode look like, unlike the first one."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import closed_loop
+    res = closed_loop.run("config_panda", ["mppi.num_samples=4000", "mppi.horizon=20", f"mppi.device={device}"],
+                          ticks=400, until_task="reach", extra_ticks=tick)
+    cap = res.get("captured")
+    if cap is None or cap.get("task") != "reach":
+        raise RuntimeError(f"no reach scene at tick {tick}: {res.get('timeline')}")
+
+    def scene(pl, sim, obj, cfg):
+        dev = sim._dof_state.device
+        sim._dof_state[:] = torch.tensor(cap["dof_state"], device=dev)
+        sim._root_state[:] = torch.tensor(cap["root_state"], device=dev)
+        sim.set_dof_state_tensor(sim._dof_state)
+        sim.set_actor_root_state_tensor(sim._root_state)
+    return scene
+
+
 def make_pick_scene(cap):
     def scene(pl, sim, obj, cfg):
         dev = sim._dof_state.device
@@ -659,17 +679,22 @@ def main():
             pick_scene = make_pick_scene(panda_pick_scene(device))
         except Exception as e:
             others["panda_pick"] = {"error": repr(e)}
+        mid_scene = None
+        try:
+            mid_scene = panda_reach_mid_scene(device)
+        except Exception as e:
+            others["panda_reach_mid"] = {"error": repr(e)}
         for oname, key, scene in (("northstar", "northstar", None), ("hybrid", "hybrid", None), ("panda", "panda", None),
-                                  ("panda", "panda_settled", settled_panda_scene),
+                                  ("panda", "panda_settled", settled_panda_scene), ("panda", "panda_reach_mid", mid_scene),
                                   ("panda_pick", "panda_pick", pick_scene), ("c5", "c5shard", None),
                                   ("c5_unsharded", "c5_unsharded", None), ("worst_case", "worst_case_scene", corner_scene),
                                   ("c1", "c1", None), ("refsize", "reference_default_size", None)):
-            if oname == name or (oname == "panda_pick" and pick_scene is None):
+            if oname == name or (oname == "panda_pick" and pick_scene is None) or (key == "panda_reach_mid" and mid_scene is None):
                 continue
             try:
                 ro = run_config(oname, args, 1, 0, device, None, max(200, min(args.steps, 400)), args.warmup, scene=scene,
                                 repeats=2)
-                others[key] = brief(ro, mix_name={"northstar": "northstar", "hybrid": "hybrid", "panda": "panda", "panda_settled": None,
+                others[key] = brief(ro, mix_name={"northstar": "northstar", "hybrid": "hybrid", "panda": "panda", "panda_settled": None, "panda_reach_mid": None,
                                                   "panda_pick": "panda_pick", "c5shard": "c5", "c5_unsharded": "c5_unsharded",
                                                   "worst_case_scene": "worst_case"}.get(key))
                 if oname == "hybrid":
@@ -680,6 +705,13 @@ def main():
                 if key == "panda_settled":
                     others[key]["workload"] += (" -- C4's reach phase once the cubes have landed and sleep (every command of an "
                                                 "episode but the first few)")
+                if key == "panda_reach_mid":
+                    e = ro["pl"]._engine
+                    others[key]["workload"] += (" -- C4's reach phase 40 ticks into the product's own closed loop (gripper on its way "
+                                                "down to the cube): the kernel form is chosen from the share of (sample, substep) pairs "
+                                                "the last rollout reported near a box")
+                    others[key]["lanes_per_sample_used"] = e.panda_lanes_per_sample_used()
+                    others[key]["near_share_permille"] = e.panda_near_share()
                 if oname == "panda_pick":
                     others[key]["workload"] += (" -- C4's pick phase: scene = 12 ticks into `pick` of the product's own closed "
                                                 "loop (cube held), gripper override close, k_rollout_panda<FORCES=true>")

@@ -67,12 +67,13 @@ def test_bench_single_gpu_line_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["reference_shaped"]["value"] > 0
-    assert set(d["other_configs"]) == {"northstar", "hybrid", "panda", "panda_settled", "panda_pick", "c5shard",
+    assert set(d["other_configs"]) == {"northstar", "hybrid", "panda", "panda_settled", "panda_reach_mid", "panda_pick", "c5shard",
                                        "c5_unsharded", "worst_case_scene", "c1", "reference_default_size"}
     assert all(v["value"] > 0 and v["scaling"] == "weak" and 0 < v["roofline"]["frac"] < 1
                for v in d["other_configs"].values()), d["other_configs"]
     oc = d["other_configs"]
     assert "K=64000" in oc["c5_unsharded"]["workload"] and "multi-modal" in oc["c5_unsharded"]["workload"]
+    assert oc["panda_reach_mid"]["lanes_per_sample_used"] == 16 and oc["panda_reach_mid"]["near_share_permille"] >= 260
     assert "task=pick" in oc["panda_pick"]["workload"] and oc["panda_pick"]["roofline"]["bytes_per_launch"] == 92 * 4000 * 20
     # the corner scene is the slow end of the same kernel: >= the initial scene's time
     assert oc["worst_case_scene"]["kernel_ms"]["rollout"] > d["kernel_ms"]["rollout"]
