@@ -113,7 +113,7 @@ class IsaacGymWrapper:
                                     self._net_contact_force)
         self._engine.sim_pull_state()
         self._engine.sim_push_state()
-        self._body_index_cache, self._rb_host, self._state_version = {}, None, 0
+        self._body_index_cache, self._actor_index_cache, self._rb_host, self._state_version = {}, {}, None, 0
         self._idx02 = torch.tensor([0, 2], device=dev)
         self._idx13 = torch.tensor([1, 3], device=dev)
         _LIVE.add(self)
@@ -128,7 +128,12 @@ class IsaacGymWrapper:
         return torch.index_select(self._dof_state, 1, self._idx13)
 
     def _get_actor_index_by_name(self, name: str):
-        return torch.tensor([a.name for a in self.env_cfg].index(name), device=self.device)
+        # (one index tensor per actor, made once: torch.tensor(..., device=) is a synchronous host-to-device copy, and the task
+        # planners look an actor up every tick)
+        t = self._actor_index_cache.get(name)
+        if t is None:
+            t = self._actor_index_cache[name] = torch.tensor([a.name for a in self.env_cfg].index(name), device=self.device)
+        return t
 
     def _get_actor_index_by_robot_index(self, robot_idx: int):
         return self.robot_indices[robot_idx]
