@@ -4,6 +4,7 @@
     python tools/closed_loop.py [-cn config_point|config_panda] [key=value ...] [--ticks N] [--json out]
     python tools/closed_loop.py --serve tcp://127.0.0.1:4242 [...]      planner process (reactive_tamp.py's role)
     python tools/closed_loop.py --connect tcp://127.0.0.1:4242 [...]    world process (sim.py's role), same overrides
+    (--torch-blobs on either side: its tensors through torch.save / torch.load instead of m3p2i_aip_amd/blobs.py's patched archives)
 
 e.g.  python tools/closed_loop.py task=push goal=[-1,-1] mppi.num_samples=2000 mppi.horizon=30
       python tools/closed_loop.py task=push_pull multi_modal=True mppi.num_samples=4000 mppi.horizon=30
@@ -259,6 +260,9 @@ def main(argv):
             connect_ep = next(it)
         elif a == "--trace":
             trace = True
+        elif a == "--torch-blobs":      # A/B: every tensor through torch.save / torch.load (m3p2i_aip_amd/blobs.py switched off)
+            from m3p2i_aip_amd import blobs
+            blobs.CODEC.enabled = False
         else:
             overrides.append(a)
     if serve_ep:
