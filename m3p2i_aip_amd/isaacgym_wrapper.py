@@ -234,6 +234,7 @@ class IsaacGymWrapper:
         if self.env_type == "point_env":
             d = 0.01 if forth else -0.01
             self._engine.sim_shift_actor(self._dyn_obs_row, d, d, 0.0)
+            self._state_version += 1
         else:
             self.set_actor_root_state_tensor(self._root_state)
 
