@@ -351,19 +351,20 @@ __global__ __launch_bounds__(64) void k_panda_reach_cost(const RolloutArgs a, co
     if (a.wave_min) wave_min_store(a.wave_min, J, first_half, mine);
 }
 
-// Lanes per sample, by what was measured at C4's size (profiles/r05/panda_lps_bench.json; K = 4000, T = 20):
-//   pick (no shadow slots, gripper + manifold rows in most wavefronts): 16 lanes 0.77 ms, 8 lanes 0.85, 1 lane 1.62 -- a wavefront
-//     is the union of what its samples do and its rows run across the lanes: sixteen while the launch has <= 1024 wavefronts
-//     (one per SIMD: the launch lasts as long as its slowest wavefront), eight up to there, else one;
-//   reach (quirk Q8: 1-2 of a wavefront's 4 / 8 sample slots are shadows): 1 lane 0.167 ms with the cubes asleep / 0.36 while
-//     they land, 8 lanes 0.201 / 0.346, 16 lanes two rounds of wavefronts -- nothing touches anything in a reach rollout, the
-//     time is the replicated part of the step, which more lanes per sample only repeat in more wavefronts: one lane.
+// Lanes per sample, by what was measured at C4's size (profiles/r05/panda_lps_bench.json, panda_reach_mid_bench.json; K = 4000,
+// T = 20):
+//   pick / place (no shadow slots, gripper + manifold rows in most wavefronts): 16 lanes 0.74 ms, 8 lanes 0.82, 1 lane 1.57 -- a
+//     wavefront is the union of what its samples do and its rows run across the lanes: sixteen while the launch has <= 1024
+//     wavefronts (one per SIMD: the launch lasts as long as its slowest wavefront), eight up to there, else one;
+//   reach (quirk Q8): with the arm away from everything nothing touches anything, the time is the replicated part of the step,
+//     which more lanes per sample only repeat in more wavefronts -- one lane with its shadow slots, 0.167 ms with the cubes asleep;
+//     once the rollouts are next to the cube (most of an episode's reach phase) the many-lane forms win by up to 2x: sixteen lanes
+//     WITHOUT shadow slots + k_panda_reach_cost where launch_rollout_panda has the record buffer, else eight lanes with them (sixteen
+//     would lose 1-2 of 4 sample slots and need two rounds of wavefronts).  pa.reach_busy says which (m3_api.hip).
 // Beyond 1024 wavefronts the launch is throughput-bound and the replicated work (16x / 8x more instructions per sample
-// outside the solver) decides: one lane.  pa.lps / M3P2I_PANDA_LPS force a form.
+// outside the solver) decides: one lane.  pa.lps (m3_set_panda_lanes_per_sample) forces a form.
 static int panda_lps_for(const RolloutArgs& a, const PandaArgs& pa) {
     if (pa.lps == 1 || pa.lps == 8 || pa.lps == 16) return pa.lps;
-    static const int env = [] { const char* e = getenv("M3P2I_PANDA_LPS"); return e ? atoi(e) : 0; }();
-    if (env == 1 || env == 8 || env == 16) return env;
     auto waves = [&](int lps) { const int per = 64 / lps - pa.shadows; return (a.Kl + per - 1) / per; };
     if (pa.shadows != 0) {
         // reach: one lane while next to nothing is near anything; eight lanes (one round of wavefronts with the shadow slots) once

@@ -22,8 +22,6 @@ def main():
     for name, key, scene in (("panda", "reach, initial scene", None), ("panda", "reach, cubes settled", bench.settled_panda_scene),
                              ("panda_pick", "pick", pick)):
         for lps in (1, 8, 16):
-            os.environ["M3P2I_PANDA_LPS_FORCE"] = str(lps)
-
             def sc(pl, sim, obj, cfg, scene=scene, lps=lps):
                 if scene is not None:
                     scene(pl, sim, obj, cfg)
