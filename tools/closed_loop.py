@@ -82,8 +82,10 @@ class Tamp:
         return torch_to_bytes(self.motion_planner.top_trajs)
 
     def status(self):
+        g = self.task_planner.curr_goal
+        host = getattr(g, "_m3_host", None)      # (a goal the task planner made from host values carries them: no read-back)
         return {"task": self.task_planner.task, "success": bool(self.task_success),
-                "goal": [float(x) for x in self.task_planner.curr_goal.float().cpu().reshape(-1).tolist()]}
+                "goal": list(host) if host is not None else [float(x) for x in g.float().cpu().reshape(-1).tolist()]}
 
     def close(self):
         self.sim.stop_sim()
