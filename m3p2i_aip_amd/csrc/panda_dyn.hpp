@@ -969,7 +969,7 @@ template <int LPS> struct FkCarry {
     bool valid;
     Frame hand;
     float Jv[3], Jw[3];
-    int near_lane_substeps; // sum over the substeps so far of the lanes whose gripper was within reach of a box (wave-uniform)
+    int near_lane_substeps; // sum over the substeps so far of the lanes whose gripper was within reach of a box or whose cubes were awake (wave-uniform)
 };
 // the friction rows' clamp to +-mx (mx >= 0, no NaN): one v_med3_f32 or a max / min pair -- the same value; which one is the
 // faster instruction stream was measured per kernel form (pick, K = 4000: one lane 1.67 -> 1.59 ms and eight lanes 0.833 ->
@@ -1052,7 +1052,10 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                             box_d2(w.obs_p, sc.obs_half) < reach * reach;
             const unsigned long long nrm = __builtin_amdgcn_ballot_w64(nr);
             near = nrm != 0ull;
-            if constexpr (CARRY) fkc->near_lane_substeps += __builtin_popcountll(nrm);
+            // (what the choice of the next reach command's kernel form reads, rollout_panda.hip: lanes with the gripper within reach
+            // of a box or with an awake cube -- the substeps that have rows to solve or detection to run)
+            if constexpr (CARRY)
+                fkc->near_lane_substeps += __builtin_popcountll(__builtin_amdgcn_ballot_w64(nr || (!held && w.awake[0] != 0.0f) || w.awake[1] != 0.0f));
         }
 #ifdef M3_PABL_NO_NEAR      // (ablations for tools/time_variants_bench.sh: they change results)
         near = false;

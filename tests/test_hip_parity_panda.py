@@ -326,10 +326,15 @@ def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle, cost_kernel):
         eng.set_panda_lanes_per_sample(lps)
         eng.set_panda_reach_cost_kernel(cost_kernel)
         return eng
-    # the initial scene, arm up: few pairs near anything -> one lane, command after command
+    # arm up, the cubes at rest on the table (the initial scene after its cubes have landed): few pairs near anything, no cube
+    # awake -> one lane, command after command
+    rest = P.init_world(1)
+    for _ in range(30):
+        P.step_batch(sc, rest, np.zeros((1, 9), np.float32))
+    rest = rest[0].copy()
     far = engine(0)
     assert far.panda_near_share() == -1
-    far.set_world_panda_raw(raw31(P, P.init_world(1)[0]))
+    far.set_world_panda_raw(raw31(P, rest))
     used, shares = [], []
     for _ in range(4):
         far.command(sync_host=True)
@@ -349,13 +354,18 @@ def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle, cost_kernel):
         for buf in (L.BUF_TRAJ_COST, L.BUF_MEAN):
             assert torch.equal(auto.buffer(buf), one.buffer(buf))
     assert used == [1, many, many, many] and auto.panda_near_share() >= 300, (used, auto.panda_near_share())
-    # back in the initial scene: one lane again from the command after the first report from there
+    # back with the arm up and the cubes at rest: one lane again from the command after the first report from there
     used = []
     for _ in range(3):
-        auto.set_world_panda_raw(raw31(P, P.init_world(1)[0]))
+        auto.set_world_panda_raw(raw31(P, rest))
         auto.command(sync_host=True)
         used.append(auto.panda_lanes_per_sample_used())
     assert used == [many, 1, 1], used
+    # the configured initial scene, whose cubes start 1 cm above the table and land: awake cubes count like a near gripper
+    for _ in range(2):
+        auto.set_world_panda_raw(raw31(P, P.init_world(1)[0]))
+        auto.command(sync_host=True)
+    assert auto.panda_lanes_per_sample_used() == many and auto.panda_near_share() >= 260
 
 
 @pytest.mark.gpu
