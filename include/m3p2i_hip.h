@@ -245,7 +245,8 @@ int m3_set_rollout_lanes(m3_handle* h, int lanes);
  * 16 (the lanes of a DPP row share a sample: the contact solver's joint-space rows run across them; eight / four sample
  * slots per wavefront), 0 = automatic: by size (16 while the launch has no more wavefronts than the chip has SIMDs, then 8,
  * then 1) and, for the reach task (whose wavefronts give 1-2 slots to quirk Q8's shadow samples), by what the last
- * commands' rollouts met -- 1 while no gripper came within reach of a box, 8 since one did.  Same results, bit for bit
+ * commands' rollouts met -- 1 while few of them had the gripper within reach of a box or an awake cube, 16 (with the reach cost
+ * kernel, below) or 8 once many did.  Same results, bit for bit
  * (world spec v3 defines the rows' sums as the pairwise tree all forms evaluate).  DESIGN.md section 6. */
 int m3_set_panda_lanes_per_sample(m3_handle* h, int lanes_per_sample);
 /* panda_env, reach task on an unsharded handle (quirk Q8: every rollout's cost is measured against environment 0's cube):
@@ -257,8 +258,8 @@ int m3_set_panda_reach_cost_kernel(m3_handle* h, int on);
 /* the form the last panda rollout ran in (1, 8, 16; 0 before the first) */
 int m3_panda_lanes_per_sample_used(m3_handle* h);
 /* what the automatic choice for reach reads: the share, in 1/1000, of the last FINISHED panda rollout launch's (sample,
- * substep) pairs in which the gripper was within reach of a box (the kernel's last wavefront reports it into mapped host
- * memory; no synchronisation); -1 before the first report */
+ * substep) pairs in which the gripper was within reach of a box or a cube was awake (the kernel's last wavefront reports
+ * it into mapped host memory; no synchronisation); -1 before the first report */
 int m3_panda_near_share(m3_handle* h);
 /* launch structure of the unsharded multi-modal update with K beyond the one-launch kernel's range: 0 (default) = three
  * launches (ladder + search in one grid, weights + sums, combine), 5 = the five launches of round 3 (minima, ladder,

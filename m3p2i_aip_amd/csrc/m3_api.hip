@@ -918,9 +918,10 @@ extern "C" int m3_rollout(m3_handle* h) {
             pa.reach_rec = h->panda_reach_rec;
         }
         // the reach command's kernel form follows what the last command's rollouts met (rollout_panda.hip: panda_lps_for): the
-        // kernel's last wavefront reports the share of (sample, substep) pairs with the gripper within reach of a box into a word
-        // of mapped host memory, read here without a synchronisation (so it is the report of the last FINISHED command); eight
-        // lanes per sample from PANDA_BUSY_ON per mille, one lane again below PANDA_BUSY_OFF.  No word, no adaptation.
+        // kernel's last wavefront reports the share of (sample, substep) pairs with the gripper within reach of a box or an awake
+        // cube into a word of mapped host memory, read here without a synchronisation (so it is the report of the last FINISHED
+        // command); a many-lane form from PANDA_BUSY_ON(_REC) per mille, one lane again below PANDA_BUSY_OFF(_REC).  No word, no
+        // adaptation.
         if (h->panda_busy_hint == nullptr && !h->panda_busy_hint_tried) {
             h->panda_busy_hint_tried = true;
             void* p = nullptr;

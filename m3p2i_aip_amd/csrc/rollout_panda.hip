@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
         if (a.wave_min) wave_min_store(a.wave_min, J, first_half, writer);
     }
     // What the NEXT reach commands' kernel form is chosen by (panda_lps_for): the share of (sample, substep) pairs of this launch
-    // in which the gripper was within reach of a box, in 1/1000.  Every wavefront adds its count; the last one to finish (the
+    // in which the gripper was within reach of a box or a cube was awake, in 1/1000.  Every wavefront adds its count; the last one to finish (the
     // same atomic is its ticket) turns the sum into the share, stores it into a word of mapped host memory and clears the counters for the next
     // launch.  A hint: results do not depend on the form.
     if (pa.busy_hint != nullptr && threadIdx.x == 0) {
