@@ -28,6 +28,9 @@ TRAFFIC_KEY=c5:K8000:T30 tools/profile_gpu.sh c5 --config c5 --no-extras > $O/pr
 TRAFFIC_KEY=c5_unsharded:K64000:T30 tools/profile_gpu.sh c5_unsharded --config c5_unsharded --no-extras > $O/prof_c5_unsharded.log 2>&1
 TRAFFIC_KEY=worst_case:K2000:T30 tools/profile_gpu.sh worst_case --config worst_case --no-extras > $O/prof_worst_case.log 2>&1
 cd $ROOT
+# ESSENTIAL=1: only what is keyed by m3_build_id (mixes, bench lines, kernel stats, PMC traffic) -- enough after a change that
+# leaves the trajectories alone
+if [ -n "$ESSENTIAL" ]; then echo done-essential; exit 0; fi
 python tools/k_sweep.py > $O/k_sweep.log 2>&1
 python tools/k_sweep.py 4000,16000,65536,262144 panda > $O/k_sweep_panda.log 2>&1
 python tools/panda_lps_bench.py --json $O/panda_lps_bench.json > $O/panda_lps_bench.log 2>&1
