@@ -17,6 +17,7 @@
 // so that the CPU oracle agrees bit-for-bit.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "spec_fma.hpp"
 
@@ -197,6 +198,11 @@ template <int LPS> struct Gen {
 template <int LPS> __device__ __forceinline__ int gen_lane() { return (LPS == 1) ? 0 : (int)(threadIdx.x & (unsigned)(LPS - 1)); }
 // the coordinate element e of this lane's Gen holds
 template <int LPS> __device__ __forceinline__ int gen_coord(int e) { return e * LPS + gen_lane<LPS>(); }
+#ifdef M3_PABL_DETECT_SHARE      // (experiment builds, tools/flag_variants.sh; not validated yet)
+constexpr bool DETECT_BY_QUADS = true;
+#else
+constexpr bool DETECT_BY_QUADS = false;
+#endif
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
@@ -419,14 +425,43 @@ __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, F
             }
         }
     };
-    float s, c;
-    trans(f, 0, 0, 0.333f); spec_sincos(q[0], s, c); rot_z(f, s, c); store(f); rec(0);
-    rot_xm(f); spec_sincos(q[1], s, c); rot_z(f, s, c); store(f); rec(1);
-    trans(f, 0, -0.316f, 0); rot_xp(f); spec_sincos(q[2], s, c); rot_z(f, s, c); store(f); rec(2);
-    trans(f, 0.0825f, 0, 0); rot_xp(f); spec_sincos(q[3], s, c); rot_z(f, s, c); store(f); rec(3);
-    trans(f, -0.0825f, 0.384f, 0); rot_xm(f); spec_sincos(q[4], s, c); rot_z(f, s, c); store(f); rec(4);
-    rot_xp(f); spec_sincos(q[5], s, c); rot_z(f, s, c); store(f); rec(5);
-    trans(f, 0.088f, 0, 0); rot_xp(f); spec_sincos(q[6], s, c); rot_z(f, s, c); store(f); rec(6);
+    // the seven joints' sines and cosines.  Sixteen lanes per sample: q is replicated over the sample's DPP row, so lane j
+    // (j < 7) forms joint j's pair alone and the row reads the seven pairs with row broadcasts -- one spec_sincos (~28 VALU)
+    // + 14 v_mov_dpp per lane instead of seven; the same function of the same argument: the same bits.  (Every caller is
+    // under a wave-uniform condition, and a sample's sixteen lanes are active together.)
+    float sj[7], cj[7];
+#ifndef M3_PABL_NO_FK_SHARE
+    if constexpr (LPS == 16) {
+        const int l = gen_lane<16>();
+        // (the operands pass through an identity quad_perm: a select between elements of the world's array would be compiled
+        // into ONE load through a selected offset -- with the whole world in scratch memory for it)
+        const float a0 = dpp_f<0xE4>(q[0]), a1 = dpp_f<0xE4>(q[1]), a2 = dpp_f<0xE4>(q[2]), a3 = dpp_f<0xE4>(q[3]),
+                    a4 = dpp_f<0xE4>(q[4]), a5 = dpp_f<0xE4>(q[5]), a6 = dpp_f<0xE4>(q[6]);
+        const float q01 = (l & 1) ? a1 : a0, q23 = (l & 1) ? a3 : a2, q45 = (l & 1) ? a5 : a4;
+        const float q03 = (l & 2) ? q23 : q01, q47 = (l & 2) ? a6 : q45;
+        const float ql = (l & 4) ? q47 : q03;          // lane l: q[l] (l < 7; lanes 7-15 form a pair nobody reads)
+        float s1, c1;
+        spec_sincos(ql, s1, c1);
+        sj[0] = dpp_f<0x150>(s1); cj[0] = dpp_f<0x150>(c1);      // (row_newbcast:j)
+        sj[1] = dpp_f<0x151>(s1); cj[1] = dpp_f<0x151>(c1);
+        sj[2] = dpp_f<0x152>(s1); cj[2] = dpp_f<0x152>(c1);
+        sj[3] = dpp_f<0x153>(s1); cj[3] = dpp_f<0x153>(c1);
+        sj[4] = dpp_f<0x154>(s1); cj[4] = dpp_f<0x154>(c1);
+        sj[5] = dpp_f<0x155>(s1); cj[5] = dpp_f<0x155>(c1);
+        sj[6] = dpp_f<0x156>(s1); cj[6] = dpp_f<0x156>(c1);
+    } else
+#endif
+    {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) spec_sincos(q[j], sj[j], cj[j]);
+    }
+    trans(f, 0, 0, 0.333f); rot_z(f, sj[0], cj[0]); store(f); rec(0);
+    rot_xm(f); rot_z(f, sj[1], cj[1]); store(f); rec(1);
+    trans(f, 0, -0.316f, 0); rot_xp(f); rot_z(f, sj[2], cj[2]); store(f); rec(2);
+    trans(f, 0.0825f, 0, 0); rot_xp(f); rot_z(f, sj[3], cj[3]); store(f); rec(3);
+    trans(f, -0.0825f, 0.384f, 0); rot_xm(f); rot_z(f, sj[4], cj[4]); store(f); rec(4);
+    rot_xp(f); rot_z(f, sj[5], cj[5]); store(f); rec(5);
+    trans(f, 0.088f, 0, 0); rot_xp(f); rot_z(f, sj[6], cj[6]); store(f); rec(6);
     trans(f, 0, 0, 0.107f); rot_z(f, -0.70710678118654752f, 0.70710678118654752f); store(f);
     hand = f;
     if constexpr (JAC) {
@@ -1132,6 +1167,53 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             for (int i = 0; i < 3; ++i) { bo.p[i] = w.obs_p[i]; bo.e[i] = sc.obs_half[i]; }
             bo.R = nullptr;
             float bgap[4];
+            if constexpr (LPS == 16 && DETECT_BY_QUADS) {
+                // Sixteen lanes per sample: the four collision spheres are tested by the four quads of the sample's DPP row
+                // (quad s = sphere s: one sphere against the near boxes instead of four) and every lane reads the four
+                // results -- target, gap, normal, contact point -- with row broadcasts of lanes 0, 4, 8, 12.  The same tests
+                // in the same order on the same values: the same bits.  (The centres pass through an identity quad_perm: see
+                // panda_fk.)
+                const int sq = gen_lane<16>() >> 2;
+                float cs[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float c0 = dpp_f<0xE4>(g.c[0][i]), c1 = dpp_f<0xE4>(g.c[1][i]), c2 = dpp_f<0xE4>(g.c[2][i]), c3 = dpp_f<0xE4>(g.c[3][i]);
+                    const float c01 = (sq & 1) ? c1 : c0, c23 = (sq & 1) ? c3 : c2;
+                    cs[i] = (sq & 2) ? c23 : c01;
+                }
+                const float r = (sq < 2) ? sc.tip_r : (sq == 2) ? sc.hand_r : sc.cube_half;
+                float mgap = sc.contact_offset;
+                int mt = -1;
+                float bn[3] = {0.0f, 0.0f, 0.0f}, bx[3] = {0.0f, 0.0f, 0.0f};
+                if (!(sq == 3 && !held)) {
+                    auto take = [&](float gap, const float* n, const float* x, int t) __attribute__((always_inline)) {
+                        if (gap < mgap) { mgap = gap; mt = t; bn[0] = n[0]; bn[1] = n[1]; bn[2] = n[2]; bx[0] = x[0]; bx[1] = x[1]; bx[2] = x[2]; }
+                    };
+                    float n[3], x[3];
+                    if (nt) take(pt_box<false>(bt, cs, r, n, x), n, x, T_TABLE);
+                    if (ns) take(pt_box<false>(bs, cs, r, n, x), n, x, T_SHELF);
+                    if (nA && !(held || (sq < 2 && in_channel))) take(pt_box<true>(bA, cs, r, n, x), n, x, T_CUBEA);
+                    if (nB) take(pt_box<true>(bB, cs, r, n, x), n, x, T_CUBEB);
+                    if (no) take(pt_box<false>(bo, cs, r, n, x), n, x, T_OBS);
+                }
+                auto fetch = [&](auto ctrl, int s) __attribute__((always_inline)) {
+                    constexpr int C = decltype(ctrl)::value;
+                    RSlot& c = rs[s];
+                    c.target = __builtin_amdgcn_update_dpp(0, mt, C, 0xF, 0xF, false);
+                    bgap[s] = dpp_f<C>(mgap);
+                    const float n0 = dpp_f<C>(bn[0]), n1 = dpp_f<C>(bn[1]), n2 = dpp_f<C>(bn[2]);
+                    const float x0 = dpp_f<C>(bx[0]), x1 = dpp_f<C>(bx[1]), x2 = dpp_f<C>(bx[2]);
+                    if (s != 3 || held) {      // (a slot that is not tested keeps its zeros)
+                        c.d[0][0] = n0; c.d[0][1] = n1; c.d[0][2] = n2;
+                        c.rho[0] = x0 - g.hand.p[0]; c.rho[1] = x1 - g.hand.p[1]; c.rho[2] = x2 - g.hand.p[2];
+                        c.rt[0] = x0; c.rt[1] = x1; c.rt[2] = x2;
+                    }
+                };
+                fetch(std::integral_constant<int, 0x150>{}, 0);
+                fetch(std::integral_constant<int, 0x154>{}, 1);
+                fetch(std::integral_constant<int, 0x158>{}, 2);
+                fetch(std::integral_constant<int, 0x15C>{}, 3);
+            } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 RSlot& c = rs[s];
@@ -1151,6 +1233,7 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 if (no) take(pt_box<false>(bo, g.c[s], r, n, x), n, x, T_OBS);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { c.d[0][i] = bn[i]; c.rho[i] = bx[i] - g.hand.p[i]; c.rt[i] = bx[i]; }
+            }
             }
             const bool cand = rs[0].target >= 0 || rs[1].target >= 0 || rs[2].target >= 0 || rs[3].target >= 0;
             if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
