@@ -198,10 +198,10 @@ template <int LPS> struct Gen {
 template <int LPS> __device__ __forceinline__ int gen_lane() { return (LPS == 1) ? 0 : (int)(threadIdx.x & (unsigned)(LPS - 1)); }
 // the coordinate element e of this lane's Gen holds
 template <int LPS> __device__ __forceinline__ int gen_coord(int e) { return e * LPS + gen_lane<LPS>(); }
-#ifdef M3_PABL_DETECT_SHARE      // (experiment builds, tools/flag_variants.sh; not validated yet)
-constexpr bool DETECT_BY_QUADS = true;
-#else
+#ifdef M3_PABL_NO_DETECT_SHARE      // (experiment builds, tools/flag_variants.sh)
 constexpr bool DETECT_BY_QUADS = false;
+#else
+constexpr bool DETECT_BY_QUADS = true;
 #endif
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
