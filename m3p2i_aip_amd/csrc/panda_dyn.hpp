@@ -769,7 +769,7 @@ struct Manifold {
     int made, up, down;  // contacts made; of them carrying the cube (n_z >= 0.99, gap < rest_gap) / carried by it
     bool centre_over;
 };
-template <bool ORIENTED>
+template <bool ORIENTED, int LPS = 1>
 __device__ __forceinline__ void manifold_detect(const PandaScene& sc, const float* pb, const float* Rb, const BoxT<ORIENTED>& tgt,
                                                 Manifold& m, float (*X)[3], float* gap) {
     m.any = false; m.on = 0u; m.made = 0; m.up = 0; m.down = 0; m.centre_over = false;
@@ -810,9 +810,8 @@ __device__ __forceinline__ void manifold_detect(const PandaScene& sc, const floa
     tangents(m.n, m.t1, m.t2);
     const float e_p = sel(tgt.e, pref), e_1 = sel(tgt.e, a1), e_2 = sel(tgt.e, a2);
     const float m1 = sel(nml, a1), m2 = sel(nml, a2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float s1 = (j & 1) ? e : -e, s2 = (j & 2) ? e : -e, sf = sgn * e;
+    const float sf = sgn * e;
+    auto corner = [&](float s1, float s2, float& gp, float* Xo) __attribute__((always_inline)) {
         // cl[f] = sf, cl[(f + 1) % 3] = s1, cl[(f + 2) % 3] = s2
         const float cl[3] = {pick3(f, sf, s2, s1), pick3(f, s1, sf, s2), pick3(f, s2, s1, sf)};
         float xw[3], lc[3], lq[3], qw[3];
@@ -825,11 +824,9 @@ __device__ __forceinline__ void manifold_detect(const PandaScene& sc, const floa
         const float q2 = fminf(fmaxf(lc2, -e_2), e_2);
         const float d1 = q1 - lc1, d2_ = q2 - lc2;
         const bool moved = (d1 != 0.0f) || (d2_ != 0.0f);
-        float gp;
         if (moved && !clip) gp = 1.0f;
         else if (moved) gp = hgt - mad(m1, d1, m2 * d2_) * rz;
         else gp = hgt;
-        gap[j] = gp;
         const float fp = side * e_p;
         // lq[a1] = q1, lq[a2] = q2, lq[pref] = fp
         lq[0] = (pref == 0) ? fp : (a1 == 0) ? q1 : q2;
@@ -837,7 +834,25 @@ __device__ __forceinline__ void manifold_detect(const PandaScene& sc, const floa
         lq[2] = (pref == 2) ? fp : (a1 == 2) ? q1 : q2;
         tgt.world(lq, qw);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) X[j][k] = tgt.p[k] + qw[k];
+        for (int k = 0; k < 3; ++k) Xo[k] = tgt.p[k] + qw[k];
+    };
+    if constexpr (LPS == 16 && DETECT_BY_QUADS) {
+        // sixteen lanes per sample: quad j of the sample's DPP row forms corner j, the row reads the four (gap, point)
+        // with row broadcasts of lanes 0 / 4 / 8 / 12 (every caller's condition is the same in a sample's sixteen lanes)
+        const int jq = gen_lane<16>() >> 2;
+        float gq, Xq[3];
+        corner((jq & 1) ? e : -e, (jq & 2) ? e : -e, gq, Xq);
+        gap[0] = dpp_f<0x150>(gq); X[0][0] = dpp_f<0x150>(Xq[0]); X[0][1] = dpp_f<0x150>(Xq[1]); X[0][2] = dpp_f<0x150>(Xq[2]);
+        gap[1] = dpp_f<0x154>(gq); X[1][0] = dpp_f<0x154>(Xq[0]); X[1][1] = dpp_f<0x154>(Xq[1]); X[1][2] = dpp_f<0x154>(Xq[2]);
+        gap[2] = dpp_f<0x158>(gq); X[2][0] = dpp_f<0x158>(Xq[0]); X[2][1] = dpp_f<0x158>(Xq[1]); X[2][2] = dpp_f<0x158>(Xq[2]);
+        gap[3] = dpp_f<0x15C>(gq); X[3][0] = dpp_f<0x15C>(Xq[0]); X[3][1] = dpp_f<0x15C>(Xq[1]); X[3][2] = dpp_f<0x15C>(Xq[2]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) corner((j & 1) ? e : -e, (j & 2) ? e : -e, gap[j], X[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float gp = gap[j];
         if (gp < sc.contact_offset) {
             m.on |= 1u << j;
             ++m.made;
@@ -1396,16 +1411,16 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
             float X[4][3], gap[4];
             if (actA) {
                 tA = nearer_is_table(sc, w.A.p);
-                manifold_detect<false>(sc, w.A.p, RA, box_static(tA ? sc.table : sc.shelf), mA, X, gap);
+                manifold_detect<false, LPS>(sc, w.A.p, RA, box_static(tA ? sc.table : sc.shelf), mA, X, gap);
                 prepare(BK_A, mA, X, gap, w.A.p, nullptr);
             }
             if (actA && actB) {
-                manifold_detect<true>(sc, w.A.p, RA, box_cube(sc, w.B.p, RB), mAB, X, gap);
+                manifold_detect<true, LPS>(sc, w.A.p, RA, box_cube(sc, w.B.p, RB), mAB, X, gap);
                 prepare(BK_AB, mAB, X, gap, w.A.p, w.B.p);
             }
             if (actB) {
                 tB = nearer_is_table(sc, w.B.p);
-                manifold_detect<false>(sc, w.B.p, RB, box_static(tB ? sc.table : sc.shelf), mB, X, gap);
+                manifold_detect<false, LPS>(sc, w.B.p, RB, box_static(tB ? sc.table : sc.shelf), mB, X, gap);
                 prepare(BK_B, mB, X, gap, w.B.p, nullptr);
             }
         }
