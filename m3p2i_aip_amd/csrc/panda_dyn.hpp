@@ -198,10 +198,16 @@ template <int LPS> struct Gen {
 template <int LPS> __device__ __forceinline__ int gen_lane() { return (LPS == 1) ? 0 : (int)(threadIdx.x & (unsigned)(LPS - 1)); }
 // the coordinate element e of this lane's Gen holds
 template <int LPS> __device__ __forceinline__ int gen_coord(int e) { return e * LPS + gen_lane<LPS>(); }
-#ifdef M3_PABL_NO_DETECT_SHARE      // (experiment builds, tools/flag_variants.sh)
-constexpr bool DETECT_BY_QUADS = false;
+// what the sixteen lanes of a sample share instead of repeating (experiment builds switch them off: tools/flag_variants.sh)
+#ifdef M3_PABL_NO_DETECT_SHARE
+constexpr bool DETECT_BY_QUADS = false;     // the gripper's four spheres / a manifold's four corners: one per quad of the DPP row
 #else
 constexpr bool DETECT_BY_QUADS = true;
+#endif
+#ifdef M3_PABL_NO_FK_SHARE
+constexpr bool SINCOS_BY_LANES = false;     // the seven joints' sines and cosines: lane j forms joint j's
+#else
+constexpr bool SINCOS_BY_LANES = true;
 #endif
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
@@ -430,8 +436,7 @@ __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, F
     // + 14 v_mov_dpp per lane instead of seven; the same function of the same argument: the same bits.  (Every caller is
     // under a wave-uniform condition, and a sample's sixteen lanes are active together.)
     float sj[7], cj[7];
-#ifndef M3_PABL_NO_FK_SHARE
-    if constexpr (LPS == 16) {
+    if constexpr (LPS == 16 && SINCOS_BY_LANES) {
         const int l = gen_lane<16>();
         // (the operands pass through an identity quad_perm: a select between elements of the world's array would be compiled
         // into ONE load through a selected offset -- with the whole world in scratch memory for it)
@@ -449,9 +454,7 @@ __device__ __forceinline__ void panda_fk(const PandaScene& sc, const float* q, F
         sj[4] = dpp_f<0x154>(s1); cj[4] = dpp_f<0x154>(c1);
         sj[5] = dpp_f<0x155>(s1); cj[5] = dpp_f<0x155>(c1);
         sj[6] = dpp_f<0x156>(s1); cj[6] = dpp_f<0x156>(c1);
-    } else
-#endif
-    {
+    } else {
 #pragma unroll
         for (int j = 0; j < 7; ++j) spec_sincos(q[j], sj[j], cj[j]);
     }
@@ -1189,12 +1192,12 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                 // in the same order on the same values: the same bits.  (The centres pass through an identity quad_perm: see
                 // panda_fk.)
                 const int sq = gen_lane<16>() >> 2;
-                float cs[3];
+                float ctr[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const float c0 = dpp_f<0xE4>(g.c[0][i]), c1 = dpp_f<0xE4>(g.c[1][i]), c2 = dpp_f<0xE4>(g.c[2][i]), c3 = dpp_f<0xE4>(g.c[3][i]);
                     const float c01 = (sq & 1) ? c1 : c0, c23 = (sq & 1) ? c3 : c2;
-                    cs[i] = (sq & 2) ? c23 : c01;
+                    ctr[i] = (sq & 2) ? c23 : c01;
                 }
                 const float r = (sq < 2) ? sc.tip_r : (sq == 2) ? sc.hand_r : sc.cube_half;
                 float mgap = sc.contact_offset;
@@ -1205,11 +1208,11 @@ __device__ __forceinline__ void panda_step(const PandaScene& sc, PandaWorld& w, 
                         if (gap < mgap) { mgap = gap; mt = t; bn[0] = n[0]; bn[1] = n[1]; bn[2] = n[2]; bx[0] = x[0]; bx[1] = x[1]; bx[2] = x[2]; }
                     };
                     float n[3], x[3];
-                    if (nt) take(pt_box<false>(bt, cs, r, n, x), n, x, T_TABLE);
-                    if (ns) take(pt_box<false>(bs, cs, r, n, x), n, x, T_SHELF);
-                    if (nA && !(held || (sq < 2 && in_channel))) take(pt_box<true>(bA, cs, r, n, x), n, x, T_CUBEA);
-                    if (nB) take(pt_box<true>(bB, cs, r, n, x), n, x, T_CUBEB);
-                    if (no) take(pt_box<false>(bo, cs, r, n, x), n, x, T_OBS);
+                    if (nt) take(pt_box<false>(bt, ctr, r, n, x), n, x, T_TABLE);
+                    if (ns) take(pt_box<false>(bs, ctr, r, n, x), n, x, T_SHELF);
+                    if (nA && !(held || (sq < 2 && in_channel))) take(pt_box<true>(bA, ctr, r, n, x), n, x, T_CUBEA);
+                    if (nB) take(pt_box<true>(bB, ctr, r, n, x), n, x, T_CUBEB);
+                    if (no) take(pt_box<false>(bo, ctr, r, n, x), n, x, T_OBS);
                 }
                 auto fetch = [&](auto ctrl, int s) __attribute__((always_inline)) {
                     constexpr int C = decltype(ctrl)::value;
