@@ -52,7 +52,7 @@ extern "C" {
 
 #define M3_MAX_NU 9
 #define M3_TOPK 20
-#define M3_ABI_VERSION 3
+#define M3_ABI_VERSION 4
 
 typedef enum {
     M3_OK = 0,
@@ -271,6 +271,12 @@ int m3_set_update_launches(m3_handle* h, int launches);
  * direction of each sample's noise path (computed on the device whenever the noise is set, so that
  * a wavefront's samples meet the same obstacles), 0 = by index.  Results do not depend on it. */
 int m3_set_wave_order(m3_handle* h, int on);
+/* bound of the waits inside the multi-modal update's launches (k_update_small's column workgroups wait for each other's
+ * beta-ladder points, k_ladder_search's search workgroup for the ladder workgroups' flags; a wait that runs out -- other
+ * kernels occupying the CUs -- makes the waiting workgroup run the reference's iterative passes itself: same pass counts,
+ * same weights): -1 = default (2^18 polls, ~20 ms), 0 = never wait (every workgroup takes the give-up branch: the tests
+ * of that branch), n > 0 = n polls. */
+int m3_set_ladder_spins(m3_handle* h, int spins);
 /* Relabels the samples instead: the noise rows are permuted ONCE (by the next m3_rollout, which knows
  * the world) into that order, within each mode's half and with the rows of the special samples (0,
  * K/2, K-1) left in place, so that afterwards sample k simply has another row of the SAME noise set
@@ -421,6 +427,19 @@ int m3_p2p_wait_ch(m3_handle* h, int channel);
 int m3_p2p_exchange_b(m3_handle* h);
 int m3_p2p_status(m3_handle* h, int* missing_rank, int* memory_kind);
 int m3_p2p_set_timeout_ms(m3_handle* h, int first_ms, int ms);
+/* Recovery after a wait that gave up (sticky error word; the finalize kernels hand out NaN plans while it is set).
+ * m3_p2p_clear_error: synchronises the stream, zeroes the OWN block's flags and error word and restarts the sequence
+ * numbers -- a COLLECTIVE step: every rank calls it, with a barrier of the caller's (host side) before (nobody is still
+ * exchanging) and after (nobody puts into a block about to be zeroed); distributed.p2p_recover does exactly that.
+ * m3_p2p_connect / m3_p2p_connect_local on a connected handle re-arm the same way.
+ * m3_p2p_detach: this handle stops using the device-side exchange (blocks stay mapped): the finalize kernels no longer
+ * read the error word, the records come from M3_BUF_RECORDS_ALL again (an RCCL all-gather) -- distributed.detach_p2p. */
+int m3_p2p_clear_error(m3_handle* h);
+int m3_p2p_detach(m3_handle* h);
+/* where the exchange block's allocation chain starts: 1 (default) uncached device memory, 2 fine-grained, 3 plain
+ * device memory (fenced puts / waits); before the block exists (m3_p2p_export / connect), else M3_ERR_STATE.  For the
+ * tests of the fallback kinds; m3_p2p_status reports the kind the block ended on. */
+int m3_p2p_set_memory_kind(m3_handle* h, int first_kind);
 /* m3_update + m3_finalize for an UNSHARDED handle in as few launches as the sizes allow (what
  * m3_command does after its rollout): for a caller that fills TRAJ_COST / ACTIONS itself (step mode,
  * planner._command_step).  M3_ERR_STATE on a sharded handle (the collectives go in between). */

@@ -10,7 +10,7 @@ import os
 
 MAX_NU = 9
 TOPK = 20
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M3P2I_HIP_LIB") or os.path.join(_HERE, "lib", "libm3p2i_hip.so")
@@ -84,6 +84,7 @@ SYMBOLS = [
     ("m3_panda_near_share", C.c_int, [_H]),
     ("m3_set_panda_reach_cost_kernel", C.c_int, [_H, C.c_int]),
     ("m3_set_update_launches", C.c_int, [_H, C.c_int]),
+    ("m3_set_ladder_spins", C.c_int, [_H, C.c_int]),
     ("m3_set_wave_order", C.c_int, [_H, C.c_int]),
     ("m3_relabel_samples", C.c_int, [_H]),
     ("m3_set_noise", C.c_int, [_H, _FP, C.c_int]),
@@ -124,6 +125,9 @@ SYMBOLS = [
     ("m3_record_b_len", C.c_int, [_H]),
     ("m3_p2p_status", C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("m3_p2p_set_timeout_ms", C.c_int, [_H, C.c_int, C.c_int]),
+    ("m3_p2p_clear_error", C.c_int, [_H]),
+    ("m3_p2p_detach", C.c_int, [_H]),
+    ("m3_p2p_set_memory_kind", C.c_int, [_H, C.c_int]),
     ("m3_get_buffer", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_longlong)]),
     ("m3_reduce_len", C.c_int, [_H]),
     ("m3_record_len", C.c_int, [_H]),

@@ -26,6 +26,16 @@ POINT_TASKS = ("navigation", "push", "pull", "push_pull")
 PANDA_TASKS = ("reach", "pick", "place")
 
 
+def attached_host_values(t):
+    """The host values a tensor carries (`_m3_host`, attached by task_planner._device_tensor together with the tensor's
+    version counter at that moment) -- or None when it carries none or was written to in place since (`curr_goal[2] += dz`):
+    the caller then reads the tensor back."""
+    host = getattr(t, "_m3_host", None)
+    if host is None or getattr(t, "_m3_host_version", None) != t._version:
+        return None
+    return host
+
+
 class Objective(object):
     def __init__(self, cfg):
         self.cfg = cfg
@@ -48,7 +58,7 @@ class Objective(object):
         self.task = task
         if torch.is_tensor(goal):
             self.goal = goal
-            host = getattr(goal, "_m3_host", None)   # (a tensor made from host values that carries them: task_planner.py)
+            host = attached_host_values(goal)   # (a tensor made from host values that carries them: task_planner.py)
             if host is not None:
                 self._goal_host = (host, id(goal), goal._version)
         else:

@@ -95,6 +95,9 @@ static int alloc_buf(m3_handle* h, int id, long long bytes) {
     return M3_OK;
 }
 
+static constexpr int PANDA_BUSY_ON = 300, PANDA_BUSY_OFF = 220;
+static constexpr int PANDA_REACH_REC_MAX_K = 8192, PANDA_BUSY_ON_REC = 260, PANDA_BUSY_OFF_REC = 190;   // (the forms tie between 116 and ~250 per mille; the arm's initial pose reads 148)
+
 extern "C" int m3_create(const m3_config* c, m3_handle** out) {
     if (!c || !out) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: null argument");
     if (c->abi_version != M3_ABI_VERSION) return fail(nullptr, M3_ERR_BAD_ARG, "m3_create: abi_version mismatch");
@@ -275,6 +278,29 @@ extern "C" int m3_create(const m3_config* c, m3_handle** out) {
         if (rc == M3_OK && hipMalloc((void**)&h->lflag, nl * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
         if (rc == M3_OK && hipMemset(h->lflag, 0, nl * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     }
+    if (rc == M3_OK && c->env_type == M3_ENV_PANDA) {
+        // Everything a panda command may need is allocated HERE (no allocation in m3_command).  The word of
+        // mapped host memory the rollout's last wavefront reports its near share into + its counter; and, for a handle
+        // whose reach task takes quirk Q8's shadow slots (unsharded), the records between the rollout and
+        // k_panda_reach_cost ([T][17][K] floats: 5.4 MB at C4).
+        void* p = nullptr;
+        void* q = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&p, sizeof(int), hipHostMallocMapped) != hipSuccess || hipMalloc(&q, sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(q, 0, sizeof(unsigned long long)) != hipSuccess || hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
+            if (p) (void)hipHostFree(p);
+            if (q) (void)hipFree(q);
+            h->err = "m3_create: the panda rollout's report word (mapped host memory) could not be allocated";
+            rc = M3_ERR_HIP;
+        } else {
+            h->panda_busy_hint = (int*)p;
+            h->panda_busy_hint_dev = (int*)d;
+            h->panda_busy_count = (unsigned long long*)q;
+            *h->panda_busy_hint = 0;
+        }
+        if (rc == M3_OK && Kl == Kg && Kg >= 2 && Kl <= PANDA_REACH_REC_MAX_K &&
+            hipMalloc((void**)&h->panda_reach_rec, (size_t)T * REACH_REC * (size_t)Kl * f) != hipSuccess) rc = M3_ERR_HIP;
+    }
     if (rc == M3_OK && hipMalloc((void**)&h->wcount, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK && hipMemset(h->wcount, 0, (size_t)(T + 2) * sizeof(int)) != hipSuccess) rc = M3_ERR_HIP;
     if (rc == M3_OK) {
@@ -372,6 +398,13 @@ extern "C" int m3_set_update_launches(m3_handle* h, int launches) {
     if (!h) return M3_ERR_BAD_ARG;
     if (launches != 0 && launches != 3 && launches != 5) return fail(h, M3_ERR_BAD_ARG, "m3_set_update_launches: 0 (default), 3 or 5");
     h->five_launches = launches == 5;
+    return M3_OK;
+}
+
+extern "C" int m3_set_ladder_spins(m3_handle* h, int spins) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (spins < -1) return fail(h, M3_ERR_BAD_ARG, "m3_set_ladder_spins: -1 (default), 0 (never wait) or a positive bound");
+    h->ladder_spins = spins < 0 ? (1 << 18) : spins;
     return M3_OK;
 }
 
@@ -720,6 +753,8 @@ extern "C" int m3_set_beta(m3_handle* h, float beta) {
 extern "C" int m3_set_call_count(m3_handle* h, unsigned calls) {
     if (!h) return M3_ERR_BAD_ARG;
     h->calls = calls;
+    // (a rollout still in flight may be about to report into the word zeroed below)
+    if (h->panda_busy_hint) HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->panda_busy_hint) { *h->panda_busy_hint = 0; h->panda_reach_busy = 0; }
     return M3_OK;
 }
@@ -835,8 +870,6 @@ extern "C" int m3_bind_sim_panda(m3_handle* h, const float* dof, const float* ro
 // its initial pose 148 per mille 0.166 / 0.210, 20 ticks into an episode 116: 0.179 / 0.206, 30 ticks 442: 0.383 / 0.287, 40 ticks
 // 842: 0.784 / 0.450, 60 ticks 993: 1.530 / 0.831 -- the forms cross near 240; the eight-lane form's own count runs ~10 % higher,
 // its shadow slots included)
-static constexpr int PANDA_BUSY_ON = 300, PANDA_BUSY_OFF = 220;
-static constexpr int PANDA_REACH_REC_MAX_K = 8192, PANDA_BUSY_ON_REC = 260, PANDA_BUSY_OFF_REC = 190;   // (the forms tie between 116 and ~250 per mille; the arm's initial pose reads 148)
 
 extern "C" int m3_rollout(m3_handle* h) {
     if (!h) return M3_ERR_BAD_ARG;
@@ -907,41 +940,13 @@ extern "C" int m3_rollout(m3_handle* h) {
         // reach on a handle that would need shadow slots: with room for one round of wavefronts in a many-lane form (K <= 8192)
         // the cost moves into a kernel of its own behind the rollout (rollout_panda.hip: k_panda_reach_cost) -- 17 floats per
         // (step, sample) in between
-        pa.reach_rec = nullptr;
-        if (pa.shadows != 0 && a.Kl <= PANDA_REACH_REC_MAX_K && h->panda_reach_deferred) {
-            if (h->panda_reach_rec == nullptr && !h->panda_reach_rec_tried) {
-                h->panda_reach_rec_tried = true;
-                void* p = nullptr;
-                if (hipMalloc(&p, (size_t)a.T * REACH_REC * (size_t)a.Kl * sizeof(float)) == hipSuccess) h->panda_reach_rec = (float*)p;
-                else (void)hipGetLastError();
-            }
-            pa.reach_rec = h->panda_reach_rec;
-        }
+        pa.reach_rec = (pa.shadows != 0 && a.Kl <= PANDA_REACH_REC_MAX_K && h->panda_reach_deferred) ? h->panda_reach_rec : nullptr;
         // the reach command's kernel form follows what the last command's rollouts met (rollout_panda.hip: panda_lps_for): the
         // kernel's last wavefront reports the share of (sample, substep) pairs with the gripper within reach of a box or an awake
-        // cube into a word of mapped host memory, read here without a synchronisation (so it is the report of the last FINISHED
-        // command); a many-lane form from PANDA_BUSY_ON(_REC) per mille, one lane again below PANDA_BUSY_OFF(_REC).  No word, no
-        // adaptation.
-        if (h->panda_busy_hint == nullptr && !h->panda_busy_hint_tried) {
-            h->panda_busy_hint_tried = true;
-            void* p = nullptr;
-            void* q = nullptr;
-            if (hipHostMalloc(&p, sizeof(int), hipHostMallocMapped) == hipSuccess && hipMalloc(&q, sizeof(unsigned long long)) == hipSuccess &&
-                hipMemsetAsync(q, 0, sizeof(unsigned long long), h->stream) == hipSuccess) {
-                h->panda_busy_hint = (int*)p;
-                h->panda_busy_count = (unsigned long long*)q;
-                *h->panda_busy_hint = 0;
-            } else {
-                (void)hipGetLastError();
-                if (p) (void)hipHostFree(p);
-                if (q) (void)hipFree(q);
-            }
-        }
-        pa.busy_hint = nullptr; pa.busy_count = h->panda_busy_count; pa.reach_busy = 0;
+        // cube into a word of mapped host memory (m3_create), read here without a synchronisation (so it is the report of the
+        // last FINISHED command); a many-lane form from PANDA_BUSY_ON(_REC) per mille, one lane again below PANDA_BUSY_OFF(_REC).
+        pa.busy_hint = h->panda_busy_hint_dev; pa.busy_count = h->panda_busy_count; pa.reach_busy = 0;
         if (h->panda_busy_hint) {
-            void* d = nullptr;
-            if (hipHostGetDevicePointer(&d, h->panda_busy_hint, 0) == hipSuccess) pa.busy_hint = (int*)d;
-            else (void)hipGetLastError();
             const int share = *(volatile const int*)h->panda_busy_hint - 1;    // (-1: nothing reported yet)
             // (with the cost kernel available the many-lane form has no shadow slots and takes over earlier)
             const int on = pa.reach_rec ? PANDA_BUSY_ON_REC : PANDA_BUSY_ON, off = pa.reach_rec ? PANDA_BUSY_OFF_REC : PANDA_BUSY_OFF;
@@ -965,6 +970,7 @@ static void fill_update_args(m3_handle* h, UpdateArgs& a) {
     a.filter_u = c.filter_u; a.u_per_command = c.u_per_command;
     a.lambda_ = c.lambda_; a.step_size_mean = c.step_size_mean;
     a.cand = h->topk_cand;
+    a.ladder_spins = h->ladder_spins;
     a.p2p_err = (h->p2p_ready && h->xb) ? (const int*)((const char*)h->xb + 2 * MIX_MAX_RANKS * sizeof(int)) : nullptr;
     a.part_min = h->part_min;
     a.n_cand = topk_workgroups(c.K_global);
@@ -1089,8 +1095,7 @@ static int update_impl(m3_handle* h, bool fuse) {
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
         return M3_OK;
     }
-    static const bool five_launches = getenv("M3P2I_UPDATE_FIVE_LAUNCHES") != nullptr;   // (A/B, tests: the round-3 path)
-    if (fuse && h->lflag && c.multi_modal && !c.mode_simple && !five_launches && !h->five_launches) {
+    if (fuse && h->lflag && c.multi_modal && !c.mode_simple && !h->five_launches) {   // (m3_set_update_launches(h, 5): the round-3 path)
         // three launches (update.hip: k_ladder_search): the minima are the rows the rollout's workgroups left behind
         // when the costs are this command's rollout's, k_mins' rows otherwise (costs written by the caller)
         if (h->use_wave_min) { a.part_min = h->wave_min; a.n_mins = h->wave_min_rows; }
@@ -1228,9 +1233,8 @@ static int p2p_alloc(m3_handle* h) {
     const size_t rl = (size_t)m3_record_len(h), rlb = (size_t)m3_record_b_len(h);
     h->xb_bytes = P2P_HDR_BYTES + 2 * (size_t)p2p_ranks(h) * (((rl + 3) & ~(size_t)3) + ((rlb + 3) & ~(size_t)3)) * sizeof(float);
     // uncached: neither the peers' stores nor the owner's loads may be served from a stale L2 line
-    // (M3P2I_P2P_MEMORY = finegrained | plain: start further down the fallback chain -- the tests of the fenced paths)
-    const char* force = std::getenv("M3P2I_P2P_MEMORY");
-    const int first = !force ? 1 : (std::strcmp(force, "finegrained") == 0 ? 2 : std::strcmp(force, "plain") == 0 ? 3 : 1);
+    // (m3_p2p_set_memory_kind: start further down the fallback chain -- the tests of the fenced paths)
+    const int first = h->xb_first_kind;
     if (first <= 1 && hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocUncached) == hipSuccess) h->xb_kind = 1;
     else if ((void)hipGetLastError(), first <= 2 && hipExtMallocWithFlags(&h->xb, h->xb_bytes, hipDeviceMallocFinegrained) == hipSuccess) h->xb_kind = 2;
     else if ((void)hipGetLastError(), hipMalloc(&h->xb, h->xb_bytes) == hipSuccess) h->xb_kind = 3;
@@ -1257,8 +1261,38 @@ extern "C" int m3_p2p_export(m3_handle* h, m3_ipc_handle* out) {
 static int p2p_finish_connect(m3_handle* h) {
     for (int p = 0; p < p2p_ranks(h); ++p)
         if (!h->peer_base[p]) return fail(h, M3_ERR_STATE, "m3_p2p_connect: a peer's block is missing");
+    // (re-)arm: own flags, error word and sequence numbers start from zero.  Collective by nature -- no peer may put
+    // between this and the barrier every caller of connect holds before its first exchange (distributed.attach_p2p).
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemset(h->xb, 0, P2P_HDR_BYTES));
+    HIPCHK(h, hipDeviceSynchronize());
     h->p2p_ready = true;
     h->p2p_seq[0] = h->p2p_seq[1] = 0;
+    h->records_src = nullptr; h->recb_src = nullptr;
+    return M3_OK;
+}
+
+extern "C" int m3_p2p_clear_error(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (!h->xb || !h->p2p_ready) return fail(h, M3_ERR_STATE, "m3_p2p_clear_error: no connected exchange block");
+    return p2p_finish_connect(h);
+}
+
+extern "C" int m3_p2p_detach(m3_handle* h) {
+    if (!h) return M3_ERR_BAD_ARG;
+    // the blocks stay mapped (m3_p2p_connect* re-arms them); the finalize kernels no longer read the error word, so a
+    // handle whose exchange gave up hands out plans again once its records come from another transport
+    if (h->xb) HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->p2p_ready = false;
+    h->records_src = nullptr; h->recb_src = nullptr;
+    return M3_OK;
+}
+
+extern "C" int m3_p2p_set_memory_kind(m3_handle* h, int first_kind) {
+    if (!h) return M3_ERR_BAD_ARG;
+    if (first_kind < 1 || first_kind > 3) return fail(h, M3_ERR_BAD_ARG, "m3_p2p_set_memory_kind: 1 uncached, 2 fine-grained, 3 plain");
+    if (h->xb) return fail(h, M3_ERR_STATE, "m3_p2p_set_memory_kind: the exchange block exists already (call before m3_p2p_export / connect)");
+    h->xb_first_kind = first_kind;
     return M3_OK;
 }
 

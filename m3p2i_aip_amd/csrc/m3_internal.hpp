@@ -321,11 +321,10 @@ struct m3_handle {
     int* local_top_idx = nullptr;  // regen: top_idx of the local pre-gather selection (scratch)
     unsigned calls = 0;
     int lanes_override = 0;  // 0 = automatic (rollout_lanes_for)
-    int* panda_busy_hint = nullptr;   // hipHostMalloc: see PandaArgs::busy_hint
-    bool panda_busy_hint_tried = false;
+    int* panda_busy_hint = nullptr;   // hipHostMalloc (m3_create, panda_env): see PandaArgs::busy_hint
+    int* panda_busy_hint_dev = nullptr;   // the same word as the device sees it
     unsigned long long* panda_busy_count = nullptr;
-    float* panda_reach_rec = nullptr;     // PandaArgs::reach_rec, allocated by the first reach rollout that can use it
-    bool panda_reach_rec_tried = false;
+    float* panda_reach_rec = nullptr;     // PandaArgs::reach_rec (m3_create: unsharded panda handles with K <= PANDA_REACH_REC_MAX_K)
     bool panda_reach_deferred = true;     // m3_set_panda_reach_cost_kernel
     int panda_reach_busy = 0;
     int panda_lps_used = 0;           // the form of the last panda rollout (m3_panda_lanes_per_sample_used)
@@ -348,6 +347,7 @@ struct m3_handle {
     int* lflag = nullptr;
     int lad_epoch = 0;
     bool five_launches = false;    // m3_set_update_launches(h, 5)
+    int ladder_spins = 1 << 18;    // bounded wait of the in-launch ladder exchange (~20 ms); m3_set_ladder_spins
     float* sim_world = nullptr;  // step mode SoA [NW][Kl]
     float* sim_u = nullptr;      // [Kl][nu]
     float* noise_stage = nullptr;
@@ -357,6 +357,7 @@ struct m3_handle {
     void* xb = nullptr;                 // own exchange block: header (flags, error word) + [2][n_ranks][rec_len]
     size_t xb_bytes = 0;
     int xb_kind = 0;                    // 1 uncached, 2 fine-grained, 3 plain device memory
+    int xb_first_kind = 1;              // where the allocation's fallback chain starts (m3_p2p_set_memory_kind)
     void* peer_base[m3::MIX_MAX_RANKS] = {};   // every rank's block as mapped here (own: xb)
     bool peer_ipc[m3::MIX_MAX_RANKS] = {};     // opened with hipIpcOpenMemHandle (closed in m3_destroy)
     bool p2p_ready = false;

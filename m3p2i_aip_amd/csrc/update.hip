@@ -455,9 +455,7 @@ __global__ __launch_bounds__(LS_T) void k_ladder_search(const UpdateArgs a) {
     search_body<true>(a, so, true, s_ok != 0, s_pre);
 }
 void launch_ladder_search(const UpdateArgs& a_, hipStream_t s) {
-    static const int spins = getenv("M3P2I_LADDER_SPINS") ? atoi(getenv("M3P2I_LADDER_SPINS")) : (1 << 18);
-    UpdateArgs a = a_;
-    a.ladder_spins = spins;
+    const UpdateArgs& a = a_;   // (a.ladder_spins: m3_set_ladder_spins)
     hipLaunchKernelGGL(k_ladder_search, dim3(a.n_lad + 1 + a.n_cand), dim3(LS_T), 0, s, a);
 }
 

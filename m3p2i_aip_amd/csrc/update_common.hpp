@@ -811,10 +811,17 @@ __device__ __forceinline__ void finalize_body(const UpdateArgs& a, float* sm /* 
     // A device-side exchange that gave up on a rank (p2p.hip: sticky error word, that rank's record filled with NaN): the plan
     // of this command is NaN -- handed out as such, so that nothing acts on a plan built from a part of the samples -- but the
     // warm-start state (means, best trajectories) is NOT overwritten with it: once the peer is back and the word is cleared
-    // the planner continues from its last good plan.  The host raises at its next poll (distributed.attach_p2p).
-    if (a.p2p_err && __hip_atomic_load(a.p2p_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
-        for (int o = tid; o < n; o += blockDim.x) a.action_out[o] = __builtin_nanf("");
-        return;
+    // (m3_p2p_clear_error, or m3_p2p_detach + another transport) the planner continues from its last good plan.  The host raises at its next poll (distributed.attach_p2p).
+    // (ONE load of the word per workgroup, shared through LDS: the word may change while the kernel runs -- a host
+    // clear, m3_p2p_clear_error -- and threads that read it on their own could part ways around the barriers below)
+    if (a.p2p_err) {
+        __shared__ int s_p2p_err;
+        if (tid == 0) s_p2p_err = __hip_atomic_load(a.p2p_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        if (s_p2p_err != 0) {
+            for (int o = tid; o < n; o += blockDim.x) a.action_out[o] = __builtin_nanf("");
+            return;
+        }
     }
     const bool multi = a.multi_modal && !a.mode_simple;
     const float* ps = a.reduce + reduce_off_psum(0, T, nu);

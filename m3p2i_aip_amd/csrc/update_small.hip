@@ -390,11 +390,9 @@ __global__ __launch_bounds__(WT) void k_update_small(const UpdateArgs a) {
     }
 }
 void launch_update_small(const UpdateArgs& a_, hipStream_t s) {
-    // bounded wait of the in-launch ladder exchange (~20 ms); M3P2I_LADDER_SPINS=0 makes every workgroup
-    // give up at once and run all its passes itself (tests/test_hip_edge_cases.py: same decisions)
-    static const int spins = getenv("M3P2I_LADDER_SPINS") ? atoi(getenv("M3P2I_LADDER_SPINS")) : (1 << 18);
+    // (a.ladder_spins: bounded wait of the in-launch ladder exchange, ~20 ms; m3_set_ladder_spins(h, 0) makes every
+    // workgroup give up at once and run all its passes itself -- tests/test_hip_edge_cases.py: same decisions)
     UpdateArgs a = a_;
-    a.ladder_spins = spins;
     const dim3 grid(a.T + a.n_cand);
     const size_t lds = (size_t)a.T * a.nu * sizeof(float);
     const bool multi = a.multi_modal && !a.mode_simple;
@@ -409,7 +407,11 @@ void launch_update_small(const UpdateArgs& a_, hipStream_t s) {
         // per-row loop of the kernel -- loads, ladder points, weights, sums -- halves; C3 24.2 -> 22.4 us, K = 8000
         // 33 -> 27.7 us).  Single mode measured no gain (panda -1 %) or a loss (C2: +10 us on the command although
         // the kernel itself is not slower -- the wider workgroups delay the next rollout's dispatch).
-        static const bool wide = getenv("M3P2I_UPDATE_WT256") == nullptr;   // (experiments: the 256-thread instances)
+#ifdef M3_EXP_UPDATE_WT256   // (experiment build: the 256-thread instances)
+        constexpr bool wide = false;
+#else
+        constexpr bool wide = true;
+#endif
         if (multi && wide && rows > 8) {   // 512 threads per workgroup, ONE top-k workgroup (32 rows of 256 costs)
             a.n_cand = 1;
             const dim3 grid1(a.T + 1);
@@ -427,8 +429,9 @@ void launch_update_small(const UpdateArgs& a_, hipStream_t s) {
 #undef M3_LAUNCH_SMALL
 }
 bool update_small_applies(const UpdateArgs& a) {
-    static const bool off = getenv("M3P2I_SPLIT_UPDATE") != nullptr;   // experiments: the multi-launch path
-    if (off) return false;
+#ifdef M3_EXP_SPLIT_UPDATE   // (experiment build: the multi-launch path at every size)
+    return false;
+#endif
     // unsharded (finalize fused in), or a shard_mix rank's local softmin (its costs ARE a.Jall)
     if (!(a.fuse_finalize || a.record) || (a.record && (a.multi_modal || a.fuse_finalize))) return false;
     // (with two controls: up to 64 register rows in single mode, K <= 16384, the north-star size; 32 in

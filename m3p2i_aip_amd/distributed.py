@@ -176,8 +176,25 @@ def attach_p2p(planner, group=None, poll_every=P2P_POLL_EVERY):
     return planner
 
 
+def p2p_recover(planner):
+    """Collective recovery after a wait that gave up (every rank calls it, e.g. from the handler of the RuntimeError that
+    `p2p_check` raised -- the ranks that did not time out see nothing wrong and must be told by the application): barrier
+    (nobody is still exchanging) -> every rank zeroes its own block's flags and error word and restarts its sequence
+    numbers (`m3_p2p_clear_error`) -> barrier (nobody puts into a block about to be zeroed).  The planners continue from
+    their last good plans: the finalize kernels never overwrote the warm-start state with the NaN plan."""
+    if getattr(planner, "transport", None) != "p2p":
+        raise RuntimeError("p2p_recover: the planner does not use the p2p transport")
+    group = getattr(planner, "_p2p_group", None)
+    dist.barrier(group=group)
+    planner._engine.p2p_clear_error()
+    dist.barrier(group=group)
+    return planner
+
+
 def detach_p2p(planner):
-    """Back to the RCCL collectives; reads the exchange's error word first (raises if a wait ever gave up)."""
+    """Back to the RCCL collectives; reads the exchange's error word first (raises if a wait ever gave up).  Either way the
+    handle stops reading the word (`m3_p2p_detach`): after the exception the planner hands out finite plans again over
+    RCCL, from its last good warm-start state."""
     chk = getattr(planner, "p2p_check", None)
     if chk is None:
         return planner
@@ -185,5 +202,6 @@ def detach_p2p(planner):
         chk()
     finally:
         planner.p2p_check = None
+        planner._engine.p2p_detach()
         attach_collectives(planner, getattr(planner, "_p2p_group", None))
     return planner

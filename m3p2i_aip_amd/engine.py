@@ -145,6 +145,10 @@ class HipEngine:
         """0 / 3: the three-launch multi-modal update beyond k_update_small's range; 5: round 3's five launches."""
         self._ck(self.lib.m3_set_update_launches(self._h, int(launches)))
 
+    def set_ladder_spins(self, spins=-1):
+        """Bound of the multi-modal update's in-launch waits: -1 default, 0 = every workgroup takes the give-up branch."""
+        self._ck(self.lib.m3_set_ladder_spins(self._h, int(spins)))
+
     def set_wave_order(self, on=True):
         """Samples sorted into coherent wavefronts (default) or assigned by index; same results."""
         self._ck(self.lib.m3_set_wave_order(self._h, int(bool(on))))
@@ -337,6 +341,19 @@ class HipEngine:
     def p2p_set_timeout_ms(self, first_ms=30000, ms=500):
         """How long a wait spins for a missing peer: a channel's first exchange (start-up skew between the ranks) / later ones."""
         self._ck(self.lib.m3_p2p_set_timeout_ms(self._h, int(first_ms), int(ms)))
+
+    def p2p_clear_error(self):
+        """Collective re-arm after a wait that gave up: own flags, error word and sequence numbers back to zero (the caller
+        holds a barrier before and after: distributed.p2p_recover)."""
+        self._ck(self.lib.m3_p2p_clear_error(self._h))
+
+    def p2p_detach(self):
+        """This handle stops using the device-side exchange: finalize no longer reads its error word."""
+        self._ck(self.lib.m3_p2p_detach(self._h))
+
+    def p2p_set_memory_kind(self, first_kind=1):
+        """Where the exchange block's allocation chain starts (1 uncached, 2 fine-grained, 3 plain); before export / connect."""
+        self._ck(self.lib.m3_p2p_set_memory_kind(self._h, int(first_kind)))
 
     def update_finalize(self):
         """update + finalize of an unsharded handle in as few launches as possible."""

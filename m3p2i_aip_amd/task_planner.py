@@ -469,6 +469,7 @@ class PLANNER_AIF_PANDA(PLANNER_SIMPLE):
         import torch
         t = torch.from_numpy(np.array(host, dtype=np.float32)).to(self.device)
         t._m3_host = [float(x) for x in host]
+        t._m3_host_version = t._version      # (an in-place write afterwards invalidates the attached values: cost_functions.py)
         return t
 
     def _poses(self, sim):
@@ -533,8 +534,11 @@ class PLANNER_AIF_PANDA(PLANNER_SIMPLE):
     def check_task_success(self, sim):
         if self.task != "place":
             return False
-        rows, goal = self._poses(sim), getattr(self.curr_goal, "_m3_host", None)
-        if rows is not None and goal is not None:     # (the tick's host copy of the link states: no further read-back)
+        from .cost_functions import attached_host_values
+        rows, goal = self._poses(sim), attached_host_values(self.curr_goal)
+        if rows is not None and goal is None:         # (a goal written to in place since it was made: its device values count)
+            goal = self.curr_goal.detach().reshape(-1).cpu().tolist()
+        if rows is not None:                          # (the tick's host copy of the link states: no further read-back)
             offset = np.asarray(goal[:2], np.float32) - rows[0][:2]
             return bool((offset * offset).sum(dtype=np.float32) < np.float32(self.SUCCESS_RADIUS ** 2))
         offset = self.curr_goal[:2] - self._pose(sim, "cubeA", "box")[:2]

@@ -297,14 +297,16 @@ def test_p2p_missed_exchange_poisons_the_plan_and_the_fallback_memory_kinds_work
     slot is filled with NaN, so THIS command's plan is NaN on the rank that missed it (and `p2p_status` names the rank;
     `distributed.attach_p2p` polls it).  And the exchange works on every kind of block the allocation chain can end on:
     uncached (1), fine-grained (2: fences as for plain memory since round 4), plain device memory (3) -- forced through
-    M3P2I_P2P_MEMORY."""
+    m3_p2p_set_memory_kind.   And the error is recoverable: m3_p2p_clear_error re-arms the exchange, m3_p2p_detach
+    takes the handle off it; either way the next plans are finite again and continue from the last good warm start."""
     import torch
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
-    if memory:
-        monkeypatch.setenv("M3P2I_P2P_MEMORY", memory)
     kw = dict(T=T, nu=2, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
     shards = [HipEngine(make_config(K=512, K_local=256, k_offset=r * 256, shard_mix=1, **kw)) for r in range(2)]
+    if memory:
+        for e in shards:
+            e.p2p_set_memory_kind({"finegrained": 2, "plain": 3}[memory])
     g = torch.Generator().manual_seed(3)
     delta = torch.randn(512, T, 2, generator=g).numpy()
     for r, e in enumerate(shards):
@@ -335,6 +337,37 @@ def test_p2p_missed_exchange_poisons_the_plan_and_the_fallback_memory_kinds_work
     e.rollout(); e.update(); e.p2p_put(); e.p2p_wait(); e.finalize()
     torch.cuda.synchronize()
     assert np.isnan(e.buffer(L.BUF_ACTION_OUT).cpu().numpy()).all() and np.array_equal(e.buffer(L.BUF_MEAN).cpu().numpy(), mean_before)
+    # recovery 1: the collective re-arm (both ranks clear; nothing is in flight in between) -> complete exchanges again
+    for e in shards:
+        e.p2p_clear_error()
+    assert all(e.p2p_status()[0] == -1 for e in shards)
+    for _ in range(2):      # (both parities)
+        for e in shards:
+            e.rollout(); e.update(); e.p2p_put()
+        for e in shards:
+            e.p2p_wait(); e.finalize()
+        torch.cuda.synchronize()
+        plans = [e.buffer(L.BUF_ACTION_OUT).cpu().numpy() for e in shards]
+        assert np.isfinite(plans[0]).all() and np.isfinite(plans[1]).all()
+    assert not np.array_equal(shards[0].buffer(L.BUF_MEAN).cpu().numpy(), mean_before)      # the warm start moves again
+    # recovery 2: a rank stalls again, the other one gives up and is taken OFF the exchange (distributed.detach_p2p): with
+    # the records handed over by another transport (here: copied by hand) its plans are finite
+    e = shards[0]
+    e.rollout(); e.update(); e.p2p_put(); e.p2p_wait(); e.finalize()
+    torch.cuda.synchronize()
+    assert e.p2p_status()[0] == 1 and np.isnan(e.buffer(L.BUF_ACTION_OUT).cpu().numpy()).all()
+    for s in shards:
+        s.p2p_detach()
+    for s in shards:
+        s.rollout(); s.update()
+    torch.cuda.synchronize()
+    recs = torch.stack([s.buffer(L.BUF_RECORD) for s in shards])
+    for s in shards:
+        s.buffer(L.BUF_RECORDS_ALL).copy_(recs)
+        s.finalize()
+    torch.cuda.synchronize()
+    plans = [s.buffer(L.BUF_ACTION_OUT).cpu().numpy() for s in shards]
+    assert np.isfinite(plans[0]).all() and np.array_equal(plans[0], plans[1])
     for e in shards:
         e.close()
 

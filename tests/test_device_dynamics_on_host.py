@@ -10,6 +10,8 @@ import subprocess
 import numpy as np
 import pytest
 
+from tests.native_flags import host_flags
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_FLAGS = ["-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
 
@@ -25,7 +27,7 @@ def fma_flag():
 @pytest.fixture(scope="module")
 def host_lib(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("planar_dyn") / "libplanar_dyn_host.so")
-    subprocess.check_call(["g++"] + HOST_FLAGS + fma_flag() + ["-I" + os.path.join(HERE, "native", "shim"),
+    subprocess.check_call(["g++"] + host_flags(HOST_FLAGS) + fma_flag() + ["-I" + os.path.join(HERE, "native", "shim"),
                            os.path.join(HERE, "native", "planar_dyn_host.cpp"), "-o", out])
     lib = C.CDLL(out)
     lib.pdh_step.argtypes = [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -102,7 +104,7 @@ def test_device_header_on_the_host_with_other_solver_settings(oracle, host_lib, 
 @pytest.fixture(scope="module")
 def panda_host_lib(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("panda_dyn") / "libpanda_dyn_host.so")
-    subprocess.check_call(["g++"] + HOST_FLAGS + fma_flag() + ["-Wno-unknown-pragmas", "-I" + os.path.join(HERE, "native", "shim"),
+    subprocess.check_call(["g++"] + host_flags(HOST_FLAGS) + fma_flag() + ["-Wno-unknown-pragmas", "-I" + os.path.join(HERE, "native", "shim"),
                            os.path.join(HERE, "native", "panda_dyn_host.cpp"), "-o", out])
     lib = C.CDLL(out)
     VP = C.c_void_p

@@ -141,7 +141,7 @@ def test_large_k_sanity():
 def test_ladder_exchange_give_up_branch_makes_the_same_decisions():
     """k_update_small (multi-modal, K <= 8192): the T column workgroups share the beta-ladder evaluations
     through memory and wait for each other with a BOUNDED spin; a workgroup whose wait runs out (other
-    kernels occupying the CUs) runs all its search passes itself.  M3P2I_LADDER_SPINS=0 forces that branch
+    kernels occupying the CUs) runs all its search passes itself.  m3_set_ladder_spins(h, 0) forces that branch
     in every workgroup: iteration counts, weights and plan must equal the normal run's."""
     import json
     import os
@@ -161,6 +161,8 @@ eng = HipEngine(make_config(K=K, T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_
 eng.set_objective("push_pull", (-3.75, -3.75))
 eng.set_noise(delta)
 eng.set_world_point_raw(np.array([0.0, 1.5, 0, 0, 0, 2, 1, 0, 0, 0, 0, -2, 2, 1, 0, 0, 0, 0], np.float32))
+for name, value in json.loads(sys.argv[1]).items():
+    getattr(eng, name)(value)
 out = []
 for _ in range(3):
     a = eng.command(sync_host=True)
@@ -170,13 +172,12 @@ for _ in range(3):
 print("RESULT" + json.dumps(out))
 """ % root
 
-    def run(env_extra):
-        r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, **env_extra), capture_output=True, text=True,
-                           timeout=600)
+    def run(setters):
+        r = subprocess.run([sys.executable, "-c", prog, json.dumps(setters)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
 
-    normal, gave_up = run({}), run({"M3P2I_LADDER_SPINS": "0"})
+    normal, gave_up = run({}), run({"set_ladder_spins": 0})
     for a, b in zip(normal, gave_up):
         assert a["iters"] == b["iters"] and min(a["iters"]) > 1
         np.testing.assert_allclose(a["eta"], b["eta"], rtol=1e-6)
@@ -188,8 +189,8 @@ print("RESULT" + json.dumps(out))
 def test_three_launch_update_equals_the_five_launch_one_and_its_give_up_branch(env):
     """Unsharded multi-modal command() with K beyond k_update_small's range: k_ladder_search (ladder workgroups + ONE search
     workgroup that waits for their flags; the minima from the rows the rollout's workgroups left behind) ->
-    k_regen_part<false> -> k_regen_done<false>, against round 3's five launches (M3P2I_UPDATE_FIVE_LAUNCHES: k_mins,
-    k_ladder, k_search, k_apply_weights, k_wsum) and against its own give-up branch (M3P2I_LADDER_SPINS=0: the search
+    k_regen_part<false> -> k_regen_done<false>, against round 3's five launches (m3_set_update_launches(h, 5): k_mins,
+    k_ladder, k_search, k_apply_weights, k_wsum) and against its own give-up branch (m3_set_ladder_spins(h, 0): the search
     workgroup does not wait and runs the reference's iterative passes over the costs): same pass counts and best samples,
     weights / plan to rounding -- the partial tables are added in another order, the sums in 2048-sample chunks."""
     import json
@@ -217,6 +218,8 @@ else:
 knots = torch.randn(K, nu, T // 4, generator=g)
 delta = torch.nn.functional.interpolate(knots, size=T, mode="linear", align_corners=True).permute(0, 2, 1).contiguous().numpy()
 eng.set_noise(delta)
+for name, value in json.loads(sys.argv[1]).items():
+    getattr(eng, name)(value)
 out = []
 for _ in range(3):
     a = eng.command(sync_host=True)
@@ -229,13 +232,12 @@ for _ in range(3):
 print("RESULT" + json.dumps(out))
 """ % (root, env)
 
-    def run(env_extra):
-        r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, **env_extra), capture_output=True, text=True,
-                           timeout=600)
+    def run(setters):
+        r = subprocess.run([sys.executable, "-c", prog, json.dumps(setters)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
 
-    three, five, gave_up = run({}), run({"M3P2I_UPDATE_FIVE_LAUNCHES": "1"}), run({"M3P2I_LADDER_SPINS": "0"})
+    three, five, gave_up = run({}), run({"set_update_launches": 5}), run({"set_ladder_spins": 0})
     for other in (five, gave_up):
         # (the first command: the same costs bit for bit; later ones start from plans that agree to rounding)
         a, b = three[0], other[0]

@@ -215,6 +215,17 @@ def test_objective_takes_a_goal_tensor_with_its_host_values_attached():
     assert o._goal_host[0] is g._m3_host and o.goal_list() == g._m3_host
     g[2] = 1.5                                    # a caller writes into it: the version counter invalidates the attached values
     assert o.goal_list()[2] == 1.5
+    #  ... also when the write happens BEFORE the hand-over: the attached values are stale then and must not be used
+    from m3p2i_aip_amd.cost_functions import attached_host_values
+    g2 = pl._device_tensor(np.array([0.2, 0.2, 1.115, 0, 0, 0, 1], np.float32))
+    assert attached_host_values(g2) is g2._m3_host
+    g2[2] += 0.25
+    assert attached_host_values(g2) is None
+    o.update_objective("pick", g2)
+    assert o.goal_list()[2] == pytest.approx(1.365, abs=1e-6)
+    pl.task, pl.curr_goal = "place", g2          # check_task_success reads the goal the same way
+    pl._poses = lambda sim: [np.array([0.2, 0.2, 1.0], np.float32)] * 4
+    assert pl.check_task_success(None) is True
 
 
 def test_new_entry_points_refuse_a_null_handle():

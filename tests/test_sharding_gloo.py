@@ -135,13 +135,13 @@ def test_sharded_command_equals_single_process(case, world, golden):
 
 @pytest.mark.parametrize("sm,mm,want", [(None, True, 2), (True, True, 2), (1, True, 1), (2, True, 2), (3, True, 3),
                                         (False, True, 0), (None, False, 1), (True, False, 1), (False, False, 0)])
-def test_shard_mix_values_map_to_protocols(sm, mm, want):
+def test_shard_mix_values_map_to_protocols(sm, mm, want, monkeypatch):
     """MPPIConfig.shard_mix: None and the BOOL True mean "the one-collective family, protocol by size" (2 below
     planner.SHARD_MIX3_FROM samples), the INTEGERS 1 / 2 / 3 force a protocol (1 = the bit-identical variant), False = gather +
     reduce; single-mode planners have one protocol (1: k_mix).  (`True` and `1` are different requests.)"""
     from m3p2i_aip_amd import planner as P
     from tests.oracle_engine import OracleEngine
-    P.ENGINE_CLS = OracleEngine
+    monkeypatch.setattr(P, "ENGINE_CLS", OracleEngine)      # (restored after the test: later tests run on the real engine)
     m = P.MPPIConfig(num_samples=K, horizon=T, nx=4, device="cpu", lambda_=0.5, u_min=[-3.0, -3.0], u_max=[3.0, 3.0],
                      noise_sigma=[[3.0, 0.0], [0.0, 3.0]], u_per_command=T, sample_null_action=True, filter_u=True, fused=True,
                      rank=0, world_size=2, shard_mix=sm)

@@ -9,14 +9,16 @@ import subprocess
 import numpy as np
 import pytest
 
+from tests.native_flags import host_flags
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.fixture(scope="module")
 def host_lib(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("splinefit") / "libsplinefit_host.so")
-    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-ffp-contract=off",
-                           os.path.join(HERE, "native", "spline_fit_host.cpp"), "-o", out])
+    subprocess.check_call(["g++"] + host_flags(["-O2", "-shared", "-fPIC", "-ffp-contract=off"]) +
+                          [os.path.join(HERE, "native", "spline_fit_host.cpp"), "-o", out])
     lib = C.CDLL(out)
     lib.sf_fit_eval_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
     return lib

@@ -83,7 +83,8 @@ class Tamp:
 
     def status(self):
         g = self.task_planner.curr_goal
-        host = getattr(g, "_m3_host", None)      # (a goal the task planner made from host values carries them: no read-back)
+        from m3p2i_aip_amd.cost_functions import attached_host_values
+        host = attached_host_values(g)      # (a goal the task planner made from host values carries them: no read-back)
         return {"task": self.task_planner.task, "success": bool(self.task_success),
                 "goal": list(host) if host is not None else [float(x) for x in g.float().cpu().reshape(-1).tolist()]}
 
