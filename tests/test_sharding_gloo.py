@@ -110,7 +110,10 @@ def test_sharded_command_equals_single_process(case, world, golden):
     ref = run_calls(ref_pl, ref_sim)
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + 3 * world
+    import socket
+    with socket.socket() as so:     # a port the kernel hands out (pid arithmetic collides between pytest-xdist workers)
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     procs = [ctx.Process(target=worker, args=(r, world, port, case, ret)) for r in range(world)]
     for p in procs:
         p.start()
