@@ -206,9 +206,10 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(env, task, goal, multi_modal, K, T, delta):
+def cpu_baseline(env, task, goal, multi_modal, K, T, delta, seconds=21.0):
     """Oracle (kind='port') on the host cores + the reference-shaped torch-CPU loop: bounded samples
-    of the same workload.  The ONLY place of this file that touches oracle/."""
+    of the same workload (`seconds` of CPU work in three equal legs: --cpu-baseline-seconds, default 21).  The ONLY
+    place of this file that touches oracle/."""
     import oracle as O
     O.load()
     if env == "point_env":
@@ -222,7 +223,8 @@ def cpu_baseline(env, task, goal, multi_modal, K, T, delta):
         make = lambda: P.OraclePandaPlanner(cfg, delta)
     out = {}
     ncpu = usable_cores()
-    for label, threads, budget in (("all", ncpu, 7.0), ("one", 1, 7.0)):
+    leg = max(0.2, seconds / 3.0)
+    for label, threads, budget in (("all", ncpu, leg), ("one", 1, leg)):
         O.load().m3o_set_threads(threads)
         pl = make()
         pl.command(w0)
@@ -244,7 +246,7 @@ def cpu_baseline(env, task, goal, multi_modal, K, T, delta):
             from oracle import refshaped
             O.load().m3o_set_threads(ncpu)
             torch.set_num_threads(ncpu)
-            res["reference_shaped"] = refshaped.time_commands(task, goal, multi_modal, K, T, delta, budget_s=7.0,
+            res["reference_shaped"] = refshaped.time_commands(task, goal, multi_modal, K, T, delta, budget_s=leg,
                                                               threads=ncpu)
         except Exception as e:  # the baseline is a report, never a reason to lose the bench line
             res["reference_shaped"] = {"error": repr(e)}
@@ -514,6 +516,9 @@ def main():
                     help="default: push (BASELINE configs[1]), 2000 samples per GPU, for every N")
     ap.add_argument("--samples-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=21.0,
+                    help="CPU work of the cpu_baseline object (three equal legs: oracle on all usable cores, on one, the "
+                         "reference-shaped torch loop); the contract tests pass a small value")
     ap.add_argument("--shard-mix", type=int, default=None, choices=[1, 2, 3],
                     help="multi-modal sharding protocol (N > 1): 2 = one collective (default), 1 = its bit-identical variant, "
                          "3 = two small exchanges with O(K_local) work per rank")
@@ -729,7 +734,7 @@ def main():
         line["other_configs"] = others
     if rank == 0:
         if delta_np is not None:
-            line["cpu_baseline"] = cpu_baseline(env, task, goal, multi_modal, K_local, T, delta_np)
+            line["cpu_baseline"] = cpu_baseline(env, task, goal, multi_modal, K_local, T, delta_np, seconds=args.cpu_baseline_seconds)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -5,12 +5,12 @@ The reference's dynamics are PhysX, a closed binary nothing in the repository pi
 the logs of its closed-loop experiments (src/m3p2i_aip/plot/{point,panda}/*.npy: n = 60 / 20 / 50 runs per
 scenario).  tests/golden/behaviour_band.json holds their statistics (generator: tests/golden/make_band.py).
 Each test below runs the same scenario end to end on this build -- 1-env "real world" + planner + task planner, the
-flow of scripts/sim.py + scripts/reactive_tamp.py (tools/closed_loop.py) -- N = 20 times with the start jittered
+flow of scripts/sim.py + scripts/reactive_tamp.py (tools/closed_loop.py) -- N times with the start jittered
 (tools/band_stats.py: phase of the dyn-obs walk, +-5 cm on box and robot; +-2 cm on the cube) and asserts on the
 STATISTICS of what the reference logged per run: success count, mean and spread of the final error and of the task
 time against the logged mean +- 3 sigma, dyn-obs collisions (plot_point.py column 17).  Sizes: K, T of the BASELINE
 configs AND the reference's shipped planner size (K = 200, T = 15).  The numbers of one run of these tests are
-committed under profiles/r05/behaviour_stats_*.json."""
+committed under profiles/r06/behaviour_stats_*.json (N = 20 and N = 60)."""
 import json
 import os
 import sys
@@ -21,7 +21,9 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BAND = json.load(open(os.path.join(ROOT, "tests", "golden", "behaviour_band.json")))
-N = 20
+N = 8          # (the driver's serial run of this suite came to 694 s of its 1200 s limit.  The suite runs 8
+               # episodes per scenario and size; the N = 20 and N = 60 statistics are produced by tools/band_stats.py with the same
+               # episode function and committed under profiles/r06/behaviour_stats_*.json -- every bound below scales with N.)
 
 # fraction of the LOGGED runs that ended by reaching the goal rather than at the experiment's time limit (the
 # logs hold the task time of every run: the limit shows as a pile-up at 18.2 s / 38.2 s; tests/golden/make_band.py

@@ -138,44 +138,53 @@ def test_large_k_sanity():
     eng.close()
 
 
+def _engine(**kw):
+    from m3p2i_aip_amd.engine import HipEngine, make_config
+    return HipEngine(make_config(**kw))
+
+
+def _noise(K, T, nu, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    knots = torch.randn(K, nu, T // 4, generator=g)
+    return torch.nn.functional.interpolate(knots, size=T, mode="linear", align_corners=True).permute(0, 2, 1).contiguous().numpy()
+
+
+def _three_commands(eng, setters, full=False):
+    """Three warm-started commands of `eng` after applying `setters` (engine method name -> argument): what the update
+    decided and produced, as host values."""
+    from m3p2i_aip_amd import _lib as L
+    for name, value in setters.items():
+        getattr(eng, name)(value)
+    out = []
+    for _ in range(3):
+        a = eng.command(sync_host=True)
+        i = eng.info()
+        d = dict(iters=[i.iters, i.iters_1, i.iters_2], eta=[i.eta, i.eta_1, i.eta_2], action=a.copy(),
+                 w=eng.buffer(L.BUF_WEIGHTS).cpu().numpy().copy())
+        if full:
+            d.update(best=[i.best_idx, i.best_idx_1, i.best_idx_2], pref=i.pull_preference,
+                     top=eng.buffer(L.BUF_TOP_IDX).cpu().numpy().tolist(), w1=eng.buffer(L.BUF_WEIGHTS_1).cpu().numpy().copy(),
+                     m1=eng.buffer(L.BUF_MEAN_1).cpu().numpy().copy(), m2=eng.buffer(L.BUF_MEAN_2).cpu().numpy().copy())
+        out.append(d)
+    eng.close()
+    return out
+
+
 def test_ladder_exchange_give_up_branch_makes_the_same_decisions():
     """k_update_small (multi-modal, K <= 8192): the T column workgroups share the beta-ladder evaluations
     through memory and wait for each other with a BOUNDED spin; a workgroup whose wait runs out (other
     kernels occupying the CUs) runs all its search passes itself.  m3_set_ladder_spins(h, 0) forces that branch
-    in every workgroup: iteration counts, weights and plan must equal the normal run's."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    prog = r"""
-import json, sys, numpy as np, torch
-sys.path.insert(0, %r)
-from m3p2i_aip_amd import _lib as L
-from m3p2i_aip_amd.engine import HipEngine, make_config
-K, T = 4000, 30
-g = torch.Generator().manual_seed(3)
-knots = torch.randn(K, 2, T // 4, generator=g)
-delta = torch.nn.functional.interpolate(knots, size=T, mode="linear", align_corners=True).permute(0, 2, 1).contiguous().numpy()
-eng = HipEngine(make_config(K=K, T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3]))
-eng.set_objective("push_pull", (-3.75, -3.75))
-eng.set_noise(delta)
-eng.set_world_point_raw(np.array([0.0, 1.5, 0, 0, 0, 2, 1, 0, 0, 0, 0, -2, 2, 1, 0, 0, 0, 0], np.float32))
-for name, value in json.loads(sys.argv[1]).items():
-    getattr(eng, name)(value)
-out = []
-for _ in range(3):
-    a = eng.command(sync_host=True)
-    i = eng.info()
-    out.append(dict(iters=[i.iters, i.iters_1, i.iters_2], eta=[i.eta, i.eta_1, i.eta_2], action=a.tolist(),
-                    w=eng.buffer(L.BUF_WEIGHTS).cpu().numpy().tolist()))
-print("RESULT" + json.dumps(out))
-""" % root
+    in every workgroup: iteration counts, weights and plan must equal the normal run's.  (Until round 5 the switch was an
+    environment variable of the library and every run a process of its own.)"""
+    K, T = 4000, 30
+    delta = _noise(K, T, 2)
 
     def run(setters):
-        r = subprocess.run([sys.executable, "-c", prog, json.dumps(setters)], capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+        eng = _engine(K=K, T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+        eng.set_objective("push_pull", (-3.75, -3.75))
+        eng.set_noise(delta)
+        eng.set_world_point_raw(np.array([0.0, 1.5, 0, 0, 0, 2, 1, 0, 0, 0, 0, -2, 2, 1, 0, 0, 0, 0], np.float32))
+        return _three_commands(eng, setters)
 
     normal, gave_up = run({}), run({"set_ladder_spins": 0})
     for a, b in zip(normal, gave_up):
@@ -193,49 +202,23 @@ def test_three_launch_update_equals_the_five_launch_one_and_its_give_up_branch(e
     k_ladder, k_search, k_apply_weights, k_wsum) and against its own give-up branch (m3_set_ladder_spins(h, 0): the search
     workgroup does not wait and runs the reference's iterative passes over the costs): same pass counts and best samples,
     weights / plan to rounding -- the partial tables are added in another order, the sums in 2048-sample chunks."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    prog = r"""
-import json, sys, numpy as np, torch
-sys.path.insert(0, %r)
-from m3p2i_aip_amd import _lib as L
-from m3p2i_aip_amd.engine import HipEngine, make_config
-env = %r
-g = torch.Generator().manual_seed(3)
-if env == "point":
-    K, T, nu = 20000, 30, 2
-    eng = HipEngine(make_config(K=K, T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3]))
-    eng.set_objective("push_pull", (-3.75, -3.75))
-    eng.set_world_point_raw(np.array([0.0, 1.5, 0, 0, 0, 2, 1, 0, 0, 0, 0, -2, 2, 1, 0, 0, 0, 0], np.float32))
-else:
-    K, T, nu = 6000, 20, 9
-    eng = HipEngine(make_config(K=K, T=T, nu=9, env_type="panda_env", multi_modal=True, u_min=[-1.2] * 9, u_max=[1.2] * 9,
-                                noise_sigma_diag=[10.0] * 7 + [0.8, 0.8], lambda_=0.05, pre_height_diff=0.05, dt=0.01))
-    eng.set_objective("reach", [0.2, 0.2, 1.115, 0, 0, 0, 1], gripper_cmd=1)
-knots = torch.randn(K, nu, T // 4, generator=g)
-delta = torch.nn.functional.interpolate(knots, size=T, mode="linear", align_corners=True).permute(0, 2, 1).contiguous().numpy()
-eng.set_noise(delta)
-for name, value in json.loads(sys.argv[1]).items():
-    getattr(eng, name)(value)
-out = []
-for _ in range(3):
-    a = eng.command(sync_host=True)
-    i = eng.info()
-    out.append(dict(iters=[i.iters, i.iters_1, i.iters_2], eta=[i.eta, i.eta_1, i.eta_2], action=a.tolist(),
-                    best=[i.best_idx, i.best_idx_1, i.best_idx_2], pref=i.pull_preference,
-                    top=eng.buffer(L.BUF_TOP_IDX).cpu().numpy().tolist(),
-                    w=eng.buffer(L.BUF_WEIGHTS).cpu().numpy().tolist(), w1=eng.buffer(L.BUF_WEIGHTS_1).cpu().numpy().tolist(),
-                    m1=eng.buffer(L.BUF_MEAN_1).cpu().numpy().tolist(), m2=eng.buffer(L.BUF_MEAN_2).cpu().numpy().tolist()))
-print("RESULT" + json.dumps(out))
-""" % (root, env)
+    if env == "point":
+        K, T, nu = 20000, 30, 2
+    else:
+        K, T, nu = 6000, 20, 9
+    delta = _noise(K, T, nu)
 
     def run(setters):
-        r = subprocess.run([sys.executable, "-c", prog, json.dumps(setters)], capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+        if env == "point":
+            eng = _engine(K=K, T=T, nu=2, multi_modal=True, u_min=[-3, -3], u_max=[3, 3], noise_sigma_diag=[3, 3])
+            eng.set_objective("push_pull", (-3.75, -3.75))
+            eng.set_world_point_raw(np.array([0.0, 1.5, 0, 0, 0, 2, 1, 0, 0, 0, 0, -2, 2, 1, 0, 0, 0, 0], np.float32))
+        else:
+            eng = _engine(K=K, T=T, nu=9, env_type="panda_env", multi_modal=True, u_min=[-1.2] * 9, u_max=[1.2] * 9,
+                          noise_sigma_diag=[10.0] * 7 + [0.8, 0.8], lambda_=0.05, pre_height_diff=0.05, dt=0.01)
+            eng.set_objective("reach", [0.2, 0.2, 1.115, 0, 0, 0, 1], gripper_cmd=1)
+        eng.set_noise(delta)
+        return _three_commands(eng, setters, full=True)
 
     three, five, gave_up = run({}), run({"set_update_launches": 5}), run({"set_ladder_spins": 0})
     for other in (five, gave_up):

@@ -30,7 +30,17 @@ SCENARIOS = {
     "corner1_push": ["task=push", "goal=[-3.75,-3.75]", "mppi.num_samples=2000", "mppi.horizon=30"],
     "corner1_pull": ["task=pull", "goal=[-3.75,-3.75]", "mppi.num_samples=2000", "mppi.horizon=30"],
     "corner1_hybrid": ["task=push_pull", "multi_modal=True", "goal=[-3.75,-3.75]", "mppi.num_samples=4000", "mppi.horizon=30"],
+    # corner2_*: the box STARTS in the far corner (BOX_START below) and has to go to the opposite one
+    "corner2_push": ["task=push", "goal=[-3.75,-3.75]", "mppi.num_samples=2000", "mppi.horizon=30"],
+    "corner2_pull": ["task=pull", "goal=[-3.75,-3.75]", "mppi.num_samples=2000", "mppi.horizon=30"],
+    "corner2_hybrid": ["task=push_pull", "multi_modal=True", "goal=[-3.75,-3.75]", "mppi.num_samples=4000", "mppi.horizon=30"],
 }
+
+# Where the box starts when it is not the scene's default (0, 2).  The logs hold final states only; corner2_push.npy tells the
+# start: 6 of its 20 runs end with the box at (3.70, 3.70) -- 10.54 m from the goal, never moved --, 11 with it pushed down the
+# wall into the next corner (3.70, -3.72), 3 succeed.  The box is 0.4 m wide and the walls' faces are at +-3.95 minus a
+# contact offset: flush in the corner its centre is at 3.70.
+BOX_START = {"corner2_push": (3.70, 3.70), "corner2_pull": (3.70, 3.70), "corner2_hybrid": (3.70, 3.70)}
 
 
 SETTLE_TICKS = 0       # the final error is taken AT the success tick.  (The reference's logs were written after the run;
@@ -41,11 +51,17 @@ SETTLE_TICKS = 0       # the final error is taken AT the success tick.  (The ref
 
 def jitter_of(scenario, episode):
     """Deterministic per (scenario, episode); episode 0 is the unjittered reference scene."""
+    start = BOX_START.get(scenario)
     if episode == 0:
-        return dict(dyn_phase=0, box=(0.0, 0.0), robot=(0.0, 0.0))
-    rng = np.random.default_rng([sorted(SCENARIOS).index(scenario), episode])
-    return dict(dyn_phase=int(rng.integers(0, 100)), box=tuple(rng.uniform(-0.05, 0.05, 2).tolist()),
-                robot=tuple(rng.uniform(-0.05, 0.05, 2).tolist()))
+        return dict(dyn_phase=0, box=(0.0, 0.0), robot=(0.0, 0.0), box_start=start)
+    # (the scenario's index in the list of round 5 for the five scenarios of round 5: their episodes keep their jitter)
+    order = sorted(k for k in SCENARIOS if not k.startswith("corner2")) + sorted(k for k in SCENARIOS if k.startswith("corner2"))
+    rng = np.random.default_rng([order.index(scenario), episode])
+    j = dict(dyn_phase=int(rng.integers(0, 100)), box=tuple(rng.uniform(-0.05, 0.05, 2).tolist()),
+             robot=tuple(rng.uniform(-0.05, 0.05, 2).tolist()), box_start=start)
+    if start is not None:      # a box flush in a corner can only be displaced INTO the arena
+        j["box"] = tuple(float(-abs(d) * np.sign(c)) for d, c in zip(j["box"], start))
+    return j
 
 
 def stats(x):

@@ -136,7 +136,7 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
     settle_ticks: after the success tick the world is stepped that many more ticks with the zero action the planner
     side returns once the task is done (reactive_tamp.py:52-54) before the final error is taken -- the reference's logs
     were written after the run, not at the success tick.
-    jitter (point_env): dict(dyn_phase=int, box=(dx, dy), robot=(dx, dy)) -- the episode starts with the dyn-obs
+    jitter (point_env): dict(dyn_phase=int, box=(dx, dy), robot=(dx, dy)[, box_start=(x, y)]) -- the episode starts with the dyn-obs
     `dyn_phase` ticks into its walk and box / robot displaced (tools/band_stats.py: N episodes per scenario)."""
     overrides = list(overrides)
     compat.install(force_standins=True)
@@ -151,6 +151,9 @@ def run(cn="config_point", overrides=(), ticks=2000, connect=None, until_task=No
     if jitter and cfg.env_type == "point_env":
         phase = int(jitter.get("dyn_phase", 0))
         ib = int(real._get_actor_index_by_name("box"))
+        if jitter.get("box_start") is not None:      # the scenario's own start of the box (corner2_*: in the far corner)
+            real._root_state[0, ib, 0] = float(jitter["box_start"][0])
+            real._root_state[0, ib, 1] = float(jitter["box_start"][1])
         real._root_state[0, ib, 0] += float(jitter.get("box", (0, 0))[0])
         real._root_state[0, ib, 1] += float(jitter.get("box", (0, 0))[1])
         # the dyn-obs where its walk (update_dyn_obs: 1 cm per tick along the diagonal, back for ticks 0-25 and
