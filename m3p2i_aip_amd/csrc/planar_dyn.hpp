@@ -584,11 +584,16 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
                    DW = M & G_DW, BD = M & G_BD, BO = M & G_BO, DO = M & G_DO;
     constexpr bool ANY_RARE = (M & ~G_RB) != 0u, ANY_WALLS = RW || BW || DW, ANY_BOXES = BD || BO || DO;
     const float h = sc.h;
-    // 1. external forces
+    // 1. external forces.  Spec v1.7: a pending force (the suction pair, Q5: staged during the previous step) is CONSUMED
+    // by the first substep of the step -- cleared right here; the later substeps evaluate the same expression on zeros,
+    // as the oracle does.  (Up to v1.6 it acted in every substep.  The joint fit against the reference's eight logged
+    // scenarios, tools/cpu_fit_physx.py -> profiles/r06/fit_physx_*.json, selects this reading of a one-shot
+    // apply_rigid_body_force_tensors under 2 substeps: DESIGN.md section 2.)
     w.rvx = mad(h * w.fRx, sc.invm_r, w.rvx);
     w.rvy = mad(h * w.fRy, sc.invm_r, w.rvy);
     w.B.vx = mad(h * w.fBx, sc.invm_b, w.B.vx);
     w.B.vy = mad(h * w.fBy, sc.invm_b, w.B.vy);
+    w.fRx = 0.0f; w.fRy = 0.0f; w.fBx = 0.0f; w.fBy = 0.0f;
 
     // 2. contacts (static slots; a group that is not in M stays `on = false` and compiles away)
     Slot s_rb, s_rd, s_ro, s_rwx, s_rwy;
@@ -913,7 +918,6 @@ __device__ __forceinline__ void point_step(const PointScene& sc, PointWorld& w, 
 #undef M3_COVERS
         }
     }
-    w.fRx = 0.0f; w.fRy = 0.0f; w.fBx = 0.0f; w.fBy = 0.0f;
 }
 
 }  // namespace m3

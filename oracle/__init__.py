@@ -45,7 +45,8 @@ class PointScene(C.Structure):
                 ("mu_rw", C.c_float), ("mu_bw", C.c_float), ("mu_dw", C.c_float),
                 ("mu_bd", C.c_float), ("mu_bo", C.c_float), ("mu_do", C.c_float),
                 ("contact_offset", C.c_float), ("baumgarte", C.c_float), ("slop", C.c_float),
-                ("max_bias", C.c_float), ("face_tol", C.c_float), ("friction_coupling", C.c_int)]
+                ("max_bias", C.c_float), ("face_tol", C.c_float), ("friction_coupling", C.c_int),
+                ("fext_substeps", C.c_int)]
 
 
 class Cfg(C.Structure):

@@ -70,6 +70,7 @@ typedef struct {
     float contact_offset; /* isaacgym_wrapper.py:30 (0.01) */
     float baumgarte, slop, max_bias, face_tol;
     int friction_coupling;   /* 1 = spec v1.5: sliding-spinning coupling of the boxes' ground friction; 0: spec v1.4; 2: the experimental four-corner patch rows (tools/cpu_ab_default_size.py only) */
+    int fext_substeps;       /* 1 = spec v1.7: a pending external force is consumed by the first substep of the next step; 0 = spec v1.6, it acts in every substep (tools/cpu_fit_physx.py's `both` column only) */
 } m3o_point_scene;
 
 typedef struct { float x, y, c, s, vx, vy, w; } m3o_body;

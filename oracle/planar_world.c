@@ -118,6 +118,7 @@ void m3o_point_scene_default(m3o_point_scene* sc) {
     sc->max_bias = 2.0f;
     sc->face_tol = 0.0005f;
     sc->friction_coupling = 1;           /* spec v1.5 */
+    sc->fext_substeps = 1;               /* spec v1.7: a pending external force is consumed by the first substep */
 }
 
 void m3o_point_world_init(m3o_point_world* w) {
@@ -474,11 +475,19 @@ void m3o_point_step(const m3o_point_scene* sc, m3o_point_world* w, const float u
     const float LangD = LlinD * sc->dyn_req;
 
     for (int sub = 0; sub < sc->substeps; ++sub) {
-        /* 1. external forces (suction), constant over the step */
+        /* 1. external forces (suction).  Spec v1.7: a pending force is CONSUMED by the first substep of the step -- the
+         * reading of a one-shot `apply_rigid_body_force_tensors` under 2 substeps that the joint fit against the
+         * reference's eight logged scenarios selects (tools/cpu_fit_physx.py, profiles/r06/fit_physx_*.json; up to v1.6
+         * it acted in every substep: fext_substeps = 0, kept for that tool).  The later substeps still evaluate the same
+         * expression, on a force of zero. */
         w->R.vx = mad(h * w->fext_R[0], s.invm[BR], w->R.vx);
         w->R.vy = mad(h * w->fext_R[1], s.invm[BR], w->R.vy);
         w->B.vx = mad(h * w->fext_B[0], s.invm[BB], w->B.vx);
         w->B.vy = mad(h * w->fext_B[1], s.invm[BB], w->B.vy);
+        if (sc->fext_substeps > 0 && sub + 1 >= sc->fext_substeps) {
+            w->fext_R[0] = w->fext_R[1] = 0.0f;
+            w->fext_B[0] = w->fext_B[1] = 0.0f;
+        }
 
         /* 2. contacts, fixed slot order */
         s.nc = 0;

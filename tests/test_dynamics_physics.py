@@ -232,15 +232,24 @@ def test_the_spec_has_no_handedness(oracle, axis):
 
 def test_external_force_acts_during_the_next_step_only(oracle):
     """apply_rigid_body_force_tensors (cost_functions.py:76, quirk Q5): the suction force set now pushes the box during
-    the next step and is cleared by it: dv = F dt / m minus what ground friction takes."""
+    the next step and is cleared by it.  Spec v1.7: it is consumed by that step's FIRST substep -- dv = F (dt / substeps) / m
+    (minus what ground friction takes); with the scene field of the fit tool at 0 (spec v1.6's reading) it acts in every
+    substep, dv = F dt / m."""
     O = oracle
     sc = O.default_scene()
     sc.box_mu_g = 0.0
+    z = np.zeros((1, 2), np.float32)
+    assert sc.fext_substeps == 1 and sc.substeps == 2
+    sc.fext_substeps = 0
     w = lonely_box(O, [0, 0, 1, 0, 0, 0, 0])
     w[0, O.W_FEXT_B:O.W_FEXT_B + 2] = [80.0, -40.0]
-    z = np.zeros((1, 2), np.float32)
     O.step_batch(sc, w, z)
     np.testing.assert_allclose(w[0, O.W_B + 4:O.W_B + 6], np.array([80.0, -40.0]) * 0.05 / M_BOX, rtol=1e-6)
+    sc.fext_substeps = 1
+    w = lonely_box(O, [0, 0, 1, 0, 0, 0, 0])
+    w[0, O.W_FEXT_B:O.W_FEXT_B + 2] = [80.0, -40.0]
+    O.step_batch(sc, w, z)
+    np.testing.assert_allclose(w[0, O.W_B + 4:O.W_B + 6], np.array([80.0, -40.0]) * (0.05 / sc.substeps) / M_BOX, rtol=1e-6)
     assert w[0, O.W_FEXT_B] == 0.0 and w[0, O.W_FEXT_B + 1] == 0.0
     v = w[0, O.W_B + 4:O.W_B + 6].copy()
     O.step_batch(sc, w, z)
