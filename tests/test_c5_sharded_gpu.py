@@ -255,7 +255,12 @@ def test_c5_one_collective_protocol_equals_unsharded(Kt, Nt, level, transport):
                 else:
                     # (first call: same inputs, summation order only; later calls: the plans the rollouts start from agree to
                     # 3e-5, and a few of the 32 000 / 64 000 rollouts in contact amplify that -- conftest.assert_close_but_few)
-                    np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), atol=3e-5 if call == 0 else 5e-4,
+                    # (the per-mode means are un-smoothed weighted sums behind a beta search that ends near 0.08: two correct
+                    # evaluations differ by up to ~2e-3 there -- DESIGN.md section 4, `ILL_CONDITIONED` in tests/test_oracle_golden.py;
+                    # observed under planar spec v1.7: 8.4e-4 in one of 60 entries at call 4.  The blended mean and the returned
+                    # plan keep 5e-4.)
+                    later = 2e-3 if name in ("BUF_MEAN_1", "BUF_MEAN_2") else 5e-4
+                    np.testing.assert_allclose(e.buffer(b).cpu().numpy(), full.buffer(b).cpu().numpy(), atol=3e-5 if call == 0 else later,
                                                rtol=1e-4, err_msg=f"call {call} rank {r} {name}")
             if exact:
                 assert torch.equal(e.states, full.states[r * kl:(r + 1) * kl])
