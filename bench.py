@@ -351,7 +351,7 @@ def run_config(name, args, world, rank, device, dist, steps, warmup, K_local=Non
                 collective_ms=coll_ms, simple=name in SIMPLE_MODE, walls_ms_per_step=[w / steps * 1e3 for w in walls])
 
 
-MIX_DIR = os.path.join(ROOT, "profiles", "r05")
+MIX_DIR = os.path.join(ROOT, "profiles", "r06")
 
 
 def lib_build_id():
@@ -363,7 +363,7 @@ def lib_build_id():
 
 def roofline_valu(name, r, n_waves):
     """The roofline that binds this path -- VALU issue, not HBM: the rollout kernel's dynamic
-    instruction counts per wavefront from the committed PMC profile of THIS build (profiles/r05/mix_<config>.json,
+    instruction counts per wavefront from the committed PMC profile of THIS build (profiles/r06/mix_<config>.json,
     written by tools/pmc_mix_bench.sh; keyed by m3_build_id(): a profile of other sources / flags is refused), against
       lone_wave_issue_frac  = VALU instructions / wave cycles -- how close ONE wavefront alone on its SIMD comes to
                               issuing a VALU instruction every 4 clocks (the bound of every BASELINE size: at most one

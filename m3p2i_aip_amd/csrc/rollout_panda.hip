@@ -324,31 +324,49 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const RolloutArgs a_, cons
 // seventeen floats the cost reads (finger positions 6, finger orientation 4, the sample's cube orientation 4 and position 3:
 // [T][17][Kl], 5.4 MB at C4) and this kernel -- one lane per sample, the same panda_cost on the same values, the same
 // discounted sum in the same order -- forms cost_horizon, the trajectory costs and the update's minima rows.
-__global__ __launch_bounds__(64) void k_panda_reach_cost(const RolloutArgs a, const PandaArgs pa) {
+// Round 6: the T steps of a sample are independent until the discounted sum, so a workgroup is 64 samples x RC_TS time slices
+// (one wavefront per slice): slice s forms the costs of steps s, s + RC_TS, ... -- seventeen loads per step in flight in four
+// wavefronts instead of one lane walking all T x 17 of them --, the costs meet in LDS and the first wavefront adds them in step
+// order with the rollout's own recurrence (J = J + g c; g = g gamma): the same operations on the same values, the same bits
+// (16 -> 7 us at C4: profiles/r06).
+constexpr int RC_TS = 4, RC_CH = 32;      // time slices per workgroup; steps per LDS chunk
+__global__ __launch_bounds__(64 * RC_TS) void k_panda_reach_cost(const RolloutArgs a, const PandaArgs pa) {
+    __shared__ float s_c[RC_CH][64];
     const int Kl = a.Kl, T = a.T;
-    const int i0 = blockIdx.x * 64 + (int)threadIdx.x;
+    const int lane = (int)threadIdx.x & 63, slice = (int)threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 64 + lane;
     const bool mine = i0 < Kl;
-    const int i = mine ? i0 : 0;          // (every lane stays for wave_min_store's barriers)
+    const int i = mine ? i0 : 0;          // (every lane stays for the barriers)
     const int k = a.k0 + i;
     const bool first_half = k < pa.cp.half_K;
     const int h = (pa.cp.multi_modal && !first_half) ? pa.cp.half_K : 0;    // whose cube orientation the tilt term reads
     float J = 0.0f, g = 1.0f;
-    for (int t = 0; t < T; ++t) {
-        const float* r = pa.reach_rec + (size_t)t * REACH_REC * Kl;
-        PandaObs o;
-        PandaWorld w;
-        float cube0[3], qh0[4];
+    for (int t0 = 0; t0 < T; t0 += RC_CH) {
+        for (int tt = slice; tt < RC_CH && t0 + tt < T; tt += RC_TS) {
+            const int t = t0 + tt;
+            const float* r = pa.reach_rec + (size_t)t * REACH_REC * Kl;
+            PandaObs o;
+            PandaWorld w;
+            float cube0[3], qh0[4];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { o.left[j] = r[(0 + j) * Kl + i]; o.right[j] = r[(3 + j) * Kl + i]; cube0[j] = r[(14 + j) * Kl]; }
+            for (int j = 0; j < 3; ++j) { o.left[j] = r[(0 + j) * Kl + i]; o.right[j] = r[(3 + j) * Kl + i]; cube0[j] = r[(14 + j) * Kl]; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { o.left_q[j] = r[(6 + j) * Kl + i]; w.A.q[j] = r[(10 + j) * Kl + i]; qh0[j] = r[(10 + j) * Kl + h]; }
-        const float c = panda_cost(pa.cp, w, o, k, cube0, qh0);
-        if (mine) a.cost_h[(size_t)t * Kl + i] = c;
-        J = J + g * c;
-        g = g * a.gamma;
+            for (int j = 0; j < 4; ++j) { o.left_q[j] = r[(6 + j) * Kl + i]; w.A.q[j] = r[(10 + j) * Kl + i]; qh0[j] = r[(10 + j) * Kl + h]; }
+            const float c = panda_cost(pa.cp, w, o, k, cube0, qh0);
+            if (mine) a.cost_h[(size_t)t * Kl + i] = c;
+            s_c[tt][lane] = c;
+        }
+        __syncthreads();
+        if (slice == 0) {
+            for (int tt = 0; tt < RC_CH && t0 + tt < T; ++tt) {
+                J = J + g * s_c[tt][lane];
+                g = g * a.gamma;
+            }
+        }
+        __syncthreads();
     }
-    if (mine) a.J[i] = J;
-    if (a.wave_min) wave_min_store(a.wave_min, J, first_half, mine);
+    if (slice == 0 && mine) a.J[i] = J;
+    if (a.wave_min) wave_min_store(a.wave_min, J, first_half, mine && slice == 0);
 }
 
 // Lanes per sample, by what was measured at C4's size (profiles/r05/panda_lps_bench.json, panda_reach_mid_bench.json; K = 4000,
@@ -415,7 +433,7 @@ int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa_in, const Pan
     if (pa.reach_rec != nullptr) {
         if (lps == 16) (void)launch_rollout_panda_lps<16>(a, pa, sc, s);
         else (void)launch_rollout_panda_lps<8>(a, pa, sc, s);
-        const dim3 grid((a.Kl + 63) / 64), block(64);
+        const dim3 grid((a.Kl + 63) / 64), block(64 * RC_TS);
         hipLaunchKernelGGL(k_panda_reach_cost, grid, block, 0, s, a, pa);
         return (int)grid.x;
     }

@@ -28,7 +28,7 @@ def test_abi_exports_every_declared_symbol():
 
 def test_library_in_tree_is_built_from_this_tree():
     """m3_build_id() -- compiled into the library -- equals the hash of the kernel sources + compiler flags of THIS checkout: the
-    .so that travels to the GPU box is not a stale one, and the committed PMC profiles (profiles/r05/mix_*.json, keyed by the same
+    .so that travels to the GPU box is not a stale one, and the committed PMC profiles (profiles/r06/mix_*.json, keyed by the same
     id; bench.py's roofline_valu) can be matched to it across rebuilds."""
     import json
     from m3p2i_aip_amd import _lib as L
@@ -36,7 +36,7 @@ def test_library_in_tree_is_built_from_this_tree():
     build.build()
     bid = L.load().m3_build_id().decode()
     assert len(bid) == 16 and bid == build.source_hash()
-    mix = json.load(open(os.path.join(ROOT, "profiles", "r05", "mix_push.json")))
+    mix = json.load(open(os.path.join(ROOT, "profiles", "r06", "mix_push.json")))
     assert len(mix["build_id"]) == 16          # (whether it is THIS build's is what bench.py reports: `stale` otherwise)
 
 

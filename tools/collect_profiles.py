@@ -5,7 +5,7 @@ import json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
-P = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "profiles/r05")
+P = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "profiles/r06")
 os.makedirs(P, exist_ok=True)
 NAMES = {"push": "push_K2000_T30", "hybrid": "hybrid_K4000_T30", "panda": "panda_K4000_T20", "panda_pick": "panda_pick_K4000_T20",
          "northstar": "northstar_K10000_T30", "c5": "c5shard_K8000_T30", "c5_unsharded": "c5_unsharded_K64000_T30",

@@ -38,5 +38,5 @@ from m3p2i_aip_amd import _lib as L
 per["build_id"] = L.load().m3_build_id().decode()
 print("$CFG per wave:", json.dumps({k: (round(v, 1) if isinstance(v, float) else v) for k, v in per.items()}, indent=1))
 json.dump(per, open("$OUT/../mixb_$CFG.json", "w"), indent=1)
-json.dump(per, open("$OUT/../mix_$CFG.json", "w"), indent=1)      # (the name bench.py looks for under profiles/r05/)
+json.dump(per, open("$OUT/../mix_$CFG.json", "w"), indent=1)      # (the name bench.py looks for under profiles/r06/)
 PY

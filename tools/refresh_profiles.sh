@@ -1,16 +1,16 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): regenerates everything under profiles/<round>/ into gpurun_out/.
-# usage: tools/refresh_profiles.sh     (then, in the build container: python tools/collect_profiles.py profiles/r05)
+# usage: tools/refresh_profiles.sh     (then, in the build container: python tools/collect_profiles.py profiles/r06)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 O=$ROOT/gpurun_out
 mkdir -p $O
 cd $ROOT
 # dynamic instruction mix of the rollout kernels FIRST (PMC passes; the thread-trace decoder is not in this image:
 # tools/att_rollout.sh): mix_<config>.json is what bench.py's roofline_valu reads, keyed by m3_build_id -- the bench lines
-# below must find the mixes of THIS build under profiles/r05/ (copied there on the box; merged back through gpurun_out/)
+# below must find the mixes of THIS build under profiles/r06/ (copied there on the box; merged back through gpurun_out/)
 for c in push hybrid panda panda_pick northstar c5 c5_unsharded worst_case; do
   tools/pmc_mix_bench.sh $c > $O/pmc_mix_bench_$c.log 2>&1
-  cp $O/mix_$c.json $ROOT/profiles/r05/mix_$c.json
+  cp $O/mix_$c.json $ROOT/profiles/r06/mix_$c.json
 done
 # the driver's own command, verbatim (BENCH_rNN.json: `python3 bench.py --gpus 1 --steps 20 --warmup 5`)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
