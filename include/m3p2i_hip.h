@@ -244,9 +244,9 @@ int m3_set_rollout_lanes(m3_handle* h, int lanes);
 /* panda_env: lanes that simulate ONE sample in the rollout kernel -- 1 (a lane per sample, 64 samples per wavefront), 8 or
  * 16 (the lanes of a DPP row share a sample: the contact solver's joint-space rows run across them; eight / four sample
  * slots per wavefront), 0 = automatic: by size (16 while the launch has no more wavefronts than the chip has SIMDs, then 8,
- * then 1) and, for the reach task (whose wavefronts give 1-2 slots to quirk Q8's shadow samples), by what the last
- * commands' rollouts met -- 1 while few of them had the gripper within reach of a box or an awake cube, 16 (with the reach cost
- * kernel, below) or 8 once many did.  Same results, bit for bit
+ * then 1); for the reach task (quirk Q8) 16 with the reach cost kernel (below) wherever that is available and one round of
+ * sixteen-lane wavefronts fits (K <= 4096), else by what the last commands' rollouts met -- 1 (with shadow sample slots) while
+ * few of them had the gripper within reach of a box or an awake cube, 8 once many did.  Same results, bit for bit
  * (world spec v3 defines the rows' sums as the pairwise tree all forms evaluate).  DESIGN.md section 6. */
 int m3_set_panda_lanes_per_sample(m3_handle* h, int lanes_per_sample);
 /* panda_env, reach task on an unsharded handle (quirk Q8: every rollout's cost is measured against environment 0's cube):

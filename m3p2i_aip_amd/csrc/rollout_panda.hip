@@ -424,7 +424,13 @@ int launch_rollout_panda(const RolloutArgs& a, const PandaArgs& pa_in, const Pan
     int lps = 0;
     if (pa.reach_rec != nullptr) {
         pa.shadows = 0;
-        const bool want = pa_in.shadows != 0 && !(a.sampling_random || a.mode_simple) && (pa.lps != 0 || pa.reach_busy != 0);
+        // (round 6: with the cost kernel in time slices the sixteen-lane form + cost kernel is at least as fast as one lane + shadow
+        // slots in EVERY scene of an episode -- 10 ticks in 0.160 / 0.161 ms, 20 ticks 0.168 / 0.190, cubes settled 0.174 / 0.177,
+        // initial scene 0.324 / 0.362, 60 ticks 0.744 / 1.545: profiles/r06/panda_reach_mid_bench.json -- so wherever one round of
+        // sixteen-lane wavefronts fits (K <= 4096) the form no longer depends on the reported share; the eight-lane form, which
+        // loses to one lane in quiet scenes, keeps following it)
+        const bool sixteen_fits = (a.Kl + 3) / 4 <= 1024;
+        const bool want = pa_in.shadows != 0 && !(a.sampling_random || a.mode_simple) && (pa.lps != 0 || pa.reach_busy != 0 || sixteen_fits);
         lps = want ? panda_lps_for(a, pa) : 1;
         if (lps == 1) pa = pa_in, pa.reach_rec = nullptr;
     }

@@ -304,12 +304,14 @@ def test_panda_ragged_sample_counts_in_every_kernel_form(oracle, K, task, mm, lp
 @pytest.mark.gpu
 @pytest.mark.parametrize("cost_kernel", [False, True])
 def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle, cost_kernel):
-    """The automatic form of the REACH command (m3_set_panda_lanes_per_sample 0): one lane per sample (with quirk Q8's shadow
-    slots) while the gripper is within reach of a box in few of the rollouts' (sample, substep) pairs; from the command after the
-    kernel reported many (m3_panda_near_share) sixteen lanes per sample without shadow slots + the cost kernel -- or, where that
-    is not available (m3_set_panda_reach_cost_kernel 0, as beyond K = 8192), eight lanes with them.  The plans do not depend on
-    it: the same commands with the form forced to one lane give the same bits."""
+    """The automatic form of the REACH command (m3_set_panda_lanes_per_sample 0).  With the cost kernel available and one round of
+    sixteen-lane wavefronts fitting (K <= 4096; round 6: that form is at least as fast in every scene of an episode): sixteen lanes
+    per sample without shadow slots + the cost kernel, always.  Where it is not (m3_set_panda_reach_cost_kernel 0, as beyond
+    K = 8192): one lane per sample (with quirk Q8's shadow slots) while the gripper is within reach of a box in few of the rollouts'
+    (sample, substep) pairs, eight lanes with them from the command after the kernel reported many (m3_panda_near_share).  The
+    plans do not depend on it: the same commands with the form forced to one lane give the same bits."""
     many = 16 if cost_kernel else 8
+    quiet = 16 if cost_kernel else 1          # the form in a scene with next to nothing near anything
     import oracle.panda as P
     from m3p2i_aip_amd import _lib as L
     from m3p2i_aip_amd.engine import HipEngine, make_config
@@ -327,7 +329,7 @@ def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle, cost_kernel):
         eng.set_panda_reach_cost_kernel(cost_kernel)
         return eng
     # arm up, the cubes at rest on the table (the initial scene after its cubes have landed): few pairs near anything, no cube
-    # awake -> one lane, command after command
+    # awake -> the quiet form, command after command
     rest = P.init_world(1)
     for _ in range(30):
         P.step_batch(sc, rest, np.zeros((1, 9), np.float32))
@@ -340,7 +342,7 @@ def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle, cost_kernel):
         far.command(sync_host=True)
         used.append(far.panda_lanes_per_sample_used())
         shares.append(far.panda_near_share())
-    assert used == [1, 1, 1, 1] and 0 <= max(shares) < 260, (used, shares)
+    assert used == [quiet] * 4 and 0 <= max(shares) < 260, (used, shares)
     # open gripper 3 cm above the cube: the rollouts are next to it all the time
     near = grasp_world(P, sc, close_gripper=False, lift=0.03)
     auto, one = engine(0), engine(1)
@@ -353,14 +355,14 @@ def test_reach_kernel_form_follows_what_the_rollouts_meet(oracle, cost_kernel):
         assert np.array_equal(np.asarray(a), np.asarray(b))
         for buf in (L.BUF_TRAJ_COST, L.BUF_MEAN):
             assert torch.equal(auto.buffer(buf), one.buffer(buf))
-    assert used == [1, many, many, many] and auto.panda_near_share() >= 300, (used, auto.panda_near_share())
-    # back with the arm up and the cubes at rest: one lane again from the command after the first report from there
+    assert used == [quiet, many, many, many] and auto.panda_near_share() >= 300, (used, auto.panda_near_share())
+    # back with the arm up and the cubes at rest: the quiet form again from the command after the first report from there
     used = []
     for _ in range(3):
         auto.set_world_panda_raw(raw31(P, rest))
         auto.command(sync_host=True)
         used.append(auto.panda_lanes_per_sample_used())
-    assert used == [many, 1, 1], used
+    assert used == [many, quiet, quiet], used
     # the configured initial scene, whose cubes start 1 cm above the table and land: awake cubes count like a near gripper
     for _ in range(2):
         auto.set_world_panda_raw(raw31(P, P.init_world(1)[0]))
