@@ -69,6 +69,24 @@ def worker(rank, world, port, multi_modal, task, goal, ret, transport="gloo", sh
         assert missing == -1, f"rank {rank}: the wait for rank {missing} timed out"
         out[0]["p2p_memory_kind"] = kind
     out[0]["transport"], out[0]["shard_mix_level"] = pl.transport, pl._shard_mix_level
+    if transport == "p2p":
+        #  the recovery paths of the exchange, across real processes: the collective re-arm (flags, error word and
+        # sequence numbers of every rank's block back to zero between two barriers) and the detach to the process group's
+        # collectives -- after either the ranks keep producing one common, finite plan from their warm start
+        from m3p2i_aip_amd.distributed import detach_p2p, p2p_recover
+
+        def same_plan_everywhere():
+            a = pl.command(sim._dof_state[0]).clone()
+            torch.cuda.synchronize()
+            got = [torch.zeros_like(a.cpu()) for _ in range(world)]
+            dist.all_gather(got, a.cpu())
+            assert all(torch.isfinite(g).all() and torch.equal(g, got[0]) for g in got), f"rank {rank}: plans differ after recovery"
+        p2p_recover(pl)
+        same_plan_everywhere()
+        assert pl._engine.p2p_status()[0] == -1
+        detach_p2p(pl)
+        assert pl.transport != "p2p"
+        same_plan_everywhere()
     if rank == 0:
         ret.put(out)
     dist.barrier()
