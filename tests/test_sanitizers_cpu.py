@@ -25,7 +25,8 @@ def asan_runtime():
 def san_env(asan):
     # (one OpenMP thread per pytest worker: the workers already fill the cores, and idle OpenMP threads spin)
     return dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",
-                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", PYTHONPATH=ROOT, OMP_NUM_THREADS="1", OMP_WAIT_POLICY="passive")
+                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", OMP_NUM_THREADS="1", OMP_WAIT_POLICY="passive",
+                PYTHONPATH=ROOT + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else ""))
 
 
 def test_the_set_up_reports_a_heap_overflow_and_an_integer_overflow(tmp_path):
