@@ -90,14 +90,12 @@ def test_oracle_point_full_size_vs_reference(full, oracle, tag):
     K, T = kw.pop("K"), kw.pop("T")
     cfg = oracle.make_cfg(K, T, 2, **kw)
     opl = oracle.OraclePointPlanner(cfg, full[f"full_{tag}_delta"])
-    half = K // 2
     for call, w in enumerate(full[f"full_{tag}_world"]):
         a = opl.command(w)
         L_, oi = opl.last, opl.last["info"]
         if kw["multi_modal"]:
             check_call(tag, call, full, a, L_["w"], opl.mean, L_["top_idx"], w1=L_["w1"], w2=L_["w2"], mean1=opl.mean1,
-                       mean2=opl.mean2, iters=(oi.iters_1, oi.iters_2, oi.iters), best=(oi.best_idx_1, oi.best_idx_2 - half
-                                                                                         if oi.best_idx_2 >= half else oi.best_idx_2),
+                       mean2=opl.mean2, iters=(oi.iters_1, oi.iters_2, oi.iters), best=(oi.best_idx_1, oi.best_idx_2),
                        pref=opl.pull_preference())
         else:
             check_call(tag, call, full, a, L_["w"], opl.mean, L_["top_idx"], J=L_["J"], beta=opl.beta)
@@ -134,8 +132,8 @@ def test_hip_point_full_size_vs_reference(full, tag):
         if kw["multi_modal"]:
             check_call(tag, call, full, a, buf(L.BUF_WEIGHTS), buf(L.BUF_MEAN), buf(L.BUF_TOP_IDX), w1=buf(L.BUF_WEIGHTS_1),
                        w2=buf(L.BUF_WEIGHTS_2), mean1=buf(L.BUF_MEAN_1), mean2=buf(L.BUF_MEAN_2),
-                       iters=(i.iters_1, i.iters_2, i.iters), best=(i.best_idx_1, i.best_idx_2 - K // 2 if i.best_idx_2 >= K // 2
-                                                                     else i.best_idx_2), pref=i.pull_preference)
+                       iters=(i.iters_1, i.iters_2, i.iters), best=(i.best_idx_1, i.best_idx_2 - K // 2),      # (m3_info: global indices)
+                       pref=i.pull_preference)
         else:
             check_call(tag, call, full, a, buf(L.BUF_WEIGHTS), buf(L.BUF_MEAN), buf(L.BUF_TOP_IDX), J=buf(L.BUF_TRAJ_COST), beta=i.beta)
         np.testing.assert_allclose(buf(L.BUF_TOP_TRAJS)[0], full[f"full_{tag}_top_trajs"][call][0], atol=1e-3)

@@ -5,7 +5,9 @@ the reference's shipped planner size (K = 200, T = 15) and its real-world suctio
 robot is within 0.6 m of the box and its action points away from it; force kp on the box towards the robot where 1 / d > 1.5,
 the opposite force on the robot, clamp +-500; acts during the NEXT step) -- with ONE mechanism toggled at a time:
 
-  spec                  planar spec v1.5, kp_suction 400 (config_point.yaml:9)
+  spec                  the oracle's default scene: planar spec v1.7 since round 6 (the suction pair consumed by the first substep)
+  spec_v16              the scene the table of round 5 was made with: the pair acts in both substeps (fext_substeps = 0);
+                        every other variant below is applied on top of THIS one, as in round 5 (profiles/r05/ab_pull*.json)
   kp_200 / kp_100       a weaker suction (the force PhysX transmits through a 1-step force tensor is not pinned)
   suction_ramp          the real-world suction force builds up over 10 ticks of uninterrupted suction instead of at once
   mu_box_1              box-ground friction 1.0 instead of the 0.75 average of (box 0.5, ground 1.0): PhysX combines friction
@@ -45,15 +47,17 @@ def variants():
                 setattr(sc, k, v)
         return f
     base = dict(kp=400.0, ramp=0, avoid=False)
+    v16 = dict(fext_substeps=0)
     return {
         "spec": (mod(), dict(base)),
-        "kp_200": (mod(), dict(base, kp=200.0)),
-        "kp_100": (mod(), dict(base, kp=100.0)),
-        "suction_ramp": (mod(), dict(base, ramp=10)),
-        "mu_box_1": (mod(box_mu_g=1.0), dict(base)),
-        "torsion_x10": (mod(box_req=1.53, dyn_req=1.53), dict(base)),
-        "effort_300": (mod(drive_fmax=300.0), dict(base)),
-        "avoid": (mod(), dict(base, avoid=True)),
+        "spec_v16": (mod(**v16), dict(base)),
+        "kp_200": (mod(**v16), dict(base, kp=200.0)),
+        "kp_100": (mod(**v16), dict(base, kp=100.0)),
+        "suction_ramp": (mod(**v16), dict(base, ramp=10)),
+        "mu_box_1": (mod(box_mu_g=1.0, **v16), dict(base)),
+        "torsion_x10": (mod(box_req=1.53, dyn_req=1.53, **v16), dict(base)),
+        "effort_300": (mod(drive_fmax=300.0, **v16), dict(base)),
+        "avoid": (mod(**v16), dict(base, avoid=True)),
     }
 
 

@@ -74,7 +74,7 @@ def episode(args):
     sc.fext_substeps = fext_sub
     sc.box_req *= torsion
     sc.dyn_req *= torsion
-    sc.box_mu_g = sc.dyn_mu_g = mu
+    sc.box_mu_g = mu                  # (the pushed box; the dyn-obs keeps its own material's 1.0)
     kp = 400.0 * kp_scale
     j = band_stats.jitter_of(name, seed)
     w = O.init_world(1)
@@ -107,7 +107,8 @@ def episode(args):
             rb = w[0, O.W_R:O.W_R + 2] - w[0, O.W_B:O.W_B + 2]
             dist = float(np.hypot(*rb))
             if dist < 0.6 and float(a @ rb) > 0.0 and 1.0 / dist > 1.5:
-                fb = np.clip(kp * rb / dist, -500.0, 500.0)              # on the box: towards the robot
+                unit = -rb / dist                                        # box - robot, normalised (the operation order of
+                fb = np.clip(-kp * unit, -500.0, 500.0)                  # tools/cpu_ab_pull.py, episode for episode); on the box: towards the robot
                 w[0, O.W_FEXT_B:O.W_FEXT_B + 2] = fb
                 w[0, O.W_FEXT_R:O.W_FEXT_R + 2] = -fb
         O.step_batch(sc, w, a[None])
