@@ -52,7 +52,8 @@ struct PointScene {
 
 // the run-time part of the scene from the reference's solver settings (host side: m3_create, and the host build of this
 // header in tests/native/): every product in binary32, in this order -- the oracle forms the same constants
-inline void make_point_scene(PointScene& s, float dt, int substeps, int iters) {
+constexpr PointScene point_scene_for(float dt, int substeps, int iters) {
+    PointScene s{};
     const float h = dt / (float)substeps;
     s.h = h; s.inv_h = 1.0f / h; s.substeps = substeps; s.iters = iters;
     const float g = 9.8f;
@@ -64,6 +65,20 @@ inline void make_point_scene(PointScene& s, float dt, int substeps, int iters) {
     s.LlinB = ((0.75f * 16.0f) * g) * h; s.LangB = s.LlinB * req;
     s.LlinD = ((1.0f * 16.0f) * g) * h; s.LangD = s.LlinD * req;
     s.RcB = 1.5f * req; s.RcD = 1.5f * req;
+    return s;
+}
+inline void make_point_scene(PointScene& s, float dt, int substeps, int iters) { s = point_scene_for(dt, substeps, iters); }
+// The reference's own solver settings (isaacgym/point.yaml:4 dt 0.05; isaacgym_wrapper.py:10,28: 2 substeps, 6 position
+// iterations) as a COMPILE-TIME scene: the rollout kernel instance of a handle with exactly these values (the bits of the
+// thirteen run-time fields compared, rollout_point_kernel.hpp) sees them as literals -- thirteen fewer live scalar registers in a
+// kernel that spills scalars, constant trip counts of the substep and pass loops.  Same values, same bits.
+constexpr PointScene POINT_SCENE_REFERENCE = point_scene_for(0.05f, 2, 6);
+inline bool point_scene_is_reference(const PointScene& s) {
+    const PointScene& r = POINT_SCENE_REFERENCE;
+    auto same = [](float a, float b) { return __builtin_memcmp(&a, &b, sizeof(float)) == 0; };
+    return s.substeps == r.substeps && s.iters == r.iters && same(s.h, r.h) && same(s.inv_h, r.inv_h) && same(s.gam, r.gam) &&
+           same(s.md, r.md) && same(s.dmax, r.dmax) && same(s.LlinB, r.LlinB) && same(s.LangB, r.LangB) && same(s.LlinD, r.LlinD) &&
+           same(s.LangD, r.LangD) && same(s.RcB, r.RcB) && same(s.RcD, r.RcD);
 }
 
 struct Box {
@@ -803,7 +818,10 @@ __device__ __forceinline__ void point_substep(const PointScene& sc, PointWorld& 
             }
         }
         };
-    auto gen_passes = [&](auto with_d, auto with_rw) { for (int it = 0; it < sc.iters; ++it) gen_pass(with_d, with_rw); };
+    auto gen_passes = [&](auto with_d, auto with_rw) {
+#pragma nounroll      // (six copies of these passes measured +7 %; with the reference scene compiled in the trip count is a constant)
+        for (int it = 0; it < sc.iters; ++it) gen_pass(with_d, with_rw);
+    };
     if constexpr (M == G_CORNER && !ALL_FORCES) {
         const bool any_rw = __builtin_amdgcn_ballot_w64(s_rwx.on | s_rwy.on) != 0ull;
         if (skipD) { if (any_rw) gen_passes(RowOff{}, RowOn{}); else gen_passes(RowOff{}, RowOff{}); }

@@ -204,6 +204,12 @@ template <bool GENERAL, int TASK>
 __global__ __launch_bounds__(64) void k_rollout_point(const RolloutArgs a, const PointScene sc) {
     rollout_point_body<GENERAL, TASK>(a, sc);
 }
+// ... and the same build with the reference's solver settings compiled in (planar_dyn.hpp: POINT_SCENE_REFERENCE)
+template <bool GENERAL, int TASK>
+__global__ __launch_bounds__(64) void k_rollout_point_ref(const RolloutArgs a) {
+    constexpr PointScene sc = POINT_SCENE_REFERENCE;
+    rollout_point_body<GENERAL, TASK>(a, sc);
+}
 template <bool GENERAL, int TASK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rollout_point_occ2(const RolloutArgs a,
                                                                                                       const PointScene sc) {
@@ -221,6 +227,7 @@ template <bool GENERAL, int TASK>
 inline void launch_rollout_point_instance(const RolloutArgs& a, const PointScene& sc, int blocks, hipStream_t s) {
     if (rollout_three_waves(blocks)) hipLaunchKernelGGL((k_rollout_point_occ3<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a, sc);
     else if (rollout_two_waves(blocks)) hipLaunchKernelGGL((k_rollout_point_occ2<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a, sc);
+    else if (point_scene_is_reference(sc)) hipLaunchKernelGGL((k_rollout_point_ref<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((k_rollout_point<GENERAL, TASK>), dim3(blocks), dim3(64), 0, s, a, sc);
 }
 
